@@ -1,0 +1,55 @@
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / driver GPU tier)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    """-> nested dict of torch tensors from tests/golden/<name>.npz ('a/b' keys nest)."""
+    raw = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    for k in raw.files:
+        node = out
+        parts = k.split("/")
+        # state-dict keys contain dots only, so '/' is safe as the nesting separator
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        v = raw[k]
+        if parts[-1].endswith("_json"):
+            node[parts[-1][:-5]] = json.loads(bytes(v).decode())
+        else:
+            node[parts[-1]] = torch.from_numpy(np.array(v))
+    return out
+
+
+@pytest.fixture(scope="session")
+def h3d():
+    return importlib.import_module("3dhumangan_amd")
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
