@@ -1,0 +1,78 @@
+"""ctypes binding of libh3d.so (the C ABI declared in include/h3d.h).
+
+There is deliberately no CPU fallback here: if the HIP library is missing or a call fails, the
+caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libh3d.so")
+
+_lib = None
+
+
+class H3DError(RuntimeError):
+    pass
+
+
+class FieldParams(C.Structure):
+    _fields_ = [("w_coord", C.c_void_p), ("b_coord", C.c_void_p), ("w_geo", C.c_void_p), ("b_geo", C.c_void_p),
+                ("w_film", C.c_void_p * 4), ("b_film", C.c_void_p * 4), ("w_sigma", C.c_void_p),
+                ("b_sigma", C.c_void_p), ("w_color", C.c_void_p), ("b_color", C.c_void_p), ("w_rgb", C.c_void_p),
+                ("b_rgb", C.c_void_p), ("w_feat", C.c_void_p), ("b_feat", C.c_void_p)]
+
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    "h3d_version": (C.c_int, []),
+    "h3d_last_error": (C.c_char_p, []),
+    "h3d_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, _i]),
+    "h3d_ray_integrate": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "h3d_ray_setup": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
+    "h3d_geo_features": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _p]),
+    "h3d_bilinear_resize": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_bias_act": (C.c_int, [_p, _p, _p, _l, _i, _l, _l, _i, _f, _f, _f, _p]),
+    "h3d_upfirdn2d": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), _i, _i, _i, _i, C.POINTER(_l),
+                                _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+}
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises H3DError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise H3DError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().h3d_last_error().decode(errors="replace")
+        raise H3DError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def need_cuda(*tensors):
+    """The product has no CPU path: refuse CPU tensors loudly."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise H3DError("3dhumangan_amd ops run on a ROCm device only (got a CPU tensor); there is no CPU fallback")
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

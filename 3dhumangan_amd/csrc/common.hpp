@@ -1,0 +1,37 @@
+// Shared host/device helpers for libh3d (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/h3d.h"
+
+namespace h3d {
+
+void set_error(const char* fmt, ...);
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return H3D_ELAUNCH;
+    }
+    return H3D_OK;
+}
+
+#define H3D_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) {                                 \
+            h3d::set_error(__VA_ARGS__);               \
+            return H3D_EINVAL;                         \
+        }                                              \
+    } while (0)
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Number of CUs of the current device (cached per process; falls back to the MI355X value).
+int compute_units();
+
+}  // namespace h3d

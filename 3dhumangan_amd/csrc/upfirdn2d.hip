@@ -1,0 +1,93 @@
+// P2 upfirdn2d forward (pad -> zero-upsample -> FIR -> decimate) for gfx950.
+// Replaces _plugin.upfirdn2d (lib/components/ops/upfirdn2d.cpp:16); per-element definition follows the gather
+// form of lib/components/ops/upfirdn2d.cu:29-92: for output (ox, oy) only the taps that land on a real input
+// sample of the zero-stuffed signal are visited, so the cost is ceil(fw/upx)*ceil(fh/upy) MACs per output.
+// Strides are explicit (NCHW or channels_last).  The filter (<= 1 K taps) is staged in LDS once per workgroup.
+#include "common.hpp"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+struct Params {
+    int B, C, H, W, fh, fw, outH, outW, upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+    int64_t xs[4], ys[4];
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) {
+    const int q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                        T* __restrict__ y, Params p) {
+    extern __shared__ float sf[];
+    for (int i = threadIdx.x; i < p.fh * p.fw; i += blockDim.x) {
+        // store in "correlation order": sf[ky][kx] multiplies padded sample (oy*down + ky, ox*down + kx)
+        const int ky = i / p.fw, kx = i % p.fw;
+        const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
+        sf[i] = f[sy * p.fw + sx] * p.gain;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)p.B * p.C * p.outH * p.outW;
+    // iterate with ox fastest for NCHW-contiguous outputs; general strides still handled
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % p.outW);
+        const int oy = (int)((i / p.outW) % p.outH);
+        const int c = (int)((i / ((int64_t)p.outW * p.outH)) % p.C);
+        const int b = (int)(i / ((int64_t)p.outW * p.outH * p.C));
+        // padded/upsampled coordinate u = o*down + k must satisfy u - pad0 = in*up
+        const int bx = ox * p.downx - p.padx0, by = oy * p.downy - p.pady0;
+        // smallest kx >= 0 with (bx + kx) % upx == 0
+        int kx0 = ((-bx) % p.upx + p.upx) % p.upx;
+        int ky0 = ((-by) % p.upy + p.upy) % p.upy;
+        const T* __restrict__ xb = x + b * p.xs[0] + c * p.xs[1];
+        A acc = 0;
+        for (int ky = ky0; ky < p.fh; ky += p.upy) {
+            const int iy = floor_div(by + ky, p.upy);
+            if (iy < 0 || iy >= p.H) continue;
+            for (int kx = kx0; kx < p.fw; kx += p.upx) {
+                const int ix = floor_div(bx + kx, p.upx);
+                if (ix < 0 || ix >= p.W) continue;
+                acc += (A)xb[iy * p.xs[2] + ix * p.xs[3]] * (A)sf[ky * p.fw + kx];
+            }
+        }
+        y[b * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3]] = (T)acc;
+    }
+}
+
+template <typename T, typename A>
+int launch(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.C * p.outH * p.outW;
+    const int64_t want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 256 * 32 ? (want < 1 ? 1 : want) : 256 * 32);
+    hipLaunchKernelGGL((upfirdn2d_kernel<T, A>), dim3(grid), dim3(256), sizeof(float) * p.fh * p.fw, st, (const T*)x, f,
+                       (T*)y, p);
+    return h3d::launch_status("h3d_upfirdn2d");
+}
+
+}  // namespace
+
+extern "C" int h3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, int B, int C, int H, int W,
+                             const int64_t xs[4], int fh, int fw, int outH, int outW, const int64_t ys[4], int upx,
+                             int upy, int downx, int downy, int padx0, int pady0, int flip, float gain,
+                             h3d_stream_t stream) {
+    H3D_REQUIRE(x && f && y && xs && ys, "h3d_upfirdn2d: null pointer");
+    H3D_REQUIRE(dtype >= 0 && dtype <= 2, "h3d_upfirdn2d: dtype %d (0=f32,1=f16,2=f64)", dtype);
+    H3D_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1, "h3d_upfirdn2d: x has zero size");
+    H3D_REQUIRE(fh >= 1 && fw >= 1, "h3d_upfirdn2d: f must be at least 1x1");
+    H3D_REQUIRE(fh * fw <= 8192, "h3d_upfirdn2d: filter too large");
+    H3D_REQUIRE(upx >= 1 && upy >= 1, "h3d_upfirdn2d: upsampling factor must be at least 1");
+    H3D_REQUIRE(downx >= 1 && downy >= 1, "h3d_upfirdn2d: downsampling factor must be at least 1");
+    H3D_REQUIRE(outH >= 1 && outW >= 1, "h3d_upfirdn2d: output must be at least 1x1");
+    Params p;
+    p.B = B; p.C = C; p.H = H; p.W = W; p.fh = fh; p.fw = fw; p.outH = outH; p.outW = outW;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip;
+    p.gain = gain;
+    for (int i = 0; i < 4; ++i) { p.xs[i] = xs[i]; p.ys[i] = ys[i]; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == 0) return launch<float, float>(x, f, y, p, st);
+    if (dtype == 1) return launch<__half, float>(x, f, y, p, st);
+    return launch<double, double>(x, f, y, p, st);
+}

@@ -1,0 +1,38 @@
+"""SMPL-conditioned geometry features (reference: lib/components/smpl.py:210-249), HIP-backed."""
+import torch
+
+from ... import _lib
+
+GEO_DIM = 31
+
+
+def vertex_inverse_transforms(fk_matrices, lbs_weights):
+    """[B,V,16]: per-vertex blended inverse bone transforms (smpl.py:217-218).  Once per pose; a
+    [V,24]x[24,16] product per sample, done by the BLAS library on the device."""
+    ik = torch.inverse(fk_matrices.float())
+    B, J = ik.shape[:2]
+    return torch.bmm(lbs_weights.float(), ik.reshape(B, J, 16)).contiguous()
+
+
+def get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, lbs_weights, legacy_mode=False,
+                     vertex_ik=None, return_index=False, out_stride=GEO_DIM):
+    """Same arguments and result as the reference function: points [B,N,3] -> [B,N,31].
+
+    ``vertex_ik`` lets a caller that evaluates many point sets for one pose reuse the blended transforms."""
+    _lib.need_cuda(points, skeletons, vertices, tpose_vertices)
+    B, N, _ = points.shape
+    V = vertices.shape[1]
+    if vertex_ik is None:
+        vertex_ik = vertex_inverse_transforms(fk_matrices, lbs_weights)
+    pts = points.contiguous().float()
+    geo = torch.empty((B, N, out_stride), device=pts.device, dtype=torch.float32)
+    if out_stride > GEO_DIM:
+        geo[..., GEO_DIM:].zero_()
+    idx = torch.empty((B, N), device=pts.device, dtype=torch.int32) if return_index else None
+    rc = _lib.load().h3d_geo_features(_lib.ptr(pts), _lib.ptr(skeletons.contiguous().float()),
+                                      _lib.ptr(vertices.contiguous().float()),
+                                      _lib.ptr(tpose_vertices.contiguous().float()), _lib.ptr(vertex_ik),
+                                      _lib.ptr(geo), _lib.ptr(idx), B, N, V, out_stride, int(bool(legacy_mode)),
+                                      _lib.stream_handle())
+    _lib.check(rc, "h3d_geo_features")
+    return (geo, idx) if return_index else geo

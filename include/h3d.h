@@ -1,0 +1,109 @@
+/*
+ * libh3d -- C ABI of the MI355X (gfx950) generator hot path.
+ *
+ * This is the drop-in boundary: plain C, device pointers + explicit sizes, a
+ * HIP stream handle, int return codes.  No torch types, no exceptions across
+ * the boundary, no allocation: the caller owns every buffer (inputs, outputs,
+ * workspaces).  All pointers are DEVICE pointers unless a comment says HOST.
+ * Every entry point is re-entrant and launches on the stream it is given.
+ *
+ * Return value: 0 on success, negative H3D_E* on failure; h3d_last_error()
+ * returns a thread-local human readable message for the last failure.
+ *
+ * Each function cites the reference interface it replaces (file:line under
+ * the upstream repository root).
+ */
+#ifndef H3D_H
+#define H3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H3D_VERSION 100            /* major*10000 + minor*100 + patch */
+
+#define H3D_OK            0
+#define H3D_EINVAL       -1        /* bad argument (shape, alignment, flag)        */
+#define H3D_EUNSUPPORTED -2        /* valid request this build has no kernel for   */
+#define H3D_ELAUNCH      -3        /* HIP launch / runtime error                   */
+
+typedef void* h3d_stream_t;        /* hipStream_t */
+
+int h3d_version(void);
+const char* h3d_last_error(void);
+/* Number of compute units / name of the current HIP device (HOST out buffers). */
+int h3d_device_info(int* n_cu, char* name, int name_len);
+
+/* ------------------------------------------------------------------------
+ * A6  volume integration  == lib/generators/volume_rendering.py:12-56
+ *     (ray_integration(input, z_vals, device, noise_std, last_back, white_back, clamp_mode))
+ * field   [n_rays, S, C+1] fp32, density in the last channel
+ * z_vals  [n_rays, S]
+ * noise   [n_rays, S] already multiplied by noise_std, or NULL
+ * feats   [n_rays, C]   depth [n_rays]   weights [n_rays, S]
+ * clamp_mode: 0 = relu, 1 = softplus.  fill_mode is not supported (None in every caller).
+ */
+int h3d_ray_integrate(const float* field, const float* z_vals, const float* noise,
+                      float* feats, float* depth, float* weights,
+                      int64_t n_rays, int S, int C,
+                      int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A3  ray set-up == lib/generators/volume_rendering.py:86-110 (get_initial_rays_weak_perspective),
+ *     :124-130 (perturb_points), :133-170 (transform_sampled_points)
+ * focals, scales [B]; cam2world [B,4,4] row-major; jitter [B,R,S] U(0,1) or NULL
+ * points [B,R*S,3] world space; z_vals [B,R,S]
+ */
+int h3d_ray_setup(const float* focals, const float* scales, const float* cam2world, const float* jitter,
+                  float* points, float* z_vals,
+                  int B, int render_h, int render_w, int S, float ray_start, float ray_end,
+                  h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A4  SMPL geometry features == lib/components/smpl.py:210-249 (get_geo_features)
+ * points [B,N,3]; joints [B,24,3]; vertices, tpose_vertices [B,V,3];
+ * vertex_ik [B,V,16]  = einsum(lbs_weights, inverse(fk_matrices)) (smpl.py:217-218; a [B,V,24]x[B,24,16]
+ *                       product the host does once per pose with a library GEMM)
+ * geo [B,N,geo_stride] (31 values written per point, order per legacy_mode), nn_index [B,N] int32 or NULL
+ */
+int h3d_geo_features(const float* points, const float* joints, const float* vertices,
+                     const float* tpose_vertices, const float* vertex_ik,
+                     float* geo, int32_t* nn_index,
+                     int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A7  bilinear resize, align_corners=False == F.interpolate at lib/generators/map3d_generator.py:244-245
+ * in [B,C,h,w] -> out [B,C,H,W]  (NCHW fp32)
+ */
+int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w, int H, int W,
+                        h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
+ *     lib/components/ops/bias_act.cpp:32 with grad=0; kernel spec lib/components/ops/bias_act.cu:23-147
+ * x, y: n dense elements; dtype: 0 = f32, 1 = f16, 2 = f64; b: size_b elements or NULL;
+ * element i uses b[(i / step_b) % size_b]; act = 1..9 (linear, relu, lrelu, tanh, sigmoid, elu, selu,
+ * softplus, swish); clamp < 0 disables clamping.
+ */
+int h3d_bias_act(const void* x, const void* b, void* y, int64_t n, int dtype,
+                 int64_t size_b, int64_t step_b, int act, float alpha, float gain, float clamp,
+                 h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * P2  upfirdn2d forward == _plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+ *     lib/components/ops/upfirdn2d.cpp:16; kernel spec lib/components/ops/upfirdn2d.cu:29-200
+ * x [B,C,H,W] with element strides xs[4]; f [fh,fw] fp32 dense; y [B,C,outH,outW] with strides ys[4];
+ * outW = (W*upx + padx0 + padx1 - fw + downx) / downx (likewise outH).  dtype as bias_act.
+ */
+int h3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                  int B, int C, int H, int W, const int64_t xs[4],
+                  int fh, int fw, int outH, int outW, const int64_t ys[4],
+                  int upx, int upy, int downx, int downy, int padx0, int pady0, int flip, float gain,
+                  h3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H3D_H */

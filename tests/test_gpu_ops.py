@@ -1,0 +1,232 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the CPU oracle / golden vectors."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+smpl = importlib.import_module("3dhumangan_amd.lib.components.smpl")
+resample = importlib.import_module("3dhumangan_amd.lib.components.resample")
+bias_act_mod = importlib.import_module("3dhumangan_amd.lib.components.ops.bias_act")
+upfirdn_mod = importlib.import_module("3dhumangan_amd.lib.components.ops.upfirdn2d")
+synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+
+DEV = "cuda"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def dev_dict(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+# ------------------------------------------------------------------ A6
+
+def test_ray_integration_golden():
+    g = load_golden("ray_integration")
+    for k, c in g.items():
+        S, C, softplus, last_back, white_back = [int(v) for v in c["flags"]]
+        f, d, w = vr.ray_integration(dev(c["field"]), dev(c["z"]), noise=dev(c["noise"]),
+                                     clamp_mode="softplus" if softplus else "relu", last_back=bool(last_back),
+                                     white_back=bool(white_back))
+        assert rel_err(f.cpu(), c["feats"]) < 1e-5, k
+        assert rel_err(d.cpu(), c["depth"]) < 1e-6, k
+        assert rel_err(w.cpu(), c["weights"]) < 1e-5, k
+
+
+@pytest.mark.parametrize("S,C", [(32, 387), (64, 259), (128, 259), (1, 3), (7, 6), (200, 1027)])
+def test_ray_integration_vs_oracle(S, C):
+    g = torch.Generator().manual_seed(S * 1000 + C)
+    B, R = 2, 37
+    field = torch.randn(B, R, S, C + 1, generator=g)
+    field[..., -1] = field[..., -1] * 10 - 2
+    z = torch.sort(torch.rand(B, R, S, 1, generator=g) + 11.0, dim=2).values
+    for last_back in (False, True):
+        ref = O.ray_integration(field.double(), z.double(), None, "relu", last_back, True)
+        got = vr.ray_integration(dev(field), dev(z), noise_std=0, clamp_mode="relu", last_back=last_back,
+                                 white_back=True)
+        for a, b, name in zip(got, ref, ("feats", "depth", "weights")):
+            assert rel_err(a.cpu(), b) < 2e-5, (name, last_back)
+
+
+def test_ray_integration_properties_full_size():
+    """cfg3-sized rays (S=64, F=256): weights are a partition of unity with last_back, and the op is linear in
+    the feature channels."""
+    g = torch.Generator().manual_seed(3)
+    B, R, S, C = 1, 4608, 64, 259
+    field = torch.randn(B, R, S, C + 1, generator=g).to(DEV)
+    z = torch.sort(torch.rand(B, R, S, 1, generator=g) + 11.0, dim=2).values.to(DEV)
+    f1, d1, w1 = vr.ray_integration(field, z, noise_std=0, clamp_mode="relu", last_back=True, white_back=False)
+    assert float((w1.sum(2) - 1).abs().max()) < 1e-5
+    assert float(w1.min()) >= 0
+    assert float((d1 - (w1 * z).sum(2)).abs().max()) < 1e-4
+    field2 = field.clone()
+    field2[..., :-1] *= 2.0
+    f2, _, w2 = vr.ray_integration(field2, z, noise_std=0, clamp_mode="relu", last_back=True, white_back=False)
+    assert torch.equal(w1, w2)
+    assert rel_err(f2.cpu(), (2 * f1).cpu()) < 1e-6
+    ref = (w1 * field[..., :-1]).sum(2)
+    assert rel_err(f1.cpu(), ref.cpu()) < 1e-5
+
+
+def test_ray_integration_rejects_bad_mode():
+    x = torch.zeros(1, 1, 4, 5, device=DEV)
+    with pytest.raises(Exception):
+        vr.ray_integration(x, torch.zeros(1, 1, 4, 1, device=DEV), clamp_mode=None)
+
+
+# ------------------------------------------------------------------ A3
+
+@pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
+def test_ray_setup_golden(name):
+    g = load_golden(name)
+    cfg, cond = g["meta"], g["cond"]
+    pts, zv = vr.sample_rays(dev(cond["intrinsics"][:, 0, 0]), dev(cond["scales"]), dev(cond["cam2world_matrices"]),
+                             cfg["num_steps"], (cfg["render_width"], cfg["render_height"]), cfg["ray_start"],
+                             cfg["ray_end"], jitter=dev(g["jitter"]))
+    assert rel_err(pts.cpu(), g["stage"]["points"]) < 5e-6
+    assert rel_err(zv.cpu(), g["stage"]["z_vals"]) < 1e-6
+
+
+def test_ray_setup_full_size_vs_oracle():
+    cond = synthetic.make_conditions(2, n_vertices=64, seed=1)
+    jit = torch.rand(2, 96 * 48, 64, 1, generator=torch.Generator().manual_seed(0))
+    ref_p, ref_z, _ = O.ray_setup(cond["intrinsics"][:, 0, 0], cond["scales"], cond["cam2world_matrices"], 96, 48, 64,
+                                  -0.5, 0.55, jit)
+    pts, zv = vr.sample_rays(dev(cond["intrinsics"][:, 0, 0]), dev(cond["scales"]), dev(cond["cam2world_matrices"]),
+                             64, (48, 96), -0.5, 0.55, jitter=dev(jit))
+    assert rel_err(pts.cpu(), ref_p) < 5e-6
+    assert rel_err(zv.cpu(), ref_z) < 1e-6
+
+
+# ------------------------------------------------------------------ A4
+
+def _geo_check(points, cond, legacy):
+    ref, ridx, rd2 = O.geo_features(points, cond["skeletons_xyz"], cond["vertices"], cond["tpose_vertices"],
+                                    cond["fk_matrices"], cond["lbs_weights"], legacy, return_index=True)
+    c = dev_dict(cond)
+    got, idx = smpl.get_geo_features(dev(points), c["skeletons_xyz"], c["vertices"], c["tpose_vertices"],
+                                     c["fk_matrices"], c["lbs_weights"], legacy, return_index=True)
+    # integer work is bit-exact: same arithmetic order, first index wins
+    assert torch.equal(idx.cpu().long(), ridx)
+    assert rel_err(got.cpu(), ref) < 1e-5
+    return got
+
+
+def test_geo_features_golden_full_mesh():
+    g = load_golden("geo_features")
+    cond = synthetic.make_conditions(2, n_vertices=6890, seed=int(g["cond_seed"][0]),
+                                     pose_scale=float(g["cond_pose_scale"][0]))
+    for legacy in (False, True):
+        got = _geo_check(g["points"], cond, legacy)
+        assert rel_err(got.cpu(), g[f"geo_legacy{int(legacy)}"]) < 1e-5
+
+
+@pytest.mark.parametrize("V,N", [(128, 64), (6890, 5000), (37, 1), (6890, 1025)])
+def test_geo_features_vs_oracle(V, N):
+    cond = synthetic.make_conditions(2, n_vertices=V, seed=V)
+    pts = (torch.rand(2, N, 3, generator=torch.Generator().manual_seed(N)) - 0.5) * torch.tensor([1.8, 2.4, 1.0])
+    _geo_check(pts, cond, False)
+
+
+def test_geo_features_exact_ties_pick_first_vertex():
+    cond = synthetic.make_conditions(1, n_vertices=64, seed=0, pose_scale=0.0)
+    cond["vertices"][0, 10] = cond["vertices"][0, 3]          # duplicate vertex: 3 must win
+    pts = cond["vertices"][:, 3:4].clone() + 1e-3
+    c = dev_dict(cond)
+    _, idx = smpl.get_geo_features(dev(pts), c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"],
+                                   c["lbs_weights"], return_index=True)
+    assert int(idx[0, 0]) == 3
+
+
+# ------------------------------------------------------------------ A7
+
+@pytest.mark.parametrize("shape", [(2, 5, 64, 32, 256, 128), (1, 3, 96, 48, 512, 256), (2, 4, 6, 5, 20, 12),
+                                   (1, 2, 8, 4, 17, 9), (1, 1, 5, 7, 5, 7), (1, 2, 16, 16, 8, 8)])
+def test_bilinear(shape):
+    B, C, h, w, H, W = shape
+    x = torch.randn(B, C, h, w, generator=torch.Generator().manual_seed(h * w))
+    ref = torch.nn.functional.interpolate(x, (H, W), mode="bilinear")
+    got = resample.bilinear_resize(dev(x), (H, W))
+    assert rel_err(got.cpu(), ref) < 2e-6
+
+
+# ------------------------------------------------------------------ P1 / P2
+
+def test_bias_act_golden():
+    g = load_golden("plugin_ops")
+    x, b = dev(g["bias_act_in"]["x"]), dev(g["bias_act_in"]["b"])
+    for act, cases in g["bias_act"].items():
+        if not isinstance(cases, dict):
+            continue
+        assert rel_err(bias_act_mod.bias_act(x, b, 1, act).cpu(), cases["default"]) < 2e-6, act
+        got = bias_act_mod.bias_act(x, b, 1, act, alpha=0.3, gain=1.7, clamp=0.9)
+        assert rel_err(got.cpu(), cases["custom"]) < 2e-6, act
+    x2, b2 = dev(g["bias_act_in"]["x2"]), dev(g["bias_act_in"]["b2"])
+    assert rel_err(bias_act_mod.bias_act(x2, b2, 1, "lrelu").cpu(), g["bias_act"]["dim_last"]) < 2e-6
+    assert rel_err(bias_act_mod.bias_act(x2, None, act="swish").cpu(), g["bias_act"]["no_bias"]) < 2e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.float64, 1e-12)])
+def test_bias_act_dtypes_and_layouts(dtype, tol):
+    g = torch.Generator().manual_seed(1)
+    for shape, dim in [((4, 8, 16, 16), 1), ((3, 7), 1), ((5, 6, 3), 0), ((2, 3, 5, 4), 3), ((1024, 384), 1)]:
+        x = torch.randn(shape, generator=g).to(dtype)
+        b = torch.randn(shape[dim], generator=g).to(dtype)
+        for act in ("linear", "lrelu", "sigmoid", "softplus", "swish", "selu", "elu", "tanh", "relu"):
+            ref = O.bias_act(x.double(), b.double(), dim, act, clamp=2.0)
+            got = bias_act_mod.bias_act(dev(x), dev(b), dim, act, clamp=2.0)
+            assert got.dtype == dtype and got.shape == x.shape
+            assert rel_err(got.cpu(), ref) < tol, (shape, act)
+
+
+def test_bias_act_empty_and_errors():
+    assert bias_act_mod.bias_act(torch.zeros(0, 4, device=DEV), None).numel() == 0
+    with pytest.raises(KeyError):
+        bias_act_mod.bias_act(torch.zeros(2, 4, device=DEV), None, act="sin")
+
+
+def test_upfirdn2d_golden():
+    g = load_golden("plugin_ops")
+    ui = g["upfirdn_in"]
+    for k, sp in g["upfirdn_specs"].items():
+        f = None if sp["f"] is None else dev(ui[sp["f"]])
+        out = upfirdn_mod.upfirdn2d(dev(ui["x"]), f, sp["up"], sp["down"], sp["padding"], sp["flip_filter"], sp["gain"])
+        assert out.shape == g["upfirdn"][k].shape, k
+        assert rel_err(out.cpu(), g["upfirdn"][k]) < 3e-6, k
+
+
+def test_upfirdn2d_helpers_and_layouts():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 6, 32, 24, generator=g)
+    f = upfirdn_mod.setup_filter([1, 3, 3, 1])
+    assert rel_err(f, O.setup_filter([1, 3, 3, 1])) < 1e-7
+    up = upfirdn_mod.upsample2d(dev(x), dev(f), up=2)
+    assert up.shape == (2, 6, 64, 48)
+    ref = O.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
+    assert rel_err(up.cpu(), ref) < 3e-6
+    down = upfirdn_mod.downsample2d(dev(x), dev(f), down=2)
+    assert rel_err(down.cpu(), O.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1])) < 3e-6
+    same = upfirdn_mod.filter2d(dev(x), dev(f))
+    assert same.shape == x.shape
+    assert rel_err(same.cpu(), O.upfirdn2d(x, f, padding=[2, 1, 2, 1])) < 3e-6
+    # constant image stays constant in the interior (DC gain 1), round trip up->down keeps the mean
+    ones = torch.ones(1, 1, 16, 16, device=DEV)
+    u = upfirdn_mod.upsample2d(ones, dev(f), up=2)
+    assert float((u[:, :, 4:-4, 4:-4] - 1).abs().max()) < 1e-6
+    # channels_last input, fp16 and fp64
+    xcl = dev(x).contiguous(memory_format=torch.channels_last)
+    assert rel_err(upfirdn_mod.upsample2d(xcl, dev(f), up=2).cpu(), ref) < 3e-6
+    assert rel_err(upfirdn_mod.upsample2d(dev(x).half(), dev(f), up=2).float().cpu(), ref) < 2e-3
+    assert rel_err(upfirdn_mod.upsample2d(dev(x).double(), dev(f), up=2).cpu(), ref.double()) < 1e-6
+    f12 = upfirdn_mod.setup_filter([1, 2, 4, 7, 9, 12, 12, 9, 7, 4, 2, 1])
+    assert f12.ndim == 1
+    assert rel_err(upfirdn_mod.upsample2d(dev(x), dev(f12), up=2).cpu(),
+                   O.upfirdn2d(x, f12, up=2, padding=[6, 5, 6, 5], gain=4)) < 3e-6

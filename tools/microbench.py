@@ -1,0 +1,59 @@
+"""Ad-hoc per-kernel timing on one GPU (development aid; bench.py is the contract)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+smpl = importlib.import_module("3dhumangan_amd.lib.components.smpl")
+synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+
+
+def timeit(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="integrate,geo")
+    ap.add_argument("--B", type=int, default=16)
+    ap.add_argument("--R", type=int, default=4608)
+    ap.add_argument("--S", type=int, default=64)
+    ap.add_argument("--F", type=int, default=256)
+    a = ap.parse_args()
+    dev = "cuda"
+    res = {}
+    if "integrate" in a.what:
+        C = a.F + 3
+        field = torch.randn(a.B, a.R, a.S, C + 1, device=dev)
+        z = torch.sort(torch.rand(a.B, a.R, a.S, 1, device=dev) + 11, dim=2).values
+        ms = timeit(lambda: vr.ray_integration(field, z, noise_std=0, clamp_mode="relu", last_back=True, white_back=True))
+        by = 4 * a.B * a.R * (a.S * (C + 1) + a.S + C + 1 + a.S)
+        res["ray_integrate"] = dict(ms=ms, GBps=by / ms / 1e6, bytes=by)
+    if "geo" in a.what:
+        cond = {k: v.to(dev) for k, v in synthetic.make_conditions(a.B, 6890, seed=0).items()}
+        N = a.R * a.S
+        pts = (torch.rand(a.B, N, 3, device=dev) - 0.5) * 2
+        vik = smpl.vertex_inverse_transforms(cond["fk_matrices"], cond["lbs_weights"])
+        ms = timeit(lambda: smpl.get_geo_features(pts, cond["skeletons_xyz"], cond["vertices"], cond["tpose_vertices"],
+                                                  cond["fk_matrices"], cond["lbs_weights"], vertex_ik=vik), iters=3, warmup=1)
+        res["geo_features"] = dict(ms=ms, pairs_per_s=a.B * N * 6890 / ms * 1e3)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
