@@ -31,6 +31,11 @@ _SIGNATURES = {
     "h3d_ray_integrate": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_ray_setup": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "h3d_geo_features": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _p]),
+    "h3d_field_pack_size": (C.c_int64, [_i, _i]),
+    "h3d_field_pack": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
+    "h3d_neural_field": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),
+    "h3d_render_fused": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i,
+                                   _i, _p]),
     "h3d_bilinear_resize": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_bias_act": (C.c_int, [_p, _p, _p, _l, _i, _l, _l, _i, _f, _f, _f, _p]),
     "h3d_upfirdn2d": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), _i, _i, _i, _i, C.POINTER(_l),

@@ -75,8 +75,9 @@ int launch(const void* x, const void* b, void* y, int64_t n, int64_t size_b, int
 
 extern "C" int h3d_bias_act(const void* x, const void* b, void* y, int64_t n, int dtype, int64_t size_b, int64_t step_b,
                             int act, float alpha, float gain, float clamp, h3d_stream_t stream) {
-    H3D_REQUIRE(x && y, "h3d_bias_act: null pointer");
     H3D_REQUIRE(n >= 0, "h3d_bias_act: n < 0");
+    if (n == 0) return H3D_OK;
+    H3D_REQUIRE(x && y, "h3d_bias_act: null pointer");
     H3D_REQUIRE(act >= 1 && act <= 9, "h3d_bias_act: no kernel for activation index %d", act);
     H3D_REQUIRE(dtype >= 0 && dtype <= 2, "h3d_bias_act: dtype %d (0=f32,1=f16,2=f64)", dtype);
     H3D_REQUIRE(!b || (size_b >= 1 && step_b >= 1), "h3d_bias_act: bias given but size_b/step_b invalid");

@@ -1,0 +1,143 @@
+"""COORDCONCATSIREN -- the pluggable pose-conditioned implicit function (reference:
+lib/implicit_funcitions/modulated.py:6-75), evaluated by the fp32-MFMA HIP kernel behind
+h3d_neural_field / h3d_render_fused.
+
+Same constructor arguments, same parameter names (so reference state_dicts load unchanged), same forward
+signature and output channel order [rgb(3), feat(F), sigma(1)].  Inference only (no autograd through the kernel).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+
+class _Dense(nn.Module):
+    """Holder that reproduces the reference's `<name>.layer.{weight,bias}` parameter paths."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.layer = nn.Linear(n_in, n_out)
+
+
+def _uniform_(linear, bound):
+    with torch.no_grad():
+        linear.weight.uniform_(-bound, bound)
+
+
+class COORDCONCATSIREN(nn.Module):
+
+    def __init__(self, input_dim=2, latent_dim=100, hidden_dim=256, geo_feature_dim=88, output_dim=1, feature_dim=32,
+                 num_blocks=9, device=None):
+        super().__init__()
+        if input_dim != 3 or geo_feature_dim != 31 or num_blocks != 4:
+            raise NotImplementedError("the HIP field kernel is built for input_dim=3, geo_feature_dim=31, 4 FiLM blocks "
+                                      "(every shipped config); got "
+                                      f"{input_dim}/{geo_feature_dim}/{num_blocks}")
+        self.device = device
+        self.input_dim, self.latent_dim, self.hidden_dim = input_dim, latent_dim, hidden_dim
+        self.geo_feature_dim, self.output_dim, self.feature_dim = geo_feature_dim, output_dim, feature_dim
+        H = hidden_dim
+        self.first_layer_coord = _Dense(input_dim, H)
+        self.first_layer_mod = _Dense(geo_feature_dim, H)
+        self.network = nn.ModuleList([_Dense(2 * H, H)] + [_Dense(H, H) for _ in range(num_blocks - 1)])
+        self.sigma_layer = nn.Linear(H, 1)
+        self.color_layer_sine = _Dense(H + 3, H)
+        self.color_layer_linear = nn.Linear(H, 3)
+        self.feature_layer_linear = nn.Linear(H, feature_dim)
+        # SIREN initialisation (reference pigan_layers.py:26-53): U(+-sqrt(6/fan_in)/25), first layers U(+-1/fan_in)
+        for lin in [d.layer for d in self.network] + [self.sigma_layer, self.color_layer_sine.layer,
+                                                      self.color_layer_linear, self.feature_layer_linear]:
+            _uniform_(lin, math.sqrt(6.0 / lin.weight.shape[1]) / 25.0)
+        for lin in (self.first_layer_coord.layer, self.first_layer_mod.layer):
+            _uniform_(lin, 1.0 / lin.weight.shape[1])
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight packing (host, once per weight version)
+    def _params_for_pack(self):
+        return [self.first_layer_coord.layer, self.first_layer_mod.layer] + [d.layer for d in self.network] + \
+               [self.sigma_layer, self.color_layer_sine.layer, self.color_layer_linear, self.feature_layer_linear]
+
+    def packed_weights(self, device):
+        """Device blob in MFMA fragment order (csrc/field_common.hpp); cached until a parameter changes."""
+        lins = self._params_for_pack()
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for l in lins for p in (l.weight, l.bias))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = _lib.load()
+        H, F = self.hidden_dim, self.feature_dim
+        host = [(l.weight.detach().float().cpu().contiguous(), l.bias.detach().float().cpu().contiguous()) for l in lins]
+        P = _lib.FieldParams()
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        P.w_coord, P.b_coord = vp(host[0][0]), vp(host[0][1])
+        P.w_geo, P.b_geo = vp(host[1][0]), vp(host[1][1])
+        for k in range(4):
+            P.w_film[k], P.b_film[k] = host[2 + k][0].data_ptr(), host[2 + k][1].data_ptr()
+        P.w_sigma, P.b_sigma = vp(host[6][0]), vp(host[6][1])
+        P.w_color, P.b_color = vp(host[7][0]), vp(host[7][1])
+        P.w_rgb, P.b_rgb = vp(host[8][0]), vp(host[8][1])
+        P.w_feat, P.b_feat = vp(host[9][0]), vp(host[9][1])
+        nbytes = lib.h3d_field_pack_size(H, F)
+        blob = torch.empty(nbytes // 4, dtype=torch.float32)
+        _lib.check(lib.h3d_field_pack(ctypes.byref(P), H, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack")
+        self._packed = blob.to(device)
+        self._packed_key = key
+        return self._packed
+
+    @torch.no_grad()
+    def forward(self, input, frequencies, phase_shifts, geo_feature, ray_directions, input_scaler=1.,
+                geo_feature_scaler=1., **kwargs):
+        """input [B,N,3], frequencies/phase_shifts [B,4H], geo_feature [B,N,31], ray_directions [B,N,3] or None
+        (None == the lock_view_dependence direction (0,0,-1))  ->  [B,N,F+4]."""
+        unsq = input.dim() < 3
+        if unsq:
+            input, geo_feature = input.unsqueeze(1), geo_feature.unsqueeze(1)
+            ray_directions = None if ray_directions is None else ray_directions.unsqueeze(1)
+        _lib.need_cuda(input, frequencies, phase_shifts, geo_feature, ray_directions)
+        B, N, _ = input.shape
+        H, F = self.hidden_dim, self.feature_dim
+        pts = input.contiguous().float()
+        geo = geo_feature if geo_feature_scaler == 1. else geo_feature * geo_feature_scaler
+        geo = geo.contiguous().float()
+        dirs = None if ray_directions is None else ray_directions.contiguous().float()
+        fr, ph = frequencies.contiguous().float(), phase_shifts.contiguous().float()
+        assert fr.shape == (B, 4 * H) and ph.shape == (B, 4 * H)
+        out = torch.empty((B, N, F + 4), device=pts.device, dtype=torch.float32)
+        blob = self.packed_weights(pts.device)
+        rc = _lib.load().h3d_neural_field(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
+                                          _lib.ptr(ph), _lib.ptr(out), B, N, H, F, geo.shape[-1], float(input_scaler),
+                                          _lib.stream_handle())
+        _lib.check(rc, "h3d_neural_field")
+        return out.squeeze(1) if unsq else out
+
+    @torch.no_grad()
+    def render(self, input, frequencies, phase_shifts, geo_feature, ray_directions, z_vals, num_steps, input_scaler=1.,
+               noise=None, clamp_mode="relu", last_back=False, white_back=False):
+        """Fused field evaluation + volume integration (reference: COORDCONCATSIREN.forward followed by
+        volume_rendering.ray_integration).  input [B,R*S,3] with the S samples of a ray contiguous.
+        -> (features [B,R,F+3], depth [B,R,1], weights [B,R,S,1])."""
+        _lib.need_cuda(input, frequencies, phase_shifts, geo_feature, ray_directions, z_vals, noise)
+        B, N, _ = input.shape
+        S = int(num_steps)
+        R = N // S
+        H, F = self.hidden_dim, self.feature_dim
+        pts = input.contiguous().float()
+        geo = geo_feature.contiguous().float()
+        dirs = None if ray_directions is None else ray_directions.contiguous().float()
+        fr, ph = frequencies.contiguous().float(), phase_shifts.contiguous().float()
+        z = z_vals.reshape(B, R, S).contiguous().float()
+        nz = None if noise is None else noise.reshape(B, R, S).contiguous().float()
+        feats = torch.empty((B, R, F + 3), device=pts.device, dtype=torch.float32)
+        depth = torch.empty((B, R, 1), device=pts.device, dtype=torch.float32)
+        weights = torch.empty((B, R, S, 1), device=pts.device, dtype=torch.float32)
+        blob = self.packed_weights(pts.device)
+        mode = {"relu": 0, "softplus": 1}[clamp_mode]
+        rc = _lib.load().h3d_render_fused(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
+                                          _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(feats), _lib.ptr(depth),
+                                          _lib.ptr(weights), B, R, S, H, F, geo.shape[-1], float(input_scaler), mode,
+                                          int(bool(last_back)), int(bool(white_back)), _lib.stream_handle())
+        _lib.check(rc, "h3d_render_fused")
+        return feats, depth, weights

@@ -74,6 +74,43 @@ int h3d_geo_features(const float* points, const float* joints, const float* vert
                      int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A5  pose-conditioned FiLM-SIREN == lib/implicit_funcitions/modulated.py:41-75 (COORDCONCATSIREN.forward)
+ *
+ * Weights are handed over once, pre-packed by h3d_field_pack() into MFMA B-fragment order.
+ * h3d_field_pack_size() returns the number of BYTES of the packed blob for hidden width Hd and
+ * feature width F.  h3d_field_pack() consumes HOST pointers to the fp32 parameters in the reference's
+ * state_dict layout ([out,in] row-major weights) and writes the HOST blob, which the caller uploads.
+ */
+typedef struct {
+    const float *w_coord, *b_coord;      /* first_layer_coord.layer  [Hd,3],[Hd]      */
+    const float *w_geo,   *b_geo;        /* first_layer_mod.layer    [Hd,31],[Hd]     */
+    const float *w_film[4], *b_film[4];  /* network.k.layer          [Hd,2Hd|Hd],[Hd] */
+    const float *w_sigma, *b_sigma;      /* sigma_layer              [1,Hd],[1]       */
+    const float *w_color, *b_color;      /* color_layer_sine.layer   [Hd,Hd+3],[Hd]   */
+    const float *w_rgb,   *b_rgb;        /* color_layer_linear       [3,Hd],[3]       */
+    const float *w_feat,  *b_feat;       /* feature_layer_linear     [F,Hd],[F]       */
+} h3d_field_params;
+
+int64_t h3d_field_pack_size(int Hd, int F);
+int h3d_field_pack(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+
+/* points [B,N,3], geo [B,N,geo_stride] (31 used), dirs [B,N,3] or NULL (=> (0,0,-1), lock_view_dependence),
+ * freq, phase [B,4*Hd] (raw mapping-network outputs; the *15+30 is applied inside, modulated.py:43)
+ * out [B,N,F+4] channel order [rgb(3), feat(F), sigma(1)] */
+int h3d_neural_field(const void* packed, const float* points, const float* geo, const float* dirs,
+                     const float* freq, const float* phase, float* out,
+                     int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler,
+                     h3d_stream_t stream);
+
+/* Fused A5+A6: the field output never reaches HBM.  N = R*S, samples of a ray contiguous.
+ * feats [B*R, F+3] (rgb first), depth [B*R], weights [B*R, S]. */
+int h3d_render_fused(const void* packed, const float* points, const float* geo, const float* dirs,
+                     const float* freq, const float* phase, const float* z_vals, const float* noise,
+                     float* feats, float* depth, float* weights,
+                     int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
+                     int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A7  bilinear resize, align_corners=False == F.interpolate at lib/generators/map3d_generator.py:244-245
  * in [B,C,h,w] -> out [B,C,H,W]  (NCHW fp32)
  */

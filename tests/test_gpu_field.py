@@ -1,0 +1,119 @@
+"""GPU parity: fp32-MFMA neural field and fused render vs golden vectors / the CPU oracle."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+DEV = "cuda"
+FIELD_TOL = 1e-3      # north_star: within 1e-3 relative fp32; measured errors are ~1e-5
+
+
+def make_field(state, hidden, feature, prefix="neural_field."):
+    net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=hidden, hidden_dim=hidden, geo_feature_dim=31,
+                                output_dim=feature + 4, feature_dim=feature, num_blocks=4)
+    sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+    net.load_state_dict(sd)
+    return net.to(DEV)
+
+
+def random_state(hidden, feature, seed):
+    torch.manual_seed(seed)
+    net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=hidden, hidden_dim=hidden, geo_feature_dim=31,
+                                output_dim=feature + 4, feature_dim=feature, num_blocks=4)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    return {"neural_field." + k: v.detach().clone() for k, v in net.state_dict().items()}, net.to(DEV)
+
+
+@pytest.mark.parametrize("name,hidden", [("field_h64", 64), ("field_h40", 40)])
+def test_field_golden(name, hidden):
+    g = load_golden(name)
+    net = make_field(g["state"], hidden, hidden)
+    out = net(g["points"].to(DEV), g["freq"].to(DEV), g["phase"].to(DEV), g["geo"].to(DEV), g["dirs"].to(DEV),
+              input_scaler=2.0 / 2.85)
+    assert out.shape == g["out"].shape
+    assert rel_err(out.cpu(), g["out"]) < FIELD_TOL
+    # per-channel-group check so a wrong small head cannot hide behind large features
+    for sl in (slice(0, 3), slice(3, 3 + hidden), slice(3 + hidden, 4 + hidden)):
+        assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL
+
+
+@pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
+def test_field_in_generator_fixture(name):
+    g = load_golden(name)
+    s, cfg = g["stage"], g["meta"]
+    H = cfg["hidden_dim"]
+    net = make_field(g["state"], H, cfg["feature_dim"])
+    B = s["points"].shape[0]
+    # lock_view_dependence: pass None (kernel folds dir=(0,0,-1)) and the explicit tensor; both must agree
+    a = net(s["points"].to(DEV), s["freq"].to(DEV), s["phase"].to(DEV), s["geo"].to(DEV), None,
+            input_scaler=2.0 / cfg["side_length"])
+    b = net(s["points"].to(DEV), s["freq"].to(DEV), s["phase"].to(DEV), s["geo"].to(DEV), s["dirs"].to(DEV),
+            input_scaler=2.0 / cfg["side_length"])
+    ref = s["field"].reshape(B, -1, H + 4)
+    assert rel_err(a.cpu(), ref) < FIELD_TOL
+    assert rel_err(b.cpu(), ref) < FIELD_TOL
+
+
+@pytest.mark.parametrize("hidden,feature,N", [(256, 256, 200), (384, 384, 130), (420, 420, 64), (32, 32, 1),
+                                              (128, 96, 77)])
+def test_field_real_widths_vs_oracle(hidden, feature, N):
+    state, net = random_state(hidden, feature, seed=hidden)
+    g = torch.Generator().manual_seed(N)
+    B = 2
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    geo = torch.rand(B, N, 31, generator=g) * 2 - 1
+    dirs = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+    freq = torch.randn(B, 4 * hidden, generator=g) * 0.5
+    phase = torch.randn(B, 4 * hidden, generator=g)
+    ref = O.neural_field({k: v.double() for k, v in state.items()}, pts.double(), freq.double(), phase.double(),
+                         geo.double(), dirs.double(), 2.0 / 2.85)
+    out = net(pts.to(DEV), freq.to(DEV), phase.to(DEV), geo.to(DEV), dirs.to(DEV), input_scaler=2.0 / 2.85)
+    for sl in (slice(0, 3), slice(3, 3 + feature), slice(3 + feature, 4 + feature)):
+        assert rel_err(out.cpu()[..., sl], ref[..., sl]) < FIELD_TOL, sl
+
+
+@pytest.mark.parametrize("S,R,hidden", [(8, 20, 32), (16, 30, 48), (32, 9, 64), (64, 5, 256), (128, 3, 64), (32, 7, 384)])
+@pytest.mark.parametrize("last_back,white_back,clamp", [(False, True, "relu"), (True, False, "softplus")])
+def test_fused_render_vs_oracle(S, R, hidden, last_back, white_back, clamp):
+    state, net = random_state(hidden, hidden, seed=S + hidden)
+    # make densities matter: scale the sigma head up
+    with torch.no_grad():
+        net.sigma_layer.weight.mul_(40.0)
+        state["neural_field.sigma_layer.weight"] = net.sigma_layer.weight.detach().cpu().clone()
+    g = torch.Generator().manual_seed(R)
+    B, N = 2, R * S
+    pts = torch.rand(B, N, 3, generator=g) * 2 - 1
+    geo = torch.rand(B, N, 31, generator=g) * 2 - 1
+    freq = torch.randn(B, 4 * hidden, generator=g) * 0.5
+    phase = torch.randn(B, 4 * hidden, generator=g)
+    z = torch.sort(torch.rand(B, R, S, 1, generator=g) + 11, dim=2).values
+    noise = torch.randn(B, R, S, 1, generator=g) * 0.3
+    dirs = torch.zeros(B, N, 3)
+    dirs[..., 2] = -1
+    sd = {k: v.double() for k, v in state.items()}
+    field = O.neural_field(sd, pts.double(), freq.double(), phase.double(), geo.double(), dirs.double(), 0.7)
+    ref = O.ray_integration(field.reshape(B, R, S, -1), z.double(), noise.double(), clamp, last_back, white_back)
+    got = net.render(pts.to(DEV), freq.to(DEV), phase.to(DEV), geo.to(DEV), None, z.to(DEV), S, input_scaler=0.7,
+                     noise=noise.to(DEV), clamp_mode=clamp, last_back=last_back, white_back=white_back)
+    for a, b, nm in zip(got, ref, ("feats", "depth", "weights")):
+        assert a.shape == b.shape, nm
+        assert rel_err(a.cpu(), b) < FIELD_TOL, nm
+    assert rel_err(got[0].cpu()[..., :3], ref[0][..., :3]) < FIELD_TOL
+
+
+def test_fused_rejects_unsupported_steps():
+    _, net = random_state(32, 32, seed=0)
+    h3dlib = importlib.import_module("3dhumangan_amd._lib")
+    B, R, S = 1, 4, 12
+    x = torch.zeros(B, R * S, 3, device=DEV)
+    with pytest.raises(h3dlib.H3DError):
+        net.render(x, torch.zeros(B, 128, device=DEV), torch.zeros(B, 128, device=DEV),
+                   torch.zeros(B, R * S, 31, device=DEV), None, torch.zeros(B, R, S, 1, device=DEV), S)

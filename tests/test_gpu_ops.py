@@ -174,7 +174,7 @@ def test_bias_act_golden():
     assert rel_err(bias_act_mod.bias_act(x2, None, act="swish").cpu(), g["bias_act"]["no_bias"]) < 2e-6
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.float64, 1e-12)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 2e-3), (torch.float64, 1e-7)])
 def test_bias_act_dtypes_and_layouts(dtype, tol):
     g = torch.Generator().manual_seed(1)
     for shape, dim in [((4, 8, 16, 16), 1), ((3, 7), 1), ((5, 6, 3), 0), ((2, 3, 5, 4), 3), ((1024, 384), 1)]:
