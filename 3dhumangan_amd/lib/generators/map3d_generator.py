@@ -1,0 +1,419 @@
+"""Map3DGenerator -- drop-in for the reference class of the same name
+(lib/generators/map3d_generator.py:101-523): same constructor kwargs (the whole config dict is splatted in), same
+state_dict key schema, same ``forward`` / ``staged_forward`` / ``set_device`` / ``generate_avg_latent`` surface and
+output dict keys.  Inference only; every hot stage is a HIP kernel behind libh3d.so:
+
+    mapping networks (B x L GEMVs)      torch GEMMs on the device + h3d_bias_act        (A1, A2)
+    ray set-up                          h3d_ray_setup                                     (A3)
+    SMPL geometry features              h3d_geo_features                                  (A4)
+    FiLM-SIREN + volume integration     h3d_render_fused  (or h3d_neural_field + h3d_ray_integrate)   (A5, A6)
+    resize + synthesis input + 9 SPADE blocks + ToRGB      h3d_synthesis                  (A7, A8, A9)
+
+The reference forward is stochastic.  The draws happen here at the same places with torch's device
+RNG; ``jitter=`` / ``noise=`` kwargs inject explicit tensors instead (used by the parity tests).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ..._stages import stage
+from ..components import smpl
+from ..components.ops.bias_act import bias_act
+from . import volume_rendering as vr
+from .synthesis_pack import SynthesisPlan
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class LatentPool(nn.Module):
+    """reference lib/components/util.py:16-29."""
+
+    def __init__(self, pool_size, latent_dim):
+        super().__init__()
+        self.latents = nn.Parameter(torch.zeros([pool_size, latent_dim]), requires_grad=True)
+
+    def init(self, latents):
+        with torch.no_grad():
+            self.latents.copy_(latents)
+
+    def forward(self, indices):
+        return self.latents[indices]
+
+
+class MappingNetwork(nn.Module):
+    """FiLM frequency/phase mapping (reference lib/components/mapping_networks.py:13-41)."""
+
+    def __init__(self, latent_dim, map_hidden_dim, map_output_dim):
+        super().__init__()
+        self.network = nn.Sequential(nn.Linear(latent_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(map_hidden_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(map_hidden_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(map_hidden_dim, map_output_dim))
+        for m in self.network:
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+        with torch.no_grad():
+            self.network[-1].weight *= 0.25
+
+    def forward(self, z):
+        out = self.network(normalize_2nd_moment(z.to(torch.float32)))
+        half = out.shape[-1] // 2
+        return out[..., :half], out[..., half:]
+
+
+class FullyConnectedLayer(nn.Module):
+    """StyleGAN equalised-lr FC layer (reference mapping_networks.py:92-121); bias+activation on the HIP op."""
+
+    def __init__(self, in_features, out_features, bias=True, activation="linear", lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = nn.Parameter(torch.full([out_features], float(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / math.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == "linear" and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class TwoPartMappingNetwork(nn.Module):
+    """reference mapping_networks.py:124-216 with c_dim == 0 (the only use)."""
+
+    def __init__(self, z_dim, c_dim, implicit_dim, w_dim, num_ws, trunk_layers=6, branch_layers=2, activation="lrelu",
+                 lr_multiplier=0.01, **_):
+        super().__init__()
+        if c_dim != 0:
+            raise NotImplementedError("label conditioning (c_dim > 0) is not used by any config")
+        self.z_dim, self.w_dim, self.num_ws = z_dim, w_dim, num_ws
+        self.trunk_layers, self.branch_layers = trunk_layers, branch_layers
+        dims = [z_dim] + [w_dim] * trunk_layers
+        for i in range(trunk_layers):
+            setattr(self, f"trunk{i}", FullyConnectedLayer(dims[i], dims[i + 1], activation=activation, lr_multiplier=lr_multiplier))
+        ich = [w_dim] * branch_layers + [implicit_dim]
+        sch = [w_dim] * branch_layers + [w_dim]
+        for i in range(branch_layers):
+            setattr(self, f"implicit{i}", FullyConnectedLayer(ich[i], ich[i + 1], lr_multiplier=lr_multiplier,
+                                                             activation="linear" if i == branch_layers - 1 else activation))
+            setattr(self, f"superres{i}", FullyConnectedLayer(sch[i], sch[i + 1], activation=activation, lr_multiplier=lr_multiplier))
+        getattr(self, f"implicit{branch_layers - 1}").weight_gain *= 0.2
+
+    def forward(self, z, c=None, **_):
+        assert z.shape[1] == self.z_dim
+        x = normalize_2nd_moment(z.to(torch.float32))
+        for i in range(self.trunk_layers):
+            x = getattr(self, f"trunk{i}")(x)
+        xi, xs = x, x
+        for i in range(self.branch_layers):
+            xi = getattr(self, f"implicit{i}")(xi)
+            xs = getattr(self, f"superres{i}")(xs)
+        if self.num_ws is not None:
+            xs = xs.unsqueeze(1).repeat([1, self.num_ws, 1])
+        return xi, xs
+
+
+# ---- parameter holders that reproduce the reference's state_dict paths for the synthesis side ---------------
+
+class _SpectralConv(nn.Module):
+    """nn.utils.spectral_norm(nn.Conv2d(cin, cout, 1)) as stored: bias, weight_orig, weight_u, weight_v."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        w = torch.empty(cout, cin, 1, 1)
+        nn.init.kaiming_normal_(w, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.weight_orig = nn.Parameter(w)
+        u, s, vh = torch.linalg.svd(w.flatten(1), full_matrices=False)
+        self.register_buffer("weight_u", u[:, 0].clone())
+        self.register_buffer("weight_v", vh[0].clone())
+
+
+class _BatchNormStats(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+def _conv1x1(cin, cout):
+    m = nn.Conv2d(cin, cout, kernel_size=1)
+    nn.init.kaiming_normal_(m.weight, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+    return m
+
+
+class _Spade(nn.Module):
+    def __init__(self, c, style_dim):
+        super().__init__()
+        self.first_norm = _BatchNormStats(c)
+        self.mlp_shared = nn.Sequential(_conv1x1(style_dim, 128), nn.ReLU())
+        self.mlp_gamma = _conv1x1(128, c)
+        self.mlp_beta = _conv1x1(128, c)
+
+
+class _SpadeBlock(nn.Module):
+    def __init__(self, cin, cout, style_dim):
+        super().__init__()
+        self.conv_0 = _SpectralConv(cin, cout)
+        self.conv_1 = _SpectralConv(cout, cout)
+        self.spade_0 = _Spade(cin, style_dim)
+        self.spade_1 = _Spade(cout, style_dim)
+
+
+class _ToRGB(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.linear = nn.Conv2d(c, 3, 1)
+        with torch.no_grad():
+            self.linear.weight *= 0.25
+
+
+class SynthesisNetwork(nn.Module):
+    """Parameters of reference map3d_generator.py:14-55; evaluation goes through SynthesisPlan / h3d_synthesis."""
+
+    def __init__(self, input_dim, style_dim, hidden_dim=256, num_blocks=8, mod_blocks=list(range(8)), name_prefix="m3d",
+                 spatial_normalization="instance_norm", map3d_mode="isolated", **_):
+        super().__init__()
+        if spatial_normalization != "batch_norm":
+            raise NotImplementedError("only spatial_normalization='batch_norm' (all shipped configs) has a HIP kernel")
+        self.style_dim, self.num_blocks, self.mod_blocks, self.map3d_mode = style_dim, num_blocks, list(mod_blocks), map3d_mode
+        net, rgbs = {}, {}
+        cin = input_dim
+        for i in range(num_blocks):
+            net[f"{name_prefix}_{i}"] = _SpadeBlock(cin, hidden_dim, style_dim)
+            rgbs[f"{name_prefix}_{i}"] = _ToRGB(hidden_dim)
+            cin = hidden_dim
+        self.network = nn.ModuleDict(net)
+        self.to_rgbs = nn.ModuleDict(rgbs)
+
+
+class _CoordInput(nn.Module):
+    """SynthesisInput parameters (reference map3d_layers.py:241-258): network.0 = Conv2d(2, F, 1)."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        conv = nn.Conv2d(input_dim, output_dim, kernel_size=1)
+        nn.init.uniform_(conv.weight, -math.sqrt(9 / input_dim), math.sqrt(9 / input_dim))
+        self.network = nn.Sequential(conv)
+
+
+class _StyleInput(nn.Module):
+    """SynthesisStyleInput parameters (reference map3d_layers.py:278-343); only reachable through
+    disable_render=True, which no config sets -- kept so reference checkpoints load with strict=True."""
+
+    def __init__(self, input_dim, latent_dim, output_dim):
+        super().__init__()
+        self.from_coords = nn.Sequential(nn.Conv2d(input_dim, latent_dim, 1))
+        self.network = nn.Sequential(nn.Conv2d(latent_dim * 2, output_dim, 1), nn.LeakyReLU(0.2),
+                                     nn.Conv2d(output_dim, output_dim, 1), nn.LeakyReLU(0.2))
+
+
+class Map3DGenerator(nn.Module):
+
+    def __init__(self, neural_field_cls, **kwargs):
+        super().__init__()
+        k = kwargs
+        self.latent_dim, self.hidden_dim, self.feature_dim = k["latent_dim"], k["hidden_dim"], k["feature_dim"]
+        self.geo_feature_dim, self.label_dim = k["geo_feature_dim"], k["label_dim"]
+        self.gen_height, self.gen_width = k["gen_height"], k["gen_width"]
+        self.disable_modulation = k.get("disable_modulation", False)
+        self.legacy_mode = k.get("legacy_mode", False)
+        for flag in ("2d_semantic_input", "2d_label_input", "2d_latent_input"):
+            if k.get(flag, False):
+                raise NotImplementedError(f"{flag}=True is not used by any shipped config and has no HIP path")
+        self.neural_field = neural_field_cls(output_dim=k["feature_dim"] + 4, latent_dim=k["latent_dim"],
+                                             input_dim=k["input_dim"], hidden_dim=k["hidden_dim"],
+                                             geo_feature_dim=k["geo_feature_dim"], feature_dim=k["feature_dim"],
+                                             num_blocks=k["neural_field_blocks"], device=None)
+        self.synthesis_input = _CoordInput(2, k["feature_dim"])
+        self.synthesis_style_input = _StyleInput(1 if "segments" in k["condition_modal_gen"] else 3, k["latent_dim"],
+                                                 k["feature_dim"])
+        self.synthesis_network = SynthesisNetwork(input_dim=k["feature_dim"], style_dim=k["feature_dim"],
+                                                  hidden_dim=k["hidden_dim"], num_blocks=k["synthesis_blocks"],
+                                                  mod_blocks=k["mod_blocks"], map3d_mode=k.get("map3d_mode", "isolated"),
+                                                  spatial_normalization=k.get("spatial_normalization", "instance_norm"))
+        self.neural_field_mapping_network = MappingNetwork(latent_dim=k["latent_dim"], map_hidden_dim=k["hidden_dim"],
+                                                           map_output_dim=2 * k["neural_field_blocks"] * k["hidden_dim"])
+        self.synthesis_mapping_network = TwoPartMappingNetwork(z_dim=k["latent_dim"], c_dim=0, implicit_dim=1,
+                                                               w_dim=k["feature_dim"], num_ws=1, trunk_layers=7,
+                                                               branch_layers=1, lr_multiplier=0.01)
+        self.epoch = 0
+        self.step = 0
+        self.side_length = k["side_length"]
+        self.latent_pool = LatentPool(k["dataset_length"], k["latent_dim"])
+        self.device = None
+        self.avg_latent = None
+        self._plan = None
+        self._plan_key = None
+        self.stage_timer = None          # set to _stages.StageTimer() to collect per-stage HIP-event timings
+
+    # ------------------------------------------------------------------ reference surface
+    def set_device(self, device):
+        self.device = device
+        self.neural_field.device = device
+
+    def generate_avg_latent(self):
+        """Mean freq / phase / styles over 10 000 random latents (reference :182-194)."""
+        z = torch.randn((10000, self.latent_dim), device=self.neural_field.device)
+        fr, ph = self.neural_field_mapping_network(z)
+        _, st = self.synthesis_mapping_network(z)
+        self.avg_latent = (z.mean(dim=0, keepdim=True), fr.mean(dim=0, keepdim=True), ph.mean(dim=0, keepdim=True),
+                           st.mean(dim=0, keepdim=True))
+        return self.avg_latent
+
+    @torch.no_grad()
+    def get_geo_features(self, points, skeletons, vertices, tpose_vertices, fk_matrices, lbs_weights, **kw):
+        if self.disable_modulation:
+            return torch.zeros(list(points.shape)[:2] + [self.geo_feature_dim], dtype=points.dtype, device=points.device)
+        return smpl.get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, lbs_weights,
+                                     self.legacy_mode, **kw)
+
+    # ------------------------------------------------------------------ synthesis plan (static packing)
+    def synthesis_plan(self, device):
+        sd = self.state_dict()
+        key = (str(device),) + tuple((v.data_ptr(), v._version) for n, v in sd.items()
+                                     if n.startswith(("synthesis_network", "synthesis_input")))
+        if self._plan is None or self._plan_key != key:
+            sn = self.synthesis_network
+            self._plan = SynthesisPlan(sd, "synthesis_network", "synthesis_input", sn.num_blocks, sn.mod_blocks,
+                                       sn.map3d_mode, device)
+            self._plan_key = key
+        return self._plan
+
+    # ------------------------------------------------------------------ stages
+    def _mapping(self, latent, kwargs):
+        with stage(self, "mapping"):
+            return self._mapping_impl(latent, kwargs)
+
+    def _mapping_impl(self, latent, kwargs):
+        if kwargs.get("neural_field_latent_input", True):
+            fr, ph = self.neural_field_mapping_network(latent)
+        else:
+            fr, ph = self.neural_field_mapping_network(torch.zeros_like(latent))
+        _, styles = self.synthesis_mapping_network(latent)
+        return fr, ph, styles
+
+    @torch.no_grad()
+    def render(self, freq, phase, conditions, render_width, render_height, ray_start, ray_end, coarse_steps, fine_steps=None,
+               h_stddev=0, v_stddev=0, h_mean=0, v_mean=0, hierarchical_sample=False, sample_dist=None,
+               lock_view_dependence=False, staged=False, max_points=50000, jitter=None, noise=None, fused=True, **kwargs):
+        """reference :381-523.  -> rgb_render [B,3,Hr,Wr], feature_maps [B,R,F] (channels LAST: it feeds the
+        synthesis kernel directly; use .transpose for NCHW), depths [B,R,1], weights [B,R,S,1], None.
+
+        ``staged``/``max_points`` chunking is a memory work-around of the reference and is not needed: the field
+        tensor never materialises in the fused path."""
+        if hierarchical_sample:
+            raise NotImplementedError("hierarchical_sample=True (off in every config, SURVEY 8a) has no HIP path yet")
+        c = conditions
+        dev = freq.device
+        B, S = freq.shape[0], int(coarse_steps)
+        R = render_width * render_height
+        focals = c["intrinsics"][:, 0, 0]
+        scales = c["scales"].float()
+        # RNG order of the reference: jitter U(0,1) [B,R,S,1]; two unused randn [B,1]; integration noise randn
+        with stage(self, "ray_setup"):
+            pts, z_vals = vr.sample_rays(focals, scales, c["cam2world_matrices"], S, (render_width, render_height),
+                                         ray_start, ray_end, jitter=jitter, perturb=True)
+        if jitter is None:
+            torch.randn((B, 1), device=dev), torch.randn((B, 1), device=dev)      # sample_camera_positions, result unused
+        nerf_noise = kwargs.get("nerf_noise", 0)
+        if noise is None:
+            drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24
+            noise = drawn * nerf_noise if nerf_noise != 0 else None
+        with stage(self, "geo_features"):
+            geo = self.get_geo_features(pts, c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"],
+                                        c["lbs_weights"])
+        dirs = None
+        if not lock_view_dependence:
+            dirs = vr.ray_directions_world(focals, c["cam2world_matrices"], (render_width, render_height), S)
+        scaler = 2.0 / self.side_length
+        clamp_mode = kwargs["clamp_mode"]
+        last_back, white_back = kwargs.get("last_back", False), kwargs.get("white_back", False)
+        can_fuse = fused and ((8 <= S <= 64 and S & (S - 1) == 0) or (S > 64 and S % 64 == 0))
+        if can_fuse:
+            with stage(self, "render_fused"):
+                feats, depths, weights = self.neural_field.render(pts, freq, phase, geo, dirs, z_vals, S,
+                                                                  input_scaler=scaler, noise=noise, clamp_mode=clamp_mode,
+                                                                  last_back=last_back, white_back=white_back)
+        else:
+            with stage(self, "neural_field"):
+                field = self.neural_field(pts, freq, phase, geo, dirs, input_scaler=scaler)
+            with stage(self, "ray_integrate"):
+                feats, depths, weights = vr.ray_integration(field.reshape(B, R, S, -1), z_vals, noise_std=0, noise=noise,
+                                                            clamp_mode=clamp_mode, last_back=last_back,
+                                                            white_back=white_back)
+        rgb_render = (feats[..., :3] * 2 - 1).reshape(B, render_height, render_width, 3).permute(0, 3, 1, 2)
+        return rgb_render, feats[..., 3:], depths, weights, None
+
+    def _synthesize(self, feature_maps, styles, render_hw):
+        plan = self.synthesis_plan(feature_maps.device)
+        return plan.run(feature_maps, styles.reshape(styles.shape[0], -1), render_hw, (self.gen_height, self.gen_width),
+                        owner=self)
+
+    @torch.no_grad()
+    def forward(self, latent, conditions, render_height, render_width, latent_indices=None, **kwargs):
+        """reference :208-280 -> {"rgbs", "rgbs_render"}"""
+        _lib.need_cuda(latent)
+        if kwargs.get("disable_render", False):
+            raise NotImplementedError("disable_render=True is not set by any config and has no HIP path")
+        num_steps = kwargs.get("num_steps", 24)
+        if latent_indices is not None:
+            latent = self.latent_pool(latent_indices)
+        fr, ph, styles = self._mapping(latent, kwargs)
+        rk = {k: v for k, v in kwargs.items() if k not in ("coarse_steps", "fine_steps", "render_width", "render_height")}
+        rgb_render, fmap, _, _, _ = self.render(fr, ph, conditions, render_width, render_height,
+                                                coarse_steps=num_steps, fine_steps=num_steps, **rk)
+        if kwargs.get("disable_synthesis", False):
+            return {"rgbs": rgb_render, "rgbs_render": rgb_render}
+        rgb = self._synthesize(fmap, styles, (render_height, render_width))
+        return {"rgbs": rgb, "rgbs_render": rgb_render}
+
+    @torch.no_grad()
+    def staged_forward(self, latent, conditions, render_height, render_width, truncation_psi, **kwargs):
+        """reference :282-378 -> {"rgbs", "rgbs_render", "depths" (CPU, as the reference), "skeletons"}.
+        ``avg_latent=`` kwarg (or a cached self.avg_latent with cache_avg_latent=True) skips the 10 000-sample pass."""
+        _lib.need_cuda(latent)
+        if kwargs.get("disable_render", False):
+            raise NotImplementedError("disable_render=True is not set by any config and has no HIP path")
+        num_steps = kwargs.get("num_steps", 24)
+        B = latent.shape[0]
+        fr, ph, styles = self._mapping(latent, kwargs)
+        if truncation_psi < 1.0:
+            avg = kwargs.get("avg_latent")
+            if avg is None:
+                avg = self.avg_latent if (kwargs.get("cache_avg_latent", False) and self.avg_latent is not None) \
+                    else self.generate_avg_latent()
+            az, af, ap, ast = avg
+            fr = af + truncation_psi * (fr - af)
+            ph = ap + truncation_psi * (ph - ap)
+            latent = az + truncation_psi * (latent - az)
+            styles = ast + truncation_psi * (styles - ast)
+        rk = {k: v for k, v in kwargs.items() if k not in ("coarse_steps", "fine_steps", "render_width", "render_height",
+                                                           "staged", "avg_latent", "cache_avg_latent")}
+        rgb_render, fmap, depths, _, _ = self.render(fr, ph, conditions, render_width, render_height,
+                                                     coarse_steps=num_steps, fine_steps=num_steps, staged=True, **rk)
+        if kwargs.get("disable_synthesis", False):
+            from ..components.resample import bilinear_resize
+            out = {"rgbs": bilinear_resize(rgb_render.contiguous(), (self.gen_height, self.gen_width)),
+                   "rgbs_render": rgb_render}
+        else:
+            out = {"rgbs": self._synthesize(fmap, styles, (render_height, render_width)), "rgbs_render": rgb_render}
+        zc = conditions["intrinsics"][:, 0, 0] / conditions["scales"].float()
+        depth = ((depths - zc.view(B, 1, 1)) / (kwargs["depth_length"] / 2.0)).clamp(-1.0, 1.0)
+        depth_map = depth.reshape(B, render_height, render_width).unsqueeze(1).contiguous()
+        out.update({"depths": depth_map if kwargs.get("keep_depth_on_device", False) else depth_map.cpu(),
+                    "skeletons": conditions["skeletons_xyz"]})
+        return out

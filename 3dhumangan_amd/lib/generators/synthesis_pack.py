@@ -1,0 +1,181 @@
+"""Host-side preparation of the SPADE synthesis network for the fused HIP kernel (csrc/synthesis.hip).
+
+Everything here is *exact* algebra on the reference's eval-mode forward
+(lib/generators/map3d_generator.py:58-97, lib/components/map3d_layers.py:176-238):
+
+  static, once per weight version (build_plan):
+    conv weight  = weight_orig / (u . (W v))                (nn.utils.spectral_norm in eval, stored u/v)
+    BatchNorm    = x * sc + sh,  sc = weight * rsqrt(running_var + eps),  sh = bias - running_mean * sc
+    all matrices packed into MFMA B-fragment order (include/h3d.h)
+  per forward (per_forward_tables), a handful of tiny library GEMMs on the device:
+    shared-MLP pre-activations of the fixed style for all SPADEs:   fixed @ Ws^T + bs
+    constant-style SPADEs -> per-(sample, channel) affine  ab = (sc * (1+gamma), sh * (1+gamma) + beta)
+    per-pixel-style SPADEs -> low-resolution maps  G = feature_maps @ Ws^T  (the 1x1 conv commutes with the
+    bilinear resize that follows it) and the per-sample constant cst
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from ..._stages import stage
+
+SHARED = 128
+EPS_BN = 1e-5
+
+
+def pack_matrix(w_out_in, KB, NT):
+    """[n_out, n_in] (reference layout) -> packed [NT*KB*64*4] fp32, same bytes as h3d_pack_matrix."""
+    n_out, n_in = w_out_in.shape
+    wt = torch.zeros(8 * KB, 32 * NT, dtype=torch.float32, device=w_out_in.device)
+    wt[:n_in, :n_out] = w_out_in.t().float()
+    return wt.view(KB, 2, 4, NT, 32).permute(3, 0, 1, 4, 2).contiguous().flatten()
+
+
+def _pad(v, n):
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.flatten().float()
+    return out
+
+
+class SpadeDesc(ctypes.Structure):
+    _fields_ = [("pixel_style", ctypes.c_int32), ("g_offset", ctypes.c_int32), ("cst_index", ctypes.c_int32),
+                ("ab_index", ctypes.c_int32), ("w_gamma", ctypes.c_int64), ("w_beta", ctypes.c_int64),
+                ("vec", ctypes.c_int64), ("w_conv", ctypes.c_int64), ("b_conv", ctypes.c_int64)]
+
+
+class BlockDesc(ctypes.Structure):
+    _fields_ = [("spade", SpadeDesc * 2), ("skip", ctypes.c_int32), ("to_rgb", ctypes.c_int32),
+                ("w_rgb", ctypes.c_int64)]
+
+
+class SynthDesc(ctypes.Structure):
+    _fields_ = [("n_blocks", ctypes.c_int32), ("C", ctypes.c_int32), ("w_in", ctypes.c_int64),
+                ("b_in", ctypes.c_int64), ("block", BlockDesc * 16)]
+
+
+class SynthesisPlan:
+    """Packed weights + launch descriptor + the small dense matrices used by per_forward_tables."""
+
+    def __init__(self, state, prefix, input_prefix, n_blocks, mod_blocks, map3d_mode, device):
+        g = lambda k: state[k].detach().to(device=device, dtype=torch.float32)
+        if map3d_mode not in ("all", "mixed", "isolated"):
+            raise ValueError("invalid map3d_mode")
+        self.mode = map3d_mode
+        self.n_blocks = n_blocks
+        C = g(f"{prefix}.network.m3d_0.conv_0.weight_orig").shape[0]
+        F = g(f"{prefix}.network.m3d_0.spade_0.mlp_shared.0.weight").shape[1]
+        if g(f"{prefix}.network.m3d_0.conv_0.weight_orig").shape[1] != C:
+            raise NotImplementedError("synthesis kernel needs input_dim == hidden_dim (true for every shipped config)")
+        self.C, self.F = C, F
+        HdP = (C + 31) // 32 * 32
+        self.HdP = HdP
+        NT, KBH = HdP // 32, HdP // 8
+        chunks, off = [], [0]
+
+        def add(t):
+            o = off[0]
+            chunks.append(t)
+            off[0] += t.numel()
+            return o
+
+        desc = SynthDesc()
+        desc.n_blocks, desc.C = n_blocks, C
+        w_in = g(f"{input_prefix}.network.0.weight").reshape(C, 2)
+        desc.w_in = add(torch.cat([_pad(w_in[:, 0], HdP), _pad(w_in[:, 1], HdP)]))
+        desc.b_in = add(_pad(g(f"{input_prefix}.network.0.bias"), HdP))
+        ws_all, bs_all, self.pixel_ids, self.const_ids = [], [], [], []
+        wg_c, bg_c, wb_c, bb_c, sc_c, sh_c = [], [], [], [], [], []
+        for k in range(n_blocks):
+            pixel = map3d_mode == "all" or k in mod_blocks
+            bd = desc.block[k]
+            bd.skip = int(k >= n_blocks // 2)
+            bd.to_rgb = int(k >= n_blocks // 2 - 1)
+            for s in range(2):
+                sp = f"{prefix}.network.m3d_{k}.spade_{s}"
+                cv = f"{prefix}.network.m3d_{k}.conv_{s}"
+                sid = 2 * k + s
+                ws_all.append(g(sp + ".mlp_shared.0.weight").reshape(SHARED, F))
+                bs_all.append(g(sp + ".mlp_shared.0.bias"))
+                sc = g(sp + ".first_norm.weight") * torch.rsqrt(g(sp + ".first_norm.running_var") + EPS_BN)
+                sh = g(sp + ".first_norm.bias") - g(sp + ".first_norm.running_mean") * sc
+                wgam = g(sp + ".mlp_gamma.weight").reshape(C, SHARED)
+                wbet = g(sp + ".mlp_beta.weight").reshape(C, SHARED)
+                bgam, bbet = g(sp + ".mlp_gamma.bias"), g(sp + ".mlp_beta.bias")
+                w = g(cv + ".weight_orig").reshape(C, C)
+                sigma = torch.dot(g(cv + ".weight_u"), torch.mv(w, g(cv + ".weight_v")))
+                d = bd.spade[s]
+                d.w_conv = add(pack_matrix(w / sigma, KBH, NT))
+                d.b_conv = add(_pad(g(cv + ".bias"), HdP))
+                if pixel:
+                    d.pixel_style = 1
+                    d.g_offset = SHARED * len(self.pixel_ids)
+                    d.cst_index = len(self.pixel_ids)
+                    self.pixel_ids.append(sid)
+                    d.w_gamma = add(pack_matrix(wgam, SHARED // 8, NT))
+                    d.w_beta = add(pack_matrix(wbet, SHARED // 8, NT))
+                    d.vec = add(torch.cat([_pad(bgam + 1.0, HdP), _pad(bbet, HdP), _pad(sc, HdP), _pad(sh, HdP)]))
+                else:
+                    d.pixel_style = 0
+                    d.ab_index = len(self.const_ids)
+                    self.const_ids.append(sid)
+                    wg_c.append(wgam.t().contiguous()); bg_c.append(bgam)
+                    wb_c.append(wbet.t().contiguous()); bb_c.append(bbet)
+                    sc_c.append(sc); sh_c.append(sh)
+            if bd.to_rgb:
+                tr = f"{prefix}.to_rgbs.m3d_{k}.linear"
+                wr = g(tr + ".weight").reshape(3, C)
+                bd.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(g(tr + ".bias"), 4)]))
+        self.desc = desc
+        self.blob = torch.cat(chunks).contiguous()
+        self.ws_all = torch.stack(ws_all)                                 # [2*nb, 128, F]
+        self.bs_all = torch.stack(bs_all)                                 # [2*nb, 128]
+        pix = torch.tensor(self.pixel_ids, dtype=torch.long, device=device)
+        self.pix_index = pix
+        self.con_index = torch.tensor(self.const_ids, dtype=torch.long, device=device)
+        # [F, 128 * n_pixel]: low-res shared conv for every per-pixel SPADE in one GEMM
+        self.ws_pixel_t = (self.ws_all[pix].reshape(-1, F).t().contiguous() if len(self.pixel_ids) else None)
+        if self.const_ids:
+            self.wg_c, self.bg_c = torch.stack(wg_c), torch.stack(bg_c)   # [nc,128,C], [nc,C]
+            self.wb_c, self.bb_c = torch.stack(wb_c), torch.stack(bb_c)
+            self.sc_c, self.sh_c = torch.stack(sc_c), torch.stack(sh_c)
+        self.g_channels = SHARED * len(self.pixel_ids)
+
+    def per_forward_tables(self, feature_maps, fixed_style):
+        """feature_maps [B,R,F] (rendered, channels last), fixed_style [B,F] -> (G, cst, ab)."""
+        B = fixed_style.shape[0]
+        dev = fixed_style.device
+        pre_fixed = torch.einsum("bf,skf->bsk", fixed_style, self.ws_all)          # [B, 2nb, 128]
+        G = cst = ab = None
+        if self.pixel_ids:
+            G = torch.matmul(feature_maps, self.ws_pixel_t).contiguous()           # [B,R,128*np]
+            cst = self.bs_all[self.pix_index].unsqueeze(0).expand(B, -1, -1)
+            if self.mode in ("all", "mixed"):                                       # style = feature map + fixed style
+                cst = cst + pre_fixed[:, self.pix_index]
+            cst = cst.contiguous()
+        if self.const_ids:
+            a = torch.relu(pre_fixed[:, self.con_index] + self.bs_all[self.con_index])         # [B,nc,128]
+            gamma1 = 1.0 + torch.einsum("bsk,skc->bsc", a, self.wg_c) + self.bg_c
+            beta = torch.einsum("bsk,skc->bsc", a, self.wb_c) + self.bb_c
+            ab = torch.zeros(B, len(self.const_ids), 2, self.HdP, device=dev, dtype=torch.float32)
+            ab[:, :, 0, : self.C] = self.sc_c * gamma1
+            ab[:, :, 1, : self.C] = self.sh_c * gamma1 + beta
+        return G, cst, ab
+
+    def run(self, feature_maps, fixed_style, render_hw, out_hw, owner=None):
+        """-> rgb [B,3,H,W]."""
+        B = fixed_style.shape[0]
+        Hr, Wr = render_hw
+        H, W = out_hw
+        with stage(owner, "synthesis_tables"):
+            G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float())
+        rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
+        with stage(owner, "synthesis"):
+            rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
+        _lib.check(rc, "h3d_synthesis")
+        return rgb
+
+    def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):
+        return _lib.load().h3d_synthesis(_lib.ptr(self.blob), ctypes.byref(self.desc), _lib.ptr(G), self.g_channels, Hr, Wr,
+                                       _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids),
+                                       _lib.ptr(rgb), B, H, W, _lib.stream_handle())

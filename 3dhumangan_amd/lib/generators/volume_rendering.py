@@ -44,6 +44,19 @@ def sample_rays(focals, scales, cam2world_matrix, num_steps, resolution, ray_sta
     return points, z_vals
 
 
+def ray_directions_world(focals, cam2world_matrix, resolution, num_steps):
+    """World-space view directions per sample [B,R*S,3] (reference volume_rendering.py:93-101, 113-121, 157-160).
+    Only needed when lock_view_dependence is off; a few small torch ops on the device."""
+    W, H = resolution
+    B, dev = focals.shape[0], focals.device
+    xs = torch.linspace(-W / H, W / H, W, device=dev).repeat(H)
+    ys = torch.linspace(-1, 1, H, device=dev).repeat_interleave(W)
+    d = torch.stack([xs.expand(B, -1), ys.expand(B, -1), focals.float()[:, None].expand(B, W * H)], dim=-1)
+    d = d / (torch.norm(d, dim=-1, keepdim=True) + 1e-12)
+    d = torch.bmm(cam2world_matrix[:, :3, :3].float(), d.transpose(1, 2)).transpose(1, 2)
+    return d.unsqueeze(2).expand(B, W * H, num_steps, 3).reshape(B, W * H * num_steps, 3).contiguous()
+
+
 def ray_integration(input, z_vals, device=None, noise_std=0.5, last_back=False, white_back=False,
                     clamp_mode=None, fill_mode=None, noise=None):
     """NeRF volume integration.  reference: volume_rendering.py:12-56.

@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- generator images/sec at 512^2 on N MI355X (one process per GPU) + kernel rooflines.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one Map3DGenerator.forward over a batch of synthetic inputs (random-init weights of the MAP3DBN512
+architecture, procedural SMPL-like pose, N(0,1) latents, U(0,1) jitter), everything resident in HBM.  The workload
+is BASELINE.json config 3: 512x512 output, 96x96 rays, 64 samples per ray, batch 16 per GPU, hidden width 256 (the
+reference's native 512x256 aspect is reported next to it as extra.native_512x256).  Inference shards over the batch
+with no data-path collective: weak scaling, value = all images of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def build_generator(cfg_name, gen_hw, render_hw, steps, device):
+    configs = importlib.import_module("3dhumangan_amd.configs")
+    gens = importlib.import_module("3dhumangan_amd.lib.generators")
+    impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+    cfg = {k: v for k, v in getattr(configs, cfg_name).items() if isinstance(k, str)}
+    cfg.update(gen_height=gen_hw[0], gen_width=gen_hw[1], render_height=render_hw[0], render_width=render_hw[1],
+               num_steps=steps, dataset_length=4, nerf_noise=0, last_back=cfg["eval_last_back"])
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    torch.manual_seed(1234)
+    G = gens.Map3DGenerator(**cfg).to(device).eval()
+    G.set_device(device)
+    return G, cfg
+
+
+def make_inputs(cfg, batch, device, seed=1234):
+    synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+    g = torch.Generator().manual_seed(seed)
+    cond = {k: v.to(device) for k, v in synthetic.make_conditions(batch, 6890, seed=seed % 1000).items()}
+    z = torch.randn(batch, cfg["latent_dim"], generator=g).to(device)
+    R = cfg["render_height"] * cfg["render_width"]
+    jitter = torch.rand(batch, R, cfg["num_steps"], 1, generator=g).to(device)
+    return z, cond, jitter
+
+
+def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        G.forward(z, cond, jitter=jitter, **cfg)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        G.forward(z, cond, jitter=jitter, **cfg)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_rooflines(G, cfg, batch, stage_ms):
+    """Algorithmic work of each HIP stage / measured HIP-event time."""
+    Hd, F = cfg["hidden_dim"], cfg["feature_dim"]
+    H, W = cfg["gen_height"], cfg["gen_width"]
+    R, S = cfg["render_height"] * cfg["render_width"], cfg["num_steps"]
+    n_mod = len(cfg["mod_blocks"]) if cfg["map3d_mode"] != "all" else cfg["synthesis_blocks"]
+    pts, px = batch * R * S, batch * H * W
+    out = {}
+    if "render_fused" in stage_ms:
+        fl = 2.0 * (7 * Hd * Hd + 41 * Hd) * pts
+        ms = stage_ms["render_fused"][0]
+        out["h3d_render_fused"] = dict(bound="mfma", achieved=fl / ms / 1e9, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                       frac=fl / ms / 1e9 / MFMA_F32_PEAK_TF, ms=ms, flop=fl)
+    if "synthesis" in stage_ms:
+        executed = 2.0 * (18 * Hd * Hd + 2 * n_mod * 128 * 2 * Hd + 6 * 3 * Hd) * px      # after the exact folding
+        reference_form = 2.0 * (18 * Hd * Hd + 6932 * Hd) * px                              # SURVEY 8(d) figure
+        ms = stage_ms["synthesis"][0]
+        out["h3d_synthesis"] = dict(bound="mfma", achieved=executed / ms / 1e9, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                                    frac=executed / ms / 1e9 / MFMA_F32_PEAK_TF, ms=ms, flop=executed,
+                                    reference_formulation_TFLOPs=reference_form / ms / 1e9)
+    if "geo_features" in stage_ms:
+        ms = stage_ms["geo_features"][0]
+        out["h3d_geo_features"] = dict(bound="valu", ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3)
+    return out
+
+
+def ray_integrate_roofline(cfg, batch, iters=10):
+    """The stand-alone A6 kernel (drop-in for vr.ray_integration) on this workload's field tensor: the HBM-bound
+    kernel the north_star's >=40% target is evaluated on."""
+    vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+    R, S, C = cfg["render_height"] * cfg["render_width"], cfg["num_steps"], cfg["feature_dim"] + 3
+    nb = batch
+    while nb > 1 and nb * R * S * (C + 1) * 4 > 12e9:
+        nb //= 2
+    field = torch.randn(nb, R, S, C + 1, device="cuda")
+    z = torch.sort(torch.rand(nb, R, S, 1, device="cuda") + 11, dim=2).values
+    run = lambda: vr.ray_integration(field, z, noise_std=0, clamp_mode="relu", last_back=True, white_back=True)
+    run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    by = 4.0 * nb * R * (S * (C + 1) + S + C + 1 + S)
+    return dict(bound="hbm", achieved=by / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / ms / 1e6 / HBM_PEAK_GBS,
+                traffic=None, ms=ms, bytes=by, batch=nb)
+
+
+def cpu_baseline(cfg, sd, seed=1234):
+    """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores:
+    ONE image of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import h3d_oracle as O
+    synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(seed)
+    cond = synthetic.make_conditions(1, 6890, seed=seed % 1000)
+    z = torch.randn(1, cfg["latent_dim"], generator=g)
+    jit = torch.rand(1, cfg["render_height"] * cfg["render_width"], cfg["num_steps"], 1, generator=g)
+    ocfg = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.generator_forward(sd, ocfg, z, cond, jit, None)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 image of the same workload ({cfg['gen_height']}x{cfg['gen_width']}, "
+                       f"{cfg['render_height']}x{cfg['render_width']} rays x {cfg['num_steps']} samples) in {dt:.1f} s; "
+                       "pure-PyTorch CPU oracle, brute-force nearest-vertex search")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--config", default="MAP3DBN512")
+    ap.add_argument("--res", default="512x512", help="output HxW; rays are 3/16 of it per axis (96 for 512)")
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")          # RCCL over xGMI
+    dev = torch.device("cuda", local)
+    StageTimer = importlib.import_module("3dhumangan_amd._stages").StageTimer
+
+    H, W = [int(v) for v in a.res.split("x")]
+    render = (H * 3 // 16, W * 3 // 16)
+    G, cfg = build_generator(a.config, (H, W), render, a.samples, dev)
+    z, cond, jitter = make_inputs(cfg, a.batch, dev, seed=1234 + rank)
+    G.stage_timer = StageTimer()
+    dt = timed_steps(G, cfg, z, cond, jitter, a.steps, a.warmup, dist_on)
+    torch.cuda.synchronize()
+    stage_all = G.stage_timer.summary_ms()
+    # drop warm-up samples: keep the last `steps` events of each stage
+    stage_ms = {}
+    for k, ev in G.stage_timer.events.items():
+        ev = ev[-a.steps:]
+        stage_ms[k] = (sum(x.elapsed_time(y) for x, y in ev) / len(ev), len(ev))
+    G.stage_timer = None
+    n_images = a.batch * world * a.steps
+    value = n_images / dt
+
+    if rank != 0:
+        if dist_on:
+            torch.distributed.destroy_process_group()
+        return
+
+    kernels = kernel_rooflines(G, cfg, a.batch, stage_ms)
+    kernels["h3d_ray_integrate"] = ray_integrate_roofline(cfg, a.batch)
+    dominant = max((k for k in kernels if "frac" in kernels[k] and k != "h3d_ray_integrate"),
+                   key=lambda k: kernels[k]["ms"])
+    roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    roof["traffic"] = None
+    roof["kernel"] = dominant
+
+    extra = {}
+    if not a.no_extra and world == 1 and (H, W) == (512, 512):
+        G2, cfg2 = build_generator(a.config, (512, 256), (96, 48), a.samples, dev)
+        z2, cond2, jit2 = make_inputs(cfg2, a.batch, dev)
+        dt2 = timed_steps(G2, cfg2, z2, cond2, jit2, max(3, a.steps // 2), 1, False)
+        extra["native_512x256_images_per_s"] = a.batch * max(3, a.steps // 2) / dt2
+        del G2
+
+    out = {
+        "metric": "generator images/sec at 512^2", "value": value, "unit": "images/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.config} generator-only forward, {H}x{W} output, {render[0]}x{render[1]} rays, "
+                               f"{a.samples} samples/ray, hidden {cfg['hidden_dim']}, batch {a.batch}/GPU, "
+                               f"map3d_mode={cfg['map3d_mode']}, random-init weights, procedural SMPL-like pose",
+                   "global_batch": a.batch * world, "parallelism": f"batch-sharded replicas x{world} (no collective)"},
+        "roofline": roof,
+        "roofline_hbm_kernel": dict(kernel="h3d_ray_integrate", **{k: kernels["h3d_ray_integrate"][k] for k in
+                                    ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
+        "kernels": kernels,
+        "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
+        "extra": extra,
+    }
+    if world == 1 and not a.no_cpu:
+        sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+        out["cpu_baseline"] = cpu_baseline(cfg, sd)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist_on:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

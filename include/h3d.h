@@ -118,6 +118,48 @@ int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w,
                         h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A7+A8+A9  SPADE synthesis network, eval mode == SynthesisNetwork.forward
+ *     (lib/generators/map3d_generator.py:58-97) over SPADEBlock (lib/components/map3d_layers.py:218-238),
+ *     fed by SynthesisInput (:260-275) and the bilinear F.interpolate of map3d_generator.py:244-245.
+ *
+ * Weight blob: fp32, every matrix packed by h3d_pack_matrix (MFMA B-fragment order
+ *   packed[nt][kb][lane][e] = W[k = 8*kb + 4*(lane>>5) + e][n = 32*nt + (lane&31)], zero padded), offsets in
+ *   FLOATS given by the descriptor; HdP = C rounded up to 32; vectors are HdP long, zero padded.
+ * Per SPADE:  pixel_style = 1  gamma/beta depend on the pixel: a = relu(bilinear(G[:, g_offset : g_offset+128])
+ *                              + cst[b, cst_index]);  gamma+1 = a*Wg + vec[0:HdP]; beta = a*Wb + vec[HdP:2HdP];
+ *                              y = lrelu((x*vec[2HdP:3HdP] + vec[3HdP:4HdP]) * (gamma+1) + beta)
+ *             pixel_style = 0  y = lrelu(x * ab[b, ab_index, 0] + ab[b, ab_index, 1])
+ *             then conv: y * Wconv + b_conv (+ block input when `skip` and it is the block's second SPADE).
+ * to_rgb: rgb += x * Wrgb^T + brgb, Wrgb stored as [3][HdP] followed by the 3 biases (+1 pad) at w_rgb.
+ * x0 = sin(w_in[0][n]*i + w_in[1][n]*j + b_in[n]) with (i, j) = linspace(-1,1) pixel coordinates.
+ */
+#define H3D_MAX_BLOCKS 16
+typedef struct {
+    int32_t pixel_style, g_offset, cst_index, ab_index;
+    int64_t w_gamma, w_beta, vec, w_conv, b_conv;
+} h3d_spade_desc;
+typedef struct {
+    h3d_spade_desc spade[2];
+    int32_t skip, to_rgb;
+    int64_t w_rgb;
+} h3d_block_desc;
+typedef struct {
+    int32_t n_blocks, C;
+    int64_t w_in, b_in;
+    h3d_block_desc block[H3D_MAX_BLOCKS];
+} h3d_synth_desc;
+
+/* HOST helper: pack W given as [n_out, ld_in] row-major (reference layout), input features
+ * [in_begin, in_begin+in_count) -> dst [NT][KB][64][4] floats. */
+int h3d_pack_matrix(const float* w, int ld_in, int in_begin, int in_count, int n_out, int KB, int NT, float* dst);
+
+/* G [B, Hr*Wr, g_channels] channels-last low-resolution shared-conv maps; cst [B, n_cst, 128];
+ * ab [B, n_ab, 2, HdP]; rgb [B, 3, H, W] (written).  desc is a HOST pointer (copied into the launch). */
+int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                  const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                  h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
  *     lib/components/ops/bias_act.cpp:32 with grad=0; kernel spec lib/components/ops/bias_act.cu:23-147
  * x, y: n dense elements; dtype: 0 = f32, 1 = f16, 2 = f64; b: size_b elements or NULL;

@@ -69,6 +69,9 @@ def condition_weights(G, seed):
                 v.copy_(1 + 0.2 * torch.randn(v.shape, generator=g))
             elif k.endswith("bias") and v.abs().max() == 0:
                 v.copy_(0.1 * torch.randn(v.shape, generator=g))
+        # make the densities matter (a fresh SIREN has sigma ~ 0.05, i.e. nearly empty space)
+        sd["neural_field.sigma_layer.weight"].mul_(60.0)
+        sd["neural_field.sigma_layer.bias"].fill_(0.5)
     G.load_state_dict(sd)
     # perturb u slightly off the singular vector on one layer so sigma != s_max exactly
     return G
@@ -281,7 +284,31 @@ def ops_fixture():
     print("plugin_ops.npz", len(cases), "arrays")
 
 
+def config_fixture():
+    import json
+    out = {}
+    for name in ("MAP3DBN", "MAP3DBN512", "MAP3DBN512L"):
+        cfg = getattr(ref_configs, name)
+        out[name] = {("step:%d" % k if isinstance(k, int) else k): (v.__name__ if isinstance(v, type) else v)
+                     for k, v in cfg.items()}
+    meta = {}
+    for name, step in (("MAP3DBN", 0), ("MAP3DBN", 150000), ("MAP3DBN", 400000), ("MAP3DBN512L", 7)):
+        m = ref_configs.extract_metadata(getattr(ref_configs, name), step)
+        meta[f"{name}@{step}"] = {k: (v.__name__ if isinstance(v, type) else v) for k, v in m.items()}
+    steps = {}
+    for name in ("MAP3DBN", "MAP3DBN512L"):
+        for step in (0, 5, 140001, 200000, 300001):
+            nxt = ref_configs.next_upsample_step(getattr(ref_configs, name), step)
+            steps[f"{name}@{step}"] = [None if nxt == float("Inf") else nxt,
+                                       ref_configs.last_upsample_step(getattr(ref_configs, name), step)]
+    with open(os.path.join(HERE, "configs.json"), "w") as f:
+        json.dump({"configs": out, "extract_metadata": meta, "upsample_steps": steps}, f, indent=1, sort_keys=True,
+                  default=list)
+    print("configs.json")
+
+
 if __name__ == "__main__":
+    config_fixture()
     generator_fixture("gen_tiny_mixed", seed=1)
     generator_fixture("gen_tiny_isolated_legacy", seed=2, map3d_mode="isolated", legacy_mode=True,
                       last_back=True, clamp_mode="softplus", hidden_dim=48, latent_dim=48, feature_dim=48,
