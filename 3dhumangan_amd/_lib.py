@@ -53,6 +53,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise H3DError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    import torch  # noqa: F401  -- load torch's HIP runtime first so libh3d binds to the same libamdhip64
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -66,6 +66,7 @@ int launch(const void* x, const void* b, void* y, int64_t n, int64_t size_b, int
            float gain, float clamp, hipStream_t st) {
     const int64_t want = (n + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 32 ? (want < 1 ? 1 : want) : 256 * 32);
+    h3d::pre_launch();
     hipLaunchKernelGGL(bias_act_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)b, (T*)y, n, size_b, step_b,
                        act, alpha, gain, clamp);
     return h3d::launch_status("h3d_bias_act");
@@ -88,6 +89,7 @@ extern "C" int h3d_bias_act(const void* x, const void* b, void* y, int64_t n, in
         if ((n & 3) == 0 && h3d::aligned16(x) && h3d::aligned16(y) && (!b || (step_b & 3) == 0)) {
             const int64_t n4 = n / 4, want = (n4 + 255) / 256;
             const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
+            h3d::pre_launch();
             hipLaunchKernelGGL(bias_act_f32x4, dim3(grid), dim3(256), 0, st, (const float4*)x, (const float*)b, (float4*)y,
                                n4, size_b, step_b, act, alpha, gain, clamp);
             return h3d::launch_status("h3d_bias_act");

@@ -60,6 +60,7 @@ extern "C" int h3d_bilinear_resize(const float* in, float* out, int B, int C, in
     const int64_t total = planes * H * ((W + 3) / 4);
     const int64_t grid = (total + 255) / 256;
     H3D_REQUIRE(grid < (int64_t(1) << 31), "h3d_bilinear_resize: tensor too large");
+    h3d::pre_launch();
     hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, h, w,
                        H, W, (float)h / (float)H, (float)w / (float)W, planes);
     return h3d::launch_status("h3d_bilinear_resize");

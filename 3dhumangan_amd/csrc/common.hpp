@@ -10,6 +10,9 @@ namespace h3d {
 
 void set_error(const char* fmt, ...);
 
+// Drop any stale (sticky) error another library left in the HIP runtime before we launch.
+inline void pre_launch() { (void)hipGetLastError(); }
+
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -30,13 +30,14 @@ constexpr int kFieldThreads = 256;
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// sin(x) with a two-constant Cody-Waite reduction by pi (exact products through FMA) and an odd Taylor
-// polynomial on [-pi/2, pi/2]; absolute error < 2e-7 for |x| < 1e4, falls back to sinf beyond.
+// sin(x): Cody-Waite reduction by pi with a three-term split constant (products exact through FMA), then an odd
+// Taylor polynomial on [-pi/2, pi/2].  Absolute error < 2e-7 for |x| < 1e5 (the FiLM arguments are O(10..100));
+// branch-free so the unrolled epilogues stay small.
 __device__ __forceinline__ float sin_accurate(float x) {
-    if (fabsf(x) > 1.0e4f) return sinf(x);
     const float k = rintf(x * 0.31830988618379067f);
-    float r = fmaf(-k, 3.14159274101257324f, x);       // fl32(pi)
-    r = fmaf(-k, -8.74227765734758577e-8f, r);         // pi - fl32(pi)
+    float r = fmaf(-k, 3.140625f, x);                  // pi = 3.140625 + 9.67502594e-4 + 1.50995799e-7 (+ ...)
+    r = fmaf(-k, 9.67502593994140625e-4f, r);
+    r = fmaf(-k, 1.509957990978376432e-7f, r);
     const float r2 = r * r;
     float p = -7.6471637318198165e-13f;                // -1/15!
     p = fmaf(p, r2, 1.6059043836821613e-10f);          //  1/13!
@@ -55,6 +56,55 @@ __device__ __forceinline__ float sin_accurate(float x) {
 //   Wp      : packed weights of this layer ([NT][KBtot][64] float4), kb0 = first k-block to use, KBtot = blocks
 //             stored per tile
 // Tiles with index >= NT are clamped to tile 0 (computed and discarded) to keep the MFMA stream branch-free.
+template <int NTW>
+struct Frag {           // operands of one k-block (8 k): A for both 32-row tiles, B for NTW column tiles
+    float a[2][4];
+    float4 b[NTW];
+};
+
+template <int NTW, bool AFF>
+__device__ __forceinline__ void load_frag(Frag<NTW>& f, const float* ap, const float4* const (&bp)[NTW], int kb,
+                                          const float* ab, int abs, int h) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) f.b[i] = bp[i][(int64_t)kb * 64];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f.a[0][e] = ap[(kb * 8 + e) * kMS];
+        f.a[1][e] = ap[(kb * 8 + e) * kMS + 32];
+    }
+    if (AFF) {
+        const float4 sc = *reinterpret_cast<const float4*>(ab + kb * 8 + 4 * h);
+        const float4 sh = *reinterpret_cast<const float4*>(ab + abs + kb * 8 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = e == 0 ? sc.x : e == 1 ? sc.y : e == 2 ? sc.z : sc.w;
+            const float o = e == 0 ? sh.x : e == 1 ? sh.y : e == 2 ? sh.z : sh.w;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float v = fmaf(f.a[mt][e], s, o);
+                f.a[mt][e] = fmaxf(v, 0.2f * v);
+            }
+        }
+    }
+}
+
+template <int NTW>
+__device__ __forceinline__ void mfma_frag(f32x16 (&acc)[2][NTW], const Frag<NTW>& f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const float bv = e == 0 ? f.b[i].x : e == 1 ? f.b[i].y : e == 2 ? f.b[i].z : f.b[i].w;
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][e], bv, acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][e], bv, acc[1][i], 0, 0, 0);
+        }
+    }
+}
+
+// The k loop is a hand-rolled two-stage software pipeline (ping-pong fragment sets): the loads of k-block kb+1
+// are issued, pinned by sched_barrier, *before* the 8*NTW MFMAs (>= 1024 cycles) of k-block kb, so L2 / LDS
+// latency hides under the matrix pipe.  (Left to itself hipcc sinks the prefetch back to its use and the loop
+// stalls for a full L2 round trip per k-block.)
 //   AFF     : the A operand is transformed on the fly, a = lrelu_0.2(x * ab[k] + ab[abs + k]) (per-input-channel
 //             affine + leaky ReLU: eval-mode BatchNorm folded with a per-sample SPADE modulation); ab in LDS.
 template <int NTW, bool AFF = false>
@@ -69,45 +119,21 @@ __device__ __forceinline__ void gemm_phase(f32x16 (&acc)[2][NTW], const float* a
         nt = nt < NT ? nt : 0;
         bp[i] = Wp + ((int64_t)nt * KBtot + kb0) * 64 + lane;
     }
-    float4 bcur[NTW], bnxt[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) bcur[i] = bp[i][0];
     const float* ap = aT + (4 * h) * kMS + row;
-    for (int kb = 0; kb < KB; ++kb) {
-        const int kn = (kb + 1 < KB) ? kb + 1 : kb;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) bnxt[i] = bp[i][(int64_t)kn * 64];
-        float a[2][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[0][e] = ap[(kb * 8 + e) * kMS];
-            a[1][e] = ap[(kb * 8 + e) * kMS + 32];
-        }
-        if (AFF) {
-            const float4 sc = *reinterpret_cast<const float4*>(ab + kb * 8 + 4 * h);
-            const float4 sh = *reinterpret_cast<const float4*>(ab + abs + kb * 8 + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float s = e == 0 ? sc.x : e == 1 ? sc.y : e == 2 ? sc.z : sc.w;
-                const float o = e == 0 ? sh.x : e == 1 ? sh.y : e == 2 ? sh.z : sh.w;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float v = fmaf(a[mt][e], s, o);
-                    a[mt][e] = fmaxf(v, 0.2f * v);
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const float bv = e == 0 ? bcur[i].x : e == 1 ? bcur[i].y : e == 2 ? bcur[i].z : bcur[i].w;
-                acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][e], bv, acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][e], bv, acc[1][i], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) bcur[i] = bnxt[i];
+    Frag<NTW> f0, f1;
+    load_frag<NTW, AFF>(f0, ap, bp, 0, ab, abs, h);
+    // KB is even by construction (odd K ranges are zero padded by the packer): no conditional inside the
+    // loop, otherwise LLVM sinks the prefetch into the branch that consumes it.
+    for (int kb = 0; kb < KB; kb += 2) {
+        load_frag<NTW, AFF>(f1, ap, bp, kb + 1, ab, abs, h);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frag<NTW>(acc, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = kb + 2 < KB ? kb + 2 : kb;      // the last prefetch re-reads a valid block and is dropped
+        load_frag<NTW, AFF>(f0, ap, bp, k2, ab, abs, h);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frag<NTW>(acc, f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

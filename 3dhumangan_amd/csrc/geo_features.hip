@@ -123,6 +123,7 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
     const int64_t per_block = (int64_t)kThreads * kPts;
     const int64_t gx = (N + per_block - 1) / per_block;
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_geo_features: N too large");
+    h3d::pre_launch();
     hipLaunchKernelGGL(geo_features_kernel, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
                        points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
                        legacy_mode);

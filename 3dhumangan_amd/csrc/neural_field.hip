@@ -34,11 +34,11 @@ Layout make_layout(int Hd, int F) {
     L.KBH = L.HdP / 8;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += n; return r; };
-    L.w_coord = take((int64_t)L.NT * 1 * 256);
+    L.w_coord = take((int64_t)L.NT * 2 * 256);            // K = 3 padded to two k-blocks (even count)
     L.w_geo = take((int64_t)L.NT * 4 * 256);
     L.w_film[0] = take((int64_t)L.NT * 2 * L.KBH * 256);
     for (int k = 1; k < 4; ++k) L.w_film[k] = take((int64_t)L.NT * L.KBH * 256);
-    L.w_color = take((int64_t)L.NT * (1 + L.KBH) * 256);
+    L.w_color = take((int64_t)L.NT * (2 + L.KBH) * 256);  // blocks 0-1: direction rows (+ zero pad), 2..: x rows
     L.w_feat = take((int64_t)L.NTF * L.KBH * 256);
     L.b_coord = take(L.HdP);
     L.b_geo = take(L.HdP);
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(kFieldThreads) void field_kernel(Args A) {
     const Layout& L = A.L;
     const int act_rows = L.HdP > 40 ? L.HdP : 40;
     float* actT = smem;                              // [act_rows][MS]; first 40 rows double as the input tile
-    float* dirT = actT + act_rows * kMS;             // [8][MS]
-    float* part = dirT + 8 * kMS;                    // [4 waves][3][64] partial dot products
+    float* dirT = actT + act_rows * kMS;             // [16][MS] (rows 3-15 zero)
+    float* part = dirT + 16 * kMS;                   // [4 waves][3][64] partial dot products
     float* wgt = part + 4 * 3 * 64;                  // [64] compositing weights
     float* bgl = wgt + 64;                           // [64] background term of the row's ray
     float* rgbv = bgl + 64;                          // [64][3]
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kFieldThreads) void field_kernel(Args A) {
             actT[(8 + k) * kMS + m] = (k < 31 && n < N) ? A.geo[((int64_t)b * N + n) * A.geo_stride + k] : 0.f;
         }
         if (A.dirs) {
-            for (int idx = t; idx < 64 * 8; idx += kFieldThreads) {
+            for (int idx = t; idx < 64 * 16; idx += kFieldThreads) {
                 const int m = idx & 63, c = idx >> 6;
                 const int64_t n = n0 + m;
                 dirT[c * kMS + m] = (c < 3 && n < N) ? A.dirs[((int64_t)b * N + n) * 3 + c] : 0.f;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kFieldThreads) void field_kernel(Args A) {
         zero_acc<NTW>(accG);
         zero_acc<NTW>(acc);
         gemm_phase<NTW>(accG, actT + 8 * kMS, reinterpret_cast<const float4*>(blob + L.w_geo), 4, 0, 4, L.NT, wave, lane);
-        gemm_phase<NTW>(acc, actT, reinterpret_cast<const float4*>(blob + L.w_coord), 1, 0, 1, L.NT, wave, lane);
+        gemm_phase<NTW>(acc, actT, reinterpret_cast<const float4*>(blob + L.w_coord), 2, 0, 2, L.NT, wave, lane);
         __syncthreads();
         {
             const float* __restrict__ bb = blob + L.b_coord;
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kFieldThreads) void field_kernel(Args A) {
         // ---- colour branch: FiLM on [dir, x] with the last frequency/phase slice (modulated.py:67-68)
         zero_acc<NTW>(acc);
         if (A.dirs)
-            gemm_phase<NTW>(acc, dirT, reinterpret_cast<const float4*>(blob + L.w_color), 1, 0, 1 + L.KBH, L.NT, wave, lane);
-        gemm_phase<NTW>(acc, actT, reinterpret_cast<const float4*>(blob + L.w_color), L.KBH, 1, 1 + L.KBH, L.NT, wave, lane);
+            gemm_phase<NTW>(acc, dirT, reinterpret_cast<const float4*>(blob + L.w_color), 2, 0, 2 + L.KBH, L.NT, wave, lane);
+        gemm_phase<NTW>(acc, actT, reinterpret_cast<const float4*>(blob + L.w_color), L.KBH, 2, 2 + L.KBH, L.NT, wave, lane);
         __syncthreads();
         {
             const float* __restrict__ bb = blob + L.b_color;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kFieldThreads) void field_kernel(Args A) {
 
 size_t lds_bytes(const Layout& L) {
     const int act_rows = L.HdP > 40 ? L.HdP : 40;
-    return sizeof(float) * ((size_t)act_rows * kMS + 8 * kMS + 4 * 3 * 64 + 64 + 64 + 64 * 3 + 64);
+    return sizeof(float) * ((size_t)act_rows * kMS + 16 * kMS + 4 * 3 * 64 + 64 + 64 + 64 * 3 + 64);
 }
 
 template <int NTW, bool FUSED>
@@ -387,6 +387,7 @@ int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    h3d::pre_launch();
     hipLaunchKernelGGL((field_kernel<NTW, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(kFieldThreads), lds, st, A);
     return h3d::launch_status(FUSED ? "h3d_render_fused" : "h3d_neural_field");
 }
@@ -429,7 +430,7 @@ extern "C" int h3d_field_pack(const h3d_field_params* p, int Hd, int F, void* bl
     const Layout L = make_layout(Hd, F);
     float* blob = static_cast<float*>(blob_);
     for (int64_t i = 0; i < L.total; ++i) blob[i] = 0.f;
-    pack_matrix(p->w_coord, 3, 0, 3, Hd, 1, L.NT, blob + L.w_coord);
+    pack_matrix(p->w_coord, 3, 0, 3, Hd, 2, L.NT, blob + L.w_coord);
     pack_matrix(p->w_geo, 31, 0, 31, Hd, 4, L.NT, blob + L.w_geo);
     // FiLM 0 consumes [coord features (Hd) | geometry features (Hd)]: two K ranges of HdP rows each
     {
@@ -451,7 +452,7 @@ extern "C" int h3d_field_pack(const h3d_field_params* p, int Hd, int F, void* bl
     // colour layer input = [dir (3) | x (Hd)]: k-block 0 holds the direction rows, blocks 1.. the x rows
     {
         float* dst = blob + L.w_color;
-        const int KBt = 1 + L.KBH;
+        const int KBt = 2 + L.KBH;
         for (int nt = 0; nt < L.NT; ++nt)
             for (int kb = 0; kb < KBt; ++kb)
                 for (int lane = 0; lane < 64; ++lane)
@@ -461,7 +462,7 @@ extern "C" int h3d_field_pack(const h3d_field_params* p, int Hd, int F, void* bl
                         float v = 0.f;
                         if (n < Hd) {
                             if (kb == 0) { if (kk < 3) v = p->w_color[(int64_t)n * (Hd + 3) + kk]; }
-                            else { const int k = 8 * (kb - 1) + kk; if (k < Hd) v = p->w_color[(int64_t)n * (Hd + 3) + 3 + k]; }
+                            else if (kb >= 2) { const int k = 8 * (kb - 2) + kk; if (k < Hd) v = p->w_color[(int64_t)n * (Hd + 3) + 3 + k]; }
                         }
                         dst[(((int64_t)nt * KBt + kb) * 64 + lane) * 4 + e] = v;
                     }

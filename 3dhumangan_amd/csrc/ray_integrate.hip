@@ -187,10 +187,12 @@ extern "C" int h3d_ray_integrate(const float* field, const float* z_vals, const 
     if (vec) {
         const int G = kThreads / NQ;
         const size_t lds = sizeof(float) * (((S + 3) & ~3) + 4 * G * NQ + 4);
+        h3d::pre_launch();
         hipLaunchKernelGGL(ray_integrate_vec4, dim3((unsigned)n_rays), dim3(kThreads), lds, st, field, z_vals, noise,
                            feats, depth, weights, S, C, clamp_mode, last_back, white_back);
     } else {
         const size_t lds = sizeof(float) * (S + 4);
+        h3d::pre_launch();
         hipLaunchKernelGGL(ray_integrate_scalar, dim3((unsigned)n_rays), dim3(kThreads), lds, st, field, z_vals,
                            noise, feats, depth, weights, S, C, clamp_mode, last_back, white_back);
     }

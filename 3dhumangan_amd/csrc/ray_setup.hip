@@ -61,6 +61,7 @@ extern "C" int h3d_ray_setup(const float* focals, const float* scales, const flo
     const int64_t per_image = (int64_t)render_h * render_w * S;
     const int64_t gx = (per_image + 255) / 256;
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_ray_setup: too many points per image");
+    h3d::pre_launch();
     hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), focals,
                        scales, cam2world, jitter, points, z_vals, render_h, render_w, S, ray_start, ray_end, per_image);
     return h3d::launch_status("h3d_ray_setup");

@@ -268,6 +268,7 @@ int launch_one(const Args& A, int B, int64_t tiles, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    h3d::pre_launch();
     hipLaunchKernelGGL((synthesis_kernel<NTW>), dim3((unsigned)tiles, (unsigned)B), dim3(kFieldThreads), lds_bytes(A.HdP), st, A);
     return h3d::launch_status("h3d_synthesis");
 }

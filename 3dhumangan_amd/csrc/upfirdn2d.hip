@@ -62,6 +62,7 @@ int launch(const void* x, const float* f, void* y, const Params& p, hipStream_t 
     const int64_t total = (int64_t)p.B * p.C * p.outH * p.outW;
     const int64_t want = (total + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 32 ? (want < 1 ? 1 : want) : 256 * 32);
+    h3d::pre_launch();
     hipLaunchKernelGGL((upfirdn2d_kernel<T, A>), dim3(grid), dim3(256), sizeof(float) * p.fh * p.fw, st, (const T*)x, f,
                        (T*)y, p);
     return h3d::launch_status("h3d_upfirdn2d");

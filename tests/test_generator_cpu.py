@@ -66,6 +66,6 @@ def test_field_pack_size_matches_layout():
     for Hd, F in [(32, 32), (256, 256), (420, 420), (64, 40)]:
         HdP, FP = (Hd + 31) // 32 * 32, (F + 31) // 32 * 32
         NT, NTF, KBH = HdP // 32, FP // 32, HdP // 8
-        mats = NT * 256 * (1 + 4 + 2 * KBH + 3 * KBH + 1 + KBH) + NTF * KBH * 256
+        mats = NT * 256 * (2 + 4 + 2 * KBH + 3 * KBH + 2 + KBH) + NTF * KBH * 256
         vecs = HdP * (1 + 1 + 4 + 1 + 3 + 1 + 3) + FP + 4
         assert lib.h3d_field_pack_size(Hd, F) == 4 * (mats + vecs)
