@@ -1,0 +1,135 @@
+"""Inference app, counterpart of the reference's apps/sample_from_generator.py: seeds -> rotating-camera frames ->
+png / gif (mp4 when imageio is installed).  Same CLI flags, same config overrides (:94-99), same seed -> latent
+convention (:26-29), angle schedule (:35-43), uint8 conversion (:59-62) and output naming (:140-149).
+
+The SMPL model file and the SHHQ dataset cannot ship, so `--synthetic-conditions` (the default when --dataroot is
+absent) drives the generator with the procedural body of `synthetic.py`; with random-init weights (no
+`--checkpoint`) it is a plumbing / throughput run.
+
+    python -m 3dhumangan_amd.apps.sample_from_generator --config MAP3DBN --seeds 1 2 --n_angles 8 --save png
+"""
+import argparse
+import math
+import os
+
+import numpy as np
+import torch
+
+from .. import configs, synthetic
+from ..lib import generators as lib_generators
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+@torch.no_grad()
+def generate_frames(generator, preprocessor, config, seed, conditions, n_angles, angle_range_h, angle_range_v, back_and_forth):
+    """-> (frames uint8 [n_angles,H,W,3], rasterized_semantics uint8 [n_angles,H,W,3])."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    dev = generator.device
+    z = torch.randn((1, config["latent_dim"]), device=device).repeat_interleave(n_angles, dim=0).to(dev)
+    conditions = {k: v.repeat_interleave(n_angles, dim=0).to(dev) for k, v in conditions.items()}
+    if back_and_forth:
+        sweep = torch.linspace(-np.pi, np.pi, n_angles).to(dev)
+        angles_h = angle_range_h * torch.sin(sweep).unsqueeze(-1)
+        angles_v = angle_range_v * torch.cos(sweep).unsqueeze(-1)
+    else:
+        angles_h = torch.linspace(-angle_range_h, angle_range_h, n_angles).to(dev).unsqueeze(-1)
+        angles_v = torch.linspace(-angle_range_v, angle_range_v, n_angles).to(dev).unsqueeze(-1)
+    angles_r = torch.zeros_like(angles_h)
+    H, W = config["gen_height"], config["gen_width"]
+    frames = torch.zeros(n_angles, 3, H, W, device=dev)
+    semantics = torch.zeros(n_angles, 3, H, W, device=dev)
+    for i in range(n_angles):
+        one = {k: v[i:i + 1] for k, v in conditions.items()}
+        one = preprocessor.forward_with_rotation(one, angles_h[i:i + 1], angles_v[i:i + 1], angles_r[i:i + 1], **config)
+        smpl = torch.clamp(one["rasterized_semantics"], -1, 1)
+        bg = torch.all(smpl == 0, dim=1, keepdim=True)
+        smpl[bg.repeat(1, 3, 1, 1)] = 1
+        semantics[i:i + 1] = smpl
+        out = generator.staged_forward(z[i:i + 1], one, **config)
+        frames[i:i + 1] = torch.clamp(out["rgbs"], -1, 1)
+
+    def to_u8(t):
+        return torch.clamp((t * 0.5 + 0.5) * 255, 0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+
+    return to_u8(frames), to_u8(semantics)
+
+
+def _save(path_stem, frames, mode):
+    from PIL import Image
+    if mode == "png":
+        Image.fromarray(np.concatenate(list(frames), axis=1)).save(path_stem + ".png")
+    elif mode == "gif":
+        ims = [Image.fromarray(f) for f in frames]
+        ims[0].save(path_stem + ".gif", save_all=True, append_images=ims[1:], duration=100, loop=0)
+    elif mode == "mp4":
+        try:
+            import imageio
+        except ImportError as e:
+            raise RuntimeError("--save mp4 needs imageio (not installed); use --save gif or png") from e
+        imageio.mimwrite(path_stem + ".mp4", frames, fps=20, quality=9)
+    else:
+        raise NotImplementedError
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default="MAP3DBN")
+    ap.add_argument("--tune", type=str, default="")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--checkpoint", type=str)
+    ap.add_argument("--seeds", nargs="+", type=int, default=list(range(1, 10)))
+    ap.add_argument("--dataroot", type=str, default=None)
+    ap.add_argument("--dataset_length", type=int, default=10)
+    ap.add_argument("--output_dir", type=str, default="results/sample_from_generator")
+    ap.add_argument("--postfix", type=str, default="")
+    ap.add_argument("--lock_view_dependence", default=None)
+    ap.add_argument("--n_angles", type=int, default=40)
+    ap.add_argument("--back_and_forth", default=False, action="store_true")
+    ap.add_argument("--save", type=str, default="png", choices=["mp4", "png", "gif"])
+    ap.add_argument("--stitch", default=False, action="store_true")
+    ap.add_argument("--synthetic-conditions", action="store_true", default=True)
+    opt = ap.parse_args(argv)
+    if opt.dataroot is not None:
+        raise NotImplementedError("the SHHQ dataset reader / SMPL preprocessor need licensed assets and pytorch3d; "
+                                  "run with the synthetic conditions")
+    config = configs.get_config(opt)
+    config = {k: v for k, v in config.items() if type(k) is str}
+    config["truncation_psi"] = 0.7
+    config["v_stddev"] = 0
+    config["h_stddev"] = 0
+    if opt.lock_view_dependence is not None:
+        config["lock_view_dependence"] = opt.lock_view_dependence
+    config["last_back"] = config.get("eval_last_back", False)
+    config["nerf_noise"] = 0
+    config["dataset_length"] = opt.dataset_length
+    config["cache_avg_latent"] = True                  # the reference recomputes the 10 000-sample mean per call
+    out_dir = os.path.join(opt.output_dir, config["name"] + opt.postfix)
+    os.makedirs(out_dir, exist_ok=True)
+
+    generator = getattr(lib_generators, config["generator"])(**config).to(device)
+    if opt.checkpoint:
+        ckpt = torch.load(opt.checkpoint, map_location=device)
+        if not isinstance(ckpt, dict):
+            raise NotImplementedError("pickled-module checkpoints of the reference trainer are not supported; "
+                                      "pass the *_generator_ema_state_dict.pth file")
+        generator.load_state_dict(ckpt)
+    generator.set_device(device)
+    generator.eval()
+    preprocessor = synthetic.SyntheticPreprocessor(device)
+    for seed in opt.seeds:
+        data = synthetic.make_conditions(1, 6890, seed=seed)
+        frames, semantics = generate_frames(generator, preprocessor, config, seed, data, opt.n_angles, math.pi / 6, 0,
+                                            opt.back_and_forth)
+        if opt.stitch:
+            frames = np.stack([np.concatenate([f, s], axis=0) for f, s in zip(frames, semantics)])
+        _save(os.path.join(out_dir, f"{seed:03d}_uncond"), frames, opt.save)
+        if not opt.stitch:
+            _save(os.path.join(out_dir, f"{seed:03d}_smpl"), semantics, opt.save)
+    return out_dir
+
+
+if __name__ == "__main__":
+    main()

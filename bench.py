@@ -67,11 +67,8 @@ def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on):
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    par = importlib.import_module("3dhumangan_amd.parallel")
+    return par.max_over_ranks(dt, device="cuda")       # the job is as slow as its slowest rank
 
 
 def kernel_rooflines(G, cfg, batch, stage_ms):

@@ -307,8 +307,26 @@ def config_fixture():
     print("configs.json")
 
 
+def harness_fixture():
+    """apps/sample_from_generator.py:generate_frames of the REFERENCE, driven with the shared stubs."""
+    import apps.sample_from_generator as ref_app
+    from _stub_generator import StubGenerator, StubPreprocessor
+    cfg = dict(latent_dim=16, gen_height=12, gen_width=6)
+    cond = {"dummy": torch.arange(6.0).view(1, 6)}
+    out = {}
+    for baf in (0, 1):
+        G = StubGenerator()
+        frames, sem = ref_app.generate_frames(G, StubPreprocessor(), cfg, 7, cond, 5, 0.5, 0.2, bool(baf))
+        out[f"frames{baf}"] = frames
+        out[f"sem{baf}"] = sem
+        out[f"z{baf}"] = torch.cat([c[0] for c in G.calls])
+        out[f"c2w{baf}"] = torch.cat([c[1] for c in G.calls])
+    save("app_harness", **out)
+
+
 if __name__ == "__main__":
     config_fixture()
+    harness_fixture()
     generator_fixture("gen_tiny_mixed", seed=1)
     generator_fixture("gen_tiny_isolated_legacy", seed=2, map3d_mode="isolated", legacy_mode=True,
                       last_back=True, clamp_mode="softplus", hidden_dim=48, latent_dim=48, feature_dim=48,
