@@ -36,7 +36,7 @@ def test_synthetic_preprocessor_camera_math():
     zero = torch.zeros(2, 1)
     out = pre.forward_with_rotation(cond, zero, zero, zero, gen_height=4, gen_width=2)
     # zero rotation reproduces the canonical camera baked into make_conditions
-    assert torch.allclose(out["cam2world_matrices"], cond["cam2world_matrices"], atol=1e-6)
+    assert torch.allclose(out["cam2world_matrices"], cond["cam2world_matrices"], atol=2e-5)
     h = torch.full((2, 1), math.pi / 6)
     out = pre.forward_with_rotation(cond, h, zero, zero, gen_height=4, gen_width=2)
     want = synthetic.make_conditions(2, n_vertices=32, seed=1, h_angle=math.pi / 6)["cam2world_matrices"]
