@@ -51,6 +51,17 @@ __device__ __forceinline__ float sin_accurate(float x) {
     return __int_as_float(__float_as_int(s) ^ ((ki & 1) << 31));
 }
 
+// sin(x) through the hardware v_sin_f32 (argument in revolutions) after an exact three-constant reduction of x
+// to [-pi, pi]: 7 instructions, |err| < 4e-7 on |x| < 300 (measured, tools/probes/sin_probe.hip) -- the raw
+// v_sin_f32(x / 2pi) alone loses the low bits of large arguments (5e-6 at |x| = 60).
+__device__ __forceinline__ float sin_hw(float x) {
+    const float k = rintf(x * 0.15915494309189535f);
+    float r = fmaf(-k, 6.28125f, x);                   // 2*pi = 6.28125 + 1.93500519e-3 + 3.01991598e-7 (+ ...)
+    r = fmaf(-k, 1.93500518798828125e-3f, r);
+    r = fmaf(-k, 3.019915981956752864e-7f, r);
+    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+}
+
 // One GEMM phase of the tile engine: acc[mt][i] += A(64 x 8*KB, from LDS) * W(8*KB x 32 per tile, packed).
 //   aT      : LDS pointer to actT row of k = 0 for this phase
 //   Wp      : packed weights of this layer ([NT][KBtot][64] float4), kb0 = first k-block to use, KBtot = blocks

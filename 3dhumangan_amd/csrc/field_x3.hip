@@ -1,0 +1,858 @@
+// A5 (+A6 fused): FiLM-SIREN field on the f16 matrix cores with split ("x3") operands, for gfx950.
+//
+// Reference semantics as neural_field.hip (lib/implicit_funcitions/modulated.py:41-75,
+// lib/generators/volume_rendering.py:12-56).  Same math, different engine:
+//
+//   precision   every fp32 operand is split x*s = hi + lo with hi = f16(x*s), lo = f16(x*s - hi) (s a power of
+//               two that keeps both halves in the normal f16 range) and a product is evaluated as
+//               hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 22 significant bits per
+//               operand, i.e. fp32-class results (measured 2e-6 on the field, same as the fp32 MFMA path) at 16/3
+//               of the fp32 MFMA rate.  A single f16 product misses the 1e-3 budget (5e-3 after the freq~45
+//               sines), which is why the split is needed.
+//   dataflow    a wavefront owns 32 samples and ALL output features.  Weights are the MFMA A operand (rows =
+//               features), activations the B operand (columns = samples), so the accumulator of a lane holds one
+//               sample's features.  The epilogue (bias, FiLM sine, split) runs in registers, and one
+//               v_permlane32_swap per register pair turns the accumulator layout into next layer's B fragments:
+//               activations never touch LDS or HBM between layers and there is no barrier in the layer loop.
+//               Weights are one linear stream in consumption order (2 KB per tile and k-step, MFMA A-fragment
+//               order); the four waves of a workgroup pull it ONCE from L2 into an LDS ring with
+//               global_load_lds (LDS-DMA, no registers), several k-steps ahead and straight through the epilogues,
+//               and every wave reads its fragments from the ring with conflict-free ds_read_b128.  One raw
+//               s_barrier per k-step (768 MFMA cycles) is the only synchronisation.
+//   fused A6    the feature head is evaluated with the operands swapped (rows = samples), so the weighted sum over
+//               the samples of a ray is a sum over accumulator registers; compositing weights come from a
+//               segmented 32-lane product scan (S = 8..32: 32/S rays per wave step; S = 64, 128: carry).
+#include "field_common.hpp"
+#include <string.h>
+#include <math.h>
+
+using namespace h3d;
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kSA = 4096.f;      // activation scale (|sin| <= 1)
+constexpr float kSIn = 64.f;       // input scale (coords / geometry features, |x| < 1000)
+#ifndef H3D_RING_DEPTH
+#define H3D_RING_DEPTH 6
+#endif
+
+enum { ST_GEO = 0, ST_COORD, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
+// weight matrices in STREAM (consumption) order
+enum { W_GEO = 0, W_F0B, W_F0A, W_F1, W_F2, W_F3, W_COLOR, W_FEAT, W_COUNT };
+
+struct LayoutX3 {        // offsets in BYTES into the blob (all multiples of 16)
+    int HdP, FP, NT, KS;
+    int64_t w[W_COUNT];
+    int64_t inv_scale;   // float[W_COUNT]: 1 / (weight scale * input scale) per matrix
+    int64_t bias;        // float[ST_COUNT][HdP]
+    int64_t wdir;        // float[3][HdP]   colour-layer weights of the view direction
+    int64_t wcoord;      // float[3][HdP]   first_layer_coord weights, transposed
+    int64_t b_feat;      // float[FP]
+    int64_t head_w;      // f16 [4 heads: sigma, r, g, b][2 hi/lo][KS][2 halves][8]  (B-fragment order per lane half)
+    int64_t head_inv;    // float[4] 1/(weight scale * kSA)
+    int64_t head_b;      // float[4]
+    int64_t total;
+};
+
+int tiles_for(int Hd) { int nt = 4; while (nt * 32 < Hd) nt *= 2; return nt; }   // engine is built for 4 or 8 tiles
+
+LayoutX3 make_layout(int Hd, int F) {
+    LayoutX3 L;
+    const int w = Hd > F ? Hd : F;
+    L.NT = tiles_for(w);
+    L.HdP = L.FP = L.NT * 32;
+    L.KS = L.HdP / 16;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 15) / 16 * 16; return r; };
+    const int64_t per_ks = (int64_t)L.NT * 2 * 64 * 16;
+    const int ks[W_COUNT] = {2, L.KS, L.KS, L.KS, L.KS, L.KS, L.KS, L.KS};
+    for (int i = 0; i < W_COUNT; ++i) L.w[i] = take(ks[i] * per_ks);
+    L.inv_scale = take(4 * W_COUNT);
+    L.bias = take(4 * (int64_t)ST_COUNT * L.HdP);
+    L.wdir = take(4 * 3 * (int64_t)L.HdP);
+    L.wcoord = take(4 * 3 * (int64_t)L.HdP);
+    L.b_feat = take(4 * (int64_t)L.FP);
+    L.head_w = take(2 * (int64_t)4 * 2 * L.KS * 16);
+    L.head_inv = take(16);
+    L.head_b = take(16);
+    L.total = o;
+    return L;
+}
+
+struct Args {
+    const unsigned char* blob;
+    const float* points;
+    const float* geo;
+    const float* dirs;
+    const float* freq;
+    const float* phase;
+    float* out;
+    const float* z_vals;
+    const float* noise;
+    float* feats;
+    float* depth;
+    float* weights;
+    int64_t N;
+    int Hd, F, geo_stride, S, clamp_mode, last_back, white_back;
+    float input_scaler;
+    LayoutX3 L;
+};
+
+__device__ __forceinline__ float density(float x, int clamp_mode) {
+    if (clamp_mode == 1) return x > 20.f ? x : log1pf(expf(x));
+    return fmaxf(x, 0.f);
+}
+
+__device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, half2v{a, b}); }
+
+// x (already scaled) -> hi, lo halves
+__device__ __forceinline__ void split(float xs, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+
+// 8 fp32 values of one lane -> hi / lo B-fragments
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& fh, half8& fl) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 h, l;
+        split(v[e] * scale, h, l);
+        fh[e] = h;
+        fl[e] = l;
+    }
+}
+
+// Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
+// ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
+template <int NT>
+struct WeightRing {
+    static constexpr int kBuf = H3D_RING_DEPTH;
+    static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
+    static constexpr int kStage = NT * 2048;
+    const unsigned char* gsrc;    // global stream + this lane's slot
+    unsigned char* ring;          // LDS ring base
+    int total, issue_pos, issue_buf, cur_buf, wave, lane;
+
+    __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
+        gsrc = stream + (w * kChunks) * 1024 + l * 16;
+        ring = lds;
+        total = total_stages;
+        issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
+#pragma unroll
+        for (int i = 0; i < kBuf - 1; ++i) issue();
+    }
+    __device__ __forceinline__ void issue() {
+        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage;
+        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks) * 1024;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
+                                             (__attribute__((address_space(3))) void*)(d + c * 1024), 16, 0, 0);
+        issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
+        issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
+    }
+    // Make the next stage readable by every wave, then refill the buffer everybody finished with.
+    __device__ __forceinline__ const unsigned char* acquire() {
+        // lgkmcnt(0): this wave's ds_reads of the stage whose buffer is about to be refilled have completed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kBuf - 2) * kChunks) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const unsigned char* r = ring + cur_buf * kStage + lane * 16;
+        cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
+        return r;
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
+//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].
+// The three partial products of a tile are issued NT MFMAs apart (no back-to-back dependent accumulations).
+template <int NT>
+struct WFrag { half8 h[NT], l[NT]; };
+
+template <int NT>
+__device__ __forceinline__ void load_wfrag_pair(WFrag<NT>& f, const unsigned char* st, int p) {
+#pragma unroll
+    for (int nt = 2 * p; nt < 2 * p + 2; ++nt) {
+        f.h[nt] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 0) * 1024));
+        f.l[nt] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 1) * 1024));
+    }
+}
+
+template <bool SWAP>
+__device__ __forceinline__ f32x16 mm(const half8& w, const half8& x, const f32x16& c) {
+    return SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0)
+                : __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+}
+
+// One k-step: the 3 partial products of tile pair p (hi*hi, hi*lo, lo*hi; the two tiles alternate so no MFMA
+// depends on its predecessor), with the 4 ds_read_b128 that fetch the NEXT k-step's fragments of the same tile
+// pair issued just ahead of them.  Never more than a handful of LDS reads are outstanding, so the compiler's
+// lgkmcnt waits stay exact (the counter saturates at 15) and no MFMA waits for a read issued in its own k-step.
+template <int NT, bool SWAP, bool PREFETCH>
+__device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFrag<NT>& cur, WFrag<NT>& nxt, const unsigned char* st_next,
+                                         const half8& xh, const half8& xl) {
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p) {
+        if (PREFETCH) load_wfrag_pair<NT>(nxt, st_next, p);
+        const int a = 2 * p, b = 2 * p + 1;
+        acc[a] = mm<SWAP>(cur.h[a], xh, acc[a]);
+        acc[b] = mm<SWAP>(cur.h[b], xh, acc[b]);
+        acc[a] = mm<SWAP>(cur.h[a], xl, acc[a]);
+        acc[b] = mm<SWAP>(cur.h[b], xl, acc[b]);
+        acc[a] = mm<SWAP>(cur.l[a], xh, acc[a]);
+        acc[b] = mm<SWAP>(cur.l[b], xh, acc[b]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
+//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].   KS is even.
+template <int NT, int KS, bool SWAP>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const half8 (&xh)[2 * NT], const half8 (&xl)[2 * NT],
+                                        WeightRing<NT>& ring) {
+    static_assert(KS % 2 == 0 && NT % 2 == 0, "k-steps and tiles come in pairs");
+    WFrag<NT> f0, f1;
+    {
+        const unsigned char* st = ring.acquire();
+#pragma unroll
+        for (int p = 0; p < NT / 2; ++p) load_wfrag_pair<NT>(f0, st, p);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+        const unsigned char* s1 = ring.acquire();
+        __builtin_amdgcn_sched_barrier(0);
+        kstep_x3<NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks]);
+        if (ks + 2 < KS) {
+            const unsigned char* s2 = ring.acquire();
+            __builtin_amdgcn_sched_barrier(0);
+            kstep_x3<NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1]);
+        } else {
+            kstep_x3<NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1]);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc1(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+// Epilogue of a feature-major accumulator: y = sin(f * (acc*inv + b [+ wdir . dir]) + p), split to f16 hi/lo and
+// re-laid out as the next layer's B fragments (one permlane32_swap per register pair).
+//   tb / tf / tp : LDS vectors [HdP] (bias, frequency, phase) of this step;  twd: LDS [3][HdP] or nullptr.
+template <int NT>
+__device__ __forceinline__ void film_epilogue(const f32x16 (&acc)[NT], half8 (&xh)[2 * NT], half8 (&xl)[2 * NT],
+                                              const float* tb, const float* tf, const float* tp, const float* twd,
+                                              float d0, float d1, float d2, float inv, int Hd, int HdP, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        unsigned H[4][2], Lo[4][2];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = nt * 32 + rg * 8 + 4 * h;
+            const float4 b = *reinterpret_cast<const float4*>(tb + n);
+            const float4 f = *reinterpret_cast<const float4*>(tf + n);
+            const float4 p = *reinterpret_cast<const float4*>(tp + n);
+            float add[4] = {b.x, b.y, b.z, b.w};
+            if (twd) {
+                const float4 w0 = *reinterpret_cast<const float4*>(twd + n);
+                const float4 w1 = *reinterpret_cast<const float4*>(twd + HdP + n);
+                const float4 w2 = *reinterpret_cast<const float4*>(twd + 2 * HdP + n);
+                add[0] += w0.x * d0 + w1.x * d1 + w2.x * d2;
+                add[1] += w0.y * d0 + w1.y * d1 + w2.y * d2;
+                add[2] += w0.z * d0 + w1.z * d1 + w2.z * d2;
+                add[3] += w0.w * d0 + w1.w * d1 + w2.w * d2;
+            }
+            const float ff[4] = {f.x, f.y, f.z, f.w}, pp[4] = {p.x, p.y, p.z, p.w};
+            _Float16 hh[4], ll[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y = sin_hw(fmaf(ff[q], fmaf(acc[nt][rg * 4 + q], inv, add[q]), pp[q]));
+                y = (n + q < Hd) ? y : 0.f;
+                split(y * kSA, hh[q], ll[q]);
+            }
+            H[rg][0] = pack2(hh[0], hh[1]); H[rg][1] = pack2(hh[2], hh[3]);
+            Lo[rg][0] = pack2(ll[0], ll[1]); Lo[rg][1] = pack2(ll[2], ll[3]);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // lanes 0-31 keep rows 8rg..+3 of register group 2pr and receive rows +4..+7 from lanes 32-63;
+            // lanes 32-63 receive rows of group 2pr+1 from lanes 0-31 and keep their own
+            u32x4 fh, fl;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                auto a = __builtin_amdgcn_permlane32_swap(H[2 * pr][c], H[2 * pr + 1][c], false, false);
+                fh[c] = a[0]; fh[2 + c] = a[1];
+                auto bq = __builtin_amdgcn_permlane32_swap(Lo[2 * pr][c], Lo[2 * pr + 1][c], false, false);
+                fl[c] = bq[0]; fl[2 + c] = bq[1];
+            }
+            xh[2 * nt + pr] = __builtin_bit_cast(half8, fh);
+            xl[2 * nt + pr] = __builtin_bit_cast(half8, fl);
+        }
+    }
+}
+
+// N=1 / N=3 heads as f16 dot products over the lane's half of K, halves combined with one cross-half add.
+template <int NT, int NH>
+__device__ __forceinline__ void heads(const half8 (&xh)[2 * NT], const half8 (&xl)[2 * NT], const u32x4* __restrict__ hw,
+                                      int first_head, int KS, int h, float (&out)[NH]) {
+#pragma unroll
+    for (int c = 0; c < NH; ++c) {
+        const u32x4* wh = hw + (((int64_t)(first_head + c) * 2 + 0) * KS) * 2 + h;
+        const u32x4* wl = hw + (((int64_t)(first_head + c) * 2 + 1) * KS) * 2 + h;
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) {
+            const u32x4 a = wh[ks * 2], bq = wl[ks * 2];
+            const u32x4 x0 = __builtin_bit_cast(u32x4, xh[ks]), x1 = __builtin_bit_cast(u32x4, xl[ks]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half2v ah = __builtin_bit_cast(half2v, (unsigned)a[e]), al = __builtin_bit_cast(half2v, (unsigned)bq[e]);
+                const half2v xhh = __builtin_bit_cast(half2v, (unsigned)x0[e]), xll = __builtin_bit_cast(half2v, (unsigned)x1[e]);
+                s = __builtin_amdgcn_fdot2(ah, xhh, s, false);
+                s = __builtin_amdgcn_fdot2(ah, xll, s, false);
+                s = __builtin_amdgcn_fdot2(al, xhh, s, false);
+            }
+        }
+        out[c] = s + __shfl_xor(s, 32, 64);
+    }
+}
+
+template <int NT, bool FUSED>
+__global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
+    constexpr int KS = 2 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LayoutX3& L = A.L;
+    const int HdP = L.HdP;
+    float* tab0 = smem;                                 // [ST_COUNT][3][HdP]  bias / frequency / phase per step
+    float* twd0 = tab0 + ST_COUNT * 3 * HdP;            // [3][HdP]
+    float* tfeat0 = twd0 + 3 * HdP;                     // [HdP] feature-head bias
+    float* twc0 = tfeat0 + HdP;                         // [3][HdP] coordinate first-layer weights (x scale folded in)
+    float* scratch = twc0 + 3 * HdP;                    // [4 waves][64]: compositing weights, background terms
+    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(scratch + 4 * 64);   // [ring depth][NT*2 KB] weight ring
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int Hd = A.Hd, F = A.F, S = A.S;
+    const int64_t N = A.N;
+    // ---- per-sample-of-the-batch tables (bias, 15*freq+30, phase) in LDS, once per workgroup
+    {
+        const unsigned char* __restrict__ blob = A.blob;
+        const float* __restrict__ bias = reinterpret_cast<const float*>(blob + L.bias);
+        const float* __restrict__ fr = A.freq + (int64_t)b * 4 * Hd;
+        const float* __restrict__ ph = A.phase + (int64_t)b * 4 * Hd;
+        const float* __restrict__ wd = reinterpret_cast<const float*>(blob + L.wdir);
+        const float* __restrict__ bf = reinterpret_cast<const float*>(blob + L.b_feat);
+        for (int idx = t; idx < ST_COUNT * HdP; idx += 256) {
+            const int st = idx / HdP, n = idx - st * HdP;
+            const bool ok = n < Hd;
+            float bb = ok ? bias[st * HdP + n] : 0.f, ff = 30.f, pp = 0.f;
+            if (st >= ST_FILM0 && ok) {
+                const int sl = st == ST_COLOR ? 3 : st - ST_FILM0;
+                ff = fr[sl * Hd + n] * 15.f + 30.f;
+                pp = ph[sl * Hd + n];
+            }
+            if (st == ST_COLOR && ok && !A.dirs) bb -= wd[2 * HdP + n];      // locked view direction (0,0,-1)
+            tab0[(st * 3 + 0) * HdP + n] = bb;
+            tab0[(st * 3 + 1) * HdP + n] = ff;
+            tab0[(st * 3 + 2) * HdP + n] = pp;
+        }
+        const float* __restrict__ wc = reinterpret_cast<const float*>(blob + L.wcoord);
+        for (int idx = t; idx < 3 * HdP; idx += 256) { twd0[idx] = wd[idx]; twc0[idx] = wc[idx]; }
+        for (int idx = t; idx < HdP; idx += 256) tfeat0[idx] = idx < F ? bf[idx] : 0.f;
+    }
+    __syncthreads();
+
+    const float* __restrict__ invs = reinterpret_cast<const float*>(A.blob + L.inv_scale);
+    const float* __restrict__ head_inv = reinterpret_cast<const float*>(A.blob + L.head_inv);
+    const float* __restrict__ head_b = reinterpret_cast<const float*>(A.blob + L.head_b);
+    float* wl_lds = scratch + wave * 64;      // [32] weights, [32] background
+
+    const int unit = FUSED ? (S > 32 ? S : 32) : 32;          // samples a wave walks per unit (whole rays when fused)
+    const int steps = unit / 32;
+    const int seglen = FUSED ? (S < 32 ? S : 32) : 32;
+    const int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
+
+    WeightRing<NT> ring;
+    ring.init(A.blob + L.w[0], ring_lds, 2 + 7 * KS, wave, lane);
+
+    float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
+    float rayacc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rayacc[i] = 0.f;
+
+    for (int si = 0; si < steps; ++si) {
+        const int64_t n0 = u0 + (int64_t)si * 32;
+        const int64_t n = n0 + m;
+        const bool ok = n < N;
+        const int64_t gi = (int64_t)b * N + (ok ? n : N - 1);      // clamped: out-of-range lanes load valid memory
+        const bool last_step = si == steps - 1;
+        // The LDS tables and head weights do not depend on the step: launder an opaque zero offset so the compiler
+        // does not hoist hundreds of loop-invariant loads out of the step loop (LICM) and spill them.
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const unsigned char* __restrict__ blob = A.blob + opaque;
+        const float* tab = tab0 + opaque;
+        const float* twd = twd0 + opaque;
+        const float* tfeat = tfeat0 + opaque;
+        const float* twc = twc0 + opaque;
+
+        f32x16 acc[NT];
+        half8 xh[KS], xl[KS];
+
+        // ---- geometry-feature first layer (K = 31 -> two k-steps on the matrix cores)
+        {
+            half8 ih[KS], il[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { ih[ks] = half8{0}; il[ks] = half8{0}; }
+            const float* __restrict__ g = A.geo + gi * A.geo_stride;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = ks * 16 + h * 8 + e;
+                    v[e] = (k < 31 && ok) ? g[k] : 0.f;
+                }
+                split8(v, kSIn, ih[ks], il[ks]);
+            }
+            zero_acc1<NT>(acc);
+            gemm_x3<NT, 2, false>(acc, ih, il, ring);
+            film_epilogue<NT>(acc, xh, xl, tab + (ST_GEO * 3 + 0) * HdP, tab + (ST_GEO * 3 + 1) * HdP,
+                              tab + (ST_GEO * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_GEO], Hd, HdP, h);
+        }
+        // ---- FiLM 0, geometry half:  acc = W0b * geo_act
+        zero_acc1<NT>(acc);
+        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        // ---- coordinate first layer (K = 3) on the VALU, in fp32, straight into B-fragment layout
+        {
+            const float* __restrict__ p = A.points + gi * 3;
+            const float px = ok ? p[0] * A.input_scaler : 0.f, py = ok ? p[1] * A.input_scaler : 0.f,
+                        pz = ok ? p[2] * A.input_scaler : 0.f;
+            const float* tbc = tab + (ST_COORD * 3 + 0) * HdP;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k0 = ks * 16 + h * 8;
+                float v[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(twc + k0 + q4 * 4);
+                    const float4 w1 = *reinterpret_cast<const float4*>(twc + HdP + k0 + q4 * 4);
+                    const float4 w2 = *reinterpret_cast<const float4*>(twc + 2 * HdP + k0 + q4 * 4);
+                    const float4 bb = *reinterpret_cast<const float4*>(tbc + k0 + q4 * 4);
+                    // same association as F.linear: ((w0*x + w1*y) + w2*z) + b
+                    v[q4 * 4 + 0] = sin_hw(30.f * (fmaf(w2.x, pz, fmaf(w1.x, py, w0.x * px)) + bb.x));
+                    v[q4 * 4 + 1] = sin_hw(30.f * (fmaf(w2.y, pz, fmaf(w1.y, py, w0.y * px)) + bb.y));
+                    v[q4 * 4 + 2] = sin_hw(30.f * (fmaf(w2.z, pz, fmaf(w1.z, py, w0.z * px)) + bb.z));
+                    v[q4 * 4 + 3] = sin_hw(30.f * (fmaf(w2.w, pz, fmaf(w1.w, py, w0.w * px)) + bb.w));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (k0 + e < Hd) ? v[e] : 0.f;
+                split8(v, kSA, xh[ks], xl[ks]);
+            }
+        }
+        // ---- FiLM 0, coordinate half: acc += W0a * coord_act
+        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        film_epilogue<NT>(acc, xh, xl, tab + (ST_FILM0 * 3 + 0) * HdP, tab + (ST_FILM0 * 3 + 1) * HdP,
+                          tab + (ST_FILM0 * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A], Hd, HdP, h);
+        // ---- FiLM 1..3
+#pragma unroll 1
+        for (int l = 1; l < 4; ++l) {
+            zero_acc1<NT>(acc);
+            gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+            const float* tb = tab + ((ST_FILM0 + l) * 3) * HdP;
+            film_epilogue<NT>(acc, xh, xl, tb, tb + HdP, tb + 2 * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A + l], Hd, HdP, h);
+        }
+
+        // ---- density head
+        const u32x4* head_w = reinterpret_cast<const u32x4*>(blob + L.head_w);
+        float sg[1];
+        heads<NT, 1>(xh, xl, head_w, 0, KS, h, sg);
+        const float sigma = sg[0] * head_inv[0] + head_b[0];
+        float w = 0.f, bg = 0.f;
+        if (!FUSED) {
+            if (ok && h == 0) A.out[gi * (F + 4) + F + 3] = sigma;
+        } else {
+            // compositing weights of these 32 samples (both lane halves compute identical values)
+            const int s_idx = (int)(n % S);
+            float alpha = 0.f, f = 1.f, z = 0.f;
+            if (ok) {
+                z = A.z_vals[gi];
+                const float delta = (s_idx == S - 1) ? 1e9f : A.z_vals[gi + 1] - z;
+                const float sgn = sigma + (A.noise ? A.noise[gi] : 0.f);
+                alpha = 1.f - expf(-delta * density(sgn, A.clamp_mode));
+                f = (1.f - alpha) + 1e-12f;
+            }
+            const int sl = m & (seglen - 1);
+            float incl = f;
+            for (int off = 1; off < seglen; off <<= 1) {
+                const float u = __shfl_up(incl, off, 32);
+                if (sl >= off) incl *= u;
+            }
+            float excl = __shfl_up(incl, 1, 32);
+            if (sl == 0) excl = 1.f;
+            w = alpha * (carryT * excl);
+            float wsum = w, dsum = w * z;
+            for (int off = seglen >> 1; off > 0; off >>= 1) {
+                wsum += __shfl_xor(wsum, off, 32);
+                dsum += __shfl_xor(dsum, off, 32);
+            }
+            const float z_last = __shfl(z, m | (seglen - 1), 32);
+            carryT *= __shfl(incl, 31, 32);
+            carryW += wsum;
+            carryD += dsum;
+            if (last_step) {
+                bg = 1.f - carryW;
+                if (ok && s_idx == S - 1) {
+                    if (h == 0) A.depth[gi / S] = carryD + bg * z_last;
+                    if (A.last_back) w += bg;
+                }
+            }
+            if (ok && h == 0) A.weights[gi] = w;
+            if (h == 0) { wl_lds[m] = w; wl_lds[32 + m] = bg; }
+        }
+
+        // ---- colour FiLM (+ view direction on the VALU when it is not locked)
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (A.dirs && ok) { d0 = A.dirs[gi * 3]; d1 = A.dirs[gi * 3 + 1]; d2 = A.dirs[gi * 3 + 2]; }
+        zero_acc1<NT>(acc);
+        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        film_epilogue<NT>(acc, xh, xl, tab + (ST_COLOR * 3 + 0) * HdP, tab + (ST_COLOR * 3 + 1) * HdP,
+                          tab + (ST_COLOR * 3 + 2) * HdP, A.dirs ? twd : nullptr, d0, d1, d2, invs[W_COLOR], Hd, HdP, h);
+
+        // ---- rgb head
+        float cc[3];
+        heads<NT, 3>(xh, xl, head_w, 1, KS, h, cc);
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-(cc[c] * head_inv[1 + c] + head_b[1 + c])));
+
+        // ---- feature head, sample-major accumulator
+        zero_acc1<NT>(acc);
+        gemm_x3<NT, KS, true>(acc, xh, xl, ring);
+        const float inv_f = invs[W_FEAT];
+        if (!FUSED) {
+            if (ok && h == 0) {
+                A.out[gi * (F + 4) + 0] = rgb[0];
+                A.out[gi * (F + 4) + 1] = rgb[1];
+                A.out[gi * (F + 4) + 2] = rgb[2];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nn = nt * 32 + m;
+                if (nn >= F) continue;
+                const float bias = tfeat[nn];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r >> 2) * 8 + 4 * h + (r & 3);
+                    const int64_t pn = n0 + row;
+                    if (pn < N) A.out[((int64_t)b * N + pn) * (F + 4) + 3 + nn] = fmaf(acc[nt][r], inv_f, bias);
+                }
+            }
+        } else {
+            const int C = F + 3;
+            // colour: weighted sum over the lanes of each ray
+            {
+                float v[3] = {w * rgb[0], w * rgb[1], w * rgb[2]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    for (int off = seglen >> 1; off > 0; off >>= 1) v[c] += __shfl_xor(v[c], off, 32);
+                // lanes 0..2 of each segment (h == 0) own one colour channel
+                const int sl = m & (seglen - 1);
+                float mine = sl == 0 ? v[0] : sl == 1 ? v[1] : v[2];
+                if (S > 32) {                      // one ray per wave: accumulate over its steps
+                    rgbacc += mine;
+                    mine = rgbacc;
+                }
+                if (last_step && h == 0 && sl < 3 && ok) {
+                    const int64_t ray = gi / S;
+                    A.feats[ray * C + sl] = mine + (A.white_back ? bg : 0.f);
+                }
+            }
+            // features: sum over the rows (samples) of each ray held in this lane's accumulator registers
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float wr[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wl_lds + rg * 8 + 4 * h);
+                wr[rg * 4 + 0] = w4.x; wr[rg * 4 + 1] = w4.y; wr[rg * 4 + 2] = w4.z; wr[rg * 4 + 3] = w4.w;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nn = nt * 32 + m;
+                const bool okn = nn < F;
+                const float bias = tfeat[okn ? nn : 0];
+                float s8[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float s = fmaf(acc[nt][rg * 4 + 0], inv_f, bias) * wr[rg * 4 + 0];
+                    s = fmaf(fmaf(acc[nt][rg * 4 + 1], inv_f, bias), wr[rg * 4 + 1], s);
+                    s = fmaf(fmaf(acc[nt][rg * 4 + 2], inv_f, bias), wr[rg * 4 + 2], s);
+                    s = fmaf(fmaf(acc[nt][rg * 4 + 3], inv_f, bias), wr[rg * 4 + 3], s);
+                    s8[rg] = s + __shfl_xor(s, 32, 64);
+                }
+                if (S >= 32) {
+                    rayacc[nt] += (s8[0] + s8[1]) + (s8[2] + s8[3]);
+                    if (last_step && okn && h == 0 && n0 < N) {
+                        const int64_t ray = ((int64_t)b * N + n0) / S;
+                        A.feats[ray * C + 3 + nn] = rayacc[nt] + (A.white_back ? wl_lds[32] : 0.f);
+                    }
+                } else {
+                    const int g8 = S >> 3;                 // 8-row groups per ray: 1 or 2
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if (rg % g8 != 0) continue;
+                        float s = s8[rg];
+                        if (g8 == 2) s += s8[rg + 1 < 4 ? rg + 1 : 3];
+                        const int64_t n_first = n0 + rg * 8;
+                        if (okn && h == 0 && n_first < N) {
+                            const int64_t ray = ((int64_t)b * N + n_first) / S;
+                            A.feats[ray * C + 3 + nn] = s + (A.white_back ? wl_lds[32 + rg * 8] : 0.f);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    ring.drain();
+}
+
+size_t lds_bytes(const LayoutX3& L) {
+    return sizeof(float) * ((size_t)ST_COUNT * 3 * L.HdP + 3 * L.HdP + L.HdP + 3 * L.HdP + 4 * 64) + H3D_RING_DEPTH * (size_t)L.NT * 2048;
+}
+
+template <int NT, bool FUSED>
+int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(field_x3_kernel<NT, FUSED>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    h3d::pre_launch();
+    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    return h3d::launch_status(FUSED ? "h3d_render_fused_x3" : "h3d_neural_field_x3");
+}
+
+template <bool FUSED>
+int launch(const Args& A, int B, int64_t groups, hipStream_t st) {
+    switch (A.L.NT) {
+        case 4: return launch_one<4, FUSED>(A, B, groups, st);
+        case 8: return launch_one<8, FUSED>(A, B, groups, st);
+        default:
+            h3d::set_error("x3 field kernel: width %d exceeds the 256 this engine keeps in registers "
+                           "(use the fp32 engine, h3d_neural_field / h3d_render_fused)", A.L.HdP);
+            return H3D_EUNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------- host-side packing
+
+uint16_t f32_to_f16_rn(float f) {            // round-to-nearest-even, handles subnormals; inputs are finite
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7bffu);          // clamp to max finite (never hit: scaled)
+    if (x < 0x38800000u) {                                             // subnormal / zero in f16
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - (int)(x >> 23);                       // 14..24
+        uint32_t r = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+float f16_to_f32(uint16_t v) {
+    const uint32_t sign = (uint32_t)(v & 0x8000u) << 16;
+    uint32_t e = (v >> 10) & 0x1f, m = v & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int s = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++s; }
+            x = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+float pow2_scale(const float* w, int64_t n, float target) {
+    float mx = 0.f;
+    for (int64_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    if (mx == 0.f) return 1.f;
+    return exp2f(floorf(log2f(target / mx)));
+}
+
+// W [n_out, ld] row-major; K range [in_begin, in_begin+in_count) -> [KSm][NT][2][64][8] f16, scaled by `scale`.
+void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, uint16_t* dst) {
+    for (int ks = 0; ks < KSm; ++ks)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * ks + 8 * (lane >> 5) + e, nn = 32 * nt + (lane & 31);
+                    float v = 0.f;
+                    if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+                    const uint16_t hi = f32_to_f16_rn(v);
+                    const uint16_t lo = f32_to_f16_rn(v - f16_to_f32(hi));
+                    const int64_t base = (((int64_t)ks * NT + nt) * 2) * 64 * 8;
+                    dst[base + lane * 8 + e] = hi;
+                    dst[base + 64 * 8 + lane * 8 + e] = lo;
+                }
+}
+
+}  // namespace
+
+extern "C" int64_t h3d_field_pack_x3_size(int Hd, int F) {
+    if (Hd < 1 || F < 1 || Hd > 256 || F > 256) return -1;
+    return make_layout(Hd, F).total;
+}
+
+extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob_) {
+    H3D_REQUIRE(p && blob_, "h3d_field_pack_x3: null pointer");
+    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_pack_x3: widths up to 256 (got %d, %d)", Hd, F);
+    const LayoutX3 L = make_layout(Hd, F);
+    unsigned char* blob = static_cast<unsigned char*>(blob_);
+    memset(blob, 0, L.total);
+    float* invs = reinterpret_cast<float*>(blob + L.inv_scale);
+    const float target = 8192.f;
+    auto mat = [&](int wi, const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, float in_scale) {
+        // scale taken over the slice actually used
+        float mx = 0.f;
+        for (int nn = 0; nn < n_out; ++nn)
+            for (int k = 0; k < in_count; ++k) mx = fmaxf(mx, fabsf(w[(int64_t)nn * ld + in_begin + k]));
+        const float sc = mx > 0.f ? exp2f(floorf(log2f(target / mx))) : 1.f;
+        pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]));
+        invs[wi] = 1.f / (sc * in_scale);
+        return sc;
+    };
+    mat(W_GEO, p->w_geo, 31, 0, 31, Hd, 2, kSIn);
+    // FiLM 0: both halves must share one scale because they accumulate into the same registers
+    {
+        const float sc = pow2_scale(p->w_film[0], (int64_t)Hd * 2 * Hd, target);
+        pack_x3(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0A]));
+        pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]));
+        invs[W_F0A] = invs[W_F0B] = 1.f / (sc * kSA);
+    }
+    for (int l = 1; l < 4; ++l) mat(W_F0A + l, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA);
+    mat(W_COLOR, p->w_color, Hd + 3, 3, Hd, Hd, L.KS, kSA);
+    mat(W_FEAT, p->w_feat, Hd, 0, Hd, F, L.KS, kSA);
+    float* bias = reinterpret_cast<float*>(blob + L.bias);
+    float* wdir = reinterpret_cast<float*>(blob + L.wdir);
+    float* wcoord = reinterpret_cast<float*>(blob + L.wcoord);
+    for (int nn = 0; nn < Hd; ++nn) {
+        bias[ST_GEO * L.HdP + nn] = p->b_geo[nn];
+        bias[ST_COORD * L.HdP + nn] = p->b_coord[nn];
+        for (int l = 0; l < 4; ++l) bias[(ST_FILM0 + l) * L.HdP + nn] = p->b_film[l][nn];
+        bias[ST_COLOR * L.HdP + nn] = p->b_color[nn];
+        for (int c = 0; c < 3; ++c) {
+            wdir[c * L.HdP + nn] = p->w_color[(int64_t)nn * (Hd + 3) + c];
+            wcoord[c * L.HdP + nn] = p->w_coord[(int64_t)nn * 3 + c];
+        }
+    }
+    float* bf = reinterpret_cast<float*>(blob + L.b_feat);
+    for (int nn = 0; nn < F; ++nn) bf[nn] = p->b_feat[nn];
+    // heads: [head][hi/lo][ks][half][8]
+    uint16_t* hw = reinterpret_cast<uint16_t*>(blob + L.head_w);
+    float* hinv = reinterpret_cast<float*>(blob + L.head_inv);
+    float* hb = reinterpret_cast<float*>(blob + L.head_b);
+    for (int hd = 0; hd < 4; ++hd) {
+        const float* w = hd == 0 ? p->w_sigma : p->w_rgb + (int64_t)(hd - 1) * Hd;
+        const float sc = pow2_scale(w, Hd, target);
+        for (int ks = 0; ks < L.KS; ++ks)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * ks + 8 * hh + e;
+                    const float v = k < Hd ? w[k] * sc : 0.f;
+                    const uint16_t hi = f32_to_f16_rn(v), lo = f32_to_f16_rn(v - f16_to_f32(hi));
+                    hw[((((int64_t)hd * 2 + 0) * L.KS + ks) * 2 + hh) * 8 + e] = hi;
+                    hw[((((int64_t)hd * 2 + 1) * L.KS + ks) * 2 + hh) * 8 + e] = lo;
+                }
+        hinv[hd] = 1.f / (sc * kSA);
+        hb[hd] = hd == 0 ? p->b_sigma[0] : p->b_rgb[hd - 1];
+    }
+    return H3D_OK;
+}
+
+static int check_x3(const void* packed, const float* points, const float* geo, const float* freq, const float* phase,
+                    int B, int64_t N, int Hd, int F, int geo_stride) {
+    H3D_REQUIRE(packed && points && geo && freq && phase, "x3 field: null pointer");
+    H3D_REQUIRE(h3d::aligned16(packed), "x3 field: packed weights must be 16-byte aligned");
+    H3D_REQUIRE(B >= 0 && B <= 65535 && N >= 0, "x3 field: bad B=%d N=%lld", B, (long long)N);
+    H3D_REQUIRE(Hd >= 1 && F >= 1, "x3 field: bad widths");
+    H3D_REQUIRE(geo_stride >= 31, "x3 field: geo_stride=%d must be >= 31", geo_stride);
+    if (Hd > 256 || F > 256) {
+        h3d::set_error("x3 field kernel: widths up to 256 (got %d/%d); use the fp32 engine", Hd, F);
+        return H3D_EUNSUPPORTED;
+    }
+    return H3D_OK;
+}
+
+extern "C" int h3d_neural_field_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                                   int geo_stride, float input_scaler, h3d_stream_t stream) {
+    int rc = check_x3(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
+    if (rc) return rc;
+    H3D_REQUIRE(out, "h3d_neural_field_x3: null output");
+    if (B == 0 || N == 0) return H3D_OK;
+    Args A{};
+    A.blob = static_cast<const unsigned char*>(packed);
+    A.points = points; A.geo = geo; A.dirs = dirs; A.freq = freq; A.phase = phase; A.out = out;
+    A.N = N; A.Hd = Hd; A.F = F; A.geo_stride = geo_stride; A.S = 32; A.input_scaler = input_scaler;
+    A.L = make_layout(Hd, F);
+    const int64_t groups = (N + 127) / 128;
+    H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_neural_field_x3: N too large");
+    return launch<false>(A, B, groups, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int h3d_render_fused_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, const float* z_vals, const float* noise,
+                                   float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                                   int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                                   h3d_stream_t stream) {
+    const int64_t N = (int64_t)R * S;
+    int rc = check_x3(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
+    if (rc) return rc;
+    H3D_REQUIRE(z_vals && feats && depth && weights, "h3d_render_fused_x3: null pointer");
+    H3D_REQUIRE(clamp_mode == 0 || clamp_mode == 1, "h3d_render_fused_x3: clamp_mode must be 0 (relu) or 1 (softplus)");
+    H3D_REQUIRE(R >= 0 && S >= 1, "h3d_render_fused_x3: bad R=%d S=%d", R, S);
+    const bool ok_s = (S >= 8 && S <= 32 && (S & (S - 1)) == 0) || (S > 32 && S % 32 == 0);
+    if (!ok_s) {
+        h3d::set_error("h3d_render_fused_x3: S=%d unsupported (needs 8, 16, 32 or a multiple of 32)", S);
+        return H3D_EUNSUPPORTED;
+    }
+    if (B == 0 || N == 0) return H3D_OK;
+    Args A{};
+    A.blob = static_cast<const unsigned char*>(packed);
+    A.points = points; A.geo = geo; A.dirs = dirs; A.freq = freq; A.phase = phase;
+    A.z_vals = z_vals; A.noise = noise; A.feats = feats; A.depth = depth; A.weights = weights;
+    A.N = N; A.Hd = Hd; A.F = F; A.geo_stride = geo_stride; A.S = S; A.input_scaler = input_scaler;
+    A.clamp_mode = clamp_mode; A.last_back = last_back; A.white_back = white_back;
+    A.L = make_layout(Hd, F);
+    const int unit = S > 32 ? S : 32;
+    const int64_t units = (N + unit - 1) / unit;
+    const int64_t groups = (units + 3) / 4;
+    H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_render_fused_x3: too many rays");
+    return launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+}

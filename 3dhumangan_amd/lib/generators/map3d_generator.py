@@ -342,7 +342,7 @@ class Map3DGenerator(nn.Module):
         scaler = 2.0 / self.side_length
         clamp_mode = kwargs["clamp_mode"]
         last_back, white_back = kwargs.get("last_back", False), kwargs.get("white_back", False)
-        can_fuse = fused and ((8 <= S <= 64 and S & (S - 1) == 0) or (S > 64 and S % 64 == 0))
+        can_fuse = fused and self.neural_field.fused_supported(S)
         if can_fuse:
             with stage(self, "render_fused"):
                 feats, depths, weights = self.neural_field.render(pts, freq, phase, geo, dirs, z_vals, S,

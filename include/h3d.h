@@ -118,6 +118,24 @@ int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w,
                         h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A5 / A5+A6 on the f16 matrix cores with split ("x3") operands: every fp32 operand is carried as hi + lo f16
+ * halves and a product is hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class results, 16/3 of the fp32 MFMA
+ * rate).  Same arguments and results as h3d_neural_field / h3d_render_fused; widths up to 256; the fused variant
+ * takes S in {8, 16, 32} or a multiple of 32.  Weights are packed by h3d_field_pack_x3 (its own blob format).
+ */
+int64_t h3d_field_pack_x3_size(int Hd, int F);
+int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+int h3d_neural_field_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                        const float* freq, const float* phase, float* out,
+                        int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler,
+                        h3d_stream_t stream);
+int h3d_render_fused_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                        const float* freq, const float* phase, const float* z_vals, const float* noise,
+                        float* feats, float* depth, float* weights,
+                        int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
+                        int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A7+A8+A9  SPADE synthesis network, eval mode == SynthesisNetwork.forward
  *     (lib/generators/map3d_generator.py:58-97) over SPADEBlock (lib/components/map3d_layers.py:218-238),
  *     fed by SynthesisInput (:260-275) and the bilinear F.interpolate of map3d_generator.py:244-245.

@@ -13,15 +13,20 @@ DEV = "cuda"
 FIELD_TOL = 1e-3      # north_star: within 1e-3 relative fp32; measured errors are ~1e-5
 
 
-def make_field(state, hidden, feature, prefix="neural_field."):
+ENGINES = ["f16x3", "f32"]
+
+
+def make_field(state, hidden, feature, prefix="neural_field.", precision=None):
     net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=hidden, hidden_dim=hidden, geo_feature_dim=31,
                                 output_dim=feature + 4, feature_dim=feature, num_blocks=4)
     sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
     net.load_state_dict(sd)
+    if precision:
+        net.precision = precision
     return net.to(DEV)
 
 
-def random_state(hidden, feature, seed):
+def random_state(hidden, feature, seed, precision=None):
     torch.manual_seed(seed)
     net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=hidden, hidden_dim=hidden, geo_feature_dim=31,
                                 output_dim=feature + 4, feature_dim=feature, num_blocks=4)
@@ -29,13 +34,16 @@ def random_state(hidden, feature, seed):
         for p in net.parameters():
             if p.ndim == 1:
                 p.add_(0.05 * torch.randn_like(p))
+    if precision:
+        net.precision = precision
     return {"neural_field." + k: v.detach().clone() for k, v in net.state_dict().items()}, net.to(DEV)
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name,hidden", [("field_h64", 64), ("field_h40", 40)])
-def test_field_golden(name, hidden):
+def test_field_golden(name, hidden, engine):
     g = load_golden(name)
-    net = make_field(g["state"], hidden, hidden)
+    net = make_field(g["state"], hidden, hidden, precision=engine)
     out = net(g["points"].to(DEV), g["freq"].to(DEV), g["phase"].to(DEV), g["geo"].to(DEV), g["dirs"].to(DEV),
               input_scaler=2.0 / 2.85)
     assert out.shape == g["out"].shape
@@ -45,12 +53,13 @@ def test_field_golden(name, hidden):
         assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
-def test_field_in_generator_fixture(name):
+def test_field_in_generator_fixture(name, engine):
     g = load_golden(name)
     s, cfg = g["stage"], g["meta"]
     H = cfg["hidden_dim"]
-    net = make_field(g["state"], H, cfg["feature_dim"])
+    net = make_field(g["state"], H, cfg["feature_dim"], precision=engine)
     B = s["points"].shape[0]
     # lock_view_dependence: pass None (kernel folds dir=(0,0,-1)) and the explicit tensor; both must agree
     a = net(s["points"].to(DEV), s["freq"].to(DEV), s["phase"].to(DEV), s["geo"].to(DEV), None,
@@ -62,10 +71,11 @@ def test_field_in_generator_fixture(name):
     assert rel_err(b.cpu(), ref) < FIELD_TOL
 
 
-@pytest.mark.parametrize("hidden,feature,N", [(256, 256, 200), (384, 384, 130), (420, 420, 64), (32, 32, 1),
-                                              (128, 96, 77)])
-def test_field_real_widths_vs_oracle(hidden, feature, N):
-    state, net = random_state(hidden, feature, seed=hidden)
+@pytest.mark.parametrize("hidden,feature,N,engine", [(256, 256, 200, "f32"), (256, 256, 200, "f16x3"), (384, 384, 130, "f32"),
+                                                     (420, 420, 64, "f32"), (32, 32, 1, "f32"), (32, 32, 1, "f16x3"),
+                                                     (128, 96, 77, "f32"), (128, 96, 77, "f16x3"), (200, 256, 333, "f16x3")])
+def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
+    state, net = random_state(hidden, feature, seed=hidden, precision=engine)
     g = torch.Generator().manual_seed(N)
     B = 2
     pts = torch.rand(B, N, 3, generator=g) * 2 - 1
@@ -80,10 +90,13 @@ def test_field_real_widths_vs_oracle(hidden, feature, N):
         assert rel_err(out.cpu()[..., sl], ref[..., sl]) < FIELD_TOL, sl
 
 
-@pytest.mark.parametrize("S,R,hidden", [(8, 20, 32), (16, 30, 48), (32, 9, 64), (64, 5, 256), (128, 3, 64), (32, 7, 384)])
+@pytest.mark.parametrize("S,R,hidden,engine", [(8, 20, 32, "f32"), (16, 30, 48, "f32"), (32, 9, 64, "f32"), (64, 5, 256, "f32"),
+                                                (128, 3, 64, "f32"), (32, 7, 384, "f32"), (8, 20, 32, "f16x3"),
+                                                (16, 30, 48, "f16x3"), (32, 9, 64, "f16x3"), (64, 5, 256, "f16x3"),
+                                                (128, 3, 64, "f16x3"), (32, 7, 256, "f16x3"), (96, 3, 128, "f16x3")])
 @pytest.mark.parametrize("last_back,white_back,clamp", [(False, True, "relu"), (True, False, "softplus")])
-def test_fused_render_vs_oracle(S, R, hidden, last_back, white_back, clamp):
-    state, net = random_state(hidden, hidden, seed=S + hidden)
+def test_fused_render_vs_oracle(S, R, hidden, engine, last_back, white_back, clamp):
+    state, net = random_state(hidden, hidden, seed=S + hidden, precision=engine)
     # make densities matter: scale the sigma head up
     with torch.no_grad():
         net.sigma_layer.weight.mul_(40.0)
@@ -107,6 +120,14 @@ def test_fused_render_vs_oracle(S, R, hidden, last_back, white_back, clamp):
         assert a.shape == b.shape, nm
         assert rel_err(a.cpu(), b) < FIELD_TOL, nm
     assert rel_err(got[0].cpu()[..., :3], ref[0][..., :3]) < FIELD_TOL
+
+
+def test_x3_engine_rejects_wide_models():
+    h3dlib = importlib.import_module("3dhumangan_amd._lib")
+    _, net = random_state(384, 384, seed=0, precision="f16x3")
+    with pytest.raises(h3dlib.H3DError):
+        net(torch.zeros(1, 4, 3, device=DEV), torch.zeros(1, 1536, device=DEV), torch.zeros(1, 1536, device=DEV),
+            torch.zeros(1, 4, 31, device=DEV), None)
 
 
 def test_fused_rejects_unsupported_steps():

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--R", type=int, default=4608)
     ap.add_argument("--S", type=int, default=64)
     ap.add_argument("--F", type=int, default=256)
+    ap.add_argument("--engine", default="")
     a = ap.parse_args()
     dev = "cuda"
     res = {}
@@ -57,6 +58,8 @@ def main():
         H = a.F
         net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=H, hidden_dim=H, geo_feature_dim=31, output_dim=H + 4,
                                     feature_dim=H, num_blocks=4).to(dev)
+        if a.engine:
+            net.precision = a.engine
         N = a.R * a.S
         pts = torch.rand(a.B, N, 3, device=dev) * 2 - 1
         geo = torch.rand(a.B, N, 31, device=dev) * 2 - 1
