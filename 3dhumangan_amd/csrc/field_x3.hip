@@ -22,7 +22,7 @@
 //   fused A6    the feature head is evaluated with the operands swapped (rows = samples), so the weighted sum over
 //               the samples of a ray is a sum over accumulator registers; compositing weights come from a
 //               segmented 32-lane product scan (S = 8..32: 32/S rays per wave step; S = 64, 128: carry).
-#include "field_common.hpp"
+#include "x3_common.hpp"
 #include <string.h>
 #include <math.h>
 
@@ -30,15 +30,11 @@ using namespace h3d;
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef F16::vec8 half8;
+typedef F16::vec2 half2v;
 
 constexpr float kSA = 4096.f;      // activation scale (|sin| <= 1)
 constexpr float kSIn = 64.f;       // input scale (coords / geometry features, |x| < 1000)
-#ifndef H3D_RING_DEPTH
-#define H3D_RING_DEPTH 6
-#endif
 
 enum { ST_GEO = 0, ST_COORD, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
 // weight matrices in STREAM (consumption) order
@@ -107,143 +103,15 @@ __device__ __forceinline__ float density(float x, int clamp_mode) {
     return fmaxf(x, 0.f);
 }
 
-__device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, half2v{a, b}); }
-
-// x (already scaled) -> hi, lo halves
-__device__ __forceinline__ void split(float xs, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)xs;
-    lo = (_Float16)(xs - (float)hi);
-}
-
 // 8 fp32 values of one lane -> hi / lo B-fragments
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& fh, half8& fl) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         _Float16 h, l;
-        split(v[e] * scale, h, l);
+        split<F16>(v[e] * scale, h, l);
         fh[e] = h;
         fl[e] = l;
     }
-}
-
-// Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
-// ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
-template <int NT>
-struct WeightRing {
-    static constexpr int kBuf = H3D_RING_DEPTH;
-    static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
-    static constexpr int kStage = NT * 2048;
-    const unsigned char* gsrc;    // global stream + this lane's slot
-    unsigned char* ring;          // LDS ring base
-    int total, issue_pos, issue_buf, cur_buf, wave, lane;
-
-    __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
-        gsrc = stream + (w * kChunks) * 1024 + l * 16;
-        ring = lds;
-        total = total_stages;
-        issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
-#pragma unroll
-        for (int i = 0; i < kBuf - 1; ++i) issue();
-    }
-    __device__ __forceinline__ void issue() {
-        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage;
-        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks) * 1024;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
-                                             (__attribute__((address_space(3))) void*)(d + c * 1024), 16, 0, 0);
-        issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
-        issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
-    }
-    // Make the next stage readable by every wave, then refill the buffer everybody finished with.
-    __device__ __forceinline__ const unsigned char* acquire() {
-        // lgkmcnt(0): this wave's ds_reads of the stage whose buffer is about to be refilled have completed
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kBuf - 2) * kChunks) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue();
-        const unsigned char* r = ring + cur_buf * kStage + lane * 16;
-        cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
-        return r;
-    }
-    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
-
-// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
-//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].
-// The three partial products of a tile are issued NT MFMAs apart (no back-to-back dependent accumulations).
-template <int NT>
-struct WFrag { half8 h[NT], l[NT]; };
-
-template <int NT>
-__device__ __forceinline__ void load_wfrag_pair(WFrag<NT>& f, const unsigned char* st, int p) {
-#pragma unroll
-    for (int nt = 2 * p; nt < 2 * p + 2; ++nt) {
-        f.h[nt] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 0) * 1024));
-        f.l[nt] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 1) * 1024));
-    }
-}
-
-template <bool SWAP>
-__device__ __forceinline__ f32x16 mm(const half8& w, const half8& x, const f32x16& c) {
-    return SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0)
-                : __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
-}
-
-// One k-step: the 3 partial products of tile pair p (hi*hi, hi*lo, lo*hi; the two tiles alternate so no MFMA
-// depends on its predecessor), with the 4 ds_read_b128 that fetch the NEXT k-step's fragments of the same tile
-// pair issued just ahead of them.  Never more than a handful of LDS reads are outstanding, so the compiler's
-// lgkmcnt waits stay exact (the counter saturates at 15) and no MFMA waits for a read issued in its own k-step.
-template <int NT, bool SWAP, bool PREFETCH>
-__device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFrag<NT>& cur, WFrag<NT>& nxt, const unsigned char* st_next,
-                                         const half8& xh, const half8& xl) {
-#pragma unroll
-    for (int p = 0; p < NT / 2; ++p) {
-        if (PREFETCH) load_wfrag_pair<NT>(nxt, st_next, p);
-        const int a = 2 * p, b = 2 * p + 1;
-        acc[a] = mm<SWAP>(cur.h[a], xh, acc[a]);
-        acc[b] = mm<SWAP>(cur.h[b], xh, acc[b]);
-        acc[a] = mm<SWAP>(cur.h[a], xl, acc[a]);
-        acc[b] = mm<SWAP>(cur.h[b], xl, acc[b]);
-        acc[a] = mm<SWAP>(cur.l[a], xh, acc[a]);
-        acc[b] = mm<SWAP>(cur.l[b], xh, acc[b]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
-//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].   KS is even.
-template <int NT, int KS, bool SWAP>
-__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const half8 (&xh)[2 * NT], const half8 (&xl)[2 * NT],
-                                        WeightRing<NT>& ring) {
-    static_assert(KS % 2 == 0 && NT % 2 == 0, "k-steps and tiles come in pairs");
-    WFrag<NT> f0, f1;
-    {
-        const unsigned char* st = ring.acquire();
-#pragma unroll
-        for (int p = 0; p < NT / 2; ++p) load_wfrag_pair<NT>(f0, st, p);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-        const unsigned char* s1 = ring.acquire();
-        __builtin_amdgcn_sched_barrier(0);
-        kstep_x3<NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks]);
-        if (ks + 2 < KS) {
-            const unsigned char* s2 = ring.acquire();
-            __builtin_amdgcn_sched_barrier(0);
-            kstep_x3<NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1]);
-        } else {
-            kstep_x3<NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1]);
-        }
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void zero_acc1(f32x16 (&acc)[NT]) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 }
 
 // Epilogue of a feature-major accumulator: y = sin(f * (acc*inv + b [+ wdir . dir]) + p), split to f16 hi/lo and
@@ -278,26 +146,13 @@ __device__ __forceinline__ void film_epilogue(const f32x16 (&acc)[NT], half8 (&x
             for (int q = 0; q < 4; ++q) {
                 float y = sin_hw(fmaf(ff[q], fmaf(acc[nt][rg * 4 + q], inv, add[q]), pp[q]));
                 y = (n + q < Hd) ? y : 0.f;
-                split(y * kSA, hh[q], ll[q]);
+                split<F16>(y * kSA, hh[q], ll[q]);
             }
-            H[rg][0] = pack2(hh[0], hh[1]); H[rg][1] = pack2(hh[2], hh[3]);
-            Lo[rg][0] = pack2(ll[0], ll[1]); Lo[rg][1] = pack2(ll[2], ll[3]);
+            H[rg][0] = pack2<F16>(hh[0], hh[1]); H[rg][1] = pack2<F16>(hh[2], hh[3]);
+            Lo[rg][0] = pack2<F16>(ll[0], ll[1]); Lo[rg][1] = pack2<F16>(ll[2], ll[3]);
         }
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            // lanes 0-31 keep rows 8rg..+3 of register group 2pr and receive rows +4..+7 from lanes 32-63;
-            // lanes 32-63 receive rows of group 2pr+1 from lanes 0-31 and keep their own
-            u32x4 fh, fl;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                auto a = __builtin_amdgcn_permlane32_swap(H[2 * pr][c], H[2 * pr + 1][c], false, false);
-                fh[c] = a[0]; fh[2 + c] = a[1];
-                auto bq = __builtin_amdgcn_permlane32_swap(Lo[2 * pr][c], Lo[2 * pr + 1][c], false, false);
-                fl[c] = bq[0]; fl[2 + c] = bq[1];
-            }
-            xh[2 * nt + pr] = __builtin_bit_cast(half8, fh);
-            xl[2 * nt + pr] = __builtin_bit_cast(half8, fl);
-        }
+        relayout_tile<F16>(H, xh[2 * nt], xh[2 * nt + 1]);
+        relayout_tile<F16>(Lo, xl[2 * nt], xl[2 * nt + 1]);
     }
 }
 
@@ -428,13 +283,13 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 split8(v, kSIn, ih[ks], il[ks]);
             }
             zero_acc1<NT>(acc);
-            gemm_x3<NT, 2, false>(acc, ih, il, ring);
+            gemm_x3<F16, NT, 2, KS, false>(acc, ih, il, ring);
             film_epilogue<NT>(acc, xh, xl, tab + (ST_GEO * 3 + 0) * HdP, tab + (ST_GEO * 3 + 1) * HdP,
                               tab + (ST_GEO * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_GEO], Hd, HdP, h);
         }
         // ---- FiLM 0, geometry half:  acc = W0b * geo_act
         zero_acc1<NT>(acc);
-        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
         // ---- coordinate first layer (K = 3) on the VALU, in fp32, straight into B-fragment layout
         {
             const float* __restrict__ p = A.points + gi * 3;
@@ -463,14 +318,14 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             }
         }
         // ---- FiLM 0, coordinate half: acc += W0a * coord_act
-        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
         film_epilogue<NT>(acc, xh, xl, tab + (ST_FILM0 * 3 + 0) * HdP, tab + (ST_FILM0 * 3 + 1) * HdP,
                           tab + (ST_FILM0 * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A], Hd, HdP, h);
         // ---- FiLM 1..3
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
             zero_acc1<NT>(acc);
-            gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+            gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
             const float* tb = tab + ((ST_FILM0 + l) * 3) * HdP;
             film_epilogue<NT>(acc, xh, xl, tb, tb + HdP, tb + 2 * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A + l], Hd, HdP, h);
         }
@@ -527,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
         if (A.dirs && ok) { d0 = A.dirs[gi * 3]; d1 = A.dirs[gi * 3 + 1]; d2 = A.dirs[gi * 3 + 2]; }
         zero_acc1<NT>(acc);
-        gemm_x3<NT, KS, false>(acc, xh, xl, ring);
+        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
         film_epilogue<NT>(acc, xh, xl, tab + (ST_COLOR * 3 + 0) * HdP, tab + (ST_COLOR * 3 + 1) * HdP,
                           tab + (ST_COLOR * 3 + 2) * HdP, A.dirs ? twd : nullptr, d0, d1, d2, invs[W_COLOR], Hd, HdP, h);
 
@@ -540,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 
         // ---- feature head, sample-major accumulator
         zero_acc1<NT>(acc);
-        gemm_x3<NT, KS, true>(acc, xh, xl, ring);
+        gemm_x3<F16, NT, KS, KS, true>(acc, xh, xl, ring);
         const float inv_f = invs[W_FEAT];
         if (!FUSED) {
             if (ok && h == 0) {

@@ -1,0 +1,388 @@
+// A7 + A8 + A9 on the bf16 matrix cores with split ("x3") operands, for gfx950.
+//
+// Same network, same exact host-side folding and same descriptor as synthesis.hip (see there for the reference
+// citations and the algebra); different engine, shared with field_x3.hip (x3_common.hpp):
+//   * a wavefront owns 32 pixels and all C channels; activations stay in registers from the coordinate input to
+//     the last ToRGB (accumulator layout -> next conv's B fragments by v_permlane32_swap), no barrier other than
+//     the weight ring's;
+//   * every conv / gamma / beta matrix is carried as bf16 hi + lo and a product is hi*hi + hi*lo + lo*hi with
+//     fp32 accumulation (16 significant bits per operand, ~1e-5 on the image -- there is no sine after these
+//     GEMMs to amplify it, and bf16 keeps the fp32 exponent range so unnormalised activations cannot overflow);
+//   * all weights of one tile form ONE linear stream in consumption order, pulled once per workgroup from L2 into
+//     the LDS ring by LDS-DMA.
+// Supported: C <= 256, per-pixel-style blocks only before the first skip block (true for map3d_mode mixed /
+// isolated with the shipped mod_blocks); anything else stays on the fp32 engine (h3d_synthesis).
+#include "x3_common.hpp"
+
+using namespace h3d;
+
+namespace {
+
+typedef BF16::vec8 bf8;
+constexpr int kShared = 128;
+constexpr int kRingDepth = 4;      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
+
+struct Args {
+    const unsigned char* stream;
+    const float* tables;
+    h3d_synth_desc D;
+    const float* G;
+    const float* cst;
+    const float* ab;
+    float* rgb;
+    int table_floats, total_stages, g_channels, Hr, Wr, n_cst, n_ab, H, W, HdP, C, first_skip;
+};
+
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
+
+__device__ __forceinline__ float linspace_pm1(int n, int i) {
+    if (n == 1) return -1.f;
+    const float step = 2.f / (float)(n - 1);
+    return (i < n / 2) ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+
+// fp32 values of one accumulator tile set -> bf16 hi/lo B fragments.  val(nt, rg) returns the 4 values of
+// register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
+template <int NT, typename F>
+__device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], F val) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        unsigned Hh[4][2], Ll[4][2];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 y = val(nt, rg);
+            __bf16 a[4], c[4];
+            split<BF16>(y.x, a[0], c[0]);
+            split<BF16>(y.y, a[1], c[1]);
+            split<BF16>(y.z, a[2], c[2]);
+            split<BF16>(y.w, a[3], c[3]);
+            Hh[rg][0] = pack2<BF16>(a[0], a[1]); Hh[rg][1] = pack2<BF16>(a[2], a[3]);
+            Ll[rg][0] = pack2<BF16>(c[0], c[1]); Ll[rg][1] = pack2<BF16>(c[2], c[3]);
+        }
+        relayout_tile<BF16>(Hh, xh[2 * nt], xh[2 * nt + 1]);
+        relayout_tile<BF16>(Ll, xl[2 * nt], xl[2 * nt + 1]);
+        // bound the scheduler's load hoisting to one tile: the table reads of all tiles at once would cost
+        // hundreds of registers on top of the resident activations
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
+    constexpr int KS = 2 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HdP = A.HdP, C = A.C;
+    float* tab0 = smem;                                      // [table_floats] static tables (descriptor offsets)
+    float* ab0 = tab0 + ((A.table_floats + 3) & ~3);         // [n_ab][2][HdP] this sample's constant-style affines
+    float* cst0 = ab0 + A.n_ab * 2 * HdP;                    // [n_cst][128]   this sample's shared-MLP constants
+    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(cst0 + A.n_cst * kShared);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int64_t HW = (int64_t)A.H * A.W;
+    const h3d_synth_desc& D = A.D;
+
+    for (int i = t; i < A.table_floats; i += 256) tab0[i] = A.tables[i];
+    for (int i = t; i < A.n_ab * 2 * HdP; i += 256) ab0[i] = A.ab[(int64_t)b * A.n_ab * 2 * HdP + i];
+    for (int i = t; i < A.n_cst * kShared; i += 256) cst0[i] = A.cst[(int64_t)b * A.n_cst * kShared + i];
+    __syncthreads();
+
+    WeightRing<NT, kRingDepth> ring;
+    ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
+
+    // ---- this lane's pixel: synthesis-input coordinates and bilinear taps into the low-res maps
+    int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
+    const bool okp = p < HW;
+    if (!okp) p = HW - 1;
+    const int Y = (int)(p / A.W), X = (int)(p % A.W);
+    const float ci = linspace_pm1(A.H, Y), cj = linspace_pm1(A.W, X);
+    float sy = fmaxf(((float)Y + 0.5f) * ((float)A.Hr / (float)A.H) - 0.5f, 0.f);
+    float sx = fmaxf(((float)X + 0.5f) * ((float)A.Wr / (float)A.W) - 0.5f, 0.f);
+    const int y0 = min((int)sy, A.Hr - 1), x0 = min((int)sx, A.Wr - 1);
+    const int y1 = min(y0 + 1, A.Hr - 1), x1 = min(x0 + 1, A.Wr - 1);
+    const float ty = sy - (float)y0, tx = sx - (float)x0;
+    const float* __restrict__ Gb = A.G + (int64_t)b * A.Hr * A.Wr * A.g_channels;
+    const float* g00 = Gb + (int64_t)(y0 * A.Wr + x0) * A.g_channels;
+    const float* g01 = Gb + (int64_t)(y0 * A.Wr + x1) * A.g_channels;
+    const float* g10 = Gb + (int64_t)(y1 * A.Wr + x0) * A.g_channels;
+    const float* g11 = Gb + (int64_t)(y1 * A.Wr + x1) * A.g_channels;
+
+    f32x16 x[NT];
+    bf8 xh[KS], xl[KS];
+    float rgb_acc[3] = {0.f, 0.f, 0.f};
+
+    // ---- A8: x0 = sin(w0*i + w1*j + b) in accumulator layout
+    {
+        const float* win = tab0 + D.w_in;
+        const float* bin = tab0 + D.b_in;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = nt * 32 + rg * 8 + 4 * h;
+                const float4 w0 = *reinterpret_cast<const float4*>(win + n);
+                const float4 w1 = *reinterpret_cast<const float4*>(win + HdP + n);
+                const float4 bb = *reinterpret_cast<const float4*>(bin + n);
+                x[nt][rg * 4 + 0] = (n + 0 < C) ? sin_hw(w0.x * ci + w1.x * cj + bb.x) : 0.f;
+                x[nt][rg * 4 + 1] = (n + 1 < C) ? sin_hw(w0.y * ci + w1.y * cj + bb.y) : 0.f;
+                x[nt][rg * 4 + 2] = (n + 2 < C) ? sin_hw(w0.z * ci + w1.z * cj + bb.z) : 0.f;
+                x[nt][rg * 4 + 3] = (n + 3 < C) ? sin_hw(w0.w * ci + w1.w * cj + bb.w) : 0.f;
+            }
+    }
+
+    // constant-style SPADE: y = lrelu(x * a + b) -> fragments
+    auto const_frags = [&](const float* ab) {
+        make_frags<NT>(xh, xl, [&](int nt, int rg) {
+            const int n = nt * 32 + rg * 8 + 4 * h;
+            const float4 sc = *reinterpret_cast<const float4*>(ab + n);
+            const float4 sh = *reinterpret_cast<const float4*>(ab + HdP + n);
+            float4 y;
+            y.x = (n + 0 < C) ? lrelu(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x)) : 0.f;
+            y.y = (n + 1 < C) ? lrelu(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y)) : 0.f;
+            y.z = (n + 2 < C) ? lrelu(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z)) : 0.f;
+            y.w = (n + 3 < C) ? lrelu(fmaf(x[nt][rg * 4 + 3], sc.w, sh.w)) : 0.f;
+            return y;
+        });
+    };
+    // ToRGB: rgb += Wrgb * x + b, an fp32 dot product over this lane's half of the channels
+    auto to_rgb = [&](const float* wr) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = nt * 32 + rg * 8 + 4 * h;
+                const float4 w0 = *reinterpret_cast<const float4*>(wr + n);
+                const float4 w1 = *reinterpret_cast<const float4*>(wr + HdP + n);
+                const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * HdP + n);
+                const float v0 = x[nt][rg * 4 + 0], v1 = x[nt][rg * 4 + 1], v2 = x[nt][rg * 4 + 2], v3 = x[nt][rg * 4 + 3];
+                s0 = fmaf(v3, w0.w, fmaf(v2, w0.z, fmaf(v1, w0.y, fmaf(v0, w0.x, s0))));
+                s1 = fmaf(v3, w1.w, fmaf(v2, w1.z, fmaf(v1, w1.y, fmaf(v0, w1.x, s1))));
+                s2 = fmaf(v3, w2.w, fmaf(v2, w2.z, fmaf(v1, w2.y, fmaf(v0, w2.x, s2))));
+                if (rg == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        if (h == 0) { s0 += wr[3 * HdP + 0]; s1 += wr[3 * HdP + 1]; s2 += wr[3 * HdP + 2]; }
+        rgb_acc[0] += s0; rgb_acc[1] += s1; rgb_acc[2] += s2;
+    };
+
+    // ================= blocks before the first skip connection (either style, no residual registers) ============
+#pragma unroll 1
+    for (int blk = 0; blk < A.first_skip; ++blk) {
+        const h3d_block_desc& Bk = D.block[blk];
+        int opaque = 0;                       // keeps the loop-invariant LDS table loads inside the body
+        asm volatile("" : "+s"(opaque));
+        const float* tab = tab0 + opaque;
+        const float* abt = ab0 + opaque;
+        const float* cstt = cst0 + opaque;
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const h3d_spade_desc& Sp = Bk.spade[s];
+            f32x16 acc[NT];
+            if (Sp.pixel_style) {
+                // ---- shared-MLP activations of this lane's pixel, straight into B-fragment layout
+                bf8 ah[8], al[8];
+                const float* cs = cstt + Sp.cst_index * kShared;
+                const float tx1 = 1.f - tx, ty1 = 1.f - ty;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k0 = Sp.g_offset + ks * 16 + h * 8;
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const float4 a = *reinterpret_cast<const float4*>(g00 + k0 + q4 * 4);
+                        const float4 bq = *reinterpret_cast<const float4*>(g01 + k0 + q4 * 4);
+                        const float4 c = *reinterpret_cast<const float4*>(g10 + k0 + q4 * 4);
+                        const float4 d = *reinterpret_cast<const float4*>(g11 + k0 + q4 * 4);
+                        const float4 k4 = *reinterpret_cast<const float4*>(cs + ks * 16 + h * 8 + q4 * 4);
+                        float v[4];
+                        v[0] = (a.x * tx1 + bq.x * tx) * ty1 + (c.x * tx1 + d.x * tx) * ty + k4.x;
+                        v[1] = (a.y * tx1 + bq.y * tx) * ty1 + (c.y * tx1 + d.y * tx) * ty + k4.y;
+                        v[2] = (a.z * tx1 + bq.z * tx) * ty1 + (c.z * tx1 + d.z * tx) * ty + k4.z;
+                        v[3] = (a.w * tx1 + bq.w * tx) * ty1 + (c.w * tx1 + d.w * tx) * ty + k4.w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            __bf16 hi, lo;
+                            split<BF16>(fmaxf(v[e], 0.f), hi, lo);
+                            ah[ks][q4 * 4 + e] = hi;
+                            al[ks][q4 * 4 + e] = lo;
+                        }
+                    }
+                    // keep the 8 gathers of one k-step together: letting the scheduler hoist all 64 of them costs
+                    // 256 registers on top of the resident activations
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float* vec = tab + Sp.vec;
+                // gamma:  x <- (x*sc + sh) * (1 + gamma)
+                zero_acc1<NT>(acc);
+                gemm_x3<BF16, NT, 8, 8, false>(acc, ah, al, ring);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int n = nt * 32 + rg * 8 + 4 * h;
+                        const float4 g1 = *reinterpret_cast<const float4*>(vec + n);
+                        const float4 sc = *reinterpret_cast<const float4*>(vec + 2 * HdP + n);
+                        const float4 sh = *reinterpret_cast<const float4*>(vec + 3 * HdP + n);
+                        x[nt][rg * 4 + 0] = fmaf(x[nt][rg * 4 + 0], sc.x, sh.x) * (acc[nt][rg * 4 + 0] + g1.x);
+                        x[nt][rg * 4 + 1] = fmaf(x[nt][rg * 4 + 1], sc.y, sh.y) * (acc[nt][rg * 4 + 1] + g1.y);
+                        x[nt][rg * 4 + 2] = fmaf(x[nt][rg * 4 + 2], sc.z, sh.z) * (acc[nt][rg * 4 + 2] + g1.z);
+                        x[nt][rg * 4 + 3] = fmaf(x[nt][rg * 4 + 3], sc.w, sh.w) * (acc[nt][rg * 4 + 3] + g1.w);
+                        if (rg == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                // beta:   y = lrelu(x + beta)
+                zero_acc1<NT>(acc);
+                gemm_x3<BF16, NT, 8, 8, false>(acc, ah, al, ring);
+                make_frags<NT>(xh, xl, [&](int nt, int rg) {
+                    const int n = nt * 32 + rg * 8 + 4 * h;
+                    const float4 bt = *reinterpret_cast<const float4*>(vec + HdP + n);
+                    float4 y;
+                    y.x = (n + 0 < C) ? lrelu(x[nt][rg * 4 + 0] + acc[nt][rg * 4 + 0] + bt.x) : 0.f;
+                    y.y = (n + 1 < C) ? lrelu(x[nt][rg * 4 + 1] + acc[nt][rg * 4 + 1] + bt.y) : 0.f;
+                    y.z = (n + 2 < C) ? lrelu(x[nt][rg * 4 + 2] + acc[nt][rg * 4 + 2] + bt.z) : 0.f;
+                    y.w = (n + 3 < C) ? lrelu(x[nt][rg * 4 + 3] + acc[nt][rg * 4 + 3] + bt.w) : 0.f;
+                    return y;
+                });
+            } else {
+                const_frags(abt + Sp.ab_index * 2 * HdP);
+            }
+            // ---- conv: x <- W * y + b
+            zero_acc1<NT>(acc);
+            gemm_x3<BF16, NT, KS, KS, false>(acc, xh, xl, ring);
+            const float* bc = tab + Sp.b_conv;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
+                    x[nt][rg * 4 + 0] = acc[nt][rg * 4 + 0] + bb.x;
+                    x[nt][rg * 4 + 1] = acc[nt][rg * 4 + 1] + bb.y;
+                    x[nt][rg * 4 + 2] = acc[nt][rg * 4 + 2] + bb.z;
+                    x[nt][rg * 4 + 3] = acc[nt][rg * 4 + 3] + bb.w;
+                    if (rg == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
+    }
+
+    // ================= blocks with a skip connection (constant style only): block input kept in registers ========
+#pragma unroll 1
+    for (int blk = A.first_skip; blk < D.n_blocks; ++blk) {
+        const h3d_block_desc& Bk = D.block[blk];
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const float* tab = tab0 + opaque;
+        const float* abt = ab0 + opaque;
+        f32x16 xres[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xres[nt] = x[nt];
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const h3d_spade_desc& Sp = Bk.spade[s];
+            f32x16 acc[NT];
+            const_frags(abt + Sp.ab_index * 2 * HdP);
+            zero_acc1<NT>(acc);
+            gemm_x3<BF16, NT, KS, KS, false>(acc, xh, xl, ring);
+            const float* bc = tab + Sp.b_conv;
+            const float keep = (s == 1 && Bk.skip) ? 1.f : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
+                    x[nt][rg * 4 + 0] = fmaf(keep, xres[nt][rg * 4 + 0], acc[nt][rg * 4 + 0] + bb.x);
+                    x[nt][rg * 4 + 1] = fmaf(keep, xres[nt][rg * 4 + 1], acc[nt][rg * 4 + 1] + bb.y);
+                    x[nt][rg * 4 + 2] = fmaf(keep, xres[nt][rg * 4 + 2], acc[nt][rg * 4 + 2] + bb.z);
+                    x[nt][rg * 4 + 3] = fmaf(keep, xres[nt][rg * 4 + 3], acc[nt][rg * 4 + 3] + bb.w);
+                    if (rg == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
+    }
+    ring.drain();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = rgb_acc[c] + __shfl_xor(rgb_acc[c], 32, 64);
+        if (okp && h == 0) A.rgb[((int64_t)b * 3 + c) * HW + p] = v;
+    }
+}
+
+size_t lds_bytes(const Args& A, int NT) {
+    return sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared) +
+           (size_t)kRingDepth * NT * 2048;
+}
+
+template <int NT>
+int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    h3d::pre_launch();
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A, NT), st, A);
+    return h3d::launch_status("h3d_synthesis_x3");
+}
+
+}  // namespace
+
+extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                h3d_stream_t stream_) {
+    H3D_REQUIRE(stream && tables && desc && rgb, "h3d_synthesis_x3: null pointer");
+    H3D_REQUIRE(h3d::aligned16(stream) && h3d::aligned16(tables), "h3d_synthesis_x3: stream/tables must be 16-byte aligned");
+    H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3: n_blocks=%d", desc->n_blocks);
+    H3D_REQUIRE(B >= 0 && B <= 65535 && H >= 1 && W >= 1, "h3d_synthesis_x3: bad output shape");
+    if (desc->C > 256) {
+        h3d::set_error("h3d_synthesis_x3: width %d exceeds the 256 this engine keeps in registers (use h3d_synthesis)", desc->C);
+        return H3D_EUNSUPPORTED;
+    }
+    const int NT = desc->C > 128 ? 8 : 4;
+    int64_t want = 0;
+    bool seen_skip = false, any_pixel = false, any_const = false;
+    int first_skip = desc->n_blocks;
+    for (int k = 0; k < desc->n_blocks; ++k) {
+        if (desc->block[k].skip && !seen_skip) first_skip = k;
+        seen_skip = seen_skip || desc->block[k].skip;
+        for (int s = 0; s < 2; ++s) {
+            const h3d_spade_desc& sp = desc->block[k].spade[s];
+            if (sp.pixel_style) {
+                any_pixel = true;
+                if (seen_skip) {
+                    h3d::set_error("h3d_synthesis_x3: a per-pixel-style block after the first skip block needs a third "
+                                   "accumulator set; use h3d_synthesis");
+                    return H3D_EUNSUPPORTED;
+                }
+                H3D_REQUIRE(sp.g_offset >= 0 && sp.g_offset + kShared <= g_channels && (sp.g_offset & 3) == 0,
+                            "h3d_synthesis_x3: g_offset out of range");
+                H3D_REQUIRE(sp.cst_index >= 0 && sp.cst_index < n_cst, "h3d_synthesis_x3: cst_index out of range");
+                want += 16;
+            } else {
+                any_const = true;
+                H3D_REQUIRE(sp.ab_index >= 0 && sp.ab_index < n_ab, "h3d_synthesis_x3: ab_index out of range");
+            }
+            want += 2 * NT;
+        }
+    }
+    H3D_REQUIRE(want == total_stages, "h3d_synthesis_x3: stream has %lld stages, descriptor needs %lld",
+                (long long)total_stages, (long long)want);
+    H3D_REQUIRE(!any_pixel || (G && cst && (g_channels & 3) == 0 && h3d::aligned16(G)), "h3d_synthesis_x3: G/cst missing");
+    H3D_REQUIRE(!any_const || ab, "h3d_synthesis_x3: ab table missing");
+    H3D_REQUIRE(desc->block[desc->n_blocks - 1].to_rgb, "h3d_synthesis_x3: the last block must feed ToRGB");
+    if (B == 0) return H3D_OK;
+    Args A{};
+    A.stream = static_cast<const unsigned char*>(stream);
+    A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
+    A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
+    A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip;
+    if (lds_bytes(A, NT) > 160 * 1024) {
+        h3d::set_error("h3d_synthesis_x3: tables (%d floats) + ring do not fit the 160 KB LDS; use h3d_synthesis", table_floats);
+        return H3D_EUNSUPPORTED;
+    }
+    const int64_t groups = ((int64_t)H * W + 127) / 128;
+    H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_synthesis_x3: image too large");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    return NT == 8 ? launch_one<8>(A, B, groups, st) : launch_one<4>(A, B, groups, st);
+}

@@ -1,0 +1,187 @@
+// Shared machinery of the split-operand ("x3") matrix-core engines (field_x3.hip: f16, synthesis_x3.hip: bf16).
+//
+//   * WeightRing   workgroup-shared LDS ring filled by LDS-DMA (global_load_lds) from a linear weight stream
+//   * gemm_x3      per-wave GEMM, weights from the ring, activations as register fragments, three partial
+//                  products per tile (hi*hi, hi*lo, lo*hi) on v_mfma_f32_32x32x16_{f16,bf16}
+//   * relayout     accumulator layout -> next layer's B fragments with v_permlane32_swap (verified on hardware by
+//                  tools/probes/x3_probe.hip)
+// Fragment convention (both operands): lane l holds 8 consecutive k of row/column (l & 31): k = 16*ks + 8*(l>>5) + e.
+#pragma once
+#include "field_common.hpp"
+
+namespace h3d {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef H3D_RING_DEPTH
+#define H3D_RING_DEPTH 6
+#endif
+
+struct F16 {          // scaled f16 halves
+    typedef _Float16 elem;
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 vec2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x16 mfma(const vec8& a, const vec8& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+struct BF16 {         // bf16 halves, no scaling needed (fp32 exponent range)
+    typedef __bf16 elem;
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 vec2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x16 mfma(const vec8& a, const vec8& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void split(float xs, typename T::elem& hi, typename T::elem& lo) {
+    hi = (typename T::elem)xs;
+    lo = (typename T::elem)(xs - (float)hi);
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned pack2(typename T::elem a, typename T::elem b) {
+    return __builtin_bit_cast(unsigned, typename T::vec2{a, b});
+}
+
+// Four 32-bit words (2 elems each) per register group rg = 0..3 of one 32x32 accumulator tile, hi or lo plane:
+// P[rg][0..1] hold rows 8rg+4h+{0,1} and +{2,3} of this lane's column.  Returns the B fragments of the two k-steps
+// the tile spans (k = feature index).  Lanes 0-31 keep rows 8rg..+3 of the even group and receive rows +4..+7 from
+// lanes 32-63; lanes 32-63 receive the odd group's rows from lanes 0-31 and keep their own.
+template <typename T>
+__device__ __forceinline__ void relayout_tile(const unsigned (&P)[4][2], typename T::vec8& f0, typename T::vec8& f1) {
+    u32x4 r[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            auto a = __builtin_amdgcn_permlane32_swap(P[2 * pr][c], P[2 * pr + 1][c], false, false);
+            r[pr][c] = a[0];
+            r[pr][2 + c] = a[1];
+        }
+    f0 = __builtin_bit_cast(typename T::vec8, r[0]);
+    f1 = __builtin_bit_cast(typename T::vec8, r[1]);
+}
+
+// Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
+// ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
+template <int NT, int DEPTH = H3D_RING_DEPTH>
+struct WeightRing {
+    static constexpr int kBuf = DEPTH;
+    static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
+    static constexpr int kStage = NT * 2048;
+    const unsigned char* gsrc;    // global stream + this lane's slot
+    unsigned char* ring;          // LDS ring base
+    int total, issue_pos, issue_buf, cur_buf, wave, lane;
+
+    __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
+        gsrc = stream + (w * kChunks) * 1024 + l * 16;
+        ring = lds;
+        total = total_stages;
+        issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
+#pragma unroll
+        for (int i = 0; i < kBuf - 1; ++i) issue();
+    }
+    __device__ __forceinline__ void issue() {
+        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage;
+        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks) * 1024;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
+                                             (__attribute__((address_space(3))) void*)(d + c * 1024), 16, 0, 0);
+        issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
+        issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
+    }
+    // Make the next stage readable by every wave, then refill the buffer everybody finished with.
+    __device__ __forceinline__ const unsigned char* acquire() {
+        // lgkmcnt(0): this wave's ds_reads of the stage whose buffer is about to be refilled have completed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kBuf - 2) * kChunks) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const unsigned char* r = ring + cur_buf * kStage + lane * 16;
+        cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
+        return r;
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
+//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].
+// The three partial products of a tile are issued NT MFMAs apart (no back-to-back dependent accumulations).
+template <typename T, int NT>
+struct WFragT { typename T::vec8 h[NT], l[NT]; };
+
+template <typename T, int NT>
+__device__ __forceinline__ void load_wfrag_pair(WFragT<T, NT>& f, const unsigned char* st, int p) {
+#pragma unroll
+    for (int nt = 2 * p; nt < 2 * p + 2; ++nt) {
+        f.h[nt] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 0) * 1024));
+        f.l[nt] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 1) * 1024));
+    }
+}
+
+template <typename T, bool SWAP>
+__device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T::vec8& x, const f32x16& c) {
+    return SWAP ? T::mfma(x, w, c) : T::mfma(w, x, c);
+}
+
+// One k-step: the 3 partial products of tile pair p (hi*hi, hi*lo, lo*hi; the two tiles alternate so no MFMA
+// depends on its predecessor), with the 4 ds_read_b128 that fetch the NEXT k-step's fragments of the same tile
+// pair issued just ahead of them.  Never more than a handful of LDS reads are outstanding, so the compiler's
+// lgkmcnt waits stay exact (the counter saturates at 15) and no MFMA waits for a read issued in its own k-step.
+template <typename T, int NT, bool SWAP, bool PREFETCH>
+__device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFragT<T, NT>& cur, WFragT<T, NT>& nxt,
+                                         const unsigned char* st_next, const typename T::vec8& xh,
+                                         const typename T::vec8& xl) {
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p) {
+        if (PREFETCH) load_wfrag_pair<T, NT>(nxt, st_next, p);
+        const int a = 2 * p, b = 2 * p + 1;
+        acc[a] = mm<T, SWAP>(cur.h[a], xh, acc[a]);
+        acc[b] = mm<T, SWAP>(cur.h[b], xh, acc[b]);
+        acc[a] = mm<T, SWAP>(cur.h[a], xl, acc[a]);
+        acc[b] = mm<T, SWAP>(cur.h[b], xl, acc[b]);
+        acc[a] = mm<T, SWAP>(cur.l[a], xh, acc[a]);
+        acc[b] = mm<T, SWAP>(cur.l[b], xh, acc[b]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
+//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].   KS is even.
+template <typename T, int NT, int KS, int KSA, bool SWAP, typename RING>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA], const typename T::vec8 (&xl)[KSA],
+                                        RING& ring) {
+    static_assert(KS % 2 == 0 && NT % 2 == 0 && KS <= KSA, "k-steps and tiles come in pairs");
+    WFragT<T, NT> f0, f1;
+    {
+        const unsigned char* st = ring.acquire();
+#pragma unroll
+        for (int p = 0; p < NT / 2; ++p) load_wfrag_pair<T, NT>(f0, st, p);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+        const unsigned char* s1 = ring.acquire();
+        __builtin_amdgcn_sched_barrier(0);
+        kstep_x3<T, NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks]);
+        if (ks + 2 < KS) {
+            const unsigned char* s2 = ring.acquire();
+            __builtin_amdgcn_sched_barrier(0);
+            kstep_x3<T, NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1]);
+        } else {
+            kstep_x3<T, NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1]);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc1(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+}  // namespace h3d

@@ -14,6 +14,7 @@ Everything here is *exact* algebra on the reference's eval-mode forward
     bilinear resize that follows it) and the per-sample constant cst
 """
 import ctypes
+import os
 
 import torch
 
@@ -85,6 +86,9 @@ class SynthesisPlan:
         desc.w_in = add(torch.cat([_pad(w_in[:, 0], HdP), _pad(w_in[:, 1], HdP)]))
         desc.b_in = add(_pad(g(f"{input_prefix}.network.0.bias"), HdP))
         ws_all, bs_all, self.pixel_ids, self.const_ids = [], [], [], []
+        self._raw = []          # per SPADE: dict of dense fp32 tensors (consumed by the x3 builder)
+        self._rgb = {}
+        self._w_in, self._b_in = w_in, g(f"{input_prefix}.network.0.bias")
         wg_c, bg_c, wb_c, bb_c, sc_c, sh_c = [], [], [], [], [], []
         for k in range(n_blocks):
             pixel = map3d_mode == "all" or k in mod_blocks
@@ -104,6 +108,8 @@ class SynthesisPlan:
                 bgam, bbet = g(sp + ".mlp_gamma.bias"), g(sp + ".mlp_beta.bias")
                 w = g(cv + ".weight_orig").reshape(C, C)
                 sigma = torch.dot(g(cv + ".weight_u"), torch.mv(w, g(cv + ".weight_v")))
+                self._raw.append(dict(pixel=pixel, conv_w=w / sigma, conv_b=g(cv + ".bias"), wgam=wgam, bgam=bgam,
+                                      wbet=wbet, bbet=bbet, sc=sc, sh=sh))
                 d = bd.spade[s]
                 d.w_conv = add(pack_matrix(w / sigma, KBH, NT))
                 d.b_conv = add(_pad(g(cv + ".bias"), HdP))
@@ -125,6 +131,7 @@ class SynthesisPlan:
             if bd.to_rgb:
                 tr = f"{prefix}.to_rgbs.m3d_{k}.linear"
                 wr = g(tr + ".weight").reshape(3, C)
+                self._rgb[k] = (wr, g(tr + ".bias"))
                 bd.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(g(tr + ".bias"), 4)]))
         self.desc = desc
         self.blob = torch.cat(chunks).contiguous()
@@ -140,9 +147,85 @@ class SynthesisPlan:
             self.wb_c, self.bb_c = torch.stack(wb_c), torch.stack(bb_c)
             self.sc_c, self.sh_c = torch.stack(sc_c), torch.stack(sh_c)
         self.g_channels = SHARED * len(self.pixel_ids)
+        self.device = device
+        self._x3 = None
+        self.engine = os.environ.get("H3D_SYNTH_PRECISION", "bf16x3" if self.x3_supported() else "f32")
 
-    def per_forward_tables(self, feature_maps, fixed_style):
+    # ------------------------------------------------------------------ split-bf16 ("x3") engine
+    def x3_supported(self):
+        """C <= 256 and no per-pixel-style block at or after the first skip block (csrc/synthesis_x3.hip)."""
+        if self.C > 256:
+            return False
+        seen_skip = False
+        for k in range(self.n_blocks):
+            seen_skip = seen_skip or bool(self.desc.block[k].skip)
+            if seen_skip and (self.desc.block[k].spade[0].pixel_style or self.desc.block[k].spade[1].pixel_style):
+                return False
+        return True
+
+    @staticmethod
+    def pack_stream_bf16(w_out_in, KS, NT):
+        """[n_out, n_in] -> bf16 hi/lo weight-stream stages [KS][NT][2][64][8] (as int16 bit patterns)."""
+        n_out, n_in = w_out_in.shape
+        wp = torch.zeros(32 * NT, 16 * KS, dtype=torch.float32, device=w_out_in.device)
+        wp[:n_out, :n_in] = w_out_in.float()
+        hi = wp.to(torch.bfloat16)
+        lo = (wp - hi.float()).to(torch.bfloat16)
+
+        def frag(t):        # [N, K] -> [KS, NT, 64 lanes, 8]; lane = 32*h + j, element e: n = 32nt + j, k = 16ks + 8h + e
+            return t.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8)
+
+        return torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(torch.int16).flatten()
+
+    def build_x3(self):
+        if self._x3 is not None:
+            return self._x3
+        C = self.C
+        NT = 8 if C > 128 else 4
+        HdP = NT * 32
+        chunks, off = [], [0]
+
+        def add(t):
+            o = off[0]
+            t = t.flatten().float()
+            pad = (-t.numel()) % 4
+            if pad:
+                t = torch.cat([t, t.new_zeros(pad)])
+            chunks.append(t)
+            off[0] += t.numel()
+            return o
+
+        desc = SynthDesc()
+        desc.n_blocks, desc.C = self.n_blocks, C
+        desc.w_in = add(torch.cat([_pad(self._w_in[:, 0], HdP), _pad(self._w_in[:, 1], HdP)]))
+        desc.b_in = add(_pad(self._b_in, HdP))
+        stream, stages = [], 0
+        for k in range(self.n_blocks):
+            src, dst = self.desc.block[k], desc.block[k]
+            dst.skip, dst.to_rgb = src.skip, src.to_rgb
+            for s in range(2):
+                raw = self._raw[2 * k + s]
+                d, so = dst.spade[s], src.spade[s]
+                d.pixel_style, d.g_offset, d.cst_index, d.ab_index = so.pixel_style, so.g_offset, so.cst_index, so.ab_index
+                if raw["pixel"]:
+                    stream.append(self.pack_stream_bf16(raw["wgam"], SHARED // 16, NT))
+                    stream.append(self.pack_stream_bf16(raw["wbet"], SHARED // 16, NT))
+                    stages += 2 * (SHARED // 16)
+                    d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), _pad(raw["sc"], HdP),
+                                           _pad(raw["sh"], HdP)]))
+                stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
+                stages += 2 * NT
+                d.b_conv = add(_pad(raw["conv_b"], HdP))
+            if dst.to_rgb:
+                wr, br = self._rgb[k]
+                dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
+        self._x3 = dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
+                        stages=stages, HdP=HdP)
+        return self._x3
+
+    def per_forward_tables(self, feature_maps, fixed_style, HdP=None):
         """feature_maps [B,R,F] (rendered, channels last), fixed_style [B,F] -> (G, cst, ab)."""
+        HdP = self.HdP if HdP is None else HdP
         B = fixed_style.shape[0]
         dev = fixed_style.device
         pre_fixed = torch.einsum("bf,skf->bsk", fixed_style, self.ws_all)          # [B, 2nb, 128]
@@ -157,7 +240,7 @@ class SynthesisPlan:
             a = torch.relu(pre_fixed[:, self.con_index] + self.bs_all[self.con_index])         # [B,nc,128]
             gamma1 = 1.0 + torch.einsum("bsk,skc->bsc", a, self.wg_c) + self.bg_c
             beta = torch.einsum("bsk,skc->bsc", a, self.wb_c) + self.bb_c
-            ab = torch.zeros(B, len(self.const_ids), 2, self.HdP, device=dev, dtype=torch.float32)
+            ab = torch.zeros(B, len(self.const_ids), 2, HdP, device=dev, dtype=torch.float32)
             ab[:, :, 0, : self.C] = self.sc_c * gamma1
             ab[:, :, 1, : self.C] = self.sh_c * gamma1 + beta
         return G, cst, ab
@@ -167,12 +250,22 @@ class SynthesisPlan:
         B = fixed_style.shape[0]
         Hr, Wr = render_hw
         H, W = out_hw
+        if self.engine not in ("bf16x3", "f32"):
+            raise ValueError(f"unknown synthesis engine {self.engine!r}")
+        x3 = self.build_x3() if self.engine == "bf16x3" else None
         with stage(owner, "synthesis_tables"):
-            G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float())
+            G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3["HdP"] if x3 else None)
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         with stage(owner, "synthesis"):
-            rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
-        _lib.check(rc, "h3d_synthesis")
+            if x3:
+                rc = _lib.load().h3d_synthesis_x3(_lib.ptr(x3["stream"]), x3["stages"], _lib.ptr(x3["tables"]),
+                                                  x3["tables"].numel(), ctypes.byref(x3["desc"]), _lib.ptr(G),
+                                                  self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids),
+                                                  _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
+                                                  _lib.stream_handle())
+            else:
+                rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
+        _lib.check(rc, "h3d_synthesis_x3" if x3 else "h3d_synthesis")
         return rgb
 
     def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):

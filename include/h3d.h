@@ -177,6 +177,18 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
                   const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                   h3d_stream_t stream);
 
+/* Same network on the bf16 matrix cores with split ("x3") operands (bf16 hi + lo, three partial products, fp32
+ * accumulation; ~1e-5 on the image).  `stream`: all conv / gamma / beta matrices of one tile in consumption order
+ * (per block, per SPADE: [gamma (8 k-steps), beta (8)] if pixel_style, then conv), each k-step stage
+ * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k = 16*kstep + 8*(lane>>5) + e];
+ * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
+ * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
+ * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256 or a per-pixel-style block after the first skip block. */
+int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                     const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                     const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                     h3d_stream_t stream_handle);
+
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
  *     lib/components/ops/bias_act.cpp:32 with grad=0; kernel spec lib/components/ops/bias_act.cu:23-147

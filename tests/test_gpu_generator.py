@@ -16,7 +16,10 @@ DEV = "cuda"
 TOL = 1e-3          # north_star: generator outputs within 1e-3 relative of the reference CPU path
 
 
-def build(meta, state=None):
+ENGINES = [("f16x3", "bf16x3"), ("f32", "f32")]      # (field engine, synthesis engine)
+
+
+def build(meta, state=None, engines=None):
     cfg = dict(meta)
     cfg["neural_field_cls"] = impl.COORDCONCATSIREN
     G = gens.Map3DGenerator(**cfg)
@@ -24,6 +27,9 @@ def build(meta, state=None):
         G.load_state_dict(state, strict=True)
     G = G.to(DEV).eval()
     G.set_device(DEV)
+    if engines is not None:
+        G.neural_field.precision = engines[0]
+        G.synthesis_plan(DEV).engine = engines[1]
     return G, cfg
 
 
@@ -31,21 +37,23 @@ def cond_to(cond):
     return {k: v.to(DEV) for k, v in cond.items()}
 
 
+@pytest.mark.parametrize("engines", ENGINES)
 @pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
-def test_synthesis_golden(name):
+def test_synthesis_golden(name, engines):
     g = load_golden(name)
-    G, cfg = build(g["meta"], g["state"])
+    G, cfg = build(g["meta"], g["state"], engines)
     fmap = g["stage"]["feats"][..., 3:].to(DEV).contiguous()
     rgb = G._synthesize(fmap, g["stage"]["styles"].to(DEV), (cfg["render_height"], cfg["render_width"]))
     assert rgb.shape == g["out"]["rgbs"].shape
     assert rel_err(rgb.cpu(), g["out"]["rgbs"]) < TOL
 
 
+@pytest.mark.parametrize("engines", ENGINES)
 @pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
 @pytest.mark.parametrize("fused", [True, False])
-def test_forward_golden(name, fused):
+def test_forward_golden(name, fused, engines):
     g = load_golden(name)
-    G, cfg = build(g["meta"], g["state"])
+    G, cfg = build(g["meta"], g["state"], engines)
     run = dict(cfg)
     out = G.forward(g["z"].to(DEV), cond_to(g["cond"]), jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV),
                     fused=fused, **run)
@@ -85,6 +93,15 @@ def test_all_mode_and_odd_sizes_vs_oracle():
     out = G.forward(z.to(DEV), cond_to(cond), jitter=jit.to(DEV), **cfg)
     assert rel_err(out["rgbs_render"].cpu(), ref["rgbs_render"]) < TOL
     assert rel_err(out["rgbs"].cpu(), ref["rgbs"]) < TOL
+
+
+def test_engine_selection_defaults():
+    g = load_golden("gen_tiny_mixed")
+    G, cfg = build(g["meta"], g["state"])
+    assert G.neural_field.precision == "f16x3" and G.synthesis_plan(DEV).engine == "bf16x3"
+    meta = dict(g["meta"]); meta["map3d_mode"] = "all"
+    G2, _ = build(meta)
+    assert G2.synthesis_plan(DEV).engine == "f32"          # per-pixel style after the first skip block
 
 
 @pytest.mark.parametrize("cfg_name", ["MAP3DBN", "MAP3DBN512"])
