@@ -67,7 +67,7 @@ __device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
     }
 }
 
-template <int NT>
+template <int NT, int DEPTH>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     for (int i = t; i < A.n_cst * kShared; i += 256) cst0[i] = A.cst[(int64_t)b * A.n_cst * kShared + i];
     __syncthreads();
 
-    WeightRing<NT, kRingDepth> ring;
+    WeightRing<NT, DEPTH> ring;
     ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
 
     // ---- this lane's pixel: synthesis-input coordinates and bilinear taps into the low-res maps
@@ -208,9 +208,6 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                             al[ks][q4 * 4 + e] = lo;
                         }
                     }
-                    // keep the 8 gathers of one k-step together: letting the scheduler hoist all 64 of them costs
-                    // 256 registers on top of the resident activations
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 const float* vec = tab + Sp.vec;
                 // gamma:  x <- (x*sc + sh) * (1 + gamma)
@@ -307,21 +304,22 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     }
 }
 
-size_t lds_bytes(const Args& A, int NT) {
+size_t lds_bytes(const Args& A, int NT, int depth) {
     return sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared) +
-           (size_t)kRingDepth * NT * 2048;
+           (size_t)depth * NT * 2048;
 }
 
-template <int NT>
+template <int NT, int DEPTH>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT, DEPTH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A, NT), st, A);
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH>), dim3((unsigned)groups, (unsigned)B), dim3(256),
+                       lds_bytes(A, NT, DEPTH), st, A);
     return h3d::launch_status("h3d_synthesis_x3");
 }
 
@@ -377,12 +375,14 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
     A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip;
-    if (lds_bytes(A, NT) > 160 * 1024) {
+    const bool deep = lds_bytes(A, NT, 6) <= 160 * 1024;      // deepest weight ring the tables leave room for
+    if (lds_bytes(A, NT, kRingDepth) > 160 * 1024) {
         h3d::set_error("h3d_synthesis_x3: tables (%d floats) + ring do not fit the 160 KB LDS; use h3d_synthesis", table_floats);
         return H3D_EUNSUPPORTED;
     }
     const int64_t groups = ((int64_t)H * W + 127) / 128;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_synthesis_x3: image too large");
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    return NT == 8 ? launch_one<8>(A, B, groups, st) : launch_one<4>(A, B, groups, st);
+    if (NT == 8) return deep ? launch_one<8, 6>(A, B, groups, st) : launch_one<8, kRingDepth>(A, B, groups, st);
+    return deep ? launch_one<4, 6>(A, B, groups, st) : launch_one<4, kRingDepth>(A, B, groups, st);
 }

@@ -14,7 +14,7 @@ namespace h3d {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef H3D_RING_DEPTH
-#define H3D_RING_DEPTH 6
+#define H3D_RING_DEPTH 7
 #endif
 
 struct F16 {          // scaled f16 halves
@@ -69,6 +69,7 @@ __device__ __forceinline__ void relayout_tile(const unsigned (&P)[4][2], typenam
 template <int NT, int DEPTH = H3D_RING_DEPTH>
 struct WeightRing {
     static constexpr int kBuf = DEPTH;
+    static_assert(DEPTH >= 3 && (DEPTH - 2) * (NT * 2 / 4) < 64, "ring depth out of range for the 6-bit vmcnt field");
     static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
     static constexpr int kStage = NT * 2048;
     const unsigned char* gsrc;    // global stream + this lane's slot
@@ -83,24 +84,37 @@ struct WeightRing {
 #pragma unroll
         for (int i = 0; i < kBuf - 1; ++i) issue();
     }
-    __device__ __forceinline__ void issue() {
-        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage;
-        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks) * 1024;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + c * 1024),
-                                             (__attribute__((address_space(3))) void*)(d + c * 1024), 16, 0, 0);
-        issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
-        issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
+    __device__ __forceinline__ void issue_chunk(int c) {           // c = 0 .. kChunks-1, in order
+        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage + c * 1024;
+        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks + c) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        if (c == kChunks - 1) {
+            issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
+            issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
+        }
     }
-    // Make the next stage readable by every wave, then refill the buffer everybody finished with.
+    __device__ __forceinline__ void issue() {
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) issue_chunk(c);
+    }
+    // Make the next stage (t) readable by every wave.  The caller then issues stage t + kBuf - 1 with
+    // issue_chunk(0..kChunks-1), one chunk after each tile pair's MFMAs of the k-step it computes next, so the DMA
+    // issue hides under the matrix pipe.  The refill lands in the buffer of stage t - 1.  Its last fragment reads
+    // were issued by every wave BEFORE it arrived at this barrier; the first refill chunk is issued >= 192 MFMA
+    // cycles after the barrier and its data lands an L2 round trip (>= 300 cycles) later still, whereas an LDS read
+    // retires within ~130 cycles of issue -- the write-after-read distance is a few hundred cycles of margin on a
+    // bounded-latency path.  (Waiting lgkmcnt(0) here instead costs ~15 % on the whole kernel.)
     __device__ __forceinline__ const unsigned char* acquire() {
-        // lgkmcnt(0): this wave's ds_reads of the stage whose buffer is about to be refilled have completed
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kBuf - 2) * kChunks) : "memory");
+        // vmcnt only (expcnt / lgkmcnt fields left at "no wait"): stages t+1 .. t+kBuf-2 may stay in flight
+        constexpr int kKeep = (kBuf - 2) * kChunks;
+        __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue();
-        const unsigned char* r = ring + cur_buf * kStage + lane * 16;
+        // the stage's ds_reads depend on this (opaque) offset: they cannot be hoisted above the barrier.  An integer
+        // is laundered, not the pointer, so the address space stays LDS (ds_read, not flat_load).
+        int off = cur_buf * kStage + lane * 16;
+        asm volatile("" : "+v"(off));
+        const unsigned char* r = ring + off;
         cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
         return r;
     }
@@ -131,10 +145,11 @@ __device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T
 // depends on its predecessor), with the 4 ds_read_b128 that fetch the NEXT k-step's fragments of the same tile
 // pair issued just ahead of them.  Never more than a handful of LDS reads are outstanding, so the compiler's
 // lgkmcnt waits stay exact (the counter saturates at 15) and no MFMA waits for a read issued in its own k-step.
-template <typename T, int NT, bool SWAP, bool PREFETCH>
+template <typename T, int NT, bool SWAP, bool PREFETCH, typename RING>
 __device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFragT<T, NT>& cur, WFragT<T, NT>& nxt,
                                          const unsigned char* st_next, const typename T::vec8& xh,
-                                         const typename T::vec8& xl) {
+                                         const typename T::vec8& xl, RING& ring, bool refill) {
+    static_assert(RING::kChunks == NT / 2, "one DMA chunk per tile pair");
 #pragma unroll
     for (int p = 0; p < NT / 2; ++p) {
         if (PREFETCH) load_wfrag_pair<T, NT>(nxt, st_next, p);
@@ -145,6 +160,7 @@ __device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFragT<T, NT>&
         acc[b] = mm<T, SWAP>(cur.h[b], xl, acc[b]);
         acc[a] = mm<T, SWAP>(cur.l[a], xh, acc[a]);
         acc[b] = mm<T, SWAP>(cur.l[b], xh, acc[b]);
+        if (refill) ring.issue_chunk(p);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -158,20 +174,22 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const typename T::vec
     WFragT<T, NT> f0, f1;
     {
         const unsigned char* st = ring.acquire();
+        ring.issue();
 #pragma unroll
         for (int p = 0; p < NT / 2; ++p) load_wfrag_pair<T, NT>(f0, st, p);
     }
+    // every acquire() is followed by exactly one refill (kChunks DMA instructions), issued inside the next k-step
 #pragma unroll
     for (int ks = 0; ks < KS; ks += 2) {
         const unsigned char* s1 = ring.acquire();
         __builtin_amdgcn_sched_barrier(0);
-        kstep_x3<T, NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks]);
+        kstep_x3<T, NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks], ring, true);
         if (ks + 2 < KS) {
             const unsigned char* s2 = ring.acquire();
             __builtin_amdgcn_sched_barrier(0);
-            kstep_x3<T, NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1]);
+            kstep_x3<T, NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1], ring, true);
         } else {
-            kstep_x3<T, NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1]);
+            kstep_x3<T, NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1], ring, false);
         }
     }
 }

@@ -161,7 +161,11 @@ class SynthesisPlan:
             seen_skip = seen_skip or bool(self.desc.block[k].skip)
             if seen_skip and (self.desc.block[k].spade[0].pixel_style or self.desc.block[k].spade[1].pixel_style):
                 return False
-        return True
+        # LDS budget of csrc/synthesis_x3.hip: static tables + per-sample tables + 4-deep weight ring <= 160 KB
+        x3 = self.build_x3()
+        NT = x3["HdP"] // 32
+        lds = 4 * (x3["tables"].numel() + len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED) + 4 * NT * 2048
+        return lds <= 160 * 1024
 
     @staticmethod
     def pack_stream_bf16(w_out_in, KS, NT):
