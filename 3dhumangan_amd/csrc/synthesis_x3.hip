@@ -31,6 +31,8 @@ struct Args {
     const float* ab;
     float* rgb;
     int table_floats, total_stages, g_channels, Hr, Wr, n_cst, n_ab, H, W, HdP, C, first_skip;
+    float* state;          // [wave tiles][NT*4 + 1][64 lanes] float4: activations (+ rgb partial sums) between segments
+    int load_state, store_state;
 };
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
@@ -67,7 +69,7 @@ __device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
     }
 }
 
-template <int NT, int DEPTH>
+template <int NT, int DEPTH, bool SEG>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -113,8 +115,21 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     bf8 xh[KS], xl[KS];
     float rgb_acc[3] = {0.f, 0.f, 0.f};
 
-    // ---- A8: x0 = sin(w0*i + w1*j + b) in accumulator layout
-    {
+    const int64_t wtile = (int64_t)b * gridDim.x * 4 + (int64_t)blockIdx.x * 4 + wave;
+    float4* st_io = reinterpret_cast<float4*>(A.state) + wtile * (NT * 4 + 1) * 64 + lane;
+    if (SEG && A.load_state) {
+        // ---- resume: activations (lane-linear, as the previous segment left them) and the ToRGB partial sums
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 v = st_io[(nt * 4 + rg) * 64];
+                x[nt][rg * 4 + 0] = v.x; x[nt][rg * 4 + 1] = v.y; x[nt][rg * 4 + 2] = v.z; x[nt][rg * 4 + 3] = v.w;
+            }
+        const float4 r = st_io[NT * 4 * 64];
+        rgb_acc[0] = r.x; rgb_acc[1] = r.y; rgb_acc[2] = r.z;
+    } else {
+        // ---- A8: x0 = sin(w0*i + w1*j + b) in accumulator layout
         const float* win = tab0 + D.w_in;
         const float* bin = tab0 + D.b_in;
 #pragma unroll
@@ -297,6 +312,15 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
     }
     ring.drain();
+    if (SEG && A.store_state) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                st_io[(nt * 4 + rg) * 64] = make_float4(x[nt][rg * 4 + 0], x[nt][rg * 4 + 1], x[nt][rg * 4 + 2], x[nt][rg * 4 + 3]);
+        st_io[NT * 4 * 64] = make_float4(rgb_acc[0], rgb_acc[1], rgb_acc[2], 0.f);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = rgb_acc[c] + __shfl_xor(rgb_acc[c], 32, 64);
@@ -309,18 +333,25 @@ size_t lds_bytes(const Args& A, int NT, int depth) {
            (size_t)depth * NT * 2048;
 }
 
-template <int NT, int DEPTH>
-int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+template <int NT, int DEPTH, bool SEG>
+int launch_seg(const Args& A, int B, int64_t groups, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT, DEPTH>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT, DEPTH, SEG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH>), dim3((unsigned)groups, (unsigned)B), dim3(256),
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG>), dim3((unsigned)groups, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH), st, A);
     return h3d::launch_status("h3d_synthesis_x3");
+}
+
+template <int NT, int DEPTH>
+int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+    // the state load/store paths are compiled only into the segmented variant (they cost registers)
+    return (A.load_state || A.store_state) ? launch_seg<NT, DEPTH, true>(A, B, groups, st)
+                                           : launch_seg<NT, DEPTH, false>(A, B, groups, st);
 }
 
 }  // namespace
@@ -328,7 +359,7 @@ int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
 extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                                 const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                                 const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
-                                h3d_stream_t stream_) {
+                                float* state, int load_state, int store_state, h3d_stream_t stream_) {
     H3D_REQUIRE(stream && tables && desc && rgb, "h3d_synthesis_x3: null pointer");
     H3D_REQUIRE(h3d::aligned16(stream) && h3d::aligned16(tables), "h3d_synthesis_x3: stream/tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3: n_blocks=%d", desc->n_blocks);
@@ -368,9 +399,11 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
                 (long long)total_stages, (long long)want);
     H3D_REQUIRE(!any_pixel || (G && cst && (g_channels & 3) == 0 && h3d::aligned16(G)), "h3d_synthesis_x3: G/cst missing");
     H3D_REQUIRE(!any_const || ab, "h3d_synthesis_x3: ab table missing");
-    H3D_REQUIRE(desc->block[desc->n_blocks - 1].to_rgb, "h3d_synthesis_x3: the last block must feed ToRGB");
+    H3D_REQUIRE(store_state || desc->block[desc->n_blocks - 1].to_rgb, "h3d_synthesis_x3: the last block must feed ToRGB");
+    H3D_REQUIRE((!load_state && !store_state) || (state && h3d::aligned16(state)), "h3d_synthesis_x3: state buffer missing");
     if (B == 0) return H3D_OK;
     Args A{};
+    A.state = state; A.load_state = load_state; A.store_state = store_state;
     A.stream = static_cast<const unsigned char*>(stream);
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;

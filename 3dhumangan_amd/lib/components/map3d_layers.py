@@ -1,0 +1,67 @@
+"""Modulated per-pixel layers of the reference's lib/components/map3d_layers.py that are named by the north_star
+(the SPADE path of the shipped configs lives in lib/generators/synthesis_pack.py + csrc/synthesis*.hip).
+
+SpatialStyleModLayer: per-pixel modulated 1x1 convolution with demodulation (reference :25-80), evaluated by
+h3d_modconv1x1 on the fp32 matrix cores.  Same constructor, parameter names/shapes and forward signature."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ..generators.synthesis_pack import pack_matrix
+
+
+def _pad_vec(v, n):
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.flatten().float()
+    return out
+
+
+class SpatialStyleModLayer(nn.Module):
+
+    def __init__(self, in_channel, out_channel, kernel_size=1, style_dim=None, demodulate=True, eps=1e-8, **kwargs):
+        super().__init__()
+        assert kernel_size == 1
+        self.eps, self.in_channel, self.out_channel = eps, in_channel, out_channel
+        self.kernel_size, self.style_dim, self.demodulate = kernel_size, style_dim, demodulate
+        self.weight = nn.Parameter(torch.randn(1, 1, in_channel, out_channel) * math.sqrt(2 / (1 + 0.2 ** 2)) / math.sqrt(in_channel))
+        self.bias = nn.Parameter(torch.zeros(1, 1, out_channel))
+        self.affine = nn.Linear(style_dim, in_channel)
+        nn.init.kaiming_normal_(self.affine.weight, mode="fan_in", nonlinearity="linear")
+        self._packed = None
+
+    def _pack(self, device):
+        ps = (self.weight, self.bias, self.affine.weight, self.affine.bias)
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or self._packed[0] != key:
+            Cin, Cout, S = self.in_channel, self.out_channel, self.style_dim
+            r32 = lambda n: (n + 31) // 32 * 32
+            w = self.weight.detach()[0, 0].to(device).float()                  # [Cin, Cout]
+            wa = self.affine.weight.detach().to(device).float()                # [Cin, S]
+            self._packed = (key, dict(
+                w_aff=pack_matrix(wa, r32(S) // 8, r32(Cin) // 32),
+                b_aff=_pad_vec(self.affine.bias.detach().to(device) + 1.0, r32(Cin)),
+                w=pack_matrix(w.t().contiguous(), r32(Cin) // 8, r32(Cout) // 32),
+                w2=pack_matrix((w * w).t().contiguous(), r32(Cin) // 8, r32(Cout) // 32),
+                bias=_pad_vec(self.bias.detach().to(device), r32(Cout))))
+        return self._packed[1]
+
+    @torch.no_grad()
+    def forward(self, x, style):
+        """x [B,P,Cin]; style [B,P,S] or [B,S,H,W]  ->  [B,P,Cout]"""
+        _lib.need_cuda(x, style)
+        if style.dim() > 3:
+            B, C, H, W = style.shape
+            style = style.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        B, P, Cin = x.shape
+        pk = self._pack(x.device)
+        xin = x.contiguous().float()
+        st = style.contiguous().float()
+        out = torch.empty(B, P, self.out_channel, device=x.device, dtype=torch.float32)
+        rc = _lib.load().h3d_modconv1x1(_lib.ptr(xin), _lib.ptr(st), _lib.ptr(pk["w_aff"]), _lib.ptr(pk["b_aff"]),
+                                        _lib.ptr(pk["w"]), _lib.ptr(pk["w2"]), _lib.ptr(pk["bias"]), _lib.ptr(out),
+                                        B * P, Cin, self.out_channel, self.style_dim, int(bool(self.demodulate)),
+                                        float(self.eps), _lib.stream_handle())
+        _lib.check(rc, "h3d_modconv1x1")
+        return out

@@ -163,9 +163,8 @@ class SynthesisPlan:
                 return False
         # LDS budget of csrc/synthesis_x3.hip: static tables + per-sample tables + 4-deep weight ring <= 160 KB
         x3 = self.build_x3()
-        NT = x3["HdP"] // 32
-        lds = 4 * (x3["tables"].numel() + len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED) + 4 * NT * 2048
-        return lds <= 160 * 1024
+        per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED
+        return all(4 * (seg["tables"].numel() + per_sample) + 4 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
 
     @staticmethod
     def pack_stream_bf16(w_out_in, KS, NT):
@@ -181,50 +180,77 @@ class SynthesisPlan:
 
         return torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(torch.int16).flatten()
 
+    # Optional split of the network into several launches whose weight streams each fit the 4 MB L2 of an XCD
+    # (H3D_SYNTH_SEGMENT_BYTES=2359296).  Measured on MI355X: the single-launch stream (6.3 MB, 63 % L2 hit rate) is
+    # FASTER than three L2-resident segments (74 vs 82 ms) -- the misses are served by the Infinity Cache and the
+    # kernel is not bound by them -- so segmentation is off by default.
+    X3_SEGMENT_BYTES = int(os.environ.get("H3D_SYNTH_SEGMENT_BYTES", 1 << 40))
+
     def build_x3(self):
+        """Segments of consecutive blocks whose weight streams each stay well inside the 4 MB L2 of an XCD; each
+        segment carries its own descriptor, fp32 tables and bf16 hi/lo stream."""
         if self._x3 is not None:
             return self._x3
         C = self.C
         NT = 8 if C > 128 else 4
         HdP = NT * 32
-        chunks, off = [], [0]
-
-        def add(t):
-            o = off[0]
-            t = t.flatten().float()
-            pad = (-t.numel()) % 4
-            if pad:
-                t = torch.cat([t, t.new_zeros(pad)])
-            chunks.append(t)
-            off[0] += t.numel()
-            return o
-
-        desc = SynthDesc()
-        desc.n_blocks, desc.C = self.n_blocks, C
-        desc.w_in = add(torch.cat([_pad(self._w_in[:, 0], HdP), _pad(self._w_in[:, 1], HdP)]))
-        desc.b_in = add(_pad(self._b_in, HdP))
-        stream, stages = [], 0
+        stage_bytes = NT * 2048
+        # greedy partition of the blocks by stream size
+        blk_stages = []
         for k in range(self.n_blocks):
-            src, dst = self.desc.block[k], desc.block[k]
-            dst.skip, dst.to_rgb = src.skip, src.to_rgb
+            n = 0
             for s in range(2):
-                raw = self._raw[2 * k + s]
-                d, so = dst.spade[s], src.spade[s]
-                d.pixel_style, d.g_offset, d.cst_index, d.ab_index = so.pixel_style, so.g_offset, so.cst_index, so.ab_index
-                if raw["pixel"]:
-                    stream.append(self.pack_stream_bf16(raw["wgam"], SHARED // 16, NT))
-                    stream.append(self.pack_stream_bf16(raw["wbet"], SHARED // 16, NT))
-                    stages += 2 * (SHARED // 16)
-                    d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), _pad(raw["sc"], HdP),
-                                           _pad(raw["sh"], HdP)]))
-                stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
-                stages += 2 * NT
-                d.b_conv = add(_pad(raw["conv_b"], HdP))
-            if dst.to_rgb:
-                wr, br = self._rgb[k]
-                dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
-        self._x3 = dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
-                        stages=stages, HdP=HdP)
+                n += (2 * (SHARED // 16) if self._raw[2 * k + s]["pixel"] else 0) + 2 * NT
+            blk_stages.append(n)
+        ranges, cur, cur_bytes = [], [], 0
+        for k, n in enumerate(blk_stages):
+            if cur and cur_bytes + n * stage_bytes > self.X3_SEGMENT_BYTES:
+                ranges.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(k)
+            cur_bytes += n * stage_bytes
+        ranges.append(cur)
+        segments = []
+        for blocks in ranges:
+            chunks, off = [], [0]
+
+            def add(t):
+                o = off[0]
+                t = t.flatten().float()
+                pad = (-t.numel()) % 4
+                if pad:
+                    t = torch.cat([t, t.new_zeros(pad)])
+                chunks.append(t)
+                off[0] += t.numel()
+                return o
+
+            desc = SynthDesc()
+            desc.n_blocks, desc.C = len(blocks), C
+            desc.w_in = add(torch.cat([_pad(self._w_in[:, 0], HdP), _pad(self._w_in[:, 1], HdP)]))
+            desc.b_in = add(_pad(self._b_in, HdP))
+            stream, stages = [], 0
+            for j, k in enumerate(blocks):
+                src, dst = self.desc.block[k], desc.block[j]
+                dst.skip, dst.to_rgb = src.skip, src.to_rgb
+                for s in range(2):
+                    raw = self._raw[2 * k + s]
+                    d, so = dst.spade[s], src.spade[s]
+                    d.pixel_style, d.g_offset, d.cst_index, d.ab_index = so.pixel_style, so.g_offset, so.cst_index, so.ab_index
+                    if raw["pixel"]:
+                        stream.append(self.pack_stream_bf16(raw["wgam"], SHARED // 16, NT))
+                        stream.append(self.pack_stream_bf16(raw["wbet"], SHARED // 16, NT))
+                        stages += 2 * (SHARED // 16)
+                        d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), _pad(raw["sc"], HdP),
+                                               _pad(raw["sh"], HdP)]))
+                    stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
+                    stages += 2 * NT
+                    d.b_conv = add(_pad(raw["conv_b"], HdP))
+                if dst.to_rgb:
+                    wr, br = self._rgb[k]
+                    dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
+            segments.append(dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
+                                 stages=stages, blocks=blocks))
+        self._x3 = dict(segments=segments, HdP=HdP, NT=NT, state=None)
         return self._x3
 
     def per_forward_tables(self, feature_maps, fixed_style, HdP=None):
@@ -262,11 +288,22 @@ class SynthesisPlan:
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         with stage(owner, "synthesis"):
             if x3:
-                rc = _lib.load().h3d_synthesis_x3(_lib.ptr(x3["stream"]), x3["stages"], _lib.ptr(x3["tables"]),
-                                                  x3["tables"].numel(), ctypes.byref(x3["desc"]), _lib.ptr(G),
-                                                  self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids),
-                                                  _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
-                                                  _lib.stream_handle())
+                segs = x3["segments"]
+                state = None
+                if len(segs) > 1:
+                    need = B * ((H * W + 127) // 128) * 4 * (x3["NT"] * 4 + 1) * 64 * 4
+                    if x3["state"] is None or x3["state"].numel() < need:
+                        x3["state"] = torch.empty(need, device=fixed_style.device, dtype=torch.float32)
+                    state = x3["state"]
+                lib, rc = _lib.load(), 0
+                for i, seg in enumerate(segs):
+                    rc = lib.h3d_synthesis_x3(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]),
+                                              seg["tables"].numel(), ctypes.byref(seg["desc"]), _lib.ptr(G),
+                                              self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab),
+                                              len(self.const_ids), _lib.ptr(rgb), B, H, W, _lib.ptr(state), int(i > 0),
+                                              int(i < len(segs) - 1), _lib.stream_handle())
+                    if rc:
+                        break
             else:
                 rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
         _lib.check(rc, "h3d_synthesis_x3" if x3 else "h3d_synthesis")

@@ -183,11 +183,36 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k = 16*kstep + 8*(lane>>5) + e];
  * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
  * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
- * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256 or a per-pixel-style block after the first skip block. */
+ * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256 or a per-pixel-style block after the first skip block.
+ *
+ * Segmented execution: the weight stream of the whole network (6.3 MB at C=256) does not fit the 4 MB L2 of an XCD,
+ * so a caller may run the blocks in several launches whose streams do (desc = the blocks of one segment).  Between
+ * launches the per-pixel activations and ToRGB partial sums live in `state`
+ * (B * ceil(H*W/128) * 4 wave tiles * (tiles*4 + 1) * 64 float4, private lane-linear layout): store_state=1 writes
+ * it instead of the image, load_state=1 resumes from it instead of generating the coordinate input. */
 int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
-                     h3d_stream_t stream_handle);
+                     float* state, int load_state, int store_state, h3d_stream_t stream_handle);
+
+/* ------------------------------------------------------------------------
+ * P3a per-pixel modulated 1x1 convolution == SpatialStyleModLayer.forward (lib/components/map3d_layers.py:60-80)
+ *     m = style * Wa^T + ba + 1 ;  out = (x*m) W * rsqrt((m*m) (W*W) + eps) + bias        (demodulate != 0)
+ * x [rows, Cin], style [rows, S], out [rows, Cout] row-major fp32; w_aff_packed = pack(Wa [Cin,S]),
+ * w_packed = pack(W^T [Cout,Cin]), w2_packed = pack((W*W)^T) (h3d_pack_matrix, KB = K/8 rounded up to a multiple
+ * of 4, NT = N/32 rounded up); b_aff_plus1 [CinP], bias [CoutP] zero padded.  Widths <= 256.
+ */
+int h3d_modconv1x1(const float* x, const float* style, const float* w_aff_packed, const float* b_aff_plus1,
+                   const float* w_packed, const float* w2_packed, const float* bias, float* out, int64_t rows,
+                   int Cin, int Cout, int S, int demodulate, float eps, h3d_stream_t stream);
+
+/* P3b StyleGAN2 modulated k x k convolution == StyleModLayer.forward_group_conv (lib/components/cips_layers.py:235-278)
+ *     out[b,o] = dmod[b,o] * sum_{i,ky,kx} W[o,i,ky,kx] * (smod[b,i] * x[b,i,.+ky-k/2,.+kx-k/2]) + bias[o]
+ * x [B,Cin,H,W], out [B,Cout,H,W] NCHW fp32; smod [B,CinP] = affine(style)+1, dmod [B,CoutP] (ones without
+ * demodulation), w_packed = k*k consecutive pack(W[:,:,ky,kx] [Cout,Cin]) blocks, bias [CoutP].  Odd k <= 7.
+ */
+int h3d_modconv2d(const float* x, const float* smod, const float* dmod, const float* w_packed, const float* bias,
+                  float* out, int B, int Cin, int Cout, int H, int W, int k, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)

@@ -78,7 +78,7 @@ def main():
         configs = importlib.import_module("3dhumangan_amd.configs")
         gens = importlib.import_module("3dhumangan_amd.lib.generators")
         impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
-        for nb, mod in ((9, [0, 1, 2]), (6, []), (3, [0, 1, 2]), (3, [])):
+        for nb, mod in ((9, [0, 1, 2]), (1, []), (2, []), (3, []), (1, [0])):
             cfg = {k: v for k, v in configs.MAP3DBN512.items() if isinstance(k, str)}
             cfg.update(gen_height=512, gen_width=512, synthesis_blocks=nb, mod_blocks=mod, dataset_length=2)
             cfg["neural_field_cls"] = impl.COORDCONCATSIREN
