@@ -20,7 +20,8 @@ namespace {
 
 typedef BF16::vec8 bf8;
 constexpr int kShared = 128;
-constexpr int kRingDepth = 4;      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
+constexpr int kRingDepth = 4;
+constexpr int kLook = 2;           // weight-fragment look-ahead in tile pairs (gemm_x3_roll)      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
 
 struct Args {
     const unsigned char* stream;
@@ -46,10 +47,11 @@ __device__ __forceinline__ float linspace_pm1(int n, int i) {
 // fp32 values of one accumulator tile set -> bf16 hi/lo B fragments.  val(nt, rg) returns the 4 values of
 // register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
 template <int NT, typename F>
-__device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], F val) {
+__device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], f32x16 (&src)[NT], F val) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         unsigned Hh[4][2], Ll[4][2];
+        pin1(src[nt]);                       // the source tile sits in AGPRs until this iteration reads it
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const float4 y = val(nt, rg);
@@ -133,39 +135,73 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         const float* win = tab0 + D.w_in;
         const float* bin = tab0 + D.b_in;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
                 const float4 w0 = *reinterpret_cast<const float4*>(win + n);
                 const float4 w1 = *reinterpret_cast<const float4*>(win + HdP + n);
                 const float4 bb = *reinterpret_cast<const float4*>(bin + n);
-                x[nt][rg * 4 + 0] = (n + 0 < C) ? sin_hw(w0.x * ci + w1.x * cj + bb.x) : 0.f;
-                x[nt][rg * 4 + 1] = (n + 1 < C) ? sin_hw(w0.y * ci + w1.y * cj + bb.y) : 0.f;
-                x[nt][rg * 4 + 2] = (n + 2 < C) ? sin_hw(w0.z * ci + w1.z * cj + bb.z) : 0.f;
-                x[nt][rg * 4 + 3] = (n + 3 < C) ? sin_hw(w0.w * ci + w1.w * cj + bb.w) : 0.f;
+                x[nt][rg * 4 + 0] = sin_hw(w0.x * ci + w1.x * cj + bb.x);
+                x[nt][rg * 4 + 1] = sin_hw(w0.y * ci + w1.y * cj + bb.y);
+                x[nt][rg * 4 + 2] = sin_hw(w0.z * ci + w1.z * cj + bb.z);
+                x[nt][rg * 4 + 3] = sin_hw(w0.w * ci + w1.w * cj + bb.w);
             }
+            pin1(x[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
-    // constant-style SPADE: y = lrelu(x * a + b) -> fragments
-    auto const_frags = [&](const float* ab) {
-        make_frags<NT>(xh, xl, [&](int nt, int rg) {
+    // constant-style SPADE: y = lrelu(v * a + b) -> fragments
+    auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {
+        make_frags<NT>(xh, xl, v, [&](int nt, int rg) {
             const int n = nt * 32 + rg * 8 + 4 * h;
             const float4 sc = *reinterpret_cast<const float4*>(ab + n);
             const float4 sh = *reinterpret_cast<const float4*>(ab + HdP + n);
             float4 y;
-            y.x = (n + 0 < C) ? lrelu(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x)) : 0.f;
-            y.y = (n + 1 < C) ? lrelu(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y)) : 0.f;
-            y.z = (n + 2 < C) ? lrelu(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z)) : 0.f;
-            y.w = (n + 3 < C) ? lrelu(fmaf(x[nt][rg * 4 + 3], sc.w, sh.w)) : 0.f;
+            y.x = lrelu(fmaf(v[nt][rg * 4 + 0], sc.x, sh.x));
+            y.y = lrelu(fmaf(v[nt][rg * 4 + 1], sc.y, sh.y));
+            y.z = lrelu(fmaf(v[nt][rg * 4 + 2], sc.z, sh.z));
+            y.w = lrelu(fmaf(v[nt][rg * 4 + 3], sc.w, sh.w));
             return y;
         });
+    };
+    // accumulator initialisation: v = keep * v + bias   (the GEMM then accumulates the convolution on top)
+    auto init_bias = [&](f32x16 (&v)[NT], const float* bc, float keep) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            pin1(v[nt]);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
+                v[nt][rg * 4 + 0] = fmaf(keep, v[nt][rg * 4 + 0], bb.x);
+                v[nt][rg * 4 + 1] = fmaf(keep, v[nt][rg * 4 + 1], bb.y);
+                v[nt][rg * 4 + 2] = fmaf(keep, v[nt][rg * 4 + 2], bb.z);
+                v[nt][rg * 4 + 3] = fmaf(keep, v[nt][rg * 4 + 3], bb.w);
+            }
+            pin1(v[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // same, discarding the old contents
+    auto set_bias = [&](f32x16 (&v)[NT], const float* bc) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
+                v[nt][rg * 4 + 0] = bb.x; v[nt][rg * 4 + 1] = bb.y; v[nt][rg * 4 + 2] = bb.z; v[nt][rg * 4 + 3] = bb.w;
+            }
+            pin1(v[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // ToRGB: rgb += Wrgb * x + b, an fp32 dot product over this lane's half of the channels
     auto to_rgb = [&](const float* wr) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            pin1(x[nt]);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
@@ -176,13 +212,16 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 s0 = fmaf(v3, w0.w, fmaf(v2, w0.z, fmaf(v1, w0.y, fmaf(v0, w0.x, s0))));
                 s1 = fmaf(v3, w1.w, fmaf(v2, w1.z, fmaf(v1, w1.y, fmaf(v0, w1.x, s1))));
                 s2 = fmaf(v3, w2.w, fmaf(v2, w2.z, fmaf(v1, w2.y, fmaf(v0, w2.x, s2))));
-                if (rg == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (h == 0) { s0 += wr[3 * HdP + 0]; s1 += wr[3 * HdP + 1]; s2 += wr[3 * HdP + 2]; }
         rgb_acc[0] += s0; rgb_acc[1] += s1; rgb_acc[2] += s2;
     };
 
-    // ================= blocks before the first skip connection (either style, no residual registers) ============
+    // Register roles: every SPADE+conv stage takes its input in x and leaves its output in x (the conv accumulates
+    // onto x = bias); acc is the scratch accumulator of the gamma / beta GEMMs and of the first conv of a skip block.
+    // ================= blocks before the first skip connection (either style) ===================================
 #pragma unroll 1
     for (int blk = 0; blk < A.first_skip; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
@@ -194,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
             const h3d_spade_desc& Sp = Bk.spade[s];
-            f32x16 acc[NT];
             if (Sp.pixel_style) {
+                f32x16 acc[NT];
                 // ---- shared-MLP activations of this lane's pixel, straight into B-fragment layout
                 bf8 ah[8], al[8];
                 const float* cs = cstt + Sp.cst_index * kShared;
@@ -225,59 +264,54 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     }
                 }
                 const float* vec = tab + Sp.vec;
-                // gamma:  x <- (x*sc + sh) * (1 + gamma)
-                zero_acc1<NT>(acc);
-                gemm_x3<BF16, NT, 8, 8, false>(acc, ah, al, ring);
+                // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
+                set_bias(acc, vec);
+                pin_agpr<NT>(x); pin_agpr<NT>(acc);
+                gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+                pin_agpr<NT>(x); pin_agpr<NT>(acc);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) {
+                    pin1(x[nt]); pin1(acc[nt]);
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int n = nt * 32 + rg * 8 + 4 * h;
-                        const float4 g1 = *reinterpret_cast<const float4*>(vec + n);
+                        const float4 bt = *reinterpret_cast<const float4*>(vec + HdP + n);
                         const float4 sc = *reinterpret_cast<const float4*>(vec + 2 * HdP + n);
                         const float4 sh = *reinterpret_cast<const float4*>(vec + 3 * HdP + n);
-                        x[nt][rg * 4 + 0] = fmaf(x[nt][rg * 4 + 0], sc.x, sh.x) * (acc[nt][rg * 4 + 0] + g1.x);
-                        x[nt][rg * 4 + 1] = fmaf(x[nt][rg * 4 + 1], sc.y, sh.y) * (acc[nt][rg * 4 + 1] + g1.y);
-                        x[nt][rg * 4 + 2] = fmaf(x[nt][rg * 4 + 2], sc.z, sh.z) * (acc[nt][rg * 4 + 2] + g1.z);
-                        x[nt][rg * 4 + 3] = fmaf(x[nt][rg * 4 + 3], sc.w, sh.w) * (acc[nt][rg * 4 + 3] + g1.w);
-                        if (rg == 3) __builtin_amdgcn_sched_barrier(0);
+                        acc[nt][rg * 4 + 0] = fmaf(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x), acc[nt][rg * 4 + 0], bt.x);
+                        acc[nt][rg * 4 + 1] = fmaf(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y), acc[nt][rg * 4 + 1], bt.y);
+                        acc[nt][rg * 4 + 2] = fmaf(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z), acc[nt][rg * 4 + 2], bt.z);
+                        acc[nt][rg * 4 + 3] = fmaf(fmaf(x[nt][rg * 4 + 3], sc.w, sh.w), acc[nt][rg * 4 + 3], bt.w);
                     }
-                // beta:   y = lrelu(x + beta)
-                zero_acc1<NT>(acc);
-                gemm_x3<BF16, NT, 8, 8, false>(acc, ah, al, ring);
-                make_frags<NT>(xh, xl, [&](int nt, int rg) {
-                    const int n = nt * 32 + rg * 8 + 4 * h;
-                    const float4 bt = *reinterpret_cast<const float4*>(vec + HdP + n);
+                    pin1(acc[nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // beta:   y = lrelu(acc + beta)
+                pin_agpr<NT>(acc);
+                gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+                pin_agpr<NT>(acc);
+                make_frags<NT>(xh, xl, acc, [&](int nt, int rg) {
                     float4 y;
-                    y.x = (n + 0 < C) ? lrelu(x[nt][rg * 4 + 0] + acc[nt][rg * 4 + 0] + bt.x) : 0.f;
-                    y.y = (n + 1 < C) ? lrelu(x[nt][rg * 4 + 1] + acc[nt][rg * 4 + 1] + bt.y) : 0.f;
-                    y.z = (n + 2 < C) ? lrelu(x[nt][rg * 4 + 2] + acc[nt][rg * 4 + 2] + bt.z) : 0.f;
-                    y.w = (n + 3 < C) ? lrelu(x[nt][rg * 4 + 3] + acc[nt][rg * 4 + 3] + bt.w) : 0.f;
+                    y.x = lrelu(acc[nt][rg * 4 + 0]);
+                    y.y = lrelu(acc[nt][rg * 4 + 1]);
+                    y.z = lrelu(acc[nt][rg * 4 + 2]);
+                    y.w = lrelu(acc[nt][rg * 4 + 3]);
                     return y;
                 });
             } else {
-                const_frags(abt + Sp.ab_index * 2 * HdP);
+                const_frags(x, abt + Sp.ab_index * 2 * HdP);
             }
             // ---- conv: x <- W * y + b
-            zero_acc1<NT>(acc);
-            gemm_x3<BF16, NT, KS, KS, false>(acc, xh, xl, ring);
-            const float* bc = tab + Sp.b_conv;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
-                    x[nt][rg * 4 + 0] = acc[nt][rg * 4 + 0] + bb.x;
-                    x[nt][rg * 4 + 1] = acc[nt][rg * 4 + 1] + bb.y;
-                    x[nt][rg * 4 + 2] = acc[nt][rg * 4 + 2] + bb.z;
-                    x[nt][rg * 4 + 3] = acc[nt][rg * 4 + 3] + bb.w;
-                    if (rg == 3) __builtin_amdgcn_sched_barrier(0);
-                }
+            set_bias(x, tab + Sp.b_conv);
+            pin_agpr<NT>(x);
+            gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(x, xh, xl, ring);
+            pin_agpr<NT>(x);
         }
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
     }
 
-    // ================= blocks with a skip connection (constant style only): block input kept in registers ========
+    // ================= blocks from the first skip connection on (constant style only) ============================
+    // conv 0 goes x -> acc (x stays live as the residual), conv 1 goes acc -> x accumulating onto keep*x + bias.
 #pragma unroll 1
     for (int blk = A.first_skip; blk < D.n_blocks; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
@@ -285,30 +319,17 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         asm volatile("" : "+s"(opaque));
         const float* tab = tab0 + opaque;
         const float* abt = ab0 + opaque;
-        f32x16 xres[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xres[nt] = x[nt];
-#pragma unroll 1
-        for (int s = 0; s < 2; ++s) {
-            const h3d_spade_desc& Sp = Bk.spade[s];
-            f32x16 acc[NT];
-            const_frags(abt + Sp.ab_index * 2 * HdP);
-            zero_acc1<NT>(acc);
-            gemm_x3<BF16, NT, KS, KS, false>(acc, xh, xl, ring);
-            const float* bc = tab + Sp.b_conv;
-            const float keep = (s == 1 && Bk.skip) ? 1.f : 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
-                    x[nt][rg * 4 + 0] = fmaf(keep, xres[nt][rg * 4 + 0], acc[nt][rg * 4 + 0] + bb.x);
-                    x[nt][rg * 4 + 1] = fmaf(keep, xres[nt][rg * 4 + 1], acc[nt][rg * 4 + 1] + bb.y);
-                    x[nt][rg * 4 + 2] = fmaf(keep, xres[nt][rg * 4 + 2], acc[nt][rg * 4 + 2] + bb.z);
-                    x[nt][rg * 4 + 3] = fmaf(keep, xres[nt][rg * 4 + 3], acc[nt][rg * 4 + 3] + bb.w);
-                    if (rg == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-        }
+        f32x16 acc[NT];
+        const_frags(x, abt + Bk.spade[0].ab_index * 2 * HdP);
+        set_bias(acc, tab + Bk.spade[0].b_conv);
+        pin_agpr<NT>(x); pin_agpr<NT>(acc);
+        gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(acc, xh, xl, ring);
+        pin_agpr<NT>(x); pin_agpr<NT>(acc);
+        const_frags(acc, abt + Bk.spade[1].ab_index * 2 * HdP);
+        init_bias(x, tab + Bk.spade[1].b_conv, Bk.skip ? 1.f : 0.f);
+        pin_agpr<NT>(x);
+        gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(x, xh, xl, ring);
+        pin_agpr<NT>(x);
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
     }
     ring.drain();

@@ -194,6 +194,66 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const typename T::vec
     }
 }
 
+// Register-lean variant of gemm_x3: instead of double-buffering a whole k-step of weight fragments (NT*16
+// registers), a rolling window of L+1 tile pairs (16 registers each) runs L pairs (L * 192 MFMA cycles) ahead of
+// the matrix pipe.  Same ring protocol: acquire(s+1) happens inside k-step s, just before the first read of stage
+// s+1 and after the last read of stage s was issued; each acquire is followed by exactly one refill, one DMA chunk
+// after each of the next NT/2 tile pairs.  acc is accumulated into (initialise it with the bias / residual).
+template <typename T, int NT, int KS, int KSA, bool SWAP, int L, typename RING>
+__device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA],
+                                             const typename T::vec8 (&xl)[KSA], RING& ring) {
+    constexpr int P = NT / 2, G = KS * P, NB = L + 1;
+    static_assert(NT % 2 == 0 && KS <= KSA && L >= 1 && L <= P, "look-ahead is at most one k-step");
+    static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
+    struct Pair { typename T::vec8 h[2], l[2]; } buf[NB];
+    const unsigned char* st[2];
+    auto load_pair = [&](int q) {
+        const unsigned char* s = st[(q / P) & 1] + (q % P) * 4096;
+        Pair& b = buf[q % NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            b.h[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 0) * 1024));
+            b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 1) * 1024));
+        }
+    };
+    st[0] = ring.acquire();
+    ring.issue();
+#pragma unroll
+    for (int q = 0; q < L; ++q) load_pair(q);
+    int chunk = P;                              // refill chunks still owed for the latest acquire (compile-time after unrolling)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int s = g / P, p = g % P;
+        if (p == P - L && s + 1 < KS) {
+            st[(s + 1) & 1] = ring.acquire();
+            chunk = 0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + L < G) load_pair(g + L);
+        const Pair& b = buf[g % NB];
+        const int n0 = 2 * p, n1 = 2 * p + 1;
+        acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
+        acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
+        acc[n0] = mm<T, SWAP>(b.h[0], xl[s], acc[n0]);
+        acc[n1] = mm<T, SWAP>(b.h[1], xl[s], acc[n1]);
+        acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);
+        acc[n1] = mm<T, SWAP>(b.l[1], xh[s], acc[n1]);
+        if (chunk < P) { ring.issue_chunk(chunk); ++chunk; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Force an accumulator set into the AGPR half of the register file at this point (MFMA reads / writes C there
+// directly; VALU users pay one v_accvgpr_read).  Used to hand the compiler the partition "accumulators in AGPRs,
+// fragments and scalars in VGPRs" that it does not find by itself at 500 live registers.
+__device__ __forceinline__ void pin1(f32x16& v) { asm volatile("" : "+a"(v)); }
+
+template <int NT>
+__device__ __forceinline__ void pin_agpr(f32x16 (&v)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" : "+a"(v[i]));
+}
+
 template <int NT>
 __device__ __forceinline__ void zero_acc1(f32x16 (&acc)[NT]) {
 #pragma unroll

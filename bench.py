@@ -145,7 +145,7 @@ def ray_integrate_roofline(cfg, batch, iters=10):
                 traffic=None, ms=ms, bytes=by, batch=nb)
 
 
-def cpu_baseline(cfg, sd, seed=1234, shrink=4):
+def cpu_baseline(cfg, sd, seed=1234, shrink=2):
     """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores.
     Bounded sample: ONE image at 1/shrink of the height and width (output pixels, rays) with the same samples per
     ray, widths and weights -- per-ray and per-pixel work is identical and the total is linear in both counts, so

@@ -19,9 +19,10 @@ cnt = defaultdict(lambda: defaultdict(int))
 for k, n, v in c.execute(f"select {kn}, {cn_}, {vn} from {view}"):
     agg[k][n] += v
     cnt[k][n] += 1
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+import re
+flt = re.compile(sys.argv[2] if len(sys.argv) > 2 else "")
 for k in agg:
-    if flt in k:
+    if flt.search(k):
         print(k[:90])
         for n in sorted(agg[k]):
             print(f"   {n:32s} total {agg[k][n]:.4g}   per-dispatch {agg[k][n] / cnt[k][n]:.4g}  (n={cnt[k][n]})")
