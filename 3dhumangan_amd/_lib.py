@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libh3d.so")
+LIB_PATH = os.environ.get("H3D_LIB", LIB_PATH)       # development: an experimental build of the same library
 
 _lib = None
 

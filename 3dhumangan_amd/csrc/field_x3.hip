@@ -127,14 +127,14 @@ __device__ __forceinline__ void film_epilogue(const f32x16 (&acc)[NT], half8 (&x
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int n = nt * 32 + rg * 8 + 4 * h;
-            const float4 b = *reinterpret_cast<const float4*>(tb + n);
-            const float4 f = *reinterpret_cast<const float4*>(tf + n);
-            const float4 p = *reinterpret_cast<const float4*>(tp + n);
+            const f32x4 b = ld4(tb + n);
+            const f32x4 f = ld4(tf + n);
+            const f32x4 p = ld4(tp + n);
             float add[4] = {b.x, b.y, b.z, b.w};
             if (twd) {
-                const float4 w0 = *reinterpret_cast<const float4*>(twd + n);
-                const float4 w1 = *reinterpret_cast<const float4*>(twd + HdP + n);
-                const float4 w2 = *reinterpret_cast<const float4*>(twd + 2 * HdP + n);
+                const f32x4 w0 = ld4(twd + n);
+                const f32x4 w1 = ld4(twd + HdP + n);
+                const f32x4 w2 = ld4(twd + 2 * HdP + n);
                 add[0] += w0.x * d0 + w1.x * d1 + w2.x * d2;
                 add[1] += w0.y * d0 + w1.y * d1 + w2.y * d2;
                 add[2] += w0.z * d0 + w1.z * d1 + w2.z * d2;
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 float v[8];
 #pragma unroll
                 for (int q4 = 0; q4 < 2; ++q4) {
-                    const float4 w0 = *reinterpret_cast<const float4*>(twc + k0 + q4 * 4);
-                    const float4 w1 = *reinterpret_cast<const float4*>(twc + HdP + k0 + q4 * 4);
-                    const float4 w2 = *reinterpret_cast<const float4*>(twc + 2 * HdP + k0 + q4 * 4);
-                    const float4 bb = *reinterpret_cast<const float4*>(tbc + k0 + q4 * 4);
+                    const f32x4 w0 = ld4(twc + k0 + q4 * 4);
+                    const f32x4 w1 = ld4(twc + HdP + k0 + q4 * 4);
+                    const f32x4 w2 = ld4(twc + 2 * HdP + k0 + q4 * 4);
+                    const f32x4 bb = ld4(tbc + k0 + q4 * 4);
                     // same association as F.linear: ((w0*x + w1*y) + w2*z) + b
                     v[q4 * 4 + 0] = sin_hw(30.f * (fmaf(w2.x, pz, fmaf(w1.x, py, w0.x * px)) + bb.x));
                     v[q4 * 4 + 1] = sin_hw(30.f * (fmaf(w2.y, pz, fmaf(w1.y, py, w0.y * px)) + bb.y));
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             float wr[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float4 w4 = *reinterpret_cast<const float4*>(wl_lds + rg * 8 + 4 * h);
+                const f32x4 w4 = ld4(wl_lds + rg * 8 + 4 * h);
                 wr[rg * 4 + 0] = w4.x; wr[rg * 4 + 1] = w4.y; wr[rg * 4 + 2] = w4.z; wr[rg * 4 + 3] = w4.w;
             }
 #pragma unroll

@@ -21,6 +21,7 @@ namespace {
 typedef BF16::vec8 bf8;
 constexpr int kShared = 128;
 constexpr int kRingDepth = 4;
+constexpr int kValuPerMfma = 5;    // VALU instructions slotted behind each MFMA of a section that carries epilogue work
 constexpr int kLook = 2;           // weight-fragment look-ahead in tile pairs (gemm_x3_roll)      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
 
 struct Args {
@@ -71,6 +72,85 @@ __device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
     }
 }
 
+struct Tabs { f32x4 sc, sh; };
+struct TileWords { unsigned Hh[4][2], Ll[4][2]; Tabs tb; };
+
+// One sixth of a tile's fragment epilogue, small enough to hide behind one tile-pair section (6 MFMAs) of the GEMM
+// that consumes the fragments: C = 0..3 register group C through val -> packed bf16 halves; 4 / 5 = relayout of
+// the hi / lo plane into the B fragments of k-steps 2*TILE, 2*TILE+1.  val.tabs(tile, rg) reads the LDS tables of
+// a register group, val.apply(tile, rg, tabs) computes its four outputs; the tables are fetched one chunk ahead so
+// that their LDS latency never stalls the (in-order) instruction stream in front of an MFMA.
+template <int NT, int TILE, int C, typename F>
+__device__ __forceinline__ void frag_chunk(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], TileWords& tw, f32x16 (&src)[NT], F& val) {
+    if constexpr (C == 0) pin1(src[TILE]);
+    if constexpr (C < 4) {
+        const f32x4 y = val.apply(IC<TILE>{}, IC<C>{}, tw.tb);
+        if constexpr (C < 3) tw.tb = val.tabs(IC<TILE>{}, IC<C + 1>{});
+        else if constexpr (TILE + 1 < NT) tw.tb = val.tabs(IC<TILE + 1>{}, IC<0>{});
+        tw.Hh[C][0] = split2_bf16(y.x, y.y, tw.Ll[C][0]);
+        tw.Hh[C][1] = split2_bf16(y.z, y.w, tw.Ll[C][1]);
+    } else if constexpr (C == 4) {
+        relayout_tile<BF16>(tw.Hh, xh[2 * TILE], xh[2 * TILE + 1]);
+    } else if constexpr (C == 5) {
+        relayout_tile<BF16>(tw.Ll, xl[2 * TILE], xl[2 * TILE + 1]);
+    }
+}
+
+// conv GEMM dst (+)= W * frags(val(src)) with the fragment epilogue of tile t+1 hidden behind the MFMAs of k-steps
+// 2t, 2t+1 (which only need tile t); only tile 0's epilogue is exposed.  src and dst are different register sets.
+template <int NT, bool ZERO, typename RING, typename F>
+__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], f32x16 (&src)[NT], bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
+                                                 RING& ring, F val) {
+    TileWords tw;
+    tw.tb = val.tabs(IC<0>{}, IC<0>{});
+    static_for<0, 6>([&](auto c) __attribute__((always_inline)) { frag_chunk<NT, 0, decltype(c)::value>(xh, xl, tw, src, val); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int W = NT, PER = 8 / W;          // sections per 2-k-step window, chunks per section
+    gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int t = g / W + 1, j = g % W;
+        if constexpr (t < NT) {
+            static_for<0, PER>([&](auto q) __attribute__((always_inline)) {
+                constexpr int c = j * PER + decltype(q)::value;
+                if constexpr (c < 6) frag_chunk<NT, t, c>(xh, xl, tw, src, val);
+            });
+        }
+    });
+}
+
+// y = lrelu(v * sc + sh), tables [2][HdP] in LDS (constant-style SPADE with the conv bias of v folded into sh)
+template <int NT>
+struct AffineLrelu {
+    f32x16 (&v)[NT];
+    const float* ab;
+    int h, HdP;
+    template <typename TI, typename RG>
+    __device__ __forceinline__ Tabs tabs(TI, RG) const {
+        const int n = TI::value * 32 + RG::value * 8 + 4 * h;
+        return Tabs{ld4(ab + n), ld4(ab + HdP + n)};
+    }
+    template <typename TI, typename RG>
+    __device__ __forceinline__ f32x4 apply(TI, RG, const Tabs& t) const {
+        constexpr int nt = TI::value, r = RG::value * 4;
+        f32x4 y = {fmaf(v[nt][r + 0], t.sc.x, t.sh.x), fmaf(v[nt][r + 1], t.sc.y, t.sh.y), fmaf(v[nt][r + 2], t.sc.z, t.sh.z),
+                   fmaf(v[nt][r + 3], t.sc.w, t.sh.w)};
+        return __builtin_elementwise_max(y, y * 0.2f);
+    }
+};
+
+// y = lrelu(v)   (per-pixel-style SPADE: v already holds (x*sc+sh)*(1+gamma) + beta)
+template <int NT>
+struct PlainLrelu {
+    f32x16 (&v)[NT];
+    template <typename TI, typename RG> __device__ __forceinline__ Tabs tabs(TI, RG) const { return Tabs{}; }
+    template <typename TI, typename RG>
+    __device__ __forceinline__ f32x4 apply(TI, RG, const Tabs&) const {
+        constexpr int nt = TI::value, r = RG::value * 4;
+        f32x4 y = {v[nt][r + 0], v[nt][r + 1], v[nt][r + 2], v[nt][r + 3]};
+        return __builtin_elementwise_max(y, y * 0.2f);
+    }
+};
+
 template <int NT, int DEPTH, bool SEG>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
@@ -93,6 +173,11 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     for (int i = t; i < A.n_cst * kShared; i += 256) cst0[i] = A.cst[(int64_t)b * A.n_cst * kShared + i];
     __syncthreads();
 
+#ifdef H3D_EXPERIMENT_TRACE
+    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.state); g_trace_n = 0; }
+    __syncthreads();
+    H3D_TRACE(0);
+#endif
     WeightRing<NT, DEPTH> ring;
     ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
 
@@ -139,9 +224,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
-                const float4 w0 = *reinterpret_cast<const float4*>(win + n);
-                const float4 w1 = *reinterpret_cast<const float4*>(win + HdP + n);
-                const float4 bb = *reinterpret_cast<const float4*>(bin + n);
+                const f32x4 w0 = ld4(win + n);
+                const f32x4 w1 = ld4(win + HdP + n);
+                const f32x4 bb = ld4(bin + n);
                 x[nt][rg * 4 + 0] = sin_hw(w0.x * ci + w1.x * cj + bb.x);
                 x[nt][rg * 4 + 1] = sin_hw(w0.y * ci + w1.y * cj + bb.y);
                 x[nt][rg * 4 + 2] = sin_hw(w0.z * ci + w1.z * cj + bb.z);
@@ -156,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {
         make_frags<NT>(xh, xl, v, [&](int nt, int rg) {
             const int n = nt * 32 + rg * 8 + 4 * h;
-            const float4 sc = *reinterpret_cast<const float4*>(ab + n);
-            const float4 sh = *reinterpret_cast<const float4*>(ab + HdP + n);
+            const f32x4 sc = ld4(ab + n);
+            const f32x4 sh = ld4(ab + HdP + n);
             float4 y;
             y.x = lrelu(fmaf(v[nt][rg * 4 + 0], sc.x, sh.x));
             y.y = lrelu(fmaf(v[nt][rg * 4 + 1], sc.y, sh.y));
@@ -166,30 +251,13 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             return y;
         });
     };
-    // accumulator initialisation: v = keep * v + bias   (the GEMM then accumulates the convolution on top)
-    auto init_bias = [&](f32x16 (&v)[NT], const float* bc, float keep) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            pin1(v[nt]);
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
-                v[nt][rg * 4 + 0] = fmaf(keep, v[nt][rg * 4 + 0], bb.x);
-                v[nt][rg * 4 + 1] = fmaf(keep, v[nt][rg * 4 + 1], bb.y);
-                v[nt][rg * 4 + 2] = fmaf(keep, v[nt][rg * 4 + 2], bb.z);
-                v[nt][rg * 4 + 3] = fmaf(keep, v[nt][rg * 4 + 3], bb.w);
-            }
-            pin1(v[nt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // same, discarding the old contents
+    // accumulator initialisation with a per-channel vector (1 + gamma bias of the per-pixel SPADE)
     auto set_bias = [&](f32x16 (&v)[NT], const float* bc) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float4 bb = *reinterpret_cast<const float4*>(bc + nt * 32 + rg * 8 + 4 * h);
+                const f32x4 bb = ld4(bc + nt * 32 + rg * 8 + 4 * h);
                 v[nt][rg * 4 + 0] = bb.x; v[nt][rg * 4 + 1] = bb.y; v[nt][rg * 4 + 2] = bb.z; v[nt][rg * 4 + 3] = bb.w;
             }
             pin1(v[nt]);
@@ -205,9 +273,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
-                const float4 w0 = *reinterpret_cast<const float4*>(wr + n);
-                const float4 w1 = *reinterpret_cast<const float4*>(wr + HdP + n);
-                const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * HdP + n);
+                const f32x4 w0 = ld4(wr + n);
+                const f32x4 w1 = ld4(wr + HdP + n);
+                const f32x4 w2 = ld4(wr + 2 * HdP + n);
                 const float v0 = x[nt][rg * 4 + 0], v1 = x[nt][rg * 4 + 1], v2 = x[nt][rg * 4 + 2], v3 = x[nt][rg * 4 + 3];
                 s0 = fmaf(v3, w0.w, fmaf(v2, w0.z, fmaf(v1, w0.y, fmaf(v0, w0.x, s0))));
                 s1 = fmaf(v3, w1.w, fmaf(v2, w1.z, fmaf(v1, w1.y, fmaf(v0, w1.x, s1))));
@@ -244,11 +312,11 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     const int k0 = Sp.g_offset + ks * 16 + h * 8;
 #pragma unroll
                     for (int q4 = 0; q4 < 2; ++q4) {
-                        const float4 a = *reinterpret_cast<const float4*>(g00 + k0 + q4 * 4);
-                        const float4 bq = *reinterpret_cast<const float4*>(g01 + k0 + q4 * 4);
-                        const float4 c = *reinterpret_cast<const float4*>(g10 + k0 + q4 * 4);
-                        const float4 d = *reinterpret_cast<const float4*>(g11 + k0 + q4 * 4);
-                        const float4 k4 = *reinterpret_cast<const float4*>(cs + ks * 16 + h * 8 + q4 * 4);
+                        const f32x4 a = ld4(g00 + k0 + q4 * 4);
+                        const f32x4 bq = ld4(g01 + k0 + q4 * 4);
+                        const f32x4 c = ld4(g10 + k0 + q4 * 4);
+                        const f32x4 d = ld4(g11 + k0 + q4 * 4);
+                        const f32x4 k4 = ld4(cs + ks * 16 + h * 8 + q4 * 4);
                         float v[4];
                         v[0] = (a.x * tx1 + bq.x * tx) * ty1 + (c.x * tx1 + d.x * tx) * ty + k4.x;
                         v[1] = (a.y * tx1 + bq.y * tx) * ty1 + (c.y * tx1 + d.y * tx) * ty + k4.y;
@@ -275,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int n = nt * 32 + rg * 8 + 4 * h;
-                        const float4 bt = *reinterpret_cast<const float4*>(vec + HdP + n);
-                        const float4 sc = *reinterpret_cast<const float4*>(vec + 2 * HdP + n);
-                        const float4 sh = *reinterpret_cast<const float4*>(vec + 3 * HdP + n);
+                        const f32x4 bt = ld4(vec + HdP + n);
+                        const f32x4 sc = ld4(vec + 2 * HdP + n);
+                        const f32x4 sh = ld4(vec + 3 * HdP + n);
                         acc[nt][rg * 4 + 0] = fmaf(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x), acc[nt][rg * 4 + 0], bt.x);
                         acc[nt][rg * 4 + 1] = fmaf(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y), acc[nt][rg * 4 + 1], bt.y);
                         acc[nt][rg * 4 + 2] = fmaf(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z), acc[nt][rg * 4 + 2], bt.z);
@@ -290,28 +358,22 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 pin_agpr<NT>(acc);
                 gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
                 pin_agpr<NT>(acc);
-                make_frags<NT>(xh, xl, acc, [&](int nt, int rg) {
-                    float4 y;
-                    y.x = lrelu(acc[nt][rg * 4 + 0]);
-                    y.y = lrelu(acc[nt][rg * 4 + 1]);
-                    y.z = lrelu(acc[nt][rg * 4 + 2]);
-                    y.w = lrelu(acc[nt][rg * 4 + 3]);
-                    return y;
-                });
+                conv_progressive<NT, true>(x, acc, xh, xl, ring, PlainLrelu<NT>{acc});
+                pin_agpr<NT>(x);
             } else {
+                // constant style before the first skip block: x is both source and destination, so the fragments
+                // are completed before the conv starts
                 const_frags(x, abt + Sp.ab_index * 2 * HdP);
+                gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+                pin_agpr<NT>(x);
             }
-            // ---- conv: x <- W * y + b
-            set_bias(x, tab + Sp.b_conv);
-            pin_agpr<NT>(x);
-            gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(x, xh, xl, ring);
-            pin_agpr<NT>(x);
         }
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
     }
 
     // ================= blocks from the first skip connection on (constant style only) ============================
-    // conv 0 goes x -> acc (x stays live as the residual), conv 1 goes acc -> x accumulating onto keep*x + bias.
+    // conv 0 goes x -> acc (x stays live as the residual), conv 1 goes acc -> x accumulating onto the residual
+    // (conv biases are folded into the consumers' tables by the host: build_x3 in synthesis_pack.py).
 #pragma unroll 1
     for (int blk = A.first_skip; blk < D.n_blocks; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
@@ -320,19 +382,17 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         const float* tab = tab0 + opaque;
         const float* abt = ab0 + opaque;
         f32x16 acc[NT];
-        const_frags(x, abt + Bk.spade[0].ab_index * 2 * HdP);
-        set_bias(acc, tab + Bk.spade[0].b_conv);
-        pin_agpr<NT>(x); pin_agpr<NT>(acc);
-        gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(acc, xh, xl, ring);
-        pin_agpr<NT>(x); pin_agpr<NT>(acc);
-        const_frags(acc, abt + Bk.spade[1].ab_index * 2 * HdP);
-        init_bias(x, tab + Bk.spade[1].b_conv, Bk.skip ? 1.f : 0.f);
         pin_agpr<NT>(x);
-        gemm_x3_roll<BF16, NT, KS, KS, false, kLook>(x, xh, xl, ring);
+        conv_progressive<NT, true>(acc, x, xh, xl, ring, AffineLrelu<NT>{x, abt + Bk.spade[0].ab_index * 2 * HdP, h, HdP});
+        pin_agpr<NT>(x); pin_agpr<NT>(acc);
+        conv_progressive<NT, false>(x, acc, xh, xl, ring, AffineLrelu<NT>{acc, abt + Bk.spade[1].ab_index * 2 * HdP, h, HdP});
         pin_agpr<NT>(x);
+        H3D_TRACE(5);
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
+        H3D_TRACE(6);
     }
     ring.drain();
+    H3D_TRACE(9);
     if (SEG && A.store_state) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -395,6 +455,11 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     int first_skip = desc->n_blocks;
     for (int k = 0; k < desc->n_blocks; ++k) {
         if (desc->block[k].skip && !seen_skip) first_skip = k;
+        if (seen_skip && !desc->block[k].skip) {
+            h3d::set_error("h3d_synthesis_x3: a block without skip connection after the first skip block is not supported; "
+                           "use h3d_synthesis");
+            return H3D_EUNSUPPORTED;
+        }
         seen_skip = seen_skip || desc->block[k].skip;
         for (int s = 0; s < 2; ++s) {
             const h3d_spade_desc& sp = desc->block[k].spade[s];

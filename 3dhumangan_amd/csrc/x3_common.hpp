@@ -12,6 +12,11 @@
 namespace h3d {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// LDS table reads go through this ext-vector type, NOT HIP's float4 struct: an aggregate (struct) load from LDS makes
+// the compiler's waitcnt pass assume it may alias the in-flight LDS-DMA and emit s_waitcnt vmcnt(0) in front of it,
+// which drains the whole weight-ring prefetch queue at every table read.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 #ifndef H3D_RING_DEPTH
 #define H3D_RING_DEPTH 7
@@ -38,6 +43,16 @@ template <typename T>
 __device__ __forceinline__ void split(float xs, typename T::elem& hi, typename T::elem& lo) {
     hi = (typename T::elem)xs;
     lo = (typename T::elem)(xs - (float)hi);
+}
+
+// Two fp32 -> packed bf16 hi halves (returned) and packed bf16 lo halves: 6 VALU ops per pair.
+__device__ __forceinline__ unsigned split2_bf16(float a, float b, unsigned& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, b2));
+    const float fa = __builtin_bit_cast(float, hb << 16), fb = __builtin_bit_cast(float, hb & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a - fa, b - fb}, b2));
+    return hb;
 }
 
 template <typename T>
@@ -85,6 +100,9 @@ struct WeightRing {
         for (int i = 0; i < kBuf - 1; ++i) issue();
     }
     __device__ __forceinline__ void issue_chunk(int c) {           // c = 0 .. kChunks-1, in order
+#ifdef H3D_EXPERIMENT_NO_REFILL
+        if (issue_pos >= kBuf - 1) { if (c == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 : issue_pos + 1; } return; }
+#endif
         const unsigned char* g = gsrc + (int64_t)issue_pos * kStage + c * 1024;
         unsigned char* d = ring + issue_buf * kStage + (wave * kChunks + c) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -107,9 +125,15 @@ struct WeightRing {
     // bounded-latency path.  (Waiting lgkmcnt(0) here instead costs ~15 % on the whole kernel.)
     __device__ __forceinline__ const unsigned char* acquire() {
         // vmcnt only (expcnt / lgkmcnt fields left at "no wait"): stages t+1 .. t+kBuf-2 may stay in flight
+#ifdef H3D_EXPERIMENT_NO_REFILL
+        constexpr int kKeep = 0;
+#else
         constexpr int kKeep = (kBuf - 2) * kChunks;
+#endif
+#ifndef H3D_EXPERIMENT_NO_BARRIER
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
         __builtin_amdgcn_s_barrier();
+#endif
         // the stage's ds_reads depend on this (opaque) offset: they cannot be hoisted above the barrier.  An integer
         // is laundered, not the pointer, so the address space stays LDS (ds_read, not flat_load).
         int off = cur_buf * kStage + lane * 16;
@@ -138,6 +162,9 @@ __device__ __forceinline__ void load_wfrag_pair(WFragT<T, NT>& f, const unsigned
 
 template <typename T, bool SWAP>
 __device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T::vec8& x, const f32x16& c) {
+#ifdef H3D_EXPERIMENT_NO_MFMA
+    f32x16 r = c; r[0] += (float)w[0] * (float)x[0]; return r;
+#endif
     return SWAP ? T::mfma(x, w, c) : T::mfma(w, x, c);
 }
 
@@ -199,48 +226,104 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const typename T::vec
 // the matrix pipe.  Same ring protocol: acquire(s+1) happens inside k-step s, just before the first read of stage
 // s+1 and after the last read of stage s was issued; each acquire is followed by exactly one refill, one DMA chunk
 // after each of the next NT/2 tile pairs.  acc is accumulated into (initialise it with the bias / residual).
-template <typename T, int NT, int KS, int KSA, bool SWAP, int L, typename RING>
+template <int I>
+struct IC { static constexpr int value = I; };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#ifdef H3D_EXPERIMENT_TRACE
+__device__ unsigned long long* g_trace;
+__device__ int g_trace_n;
+#define H3D_TRACE(tag)                                                                         \
+    do {                                                                                       \
+        if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0 && g_trace_n < 4000) {   \
+            g_trace[g_trace_n++] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag); \
+        }                                                                                      \
+    } while (0)
+#else
+#define H3D_TRACE(tag) do { } while (0)
+#endif
+
+struct NoHook {
+    template <typename G> __device__ __forceinline__ void operator()(G) const {}
+};
+
+// HOOK: side work (the caller's VALU epilogue of the previous layer, producing the fragments of later k-steps),
+// called as hook(IC<g>{}) once per tile-pair section g = ks * NT/2 + p, in program order before the section's six
+// MFMAs; VALU_PER_MFMA > 0 asks the scheduler to slot that many VALU instructions behind each MFMA of the section.
+// Every index is a compile-time constant (static_for), so fragment / accumulator arrays stay in registers.
+template <typename T, int NT, int KS, int KSA, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA],
-                                             const typename T::vec8 (&xl)[KSA], RING& ring) {
+                                             const typename T::vec8 (&xl)[KSA], RING& ring, HOOK hook = HOOK()) {
     constexpr int P = NT / 2, G = KS * P, NB = L + 1;
     static_assert(NT % 2 == 0 && KS <= KSA && L >= 1 && L <= P, "look-ahead is at most one k-step");
     static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
     struct Pair { typename T::vec8 h[2], l[2]; } buf[NB];
     const unsigned char* st[2];
-    auto load_pair = [&](int q) {
+    auto load_pair = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
         const unsigned char* s = st[(q / P) & 1] + (q % P) * 4096;
         Pair& b = buf[q % NB];
+#ifdef H3D_EXPERIMENT_NO_WREAD
+        if (q >= NB) return;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             b.h[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 0) * 1024));
             b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 1) * 1024));
         }
     };
+    H3D_TRACE(1);
     st[0] = ring.acquire();
     ring.issue();
-#pragma unroll
-    for (int q = 0; q < L; ++q) load_pair(q);
-    int chunk = P;                              // refill chunks still owed for the latest acquire (compile-time after unrolling)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int s = g / P, p = g % P;
-        if (p == P - L && s + 1 < KS) {
+    static_for<0, L>(load_pair);
+    static_for<0, G>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int s = g / P, p = g % P;
+        if constexpr (p == P - L && s + 1 < KS) {
+            if constexpr (s % 4 == 0) H3D_TRACE(2);
             st[(s + 1) & 1] = ring.acquire();
-            chunk = 0;
+            if constexpr (s % 4 == 0) H3D_TRACE(3);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (g + L < G) load_pair(g + L);
+        if constexpr (g + L < G) load_pair(IC<g + L>{});
+#ifndef H3D_EXPERIMENT_NO_HOOK
+        hook(gc);
+#endif
         const Pair& b = buf[g % NB];
-        const int n0 = 2 * p, n1 = 2 * p + 1;
-        acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
-        acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
+        constexpr int n0 = 2 * p, n1 = 2 * p + 1;
+        if constexpr (ZERO && s == 0) {          // fresh accumulators: C = 0 is an inline constant, no init pass
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], zero);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], zero);
+        } else {
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
+        }
         acc[n0] = mm<T, SWAP>(b.h[0], xl[s], acc[n0]);
         acc[n1] = mm<T, SWAP>(b.h[1], xl[s], acc[n1]);
         acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);
         acc[n1] = mm<T, SWAP>(b.l[1], xh[s], acc[n1]);
-        if (chunk < P) { ring.issue_chunk(chunk); ++chunk; }
+        // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
+        // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()
+        constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
+        if constexpr (since >= 0 && since / P + 1 < KS) ring.issue_chunk(since % P);
+        if constexpr (VALU_PER_MFMA > 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER_MFMA, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
+    H3D_TRACE(4);
 }
 
 // Force an accumulator set into the AGPR half of the register file at this point (MFMA reads / writes C there

@@ -153,11 +153,14 @@ class SynthesisPlan:
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
     def x3_supported(self):
-        """C <= 256 and no per-pixel-style block at or after the first skip block (csrc/synthesis_x3.hip)."""
+        """C <= 256, no per-pixel-style block at or after the first skip block, every block after the first skip block
+        has a skip connection too (csrc/synthesis_x3.hip)."""
         if self.C > 256:
             return False
         seen_skip = False
         for k in range(self.n_blocks):
+            if seen_skip and not self.desc.block[k].skip:
+                return False
             seen_skip = seen_skip or bool(self.desc.block[k].skip)
             if seen_skip and (self.desc.block[k].spade[0].pixel_style or self.desc.block[k].spade[1].pixel_style):
                 return False
@@ -210,7 +213,14 @@ class SynthesisPlan:
             cur.append(k)
             cur_bytes += n * stage_bytes
         ranges.append(cur)
+        # Conv biases are folded on the host (the x3 kernel never adds one): the kernel's activations are the true ones
+        # minus a per-channel "carry" -- the bias of the conv that produced them plus, along a skip chain, the carry of
+        # the block input.  Every consumer is affine in its input, so the carry moves into its shift:
+        #   SPADE  y = lrelu(sc * (x + c) + sh)  ->  sh' = sh + sc * c      (per-sample ab tables: run(); vec: here)
+        #   ToRGB  rgb += Wr (x + c) + br        ->  br' = br + Wr c
         segments = []
+        carry = torch.zeros(HdP, device=self.device, dtype=torch.float32)
+        ab_carry = torch.zeros(max(1, len(self.const_ids)), HdP, device=self.device, dtype=torch.float32)
         for blocks in ranges:
             chunks, off = [], [0]
 
@@ -232,6 +242,7 @@ class SynthesisPlan:
             for j, k in enumerate(blocks):
                 src, dst = self.desc.block[k], desc.block[j]
                 dst.skip, dst.to_rgb = src.skip, src.to_rgb
+                c_in = carry
                 for s in range(2):
                     raw = self._raw[2 * k + s]
                     d, so = dst.spade[s], src.spade[s]
@@ -240,17 +251,23 @@ class SynthesisPlan:
                         stream.append(self.pack_stream_bf16(raw["wgam"], SHARED // 16, NT))
                         stream.append(self.pack_stream_bf16(raw["wbet"], SHARED // 16, NT))
                         stages += 2 * (SHARED // 16)
-                        d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), _pad(raw["sc"], HdP),
-                                               _pad(raw["sh"], HdP)]))
+                        sc, sh = _pad(raw["sc"], HdP), _pad(raw["sh"], HdP)
+                        d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), sc, sh + sc * carry]))
+                    else:
+                        ab_carry[so.ab_index] = carry
                     stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
                     stages += 2 * NT
-                    d.b_conv = add(_pad(raw["conv_b"], HdP))
+                    d.b_conv = -1                                   # folded: the kernel has no bias add
+                    carry = _pad(raw["conv_b"], HdP)
+                    if s == 1 and src.skip:
+                        carry = carry + c_in
                 if dst.to_rgb:
                     wr, br = self._rgb[k]
+                    br = br.float() + wr.float() @ carry[: wr.shape[1]]
                     dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
             segments.append(dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
                                  stages=stages, blocks=blocks))
-        self._x3 = dict(segments=segments, HdP=HdP, NT=NT, state=None)
+        self._x3 = dict(segments=segments, HdP=HdP, NT=NT, state=None, ab_carry=ab_carry)
         return self._x3
 
     def per_forward_tables(self, feature_maps, fixed_style, HdP=None):
@@ -285,6 +302,8 @@ class SynthesisPlan:
         x3 = self.build_x3() if self.engine == "bf16x3" else None
         with stage(owner, "synthesis_tables"):
             G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3["HdP"] if x3 else None)
+            if x3 and ab is not None:
+                ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]      # folded conv biases (build_x3)
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         with stage(owner, "synthesis"):
             if x3:
@@ -295,6 +314,9 @@ class SynthesisPlan:
                     if x3["state"] is None or x3["state"].numel() < need:
                         x3["state"] = torch.empty(need, device=fixed_style.device, dtype=torch.float32)
                     state = x3["state"]
+                if os.environ.get("H3D_SYNTH_TRACE"):          # development: cycle trace of one workgroup (tools/)
+                    x3["trace"] = torch.zeros(4096, dtype=torch.int64, device=fixed_style.device)
+                    state = x3["trace"]
                 lib, rc = _lib.load(), 0
                 for i, seg in enumerate(segs):
                     rc = lib.h3d_synthesis_x3(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]),

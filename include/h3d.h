@@ -183,7 +183,11 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k = 16*kstep + 8*(lane>>5) + e];
  * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
  * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
- * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256 or a per-pixel-style block after the first skip block.
+ * The conv biases are NOT read by this engine: the caller folds them into the consumers' tables (the activations it
+ * carries are the true ones minus a per-channel carry c; SPADE shift sh' = sh + sc*c in `ab` / `vec`, ToRGB bias
+ * br' = br + Wr*c -- see SynthesisPlan.build_x3 in lib/generators/synthesis_pack.py).
+ * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256, a per-pixel-style block after the first skip block, or a
+ * block without skip connection after the first one that has it.
  *
  * Segmented execution: the weight stream of the whole network (6.3 MB at C=256) does not fit the 4 MB L2 of an XCD,
  * so a caller may run the blocks in several launches whose streams do (desc = the blocks of one segment).  Between
