@@ -182,22 +182,41 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
 
     // ---- this lane's pixel: synthesis-input coordinates and bilinear taps into the low-res maps
-    int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
+    const int64_t p_tile = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    int64_t p = p_tile + m;
     const bool okp = p < HW;
-    if (!okp) p = HW - 1;
+    if (!okp) p = min(p_tile, HW - 1);          // lanes past the image shadow the tile's first pixel (never stored)
     const int Y = (int)(p / A.W), X = (int)(p % A.W);
     const float ci = linspace_pm1(A.H, Y), cj = linspace_pm1(A.W, X);
     float sy = fmaxf(((float)Y + 0.5f) * ((float)A.Hr / (float)A.H) - 0.5f, 0.f);
     float sx = fmaxf(((float)X + 0.5f) * ((float)A.Wr / (float)A.W) - 0.5f, 0.f);
     const int y0 = min((int)sy, A.Hr - 1), x0 = min((int)sx, A.Wr - 1);
-    const int y1 = min(y0 + 1, A.Hr - 1), x1 = min(x0 + 1, A.Wr - 1);
     const float ty = sy - (float)y0, tx = sx - (float)x0;
     const float* __restrict__ Gb = A.G + (int64_t)b * A.Hr * A.Wr * A.g_channels;
-    const float* g00 = Gb + (int64_t)(y0 * A.Wr + x0) * A.g_channels;
-    const float* g01 = Gb + (int64_t)(y0 * A.Wr + x1) * A.g_channels;
-    const float* g10 = Gb + (int64_t)(y1 * A.Wr + x0) * A.g_channels;
-    const float* g11 = Gb + (int64_t)(y1 * A.Wr + x1) * A.g_channels;
-
+    // Bilinear resize of the low-res maps as a matrix product (the usual case: the wave's 32 pixels lie in one image
+    // row and touch at most 8 low-res columns): D[ch][px] = sum_k T[k][ch] * wi[k][px] over the 16 texels
+    // k = 8*r + e <-> (row ya + r, column xa + e), wi = the pixel's bilinear weights (<= 4 non-zeros).  Edge clamping
+    // happens in the texel addresses, so a clamped x1 / y1 lands on the same texel with the summed weight.
+    const int ya = __builtin_amdgcn_readfirstlane(y0), xa = __builtin_amdgcn_readfirstlane(x0);
+    const int Ya = __builtin_amdgcn_readfirstlane(Y);
+    const int jx = x0 - xa;
+    // the host guarantees this geometry (h3d_synthesis_x3 refuses anything else); a violation must not pass silently
+    if (A.g_channels > 0 && !__all(Y == Ya && jx >= 0 && jx <= 6)) __builtin_trap();
+    bf8 wih, wil;
+    {
+        const float wy = h ? ty : 1.f - ty;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float w0 = wy * (e == jx ? 1.f - tx : (e == jx + 1 ? tx : 0.f));
+            const float w1 = wy * (e + 1 == jx ? 1.f - tx : (e == jx ? tx : 0.f));
+            hw[e / 2] = split2_bf16(w0, w1, lw[e / 2]);
+        }
+        wih = __builtin_bit_cast(bf8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+        wil = __builtin_bit_cast(bf8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+    }
+    // texel row of this half-wave (k = 8h + e) and the per-column offsets (wave-uniform)
+    const float* trow = Gb + ((int64_t)min(ya + h, A.Hr - 1) * A.Wr) * A.g_channels + m;
     f32x16 x[NT];
     bf8 xh[KS], xl[KS];
     float rgb_acc[3] = {0.f, 0.f, 0.f};
@@ -303,33 +322,38 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             const h3d_spade_desc& Sp = Bk.spade[s];
             if (Sp.pixel_style) {
                 f32x16 acc[NT];
-                // ---- shared-MLP activations of this lane's pixel, straight into B-fragment layout
+                // ---- shared-MLP activations a = relu(resize(G) + cst) of this lane's pixel as B fragments
                 bf8 ah[8], al[8];
                 const float* cs = cstt + Sp.cst_index * kShared;
-                const float tx1 = 1.f - tx, ty1 = 1.f - ty;
+                {
+                    float tq[4][8];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int k0 = Sp.g_offset + ks * 16 + h * 8;
+                    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                    for (int q4 = 0; q4 < 2; ++q4) {
-                        const f32x4 a = ld4(g00 + k0 + q4 * 4);
-                        const f32x4 bq = ld4(g01 + k0 + q4 * 4);
-                        const f32x4 c = ld4(g10 + k0 + q4 * 4);
-                        const f32x4 d = ld4(g11 + k0 + q4 * 4);
-                        const f32x4 k4 = ld4(cs + ks * 16 + h * 8 + q4 * 4);
-                        float v[4];
-                        v[0] = (a.x * tx1 + bq.x * tx) * ty1 + (c.x * tx1 + d.x * tx) * ty + k4.x;
-                        v[1] = (a.y * tx1 + bq.y * tx) * ty1 + (c.y * tx1 + d.y * tx) * ty + k4.y;
-                        v[2] = (a.z * tx1 + bq.z * tx) * ty1 + (c.z * tx1 + d.z * tx) * ty + k4.z;
-                        v[3] = (a.w * tx1 + bq.w * tx) * ty1 + (c.w * tx1 + d.w * tx) * ty + k4.w;
+                        for (int e = 0; e < 8; ++e)
+                            tq[tt][e] = trow[(int64_t)min(xa + e, A.Wr - 1) * A.g_channels + Sp.g_offset + 32 * tt];
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    f32x16 (&d)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            __bf16 hi, lo;
-                            split<BF16>(fmaxf(v[e], 0.f), hi, lo);
-                            ah[ks][q4 * 4 + e] = hi;
-                            al[ks][q4 * 4 + e] = lo;
-                        }
+                    for (int tt = 0; tt < 4; ++tt) {
+                        unsigned hw[4], lw[4];
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) hw[e / 2] = split2_bf16(tq[tt][e], tq[tt][e + 1], lw[e / 2]);
+                        const bf8 th = __builtin_bit_cast(bf8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+                        const bf8 tl = __builtin_bit_cast(bf8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+                        d[tt] = BF16::mfma(th, wih, zero);
+                        d[tt] = BF16::mfma(th, wil, d[tt]);
+                        d[tt] = BF16::mfma(tl, wih, d[tt]);
                     }
+                    make_frags<4>(ah, al, d, [&](int nt, int rg) {
+                        const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
+                        float4 y;
+                        y.x = fmaxf(d[nt][rg * 4 + 0] + k4.x, 0.f);
+                        y.y = fmaxf(d[nt][rg * 4 + 1] + k4.y, 0.f);
+                        y.z = fmaxf(d[nt][rg * 4 + 2] + k4.z, 0.f);
+                        y.w = fmaxf(d[nt][rg * 4 + 3] + k4.w, 0.f);
+                        return y;
+                    });
                 }
                 const float* vec = tab + Sp.vec;
                 // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
@@ -437,6 +461,11 @@ int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr) {
+    // 32 consecutive pixels of one image row must touch at most 8 low-res columns (x0 spread <= 6, conservative bound)
+    return H >= 1 && Hr >= 1 && Wr >= 1 && W >= 32 && W % 32 == 0 && (int64_t)31 * Wr < (int64_t)6 * W;
+}
+
 extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                                 const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                                 const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
@@ -484,6 +513,11 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     H3D_REQUIRE(want == total_stages, "h3d_synthesis_x3: stream has %lld stages, descriptor needs %lld",
                 (long long)total_stages, (long long)want);
     H3D_REQUIRE(!any_pixel || (G && cst && (g_channels & 3) == 0 && h3d::aligned16(G)), "h3d_synthesis_x3: G/cst missing");
+    if (any_pixel && !h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr)) {
+        h3d::set_error("h3d_synthesis_x3: %dx%d from %dx%d: the matrix-core resize needs W %% 32 == 0 and 31*Wr/W < 6; "
+                       "use h3d_synthesis", H, W, Hr, Wr);
+        return H3D_EUNSUPPORTED;
+    }
     H3D_REQUIRE(!any_const || ab, "h3d_synthesis_x3: ab table missing");
     H3D_REQUIRE(store_state || desc->block[desc->n_blocks - 1].to_rgb, "h3d_synthesis_x3: the last block must feed ToRGB");
     H3D_REQUIRE((!load_state && !store_state) || (state && h3d::aligned16(state)), "h3d_synthesis_x3: state buffer missing");
@@ -493,6 +527,7 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     A.stream = static_cast<const unsigned char*>(stream);
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
+    if (!any_pixel) A.g_channels = 0;
     A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip;
     const bool deep = lds_bytes(A, NT, 6) <= 160 * 1024;      // deepest weight ring the tables leave room for
     if (lds_bytes(A, NT, kRingDepth) > 160 * 1024) {

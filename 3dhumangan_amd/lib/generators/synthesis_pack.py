@@ -300,6 +300,8 @@ class SynthesisPlan:
         if self.engine not in ("bf16x3", "f32"):
             raise ValueError(f"unknown synthesis engine {self.engine!r}")
         x3 = self.build_x3() if self.engine == "bf16x3" else None
+        if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
+            x3 = None            # the x3 engine's matrix-core resize does not cover this geometry: fp32 engine
         with stage(owner, "synthesis_tables"):
             G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3["HdP"] if x3 else None)
             if x3 and ab is not None:

@@ -186,14 +186,19 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * The conv biases are NOT read by this engine: the caller folds them into the consumers' tables (the activations it
  * carries are the true ones minus a per-channel carry c; SPADE shift sh' = sh + sc*c in `ab` / `vec`, ToRGB bias
  * br' = br + Wr*c -- see SynthesisPlan.build_x3 in lib/generators/synthesis_pack.py).
- * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256, a per-pixel-style block after the first skip block, or a
- * block without skip connection after the first one that has it.
+ * Returns H3D_EUNSUPPORTED (use h3d_synthesis) for C > 256, a per-pixel-style block after the first skip block, a
+ * block without skip connection after the first one that has it, or (with per-pixel-style blocks) a geometry
+ * h3d_synthesis_x3_geometry_ok rejects.
  *
  * Segmented execution: the weight stream of the whole network (6.3 MB at C=256) does not fit the 4 MB L2 of an XCD,
  * so a caller may run the blocks in several launches whose streams do (desc = the blocks of one segment).  Between
  * launches the per-pixel activations and ToRGB partial sums live in `state`
  * (B * ceil(H*W/128) * 4 wave tiles * (tiles*4 + 1) * 64 float4, private lane-linear layout): store_state=1 writes
  * it instead of the image, load_state=1 resumes from it instead of generating the coordinate input. */
+/* 1 when the x3 engine's matrix-core bilinear resize covers this geometry (only needed with per-pixel-style blocks):
+ * W a multiple of 32 and 32 consecutive output pixels touching at most 8 low-res columns (31*Wr < 6*W). */
+int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr);
+
 int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
