@@ -2,10 +2,22 @@
 // Reference semantics: lib/components/smpl.py:210-249 (get_geo_features); K=1 nearest vertex per
 // pytorch3d.ops.knn_points contract (squared L2, first index wins exact ties).
 //
-// Workgroup = 512 threads, 2 points per thread.  The pose's mesh (V x 3 fp32 = 83 KB for SMPL) is staged once
-// per workgroup into LDS as three SoA planes; every lane then sweeps all V vertices, 4 per step, reading the
-// planes with wave-uniform (broadcast) ds_read_b128.  Squared distance is evaluated exactly as the oracle does
-// -- (dx*dx + dy*dy) + dz*dz with no fused multiply-add -- so the arg-min is bit-for-bit reproducible.
+// Workgroup = 512 threads, 4 points per thread.  The pose's mesh (V x 3 fp32 = 83 KB for SMPL) is staged once per
+// workgroup into LDS as four SoA planes (x, y, z, |v|^2); every lane sweeps all V vertices, 4 per step, reading the
+// planes with wave-uniform (broadcast) ds_read_b128.
+//
+// The search is filter + refine, and bit-exact:
+//   filter  a(v) = |v|^2 - 2 p.v  (= |p - v|^2 - |p|^2) with three packed FMAs per two vertices -- 2 VALU
+//           instructions per (point, vertex) pair instead of the 11 the exact evaluation with index tracking needs.
+//           Per chunk of 64 consecutive vertices only the minimum of a is kept.
+//   refine  the oracle's own arithmetic, d = (dx*dx + dy*dy) + dz*dz with no fused multiply-add and a strict "<" in
+//           ascending vertex order, runs only over candidate chunks.
+// A chunk is a candidate when its filter minimum is within tol of the running filter minimum at the time it is
+// scanned.  With e >= |a(v) + |p|^2 - d_float(v)| for every vertex (rounding of both formulas; e <= 28 eps S,
+// S = |p|^2 + max|v|^2) and tol = 256 eps S >= 2e: the exact winner w has a(w) <= d_w - |p|^2 + e, every vertex has
+// a >= d_w - |p|^2 - e, so the chunk of w is within 2e of the final -- hence of the running -- minimum.  The last
+// eight candidates are remembered (id + filter minimum) and those still within tol of the FINAL minimum are
+// refined in scan order; a point that overflows the list (pathological ties) is refined over the whole mesh.
 // The per-point tail gathers the blended inverse bone transform of the winner (64 B), canonicalises the point,
 // gathers the T-pose vertex and evaluates the 24 joint distances.
 #include "common.hpp"
@@ -13,12 +25,33 @@
 namespace {
 
 constexpr int kThreads = 512;
-constexpr int kPts = 2;
+constexpr int kPts = 4;
 constexpr int kJoints = 24;
+constexpr int kChunk = 64;                 // vertices per filter chunk
+constexpr int kCand = 8;                   // remembered candidate chunks per point
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sqdist_exact(float px, float py, float pz, float vx, float vy, float vz) {
     const float dx = __fsub_rn(px, vx), dy = __fsub_rn(py, vy), dz = __fsub_rn(pz, vz);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// exact scan of vertices [v4_begin*4, v4_end*4) in ascending order, strict "<": first index among exact minima
+__device__ __forceinline__ void refine(const f4* vx4, const f4* vy4, const f4* vz4, int v4_begin, int v4_end, float px,
+                                       float py, float pz, float& best, int& bi) {
+    for (int v4 = v4_begin; v4 < v4_end; ++v4) {
+        const f4 X = vx4[v4], Y = vy4[v4], Z = vz4[v4];
+        const float d0 = sqdist_exact(px, py, pz, X.x, Y.x, Z.x);
+        const float d1 = sqdist_exact(px, py, pz, X.y, Y.y, Z.y);
+        const float d2 = sqdist_exact(px, py, pz, X.z, Y.z, Z.z);
+        const float d3 = sqdist_exact(px, py, pz, X.w, Y.w, Z.w);
+        if (d0 < best) { best = d0; bi = v4 * 4 + 0; }
+        if (d1 < best) { best = d1; bi = v4 * 4 + 1; }
+        if (d2 < best) { best = d2; bi = v4 * 4 + 2; }
+        if (d3 < best) { best = d3; bi = v4 * 4 + 3; }
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void geo_features_kernel(
@@ -29,19 +62,28 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     float* vx = smem;
     float* vy = smem + Vpad;
     float* vz = smem + 2 * Vpad;
-    float* jl = smem + 3 * Vpad;   // 24*3 joints
+    float* vw = smem + 3 * Vpad;   // |v|^2 (filter only)
+    float* jl = smem + 4 * Vpad;   // 24*3 joints
+    unsigned* v2max_bits = reinterpret_cast<unsigned*>(jl + kJoints * 3);
     const int b = blockIdx.y;
     const int t = threadIdx.x;
     const float* __restrict__ vb = vertices + (int64_t)b * V * 3;
+    if (t == 0) *v2max_bits = 0u;
+    __syncthreads();
+    float v2 = 0.f;
     for (int i = t; i < Vpad; i += kThreads) {
         const bool ok = i < V;
-        // padding vertices sit at +inf distance and can never win
-        vx[i] = ok ? vb[i * 3 + 0] : 3.0e18f;
-        vy[i] = ok ? vb[i * 3 + 1] : 3.0e18f;
-        vz[i] = ok ? vb[i * 3 + 2] : 3.0e18f;
+        // padding vertices sit at +inf distance for both the filter and the exact scan and can never win
+        const float x = ok ? vb[i * 3 + 0] : 3.0e18f, y = ok ? vb[i * 3 + 1] : 3.0e18f, z = ok ? vb[i * 3 + 2] : 3.0e18f;
+        const float w = x * x + y * y + z * z;
+        vx[i] = x; vy[i] = y; vz[i] = z;
+        vw[i] = ok ? w : 3.0e38f;
+        if (ok) v2 = fmaxf(v2, w);
     }
+    atomicMax(v2max_bits, __float_as_uint(v2));      // non-negative floats order like their bit patterns
     if (t < kJoints * 3) jl[t] = joints[(int64_t)b * kJoints * 3 + t];
     __syncthreads();
+    const float v2max = __uint_as_float(*v2max_bits);
 
     const int64_t base = ((int64_t)blockIdx.x * kThreads + t) * kPts;
     float px[kPts], py[kPts], pz[kPts], best[kPts];
@@ -55,21 +97,76 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
         best[k] = 3.4e38f;
         bi[k] = 0;
     }
-    const float4* vx4 = reinterpret_cast<const float4*>(vx);
-    const float4* vy4 = reinterpret_cast<const float4*>(vy);
-    const float4* vz4 = reinterpret_cast<const float4*>(vz);
-    for (int v4 = 0; v4 < Vpad / 4; ++v4) {
-        const float4 X = vx4[v4], Y = vy4[v4], Z = vz4[v4];
+    const f4* vx4 = reinterpret_cast<const f4*>(vx);
+    const f4* vy4 = reinterpret_cast<const f4*>(vy);
+    const f4* vz4 = reinterpret_cast<const f4*>(vz);
+    const f4* vw4 = reinterpret_cast<const f4*>(vw);
+
+    // ---- filter: per-chunk minima of a(v) = |v|^2 - 2 p.v, candidate list per point
+    f2 mx[kPts], my[kPts], mz[kPts];
+    float run[kPts], tol[kPts], cval[kPts][kCand];
+    unsigned long long cid[kPts];
+    int ncand[kPts];
+#pragma unroll
+    for (int k = 0; k < kPts; ++k) {
+        mx[k] = f2{-2.f * px[k], -2.f * px[k]};
+        my[k] = f2{-2.f * py[k], -2.f * py[k]};
+        mz[k] = f2{-2.f * pz[k], -2.f * pz[k]};
+        const float S = px[k] * px[k] + py[k] * py[k] + pz[k] * pz[k] + v2max;
+        tol[k] = 256.f * 5.9604645e-8f * S;
+        run[k] = 3.0e38f;
+        cid[k] = 0ull;
+        ncand[k] = 0;
+#pragma unroll
+        for (int q = 0; q < kCand; ++q) cval[k][q] = 3.4e38f;
+    }
+    const int n_chunks = Vpad / kChunk;
+    for (int c = 0; c < n_chunks; ++c) {
+        float cm[kPts];
+#pragma unroll
+        for (int k = 0; k < kPts; ++k) cm[k] = 3.4e38f;
+#pragma unroll 4
+        for (int i = 0; i < kChunk / 4; ++i) {
+            const int v4 = c * (kChunk / 4) + i;
+            const f4 X = vx4[v4], Y = vy4[v4], Z = vz4[v4], Wv = vw4[v4];
+#pragma unroll
+            for (int k = 0; k < kPts; ++k) {
+                const f2 a01 = __builtin_elementwise_fma(mx[k], X.xy, __builtin_elementwise_fma(my[k], Y.xy, __builtin_elementwise_fma(mz[k], Z.xy, Wv.xy)));
+                const f2 a23 = __builtin_elementwise_fma(mx[k], X.zw, __builtin_elementwise_fma(my[k], Y.zw, __builtin_elementwise_fma(mz[k], Z.zw, Wv.zw)));
+                cm[k] = fminf(fminf(cm[k], a01.x), a01.y);
+                cm[k] = fminf(fminf(cm[k], a23.x), a23.y);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kPts; ++k) {
-            const float d0 = sqdist_exact(px[k], py[k], pz[k], X.x, Y.x, Z.x);
-            const float d1 = sqdist_exact(px[k], py[k], pz[k], X.y, Y.y, Z.y);
-            const float d2 = sqdist_exact(px[k], py[k], pz[k], X.z, Y.z, Z.z);
-            const float d3 = sqdist_exact(px[k], py[k], pz[k], X.w, Y.w, Z.w);
-            if (d0 < best[k]) { best[k] = d0; bi[k] = v4 * 4 + 0; }
-            if (d1 < best[k]) { best[k] = d1; bi[k] = v4 * 4 + 1; }
-            if (d2 < best[k]) { best[k] = d2; bi[k] = v4 * 4 + 2; }
-            if (d3 < best[k]) { best[k] = d3; bi[k] = v4 * 4 + 3; }
+            if (cm[k] <= run[k] + tol[k]) {           // rare: a (near-)record chunk -> remember it
+#pragma unroll
+                for (int q = 0; q < kCand - 1; ++q) cval[k][q] = cval[k][q + 1];
+                cval[k][kCand - 1] = cm[k];
+                cid[k] = (cid[k] << 8) | (unsigned long long)(c & 0xff);
+                ++ncand[k];
+                run[k] = fminf(run[k], cm[k]);
+            }
+        }
+    }
+    // ---- refine: exact arithmetic over the surviving candidates, oldest (lowest chunk) first
+#pragma unroll
+    for (int k = 0; k < kPts; ++k) {
+        // Candidates older than the remembered eight were dropped.  If a dropped one were still within tol of the
+        // final minimum, every later candidate j (appended with a_j <= run_j + tol, run_j <= that one's value) would be
+        // within 2 tol of it -- including the oldest remembered one.  So "oldest remembered > final + 2 tol" proves
+        // nothing relevant was dropped; otherwise (eight near-ties in a row) scan the whole mesh exactly.
+        const bool overflow = ncand[k] > kCand && cval[k][0] <= run[k] + 2.f * tol[k];
+        if (overflow) {
+            refine(vx4, vy4, vz4, 0, Vpad / 4, px[k], py[k], pz[k], best[k], bi[k]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kCand; ++q) {
+                if (cval[k][q] <= run[k] + tol[k]) {
+                    const int c = (int)((cid[k] >> (8 * (kCand - 1 - q))) & 0xffull);
+                    refine(vx4, vy4, vz4, c * (kChunk / 4), (c + 1) * (kChunk / 4), px[k], py[k], pz[k], best[k], bi[k]);
+                }
+            }
         }
     }
 
@@ -111,8 +208,8 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
     H3D_REQUIRE(geo_stride >= 31, "h3d_geo_features: geo_stride=%d must be >= 31", geo_stride);
     H3D_REQUIRE(h3d::aligned16(vertex_ik), "h3d_geo_features: vertex_ik must be 16-byte aligned");
     if (B == 0 || N == 0) return H3D_OK;
-    const int Vpad = (V + 3) & ~3;
-    const size_t lds = sizeof(float) * (3 * (size_t)Vpad + kJoints * 3);
+    const int Vpad = (V + kChunk - 1) / kChunk * kChunk;
+    const size_t lds = sizeof(float) * (4 * (size_t)Vpad + kJoints * 3 + 4);
     H3D_REQUIRE(lds <= 160 * 1024, "h3d_geo_features: mesh with V=%d vertices does not fit the 160 KB LDS", V);
     static bool attr_set = false;
     if (!attr_set) {

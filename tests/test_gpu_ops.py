@@ -146,6 +146,25 @@ def test_geo_features_exact_ties_pick_first_vertex():
     assert int(idx[0, 0]) == 3
 
 
+def test_geo_features_ties_across_chunks_and_near_tie_overflow():
+    """Filter + refine search: duplicates of the winner spread over many 64-vertex chunks (more than the eight
+    remembered candidates -> whole-mesh refine), points on a sphere of equidistant vertices, far-away points."""
+    V = 1500
+    cond = synthetic.make_conditions(2, n_vertices=V, seed=3)
+    g = torch.Generator().manual_seed(7)
+    # batch 0: the same vertex repeated once per chunk, in descending chunk order of appearance
+    for c in range(0, V, 64):
+        cond["vertices"][0, c + 17] = cond["vertices"][0, 900]
+    # batch 1: 700 vertices on a unit sphere around the origin (all within rounding of distance 1 from (0,0,0))
+    d = torch.randn(700, 3, generator=g)
+    cond["vertices"][1, 100:800] = d / d.norm(dim=1, keepdim=True)
+    pts = (torch.rand(2, 777, 3, generator=g) - 0.5) * 2
+    pts[0, :50] = cond["vertices"][0, 900] + 1e-4 * torch.randn(50, 3, generator=g)
+    pts[1, :50] = 1e-3 * torch.randn(50, 3, generator=g)
+    pts[:, 50:60] *= 40.0
+    _geo_check(pts, cond, False)
+
+
 # ------------------------------------------------------------------ A7
 
 @pytest.mark.parametrize("shape", [(2, 5, 64, 32, 256, 128), (1, 3, 96, 48, 512, 256), (2, 4, 6, 5, 20, 12),
