@@ -145,6 +145,20 @@ def ray_integrate_roofline(cfg, batch, iters=10):
                 traffic=None, ms=ms, bytes=by, batch=nb)
 
 
+def load_traffic(workload_key):
+    """{kernel: HBM bytes per launch} from the newest profiles/*_hbm_traffic.json measured on this workload."""
+    import glob
+    best = {}
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload_key:
+            best = {k: v["bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
+    return best
+
+
 def cpu_baseline(cfg, sd, seed=1234, shrink=2):
     """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores.
     Bounded sample: ONE image at 1/shrink of the height and width (output pixels, rays) with the same samples per
@@ -225,8 +239,15 @@ def main():
                    key=lambda k: kernels[k]["ms"])
     roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "engine", "mfma_pipe_util",
                                               "frac_of_fp32_mfma_peak")}
-    roof["traffic"] = None
     roof["kernel"] = dominant
+    # HBM traffic per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate passes,
+    # corrected as MI355X_MICROARCH.md prescribes); only valid for the workload it was measured on.
+    traffic = load_traffic(f"{a.config}_{H}x{W}_b{a.batch}_s{a.samples}")
+    roof["traffic"] = traffic.get(dominant)
+    kernels["h3d_ray_integrate"]["traffic"] = traffic.get("h3d_ray_integrate")
+    for k, v in traffic.items():
+        if k in kernels:
+            kernels[k]["traffic"] = v
 
     extra = {}
     if not a.no_extra and world == 1 and (H, W) == (512, 512):

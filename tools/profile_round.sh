@@ -19,5 +19,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   DB=$(find $OUT/pmc_$c -name '*.db' | head -1)
   python tools/pmc_dump.py $DB 'x3_kernel|geo_features|ray_integrate' > $OUT/pmc_$c.txt
 done
+python tools/traffic_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt MAP3DBN512_512x512_b16_s64 $OUT/hbm_traffic.json
 find $OUT -name '*.db' -size +12M -delete; ls -la $OUT/*/*/* 2>/dev/null | head
 tail -c 600 $OUT/bench.json

@@ -1,0 +1,41 @@
+"""profiles/<round>_hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE PMC dumps of tools/profile_round.sh.
+
+rocprofv3 reports both in KiB per dispatch.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 64 B per
+128-B read request, i.e. HALF the bytes of wide coalesced reads -> doubled here; WRITE_SIZE is taken as reported
+(calibrated below against h3d_ray_integrate, whose algorithmic read/write bytes are known exactly)."""
+import json
+import re
+import sys
+
+NAMES = {"synthesis_x3_kernel": "h3d_synthesis", "field_x3_kernel": "h3d_render_fused", "geo_features_kernel": "h3d_geo_features",
+         "ray_integrate": "h3d_ray_integrate"}
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = next((v for k, v in NAMES.items() if k in line), None)
+        else:
+            m = re.search(r"(\w+)\s+total [\d.e+]+\s+per-dispatch ([\d.e+]+)\s+\(n=(\d+)\)", line)
+            if m and cur:
+                out.setdefault(cur, {})[m.group(1)] = (float(m.group(2)), int(m.group(3)))
+    return out
+
+
+def main(fetch_txt, write_txt, workload, out_json):
+    f, w = parse(fetch_txt), parse(write_txt)
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        fk = f.get(k, {}).get("FETCH_SIZE", (0.0, 0))
+        wk = w.get(k, {}).get("WRITE_SIZE", (0.0, 0))
+        rd, wr = 2.0 * fk[0] * 1024.0, wk[0] * 1024.0
+        kernels[k] = dict(bytes_per_launch=rd + wr, read_bytes=rd, write_bytes=wr, fetch_size_kib_raw=fk[0],
+                          write_size_kib_raw=wk[0], dispatches=fk[1])
+    json.dump(dict(workload=workload, source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
+                   "read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE", kernels=kernels), open(out_json, "w"), indent=1)
+    print(json.dumps(kernels, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
