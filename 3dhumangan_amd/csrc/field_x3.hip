@@ -6,19 +6,23 @@
 //   precision   every fp32 operand is split x*s = hi + lo with hi = f16(x*s), lo = f16(x*s - hi) (s a power of
 //               two that keeps both halves in the normal f16 range) and a product is evaluated as
 //               hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 22 significant bits per
-//               operand, i.e. fp32-class results (measured 2e-6 on the field, same as the fp32 MFMA path) at 16/3
-//               of the fp32 MFMA rate.  A single f16 product misses the 1e-3 budget (5e-3 after the freq~45
-//               sines), which is why the split is needed.
+//               operand, i.e. fp32-class results at 16/3 of the fp32 MFMA rate.  A single f16 product misses the
+//               1e-3 budget (5e-3 after the freq~45 sines), which is why the split is needed.
 //   dataflow    a wavefront owns 32 samples and ALL output features.  Weights are the MFMA A operand (rows =
 //               features), activations the B operand (columns = samples), so the accumulator of a lane holds one
-//               sample's features.  The epilogue (bias, FiLM sine, split) runs in registers, and one
-//               v_permlane32_swap per register pair turns the accumulator layout into next layer's B fragments:
-//               activations never touch LDS or HBM between layers and there is no barrier in the layer loop.
-//               Weights are one linear stream in consumption order (2 KB per tile and k-step, MFMA A-fragment
-//               order); the four waves of a workgroup pull it ONCE from L2 into an LDS ring with
-//               global_load_lds (LDS-DMA, no registers), several k-steps ahead and straight through the epilogues,
-//               and every wave reads its fragments from the ring with conflict-free ds_read_b128.  One raw
-//               s_barrier per k-step (768 MFMA cycles) is the only synchronisation.
+//               sample's features and one v_permlane32_swap per register pair turns it into the next layer's B
+//               fragments: activations never touch LDS or HBM between layers.  Two accumulator sets (2 x 128
+//               AGPRs) ping-pong through the layers, so the epilogue of layer l (FiLM sine + split) runs tile by
+//               tile INSIDE the GEMM of layer l+1 -- k-steps 2t, 2t+1 only need tile t -- hidden behind its MFMAs
+//               (x3_common.hpp: gemm_x3_roll hook).  Every input enters as a GEMM: the coordinate layer (K = 3),
+//               the geometry-feature layer (K = 31) and the view direction (one extra k-step of the colour layer).
+//               The density and colour heads ride along as a ninth 32-row tile of the colour / feature GEMMs.
+//   weights     one linear stream in consumption order (2 KB per tile and k-step, MFMA A-fragment order); the four
+//               waves of a workgroup pull it ONCE from L2 into an LDS ring with global_load_lds (LDS-DMA), several
+//               k-steps ahead and straight through the epilogues; one raw s_barrier per k-step.
+//   sine        the FiLM affine and the 1/2pi of v_sin_f32 (argument in revolutions) are folded into two per-channel
+//               table values, u = acc*A1 + A0, y = v_sin(u): 1 FMA + 1 transcendental per activation.  fl(u) carries
+//               the same |y| * 2^-24 argument error as the reference's own fp32 evaluation of f*(Wx+b)+p.
 //   fused A6    the feature head is evaluated with the operands swapped (rows = samples), so the weighted sum over
 //               the samples of a ray is a sum over accumulator registers; compositing weights come from a
 //               segmented 32-lane product scan (S = 8..32: 32/S rays per wave step; S = 64, 128: carry).
@@ -32,29 +36,33 @@ namespace {
 
 typedef F16::vec8 half8;
 typedef F16::vec2 half2v;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float kSA = 4096.f;      // activation scale (|sin| <= 1)
+constexpr float kSA = 4096.f;      // activation scale (|sin| <= 1, |view direction| <= 1)
 constexpr float kSIn = 64.f;       // input scale (coords / geometry features, |x| < 1000)
+constexpr int kLookF = 2;          // weight-fragment look-ahead in tile pairs
+constexpr int kValuF = 4;          // VALU instructions slotted behind each MFMA of a section carrying epilogue work
 
-enum { ST_GEO = 0, ST_COORD, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
+// per-step activation tables (A1, A0) in LDS
+enum { ST_COORD = 0, ST_GEO, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
 // weight matrices in STREAM (consumption) order
-enum { W_GEO = 0, W_F0B, W_F0A, W_F1, W_F2, W_F3, W_COLOR, W_FEAT, W_COUNT };
+enum { W_COORD = 0, W_F0A, W_GEO, W_F0B, W_F1, W_F2, W_F3, W_COLOR, W_FEAT, W_COUNT };
 
 struct LayoutX3 {        // offsets in BYTES into the blob (all multiples of 16)
-    int HdP, FP, NT, KS;
+    int HdP, FP, NT, KS, stages;
     int64_t w[W_COUNT];
     int64_t inv_scale;   // float[W_COUNT]: 1 / (weight scale * input scale) per matrix
     int64_t bias;        // float[ST_COUNT][HdP]
-    int64_t wdir;        // float[3][HdP]   colour-layer weights of the view direction
-    int64_t wcoord;      // float[3][HdP]   first_layer_coord weights, transposed
     int64_t b_feat;      // float[FP]
-    int64_t head_w;      // f16 [4 heads: sigma, r, g, b][2 hi/lo][KS][2 halves][8]  (B-fragment order per lane half)
+    int64_t head_w;      // f16 [4 heads: sigma, r, g, b][2 hi/lo][KS][2 halves][8]  (A-fragment rows of the head tile)
     int64_t head_inv;    // float[4] 1/(weight scale * kSA)
     int64_t head_b;      // float[4]
     int64_t total;
 };
 
 int tiles_for(int Hd) { int nt = 4; while (nt * 32 < Hd) nt *= 2; return nt; }   // engine is built for 4 or 8 tiles
+
+int stages_of(int wi, int KS) { return wi == W_COORD ? 1 : wi == W_GEO ? 2 : wi == W_COLOR ? KS + 1 : KS; }
 
 LayoutX3 make_layout(int Hd, int F) {
     LayoutX3 L;
@@ -65,12 +73,10 @@ LayoutX3 make_layout(int Hd, int F) {
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += (n + 15) / 16 * 16; return r; };
     const int64_t per_ks = (int64_t)L.NT * 2 * 64 * 16;
-    const int ks[W_COUNT] = {2, L.KS, L.KS, L.KS, L.KS, L.KS, L.KS, L.KS};
-    for (int i = 0; i < W_COUNT; ++i) L.w[i] = take(ks[i] * per_ks);
+    L.stages = 0;
+    for (int i = 0; i < W_COUNT; ++i) { L.w[i] = take(stages_of(i, L.KS) * per_ks); L.stages += stages_of(i, L.KS); }
     L.inv_scale = take(4 * W_COUNT);
     L.bias = take(4 * (int64_t)ST_COUNT * L.HdP);
-    L.wdir = take(4 * 3 * (int64_t)L.HdP);
-    L.wcoord = take(4 * 3 * (int64_t)L.HdP);
     L.b_feat = take(4 * (int64_t)L.FP);
     L.head_w = take(2 * (int64_t)4 * 2 * L.KS * 16);
     L.head_inv = take(16);
@@ -103,84 +109,127 @@ __device__ __forceinline__ float density(float x, int clamp_mode) {
     return fmaxf(x, 0.f);
 }
 
+// two fp32 (already scaled) -> packed f16 hi halves (returned) and packed f16 lo halves
+__device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {
+    const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
+    const float fa = (float)h2.x, fb = (float)h2.y;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a - fa, b - fb}, half2v));
+    return __builtin_bit_cast(unsigned, h2);
+}
+
 // 8 fp32 values of one lane -> hi / lo B-fragments
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& fh, half8& fl) {
+    unsigned hw[4], lw[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        _Float16 h, l;
-        split<F16>(v[e] * scale, h, l);
-        fh[e] = h;
-        fl[e] = l;
-    }
+    for (int e = 0; e < 8; e += 2) hw[e / 2] = split2_f16(v[e] * scale, v[e + 1] * scale, lw[e / 2]);
+    fh = __builtin_bit_cast(half8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    fl = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
 }
 
-// Epilogue of a feature-major accumulator: y = sin(f * (acc*inv + b [+ wdir . dir]) + p), split to f16 hi/lo and
-// re-laid out as the next layer's B fragments (one permlane32_swap per register pair).
-//   tb / tf / tp : LDS vectors [HdP] (bias, frequency, phase) of this step;  twd: LDS [3][HdP] or nullptr.
+// B fragments of k-steps 2*pr and 2*pr+1... of one plane: rows of register groups 2*PR, 2*PR+1 (x3_common.hpp relayout)
+template <int PR>
+__device__ __forceinline__ half8 relayout_half(const unsigned (&P)[4][2]) {
+    u32x4 r;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        auto a = __builtin_amdgcn_permlane32_swap(P[2 * PR][c], P[2 * PR + 1][c], false, false);
+        r[c] = a[0];
+        r[2 + c] = a[1];
+    }
+    return __builtin_bit_cast(half8, r);
+}
+
+// Producer of the next layer's B fragments from a feature-major accumulator set: y = v_sin(acc * A1[n] + A0[n])
+// (FiLM affine, bias, de-scaling and 1/2pi folded into the two LDS tables), split to f16 hi/lo.  The work of one
+// 32-feature tile is cut into eight chunks of two activations so that the consuming GEMM can hide one chunk behind
+// each of the eight tile-pair sections that precede the tile's first use; table values are fetched one chunk ahead.
 template <int NT>
-__device__ __forceinline__ void film_epilogue(const f32x16 (&acc)[NT], half8 (&xh)[2 * NT], half8 (&xl)[2 * NT],
-                                              const float* tb, const float* tf, const float* tp, const float* twd,
-                                              float d0, float d1, float d2, float inv, int Hd, int HdP, int h) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        unsigned H[4][2], Lo[4][2];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int n = nt * 32 + rg * 8 + 4 * h;
-            const f32x4 b = ld4(tb + n);
-            const f32x4 f = ld4(tf + n);
-            const f32x4 p = ld4(tp + n);
-            float add[4] = {b.x, b.y, b.z, b.w};
-            if (twd) {
-                const f32x4 w0 = ld4(twd + n);
-                const f32x4 w1 = ld4(twd + HdP + n);
-                const f32x4 w2 = ld4(twd + 2 * HdP + n);
-                add[0] += w0.x * d0 + w1.x * d1 + w2.x * d2;
-                add[1] += w0.y * d0 + w1.y * d1 + w2.y * d2;
-                add[2] += w0.z * d0 + w1.z * d1 + w2.z * d2;
-                add[3] += w0.w * d0 + w1.w * d1 + w2.w * d2;
-            }
-            const float ff[4] = {f.x, f.y, f.z, f.w}, pp[4] = {p.x, p.y, p.z, p.w};
-            _Float16 hh[4], ll[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float y = sin_hw(fmaf(ff[q], fmaf(acc[nt][rg * 4 + q], inv, add[q]), pp[q]));
-                y = (n + q < Hd) ? y : 0.f;
-                split<F16>(y * kSA, hh[q], ll[q]);
-            }
-            H[rg][0] = pack2<F16>(hh[0], hh[1]); H[rg][1] = pack2<F16>(hh[2], hh[3]);
-            Lo[rg][0] = pack2<F16>(ll[0], ll[1]); Lo[rg][1] = pack2<F16>(ll[2], ll[3]);
-        }
-        relayout_tile<F16>(H, xh[2 * nt], xh[2 * nt + 1]);
-        relayout_tile<F16>(Lo, xl[2 * nt], xl[2 * nt + 1]);
+struct FilmProducer {
+    f32x16 (&src)[NT];
+    half8 (&xh)[2 * NT + 1];
+    half8 (&xl)[2 * NT + 1];
+    const float* a1;          // LDS [HdP]
+    const float* a0;          // LDS [HdP]
+    int h;
+    unsigned Hh[4][2], Ll[4][2];
+    f32x2 t1, t0;
+
+    template <int TILE, int C>
+    __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
+    __device__ __forceinline__ void prime() {
+        t1 = *reinterpret_cast<const f32x2*>(a1 + chan<0, 0>());
+        t0 = *reinterpret_cast<const f32x2*>(a0 + chan<0, 0>());
     }
+    template <int TILE, int C>
+    __device__ __forceinline__ void chunk() {
+        if constexpr (C == 0) pin1(src[TILE]);
+        constexpr int rg = C / 2, q0 = (C % 2) * 2;
+        const float u0 = fmaf(src[TILE][rg * 4 + q0], t1.x, t0.x);
+        const float u1 = fmaf(src[TILE][rg * 4 + q0 + 1], t1.y, t0.y);
+        if constexpr (C < 7) {
+            t1 = *reinterpret_cast<const f32x2*>(a1 + chan<TILE, C + 1>());
+            t0 = *reinterpret_cast<const f32x2*>(a0 + chan<TILE, C + 1>());
+        } else if constexpr (TILE + 1 < NT) {
+            t1 = *reinterpret_cast<const f32x2*>(a1 + chan<TILE + 1, 0>());
+            t0 = *reinterpret_cast<const f32x2*>(a0 + chan<TILE + 1, 0>());
+        }
+        const float y0 = __builtin_amdgcn_sinf(u0) * kSA, y1 = __builtin_amdgcn_sinf(u1) * kSA;
+        Hh[rg][C % 2] = split2_f16(y0, y1, Ll[rg][C % 2]);
+        if constexpr (C == 4) xh[2 * TILE] = relayout_half<0>(Hh);
+        if constexpr (C == 5) xl[2 * TILE] = relayout_half<0>(Ll);
+        if constexpr (C == 7) {
+            xh[2 * TILE + 1] = relayout_half<1>(Hh);
+            xl[2 * TILE + 1] = relayout_half<1>(Ll);
+        }
+    }
+};
+
+// One layer: dst (+)= W * frags(producer(src)).  Tile 0 of the producer runs up front, tile t+1 inside the sections of
+// k-steps 2t, 2t+1.  HEAD: the four head rows (sigma, r, g, b) ride along as a ninth tile accumulated in hacc
+// (feature-major: row = head, column = sample), A fragments from LDS, one k-step of look-ahead.
+template <int NT, int KSG, bool ZERO, bool SWAP, bool HEAD, typename RING, typename PROD>
+__device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1], half8 (&xl)[2 * NT + 1], RING& ring, PROD& prod,
+                                      f32x16& hacc, const unsigned char* head_lds, int lane) {
+    constexpr int KS = 2 * NT, P = NT / 2, W = NT, PER = 8 / W;
+    prod.prime();
+    static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
+    u32x4 hwh, hwl;
+    // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo: [head][plane][KS][half][16 B]
+    const unsigned char* hbase = head_lds + ((((lane & 3) * 2) * KS) * 2 + (lane >> 5)) * 16;
+    auto load_head = [&](int s) __attribute__((always_inline)) {
+        hwh = *reinterpret_cast<const u32x4*>(hbase + s * 32);
+        hwl = *reinterpret_cast<const u32x4*>(hbase + (KS + s) * 32);
+    };
+    if constexpr (HEAD) load_head(0);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_x3_roll<F16, NT, KSG, 2 * NT + 1, SWAP, kLookF, kValuF, ZERO>(dst, xh, xl, ring, [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int t = g / W + 1, j = g % W;
+        if constexpr (t < NT) {
+            static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
+        }
+        if constexpr (HEAD) {
+            constexpr int s = g / P, p = g % P;
+            if constexpr (p == 0 && s < KS) {
+                const half8 ah = __builtin_bit_cast(half8, hwh), al = __builtin_bit_cast(half8, hwl);
+                if constexpr (s == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    hacc = F16::mfma(ah, xh[s], zero);
+                } else {
+                    hacc = F16::mfma(ah, xh[s], hacc);
+                }
+                hacc = F16::mfma(ah, xl[s], hacc);
+                hacc = F16::mfma(al, xh[s], hacc);
+            }
+            if constexpr (p == 1 % P && s + 1 < KS) load_head(s + 1);
+        }
+    });
 }
 
-// N=1 / N=3 heads as f16 dot products over the lane's half of K, halves combined with one cross-half add.
-template <int NT, int NH>
-__device__ __forceinline__ void heads(const half8 (&xh)[2 * NT], const half8 (&xl)[2 * NT], const u32x4* __restrict__ hw,
-                                      int first_head, int KS, int h, float (&out)[NH]) {
-#pragma unroll
-    for (int c = 0; c < NH; ++c) {
-        const u32x4* wh = hw + (((int64_t)(first_head + c) * 2 + 0) * KS) * 2 + h;
-        const u32x4* wl = hw + (((int64_t)(first_head + c) * 2 + 1) * KS) * 2 + h;
-        float s = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2 * NT; ++ks) {
-            const u32x4 a = wh[ks * 2], bq = wl[ks * 2];
-            const u32x4 x0 = __builtin_bit_cast(u32x4, xh[ks]), x1 = __builtin_bit_cast(u32x4, xl[ks]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const half2v ah = __builtin_bit_cast(half2v, (unsigned)a[e]), al = __builtin_bit_cast(half2v, (unsigned)bq[e]);
-                const half2v xhh = __builtin_bit_cast(half2v, (unsigned)x0[e]), xll = __builtin_bit_cast(half2v, (unsigned)x1[e]);
-                s = __builtin_amdgcn_fdot2(ah, xhh, s, false);
-                s = __builtin_amdgcn_fdot2(ah, xll, s, false);
-                s = __builtin_amdgcn_fdot2(al, xhh, s, false);
-            }
-        }
-        out[c] = s + __shfl_xor(s, 32, 64);
-    }
-}
+struct NoProducer {
+    __device__ __forceinline__ void prime() {}
+    template <int TILE, int C> __device__ __forceinline__ void chunk() {}
+};
 
 template <int NT, bool FUSED>
 __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
@@ -188,12 +237,11 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LayoutX3& L = A.L;
     const int HdP = L.HdP;
-    float* tab0 = smem;                                 // [ST_COUNT][3][HdP]  bias / frequency / phase per step
-    float* twd0 = tab0 + ST_COUNT * 3 * HdP;            // [3][HdP]
-    float* tfeat0 = twd0 + 3 * HdP;                     // [HdP] feature-head bias
-    float* twc0 = tfeat0 + HdP;                         // [3][HdP] coordinate first-layer weights (x scale folded in)
-    float* scratch = twc0 + 3 * HdP;                    // [4 waves][64]: compositing weights, background terms
-    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(scratch + 4 * 64);   // [ring depth][NT*2 KB] weight ring
+    float* tab0 = smem;                                 // [ST_COUNT][2][HdP]  A1 / A0 per step
+    float* tfeat0 = tab0 + ST_COUNT * 2 * HdP;          // [HdP] feature-head bias
+    float* scratch = tfeat0 + HdP;                      // [4 waves][64]: compositing weights, background terms
+    unsigned char* head0 = reinterpret_cast<unsigned char*>(scratch + 4 * 64);          // head A-fragment rows
+    unsigned char* ring_lds = head0 + 4 * 2 * KS * 32;                                   // [ring depth][NT*2 KB]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -201,37 +249,46 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int b = blockIdx.y;
     const int Hd = A.Hd, F = A.F, S = A.S;
     const int64_t N = A.N;
-    // ---- per-sample-of-the-batch tables (bias, 15*freq+30, phase) in LDS, once per workgroup
+    const float* __restrict__ invs = reinterpret_cast<const float*>(A.blob + L.inv_scale);
+    // ---- per-sample-of-the-batch activation tables in LDS, once per workgroup:
+    //      y = sin(f * (acc*inv + bias) + p) = v_sin(acc * A1 + A0),  A1 = inv*f/2pi,  A0 = (bias*f + p)/2pi
     {
         const unsigned char* __restrict__ blob = A.blob;
         const float* __restrict__ bias = reinterpret_cast<const float*>(blob + L.bias);
         const float* __restrict__ fr = A.freq + (int64_t)b * 4 * Hd;
         const float* __restrict__ ph = A.phase + (int64_t)b * 4 * Hd;
-        const float* __restrict__ wd = reinterpret_cast<const float*>(blob + L.wdir);
         const float* __restrict__ bf = reinterpret_cast<const float*>(blob + L.b_feat);
+        const float inv2pi = 0.15915494309189535f;
         for (int idx = t; idx < ST_COUNT * HdP; idx += 256) {
             const int st = idx / HdP, n = idx - st * HdP;
-            const bool ok = n < Hd;
-            float bb = ok ? bias[st * HdP + n] : 0.f, ff = 30.f, pp = 0.f;
-            if (st >= ST_FILM0 && ok) {
-                const int sl = st == ST_COLOR ? 3 : st - ST_FILM0;
-                ff = fr[sl * Hd + n] * 15.f + 30.f;
-                pp = ph[sl * Hd + n];
+            float a1 = 0.f, a0 = 0.f;                   // padding channels: sin(0) = 0
+            if (n < Hd) {
+                float ff = 30.f, pp = 0.f;
+                if (st >= ST_FILM0) {
+                    const int sl = st == ST_COLOR ? 3 : st - ST_FILM0;
+                    ff = fr[sl * Hd + n] * 15.f + 30.f;
+                    pp = ph[sl * Hd + n];
+                }
+                const int wi = st == ST_COORD ? W_COORD : st == ST_GEO ? W_GEO : st == ST_FILM0 ? W_F0A
+                             : st == ST_COLOR ? W_COLOR : W_F1 + (st - ST_FILM1);
+                a1 = invs[wi] * ff * inv2pi;
+                a0 = fmaf(bias[st * HdP + n], ff, pp) * inv2pi;
             }
-            if (st == ST_COLOR && ok && !A.dirs) bb -= wd[2 * HdP + n];      // locked view direction (0,0,-1)
-            tab0[(st * 3 + 0) * HdP + n] = bb;
-            tab0[(st * 3 + 1) * HdP + n] = ff;
-            tab0[(st * 3 + 2) * HdP + n] = pp;
+            tab0[(st * 2 + 0) * HdP + n] = a1;
+            tab0[(st * 2 + 1) * HdP + n] = a0;
         }
-        const float* __restrict__ wc = reinterpret_cast<const float*>(blob + L.wcoord);
-        for (int idx = t; idx < 3 * HdP; idx += 256) { twd0[idx] = wd[idx]; twc0[idx] = wc[idx]; }
         for (int idx = t; idx < HdP; idx += 256) tfeat0[idx] = idx < F ? bf[idx] : 0.f;
+        const u32x4* hsrc = reinterpret_cast<const u32x4*>(blob + L.head_w);
+        u32x4* hdst = reinterpret_cast<u32x4*>(head0);
+        for (int idx = t; idx < 4 * 2 * KS * 2; idx += 256) hdst[idx] = hsrc[idx];
     }
     __syncthreads();
 
-    const float* __restrict__ invs = reinterpret_cast<const float*>(A.blob + L.inv_scale);
     const float* __restrict__ head_inv = reinterpret_cast<const float*>(A.blob + L.head_inv);
     const float* __restrict__ head_b = reinterpret_cast<const float*>(A.blob + L.head_b);
+    const float inv_f = invs[W_FEAT];
+    const float hi0 = head_inv[0], hi1 = head_inv[1], hi2 = head_inv[2], hi3 = head_inv[3];
+    const float hb0 = head_b[0], hb1 = head_b[1], hb2 = head_b[2], hb3 = head_b[3];
     float* wl_lds = scratch + wave * 64;      // [32] weights, [32] background
 
     const int unit = FUSED ? (S > 32 ? S : 32) : 32;          // samples a wave walks per unit (whole rays when fused)
@@ -240,12 +297,14 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
 
     WeightRing<NT> ring;
-    ring.init(A.blob + L.w[0], ring_lds, 2 + 7 * KS, wave, lane);
+    ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
 
     float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
     float rayacc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) rayacc[i] = 0.f;
+
+    f32x16 X[NT], Y[NT];          // the two accumulator sets
 
     for (int si = 0; si < steps; ++si) {
         const int64_t n0 = u0 + (int64_t)si * 32;
@@ -253,88 +312,90 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         const bool ok = n < N;
         const int64_t gi = (int64_t)b * N + (ok ? n : N - 1);      // clamped: out-of-range lanes load valid memory
         const bool last_step = si == steps - 1;
-        // The LDS tables and head weights do not depend on the step: launder an opaque zero offset so the compiler
-        // does not hoist hundreds of loop-invariant loads out of the step loop (LICM) and spill them.
+        // The LDS tables do not depend on the step: launder an opaque zero offset so the compiler does not hoist
+        // hundreds of loop-invariant loads out of the step loop (LICM) and spill them.
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
-        const unsigned char* __restrict__ blob = A.blob + opaque;
         const float* tab = tab0 + opaque;
-        const float* twd = twd0 + opaque;
         const float* tfeat = tfeat0 + opaque;
-        const float* twc = twc0 + opaque;
+        const unsigned char* head_lds = head0 + opaque;
 
-        f32x16 acc[NT];
-        half8 xh[KS], xl[KS];
+        half8 xh[KS + 1], xl[KS + 1];
+        f32x16 hacc;
+        NoProducer none;
 
-        // ---- geometry-feature first layer (K = 31 -> two k-steps on the matrix cores)
+        // ---- inputs as B fragments: coordinates (K = 3), geometry features (K = 31), view direction (K = 3)
+        half8 ch, cl, gh[2], gl[2];
         {
-            half8 ih[KS], il[KS];
+            const float* __restrict__ p = A.points + gi * 3;
+            float v[8];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { ih[ks] = half8{0}; il[ks] = half8{0}; }
+            for (int e = 0; e < 8; ++e) v[e] = (e < 3 && h == 0 && ok) ? p[e < 3 ? e : 0] * A.input_scaler : 0.f;
+            split8(v, kSIn, ch, cl);
             const float* __restrict__ g = A.geo + gi * A.geo_stride;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int k = ks * 16 + h * 8 + e;
-                    v[e] = (k < 31 && ok) ? g[k] : 0.f;
+                    v[e] = (k < 31 && ok) ? g[k < 31 ? k : 0] : 0.f;
                 }
-                split8(v, kSIn, ih[ks], il[ks]);
+                split8(v, kSIn, gh[ks], gl[ks]);
             }
-            zero_acc1<NT>(acc);
-            gemm_x3<F16, NT, 2, KS, false>(acc, ih, il, ring);
-            film_epilogue<NT>(acc, xh, xl, tab + (ST_GEO * 3 + 0) * HdP, tab + (ST_GEO * 3 + 1) * HdP,
-                              tab + (ST_GEO * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_GEO], Hd, HdP, h);
         }
-        // ---- FiLM 0, geometry half:  acc = W0b * geo_act
-        zero_acc1<NT>(acc);
-        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
-        // ---- coordinate first layer (K = 3) on the VALU, in fp32, straight into B-fragment layout
+        // ---- coordinate first layer -> Y ; FiLM 0, coordinate half: X = W0a * sin(30 * (Wc p + bc))
+        xh[0] = ch; xl[0] = cl;
+        gemm_x3_roll<F16, NT, 1, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
+        pin_agpr<NT>(Y);
         {
-            const float* __restrict__ p = A.points + gi * 3;
-            const float px = ok ? p[0] * A.input_scaler : 0.f, py = ok ? p[1] * A.input_scaler : 0.f,
-                        pz = ok ? p[2] * A.input_scaler : 0.f;
-            const float* tbc = tab + (ST_COORD * 3 + 0) * HdP;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int k0 = ks * 16 + h * 8;
-                float v[8];
-#pragma unroll
-                for (int q4 = 0; q4 < 2; ++q4) {
-                    const f32x4 w0 = ld4(twc + k0 + q4 * 4);
-                    const f32x4 w1 = ld4(twc + HdP + k0 + q4 * 4);
-                    const f32x4 w2 = ld4(twc + 2 * HdP + k0 + q4 * 4);
-                    const f32x4 bb = ld4(tbc + k0 + q4 * 4);
-                    // same association as F.linear: ((w0*x + w1*y) + w2*z) + b
-                    v[q4 * 4 + 0] = sin_hw(30.f * (fmaf(w2.x, pz, fmaf(w1.x, py, w0.x * px)) + bb.x));
-                    v[q4 * 4 + 1] = sin_hw(30.f * (fmaf(w2.y, pz, fmaf(w1.y, py, w0.y * px)) + bb.y));
-                    v[q4 * 4 + 2] = sin_hw(30.f * (fmaf(w2.z, pz, fmaf(w1.z, py, w0.z * px)) + bb.z));
-                    v[q4 * 4 + 3] = sin_hw(30.f * (fmaf(w2.w, pz, fmaf(w1.w, py, w0.w * px)) + bb.w));
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (k0 + e < Hd) ? v[e] : 0.f;
-                split8(v, kSA, xh[ks], xl[ks]);
-            }
+            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_COORD * 2 + 0) * HdP, tab + (ST_COORD * 2 + 1) * HdP, h};
+            layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
-        // ---- FiLM 0, coordinate half: acc += W0a * coord_act
-        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
-        film_epilogue<NT>(acc, xh, xl, tab + (ST_FILM0 * 3 + 0) * HdP, tab + (ST_FILM0 * 3 + 1) * HdP,
-                          tab + (ST_FILM0 * 3 + 2) * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A], Hd, HdP, h);
+        pin_agpr<NT>(X);
+        // ---- geometry first layer -> Y ; FiLM 0, geometry half: X += W0b * sin(30 * (Wg g + bg))
+        xh[0] = gh[0]; xl[0] = gl[0]; xh[1] = gh[1]; xl[1] = gl[1];
+        gemm_x3_roll<F16, NT, 2, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
+        pin_agpr<NT>(X); pin_agpr<NT>(Y);
+        {
+            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_GEO * 2 + 0) * HdP, tab + (ST_GEO * 2 + 1) * HdP, h};
+            layer<NT, KS, false, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
+        }
+        pin_agpr<NT>(X);
         // ---- FiLM 1..3
-#pragma unroll 1
-        for (int l = 1; l < 4; ++l) {
-            zero_acc1<NT>(acc);
-            gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
-            const float* tb = tab + ((ST_FILM0 + l) * 3) * HdP;
-            film_epilogue<NT>(acc, xh, xl, tb, tb + HdP, tb + 2 * HdP, nullptr, 0.f, 0.f, 0.f, invs[W_F0A + l], Hd, HdP, h);
+        {
+            FilmProducer<NT> prod{X, xh, xl, tab + (ST_FILM0 * 2 + 0) * HdP, tab + (ST_FILM0 * 2 + 1) * HdP, h};
+            layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
         }
-
-        // ---- density head
-        const u32x4* head_w = reinterpret_cast<const u32x4*>(blob + L.head_w);
-        float sg[1];
-        heads<NT, 1>(xh, xl, head_w, 0, KS, h, sg);
-        const float sigma = sg[0] * head_inv[0] + head_b[0];
+        pin_agpr<NT>(Y);
+        {
+            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_FILM1 * 2 + 0) * HdP, tab + (ST_FILM1 * 2 + 1) * HdP, h};
+            layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
+        }
+        pin_agpr<NT>(X);
+        {
+            FilmProducer<NT> prod{X, xh, xl, tab + (ST_FILM2 * 2 + 0) * HdP, tab + (ST_FILM2 * 2 + 1) * HdP, h};
+            layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
+        }
+        pin_agpr<NT>(Y);
+        // ---- colour FiLM: X = Wc[:, 3:] * film3(Y) + Wc[:, :3] * dir  (+ density head on film3(Y))
+        {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (h == 0) {
+                if (A.dirs) {
+                    if (ok) { v[0] = A.dirs[gi * 3]; v[1] = A.dirs[gi * 3 + 1]; v[2] = A.dirs[gi * 3 + 2]; }
+                } else {
+                    v[2] = -1.f;                      // lock_view_dependence: (0, 0, -1)
+                }
+            }
+            split8(v, kSA, xh[KS], xl[KS]);
+            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_FILM3 * 2 + 0) * HdP, tab + (ST_FILM3 * 2 + 1) * HdP, h};
+            layer<NT, KS + 1, true, false, true>(X, xh, xl, ring, prod, hacc, head_lds, lane);
+        }
+        pin_agpr<NT>(X);
+        // density of this lane's sample: head row 0 = accumulator register 0 of the lower lane half
+        const float sigma = __shfl(hacc[0], m, 64) * hi0 + hb0;
         float w = 0.f, bg = 0.f;
         if (!FUSED) {
             if (ok && h == 0) A.out[gi * (F + 4) + F + 3] = sigma;
@@ -378,25 +439,20 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             if (h == 0) { wl_lds[m] = w; wl_lds[32 + m] = bg; }
         }
 
-        // ---- colour FiLM (+ view direction on the VALU when it is not locked)
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        if (A.dirs && ok) { d0 = A.dirs[gi * 3]; d1 = A.dirs[gi * 3 + 1]; d2 = A.dirs[gi * 3 + 2]; }
-        zero_acc1<NT>(acc);
-        gemm_x3<F16, NT, KS, KS, false>(acc, xh, xl, ring);
-        film_epilogue<NT>(acc, xh, xl, tab + (ST_COLOR * 3 + 0) * HdP, tab + (ST_COLOR * 3 + 1) * HdP,
-                          tab + (ST_COLOR * 3 + 2) * HdP, A.dirs ? twd : nullptr, d0, d1, d2, invs[W_COLOR], Hd, HdP, h);
-
-        // ---- rgb head
-        float cc[3];
-        heads<NT, 3>(xh, xl, head_w, 1, KS, h, cc);
+        // ---- feature head, sample-major accumulator: Y = film_color(X)^T * Wf^T  (+ colour heads on film_color(X))
+        {
+            FilmProducer<NT> prod{X, xh, xl, tab + (ST_COLOR * 2 + 0) * HdP, tab + (ST_COLOR * 2 + 1) * HdP, h};
+            layer<NT, KS, true, true, true>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
+        }
+        pin_agpr<NT>(Y);
         float rgb[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-(cc[c] * head_inv[1 + c] + head_b[1 + c])));
-
-        // ---- feature head, sample-major accumulator
-        zero_acc1<NT>(acc);
-        gemm_x3<F16, NT, KS, KS, true>(acc, xh, xl, ring);
-        const float inv_f = invs[W_FEAT];
+        {
+            const float c0 = __shfl(hacc[1], m, 64), c1 = __shfl(hacc[2], m, 64), c2 = __shfl(hacc[3], m, 64);
+            rgb[0] = 1.f / (1.f + expf(-(c0 * hi1 + hb1)));
+            rgb[1] = 1.f / (1.f + expf(-(c1 * hi2 + hb2)));
+            rgb[2] = 1.f / (1.f + expf(-(c2 * hi3 + hb3)));
+        }
+        f32x16 (&acc)[NT] = Y;
         if (!FUSED) {
             if (ok && h == 0) {
                 A.out[gi * (F + 4) + 0] = rgb[0];
@@ -486,7 +542,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 }
 
 size_t lds_bytes(const LayoutX3& L) {
-    return sizeof(float) * ((size_t)ST_COUNT * 3 * L.HdP + 3 * L.HdP + L.HdP + 3 * L.HdP + 4 * 64) + H3D_RING_DEPTH * (size_t)L.NT * 2048;
+    return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64) + (size_t)4 * 2 * L.KS * 32 +
+           H3D_RING_DEPTH * (size_t)L.NT * 2048;
 }
 
 template <int NT, bool FUSED>
@@ -602,6 +659,7 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
         invs[wi] = 1.f / (sc * in_scale);
         return sc;
     };
+    mat(W_COORD, p->w_coord, 3, 0, 3, Hd, 1, kSIn);
     mat(W_GEO, p->w_geo, 31, 0, 31, Hd, 2, kSIn);
     // FiLM 0: both halves must share one scale because they accumulate into the same registers
     {
@@ -610,21 +668,23 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
         pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]));
         invs[W_F0A] = invs[W_F0B] = 1.f / (sc * kSA);
     }
-    for (int l = 1; l < 4; ++l) mat(W_F0A + l, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA);
-    mat(W_COLOR, p->w_color, Hd + 3, 3, Hd, Hd, L.KS, kSA);
+    for (int l = 1; l < 4; ++l) mat(W_F1 + l - 1, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA);
+    // colour layer: KS k-steps over the hidden features (columns 3..) + one k-step over the view direction (columns 0..2),
+    // one scale for the whole matrix (same accumulators)
+    {
+        const float sc = pow2_scale(p->w_color, (int64_t)Hd * (Hd + 3), target);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(blob + L.w[W_COLOR]);
+        pack_x3(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, dst);
+        pack_x3(p->w_color, Hd + 3, 0, 3, Hd, 1, L.NT, sc, dst + (int64_t)L.KS * L.NT * 2 * 64 * 8);
+        invs[W_COLOR] = 1.f / (sc * kSA);
+    }
     mat(W_FEAT, p->w_feat, Hd, 0, Hd, F, L.KS, kSA);
     float* bias = reinterpret_cast<float*>(blob + L.bias);
-    float* wdir = reinterpret_cast<float*>(blob + L.wdir);
-    float* wcoord = reinterpret_cast<float*>(blob + L.wcoord);
     for (int nn = 0; nn < Hd; ++nn) {
         bias[ST_GEO * L.HdP + nn] = p->b_geo[nn];
         bias[ST_COORD * L.HdP + nn] = p->b_coord[nn];
         for (int l = 0; l < 4; ++l) bias[(ST_FILM0 + l) * L.HdP + nn] = p->b_film[l][nn];
         bias[ST_COLOR * L.HdP + nn] = p->b_color[nn];
-        for (int c = 0; c < 3; ++c) {
-            wdir[c * L.HdP + nn] = p->w_color[(int64_t)nn * (Hd + 3) + c];
-            wcoord[c * L.HdP + nn] = p->w_coord[(int64_t)nn * 3 + c];
-        }
     }
     float* bf = reinterpret_cast<float*>(blob + L.b_feat);
     for (int nn = 0; nn < F; ++nn) bf[nn] = p->b_feat[nn];
