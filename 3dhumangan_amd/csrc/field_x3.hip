@@ -29,6 +29,8 @@
 #include "x3_common.hpp"
 #include <string.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 using namespace h3d;
 
@@ -38,10 +40,17 @@ typedef F16::vec8 half8;
 typedef F16::vec2 half2v;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float kSA = 4096.f;      // activation scale (|sin| <= 1, |view direction| <= 1)
+constexpr float kSA = 1.f;         // activation scale: none -- the matrix cores honour f16 subnormals (tools/probes/denorm_probe.hip),
+                                   // so hi = f16(y), lo = f16(y - hi) keeps |error| <= 2^-25 for |y| <= 1 without pre-scaling
 constexpr float kSIn = 64.f;       // input scale (coords / geometry features, |x| < 1000)
-constexpr int kLookF = 2;          // weight-fragment look-ahead in tile pairs
-constexpr int kValuF = 4;          // VALU instructions slotted behind each MFMA of a section carrying epilogue work
+#ifndef H3D_FIELD_LOOK
+#define H3D_FIELD_LOOK 2
+#endif
+#ifndef H3D_FIELD_VALU
+#define H3D_FIELD_VALU 4
+#endif
+constexpr int kLookF = H3D_FIELD_LOOK;          // weight-fragment look-ahead in tile pairs
+constexpr int kValuF = H3D_FIELD_VALU;          // VALU instructions slotted behind each MFMA of a section carrying epilogue work
 
 // per-step activation tables (A1, A0) in LDS
 enum { ST_COORD = 0, ST_GEO, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
@@ -109,6 +118,19 @@ __device__ __forceinline__ float density(float x, int clamp_mode) {
     return fmaxf(x, 0.f);
 }
 
+// two fp32 activations -> packed f16 hi halves (returned) and packed f16 lo halves, plain (non-packed) VALU only:
+// VOP3P instructions (v_pk_*, v_fma_mix) beside MFMAs cost several times their issue slot on this chip, and hipcc's SLP
+// vectoriser would turn the two subtractions into one v_pk_add_f32, hence the asm.
+__device__ __forceinline__ unsigned split2_act(float a, float b, unsigned& lo) {
+    const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
+    const float fa = (float)h2.x, fb = (float)h2.y;
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{la, lb}, half2v));
+    return __builtin_bit_cast(unsigned, h2);
+}
+
 // two fp32 (already scaled) -> packed f16 hi halves (returned) and packed f16 lo halves
 __device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {
     const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
@@ -148,33 +170,55 @@ struct FilmProducer {
     f32x16 (&src)[NT];
     half8 (&xh)[2 * NT + 1];
     half8 (&xl)[2 * NT + 1];
-    const float* a1;          // LDS [HdP]
-    const float* a0;          // LDS [HdP]
+    const float* tab;         // LDS [HdP/2][4]: A1[n], A1[n+1], A0[n], A0[n+1]
     int h;
     unsigned Hh[4][2], Ll[4][2];
-    f32x2 t1, t0;
+    f32x4 tv;
+    float sv[8];              // half a tile of the source accumulators, read from the AGPRs in one batch: a
+                              // v_accvgpr_read issued between MFMAs waits for the matrix pipe, so 2 batches per tile
+                              // instead of 8 pairs
 
     template <int TILE, int C>
     __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
-    __device__ __forceinline__ void prime() {
-        t1 = *reinterpret_cast<const f32x2*>(a1 + chan<0, 0>());
-        t0 = *reinterpret_cast<const f32x2*>(a0 + chan<0, 0>());
-    }
+    __device__ __forceinline__ void prime() { tv = ld4(tab + 2 * chan<0, 0>()); }
     template <int TILE, int C>
     __device__ __forceinline__ void chunk() {
         if constexpr (C == 0) pin1(src[TILE]);
         constexpr int rg = C / 2, q0 = (C % 2) * 2;
-        const float u0 = fmaf(src[TILE][rg * 4 + q0], t1.x, t0.x);
-        const float u1 = fmaf(src[TILE][rg * 4 + q0 + 1], t1.y, t0.y);
-        if constexpr (C < 7) {
-            t1 = *reinterpret_cast<const f32x2*>(a1 + chan<TILE, C + 1>());
-            t0 = *reinterpret_cast<const f32x2*>(a0 + chan<TILE, C + 1>());
-        } else if constexpr (TILE + 1 < NT) {
-            t1 = *reinterpret_cast<const f32x2*>(a1 + chan<TILE + 1, 0>());
-            t0 = *reinterpret_cast<const f32x2*>(a0 + chan<TILE + 1, 0>());
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[i] = src[TILE][(C / 4) * 8 + i];
         }
-        const float y0 = __builtin_amdgcn_sinf(u0) * kSA, y1 = __builtin_amdgcn_sinf(u1) * kSA;
-        Hh[rg][C % 2] = split2_f16(y0, y1, Ll[rg][C % 2]);
+#ifdef H3D_ABL_NOREAD
+        const float s0 = tv.x, s1 = tv.y;
+#else
+        const float s0 = sv[(C % 4) * 2], s1 = sv[(C % 4) * 2 + 1];
+#endif
+        const float u0 = fmaf(s0, tv.x, tv.z);
+        const float u1 = fmaf(s1, tv.y, tv.w);
+#ifndef H3D_ABL_NOTAB
+        if constexpr (C < 7) tv = ld4(tab + 2 * chan<TILE, C + 1>());
+        else if constexpr (TILE + 1 < NT) tv = ld4(tab + 2 * chan<TILE + 1, 0>());
+#endif
+#ifdef H3D_ABL_NOSIN
+        const float y0 = u0, y1 = u1;
+#else
+        const float y0 = __builtin_amdgcn_sinf(u0), y1 = __builtin_amdgcn_sinf(u1);
+#endif
+#ifdef H3D_ABL_NOSPLIT
+        Hh[rg][C % 2] = __builtin_bit_cast(unsigned, y0); Ll[rg][C % 2] = __builtin_bit_cast(unsigned, y1);
+#else
+        Hh[rg][C % 2] = split2_act(y0, y1, Ll[rg][C % 2]);
+#endif
+#ifdef H3D_ABL_NOPERM
+        if constexpr (C == 4) xh[2 * TILE] = __builtin_bit_cast(half8, u32x4{Hh[0][0], Hh[0][1], Hh[1][0], Hh[1][1]});
+        if constexpr (C == 5) xl[2 * TILE] = __builtin_bit_cast(half8, u32x4{Ll[0][0], Ll[0][1], Ll[1][0], Ll[1][1]});
+        if constexpr (C == 7) {
+            xh[2 * TILE + 1] = __builtin_bit_cast(half8, u32x4{Hh[2][0], Hh[2][1], Hh[3][0], Hh[3][1]});
+            xl[2 * TILE + 1] = __builtin_bit_cast(half8, u32x4{Ll[2][0], Ll[2][1], Ll[3][0], Ll[3][1]});
+        }
+        return;
+#endif
         if constexpr (C == 4) xh[2 * TILE] = relayout_half<0>(Hh);
         if constexpr (C == 5) xl[2 * TILE] = relayout_half<0>(Ll);
         if constexpr (C == 7) {
@@ -274,8 +318,9 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 a1 = invs[wi] * ff * inv2pi;
                 a0 = fmaf(bias[st * HdP + n], ff, pp) * inv2pi;
             }
-            tab0[(st * 2 + 0) * HdP + n] = a1;
-            tab0[(st * 2 + 1) * HdP + n] = a0;
+            float* q = tab0 + st * 2 * HdP + (n >> 1) * 4 + (n & 1);
+            q[0] = a1;
+            q[2] = a0;
         }
         for (int idx = t; idx < HdP; idx += 256) tfeat0[idx] = idx < F ? bf[idx] : 0.f;
         const u32x4* hsrc = reinterpret_cast<const u32x4*>(blob + L.head_w);
@@ -296,6 +341,11 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int seglen = FUSED ? (S < 32 ? S : 32) : 32;
     const int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
 
+#ifdef H3D_EXPERIMENT_TRACE
+    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.out); g_trace_n = 0; }
+    __syncthreads();
+    H3D_TRACE(0);
+#endif
     WeightRing<NT> ring;
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
 
@@ -320,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         const float* tfeat = tfeat0 + opaque;
         const unsigned char* head_lds = head0 + opaque;
 
+        H3D_TRACE(6);
         half8 xh[KS + 1], xl[KS + 1];
         f32x16 hacc;
         NoProducer none;
@@ -348,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         gemm_x3_roll<F16, NT, 1, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
         pin_agpr<NT>(Y);
         {
-            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_COORD * 2 + 0) * HdP, tab + (ST_COORD * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{Y, xh, xl, tab + ST_COORD * 2 * HdP, h};
             layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(X);
@@ -357,23 +408,23 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         gemm_x3_roll<F16, NT, 2, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
         pin_agpr<NT>(X); pin_agpr<NT>(Y);
         {
-            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_GEO * 2 + 0) * HdP, tab + (ST_GEO * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{Y, xh, xl, tab + ST_GEO * 2 * HdP, h};
             layer<NT, KS, false, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(X);
         // ---- FiLM 1..3
         {
-            FilmProducer<NT> prod{X, xh, xl, tab + (ST_FILM0 * 2 + 0) * HdP, tab + (ST_FILM0 * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{X, xh, xl, tab + ST_FILM0 * 2 * HdP, h};
             layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(Y);
         {
-            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_FILM1 * 2 + 0) * HdP, tab + (ST_FILM1 * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{Y, xh, xl, tab + ST_FILM1 * 2 * HdP, h};
             layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(X);
         {
-            FilmProducer<NT> prod{X, xh, xl, tab + (ST_FILM2 * 2 + 0) * HdP, tab + (ST_FILM2 * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{X, xh, xl, tab + ST_FILM2 * 2 * HdP, h};
             layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(Y);
@@ -390,10 +441,11 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 }
             }
             split8(v, kSA, xh[KS], xl[KS]);
-            FilmProducer<NT> prod{Y, xh, xl, tab + (ST_FILM3 * 2 + 0) * HdP, tab + (ST_FILM3 * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{Y, xh, xl, tab + ST_FILM3 * 2 * HdP, h};
             layer<NT, KS + 1, true, false, true>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(X);
+        H3D_TRACE(7);
         // density of this lane's sample: head row 0 = accumulator register 0 of the lower lane half
         const float sigma = __shfl(hacc[0], m, 64) * hi0 + hb0;
         float w = 0.f, bg = 0.f;
@@ -441,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 
         // ---- feature head, sample-major accumulator: Y = film_color(X)^T * Wf^T  (+ colour heads on film_color(X))
         {
-            FilmProducer<NT> prod{X, xh, xl, tab + (ST_COLOR * 2 + 0) * HdP, tab + (ST_COLOR * 2 + 1) * HdP, h};
+            FilmProducer<NT> prod{X, xh, xl, tab + ST_COLOR * 2 * HdP, h};
             layer<NT, KS, true, true, true>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
         }
         pin_agpr<NT>(Y);
@@ -453,6 +505,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             rgb[2] = 1.f / (1.f + expf(-(c2 * hi3 + hb3)));
         }
         f32x16 (&acc)[NT] = Y;
+        H3D_TRACE(5);
         if (!FUSED) {
             if (ok && h == 0) {
                 A.out[gi * (F + 4) + 0] = rgb[0];
@@ -539,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         }
     }
     ring.drain();
+    H3D_TRACE(9);
 }
 
 size_t lds_bytes(const LayoutX3& L) {
@@ -769,5 +823,29 @@ extern "C" int h3d_render_fused_x3(const void* packed, const float* points, cons
     const int64_t units = (N + unit - 1) / unit;
     const int64_t groups = (units + 3) / 4;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_render_fused_x3: too many rays");
+#ifdef H3D_EXPERIMENT_TRACE
+    {   // development build: dump the cycle trace of workgroup (1000, 3) to $H3D_TRACE_FILE after every launch
+        static unsigned long long* tb = nullptr;
+        if (!tb) (void)hipMalloc(&tb, 4096 * 8);
+        (void)hipMemset(tb, 0, 4096 * 8);
+        A.out = reinterpret_cast<float*>(tb);
+        const int rc2 = launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[4096];
+        (void)hipMemcpy(host, tb, sizeof(host), hipMemcpyDeviceToHost);
+        if (const char* f = getenv("H3D_TRACE_FILE")) {
+            if (FILE* fp = fopen(f, "w")) {
+                unsigned long long t0 = host[0] >> 8, prev = t0;
+                for (int i = 0; i < 4096 && host[i]; ++i) {
+                    const unsigned long long tt = host[i] >> 8;
+                    fprintf(fp, "%llu %llu +%llu\n", host[i] & 255ull, tt - t0, tt - prev);
+                    prev = tt;
+                }
+                fclose(fp);
+            }
+        }
+        return rc2;
+    }
+#endif
     return launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
 }

@@ -18,6 +18,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+template <int I>
+struct IC { static constexpr int value = I; };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 #ifndef H3D_RING_DEPTH
 #define H3D_RING_DEPTH 7
 #endif
@@ -89,32 +100,41 @@ struct WeightRing {
     static constexpr int kStage = NT * 2048;
     const unsigned char* gsrc;    // global stream + this lane's slot
     unsigned char* ring;          // LDS ring base
-    int total, issue_pos, issue_buf, cur_buf, wave, lane;
+    const unsigned char* cur_g;   // global address of the stage being filled (this lane's slot of piece 0)
+    int total, issue_pos, issue_buf, cur_buf, wave, lane, ring_base, cur_m0;
 
     __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
         gsrc = stream + (w * kChunks) * 1024 + l * 16;
         ring = lds;
+        ring_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
         total = total_stages;
         issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
 #pragma unroll
         for (int i = 0; i < kBuf - 1; ++i) issue();
     }
-    __device__ __forceinline__ void issue_chunk(int c) {           // c = 0 .. kChunks-1, in order
+    // One 1 KB piece of the stage being filled.  Issued through inline asm on purpose: hipcc models
+    // global_load_lds as a FLAT access that touches both LDS and memory and, while one is pending, degrades EVERY
+    // later s_waitcnt it inserts to vmcnt(0) / lgkmcnt(0) -- each LDS fragment read then stalls for the full LDS
+    // latency and each table read drains the whole weight prefetch queue.  The ring is synchronised by hand
+    // (acquire()), so the compiler does not need to know about these writes.  The global and the LDS address advance
+    // by the same 1 KB per piece, so the instruction's immediate offset serves both (one address per stage).
+    template <int C>
+    __device__ __forceinline__ void issue_chunk() {           // C = 0 .. kChunks-1, in order
 #ifdef H3D_EXPERIMENT_NO_REFILL
-        if (issue_pos >= kBuf - 1) { if (c == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 : issue_pos + 1; } return; }
+        if (issue_pos >= kBuf - 1) { if (C == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 : issue_pos + 1; } return; }
 #endif
-        const unsigned char* g = gsrc + (int64_t)issue_pos * kStage + c * 1024;
-        unsigned char* d = ring + issue_buf * kStage + (wave * kChunks + c) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
-        if (c == kChunks - 1) {
+        if (C == 0) {
+            cur_g = gsrc + (int64_t)issue_pos * kStage;
+            cur_m0 = __builtin_amdgcn_readfirstlane(ring_base + issue_buf * kStage + wave * kChunks * 1024);
+        }
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off offset:%2" : : "s"(cur_m0), "v"(cur_g), "n"(C * 1024) : "m0");
+        if (C == kChunks - 1) {
             issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
             issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
         }
     }
     __device__ __forceinline__ void issue() {
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) issue_chunk(c);
+        static_for<0, kChunks>([&](auto c) __attribute__((always_inline)) { issue_chunk<decltype(c)::value>(); });
     }
     // Make the next stage (t) readable by every wave.  The caller then issues stage t + kBuf - 1 with
     // issue_chunk(0..kChunks-1), one chunk after each tile pair's MFMAs of the k-step it computes next, so the DMA
@@ -145,21 +165,6 @@ struct WeightRing {
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
-//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].
-// The three partial products of a tile are issued NT MFMAs apart (no back-to-back dependent accumulations).
-template <typename T, int NT>
-struct WFragT { typename T::vec8 h[NT], l[NT]; };
-
-template <typename T, int NT>
-__device__ __forceinline__ void load_wfrag_pair(WFragT<T, NT>& f, const unsigned char* st, int p) {
-#pragma unroll
-    for (int nt = 2 * p; nt < 2 * p + 2; ++nt) {
-        f.h[nt] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 0) * 1024));
-        f.l[nt] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(st + (nt * 2 + 1) * 1024));
-    }
-}
-
 template <typename T, bool SWAP>
 __device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T::vec8& x, const f32x16& c) {
 #ifdef H3D_EXPERIMENT_NO_MFMA
@@ -168,75 +173,12 @@ __device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T
     return SWAP ? T::mfma(x, w, c) : T::mfma(w, x, c);
 }
 
-// One k-step: the 3 partial products of tile pair p (hi*hi, hi*lo, lo*hi; the two tiles alternate so no MFMA
-// depends on its predecessor), with the 4 ds_read_b128 that fetch the NEXT k-step's fragments of the same tile
-// pair issued just ahead of them.  Never more than a handful of LDS reads are outstanding, so the compiler's
-// lgkmcnt waits stay exact (the counter saturates at 15) and no MFMA waits for a read issued in its own k-step.
-template <typename T, int NT, bool SWAP, bool PREFETCH, typename RING>
-__device__ __forceinline__ void kstep_x3(f32x16 (&acc)[NT], const WFragT<T, NT>& cur, WFragT<T, NT>& nxt,
-                                         const unsigned char* st_next, const typename T::vec8& xh,
-                                         const typename T::vec8& xl, RING& ring, bool refill) {
-    static_assert(RING::kChunks == NT / 2, "one DMA chunk per tile pair");
-#pragma unroll
-    for (int p = 0; p < NT / 2; ++p) {
-        if (PREFETCH) load_wfrag_pair<T, NT>(nxt, st_next, p);
-        const int a = 2 * p, b = 2 * p + 1;
-        acc[a] = mm<T, SWAP>(cur.h[a], xh, acc[a]);
-        acc[b] = mm<T, SWAP>(cur.h[b], xh, acc[b]);
-        acc[a] = mm<T, SWAP>(cur.h[a], xl, acc[a]);
-        acc[b] = mm<T, SWAP>(cur.h[b], xl, acc[b]);
-        acc[a] = mm<T, SWAP>(cur.l[a], xh, acc[a]);
-        acc[b] = mm<T, SWAP>(cur.l[b], xh, acc[b]);
-        if (refill) ring.issue_chunk(p);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// acc[nt] += W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
-//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].   KS is even.
-template <typename T, int NT, int KS, int KSA, bool SWAP, typename RING>
-__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA], const typename T::vec8 (&xl)[KSA],
-                                        RING& ring) {
-    static_assert(KS % 2 == 0 && NT % 2 == 0 && KS <= KSA, "k-steps and tiles come in pairs");
-    WFragT<T, NT> f0, f1;
-    {
-        const unsigned char* st = ring.acquire();
-        ring.issue();
-#pragma unroll
-        for (int p = 0; p < NT / 2; ++p) load_wfrag_pair<T, NT>(f0, st, p);
-    }
-    // every acquire() is followed by exactly one refill (kChunks DMA instructions), issued inside the next k-step
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-        const unsigned char* s1 = ring.acquire();
-        __builtin_amdgcn_sched_barrier(0);
-        kstep_x3<T, NT, SWAP, true>(acc, f0, f1, s1, xh[ks], xl[ks], ring, true);
-        if (ks + 2 < KS) {
-            const unsigned char* s2 = ring.acquire();
-            __builtin_amdgcn_sched_barrier(0);
-            kstep_x3<T, NT, SWAP, true>(acc, f1, f0, s2, xh[ks + 1], xl[ks + 1], ring, true);
-        } else {
-            kstep_x3<T, NT, SWAP, false>(acc, f1, f0, nullptr, xh[ks + 1], xl[ks + 1], ring, false);
-        }
-    }
-}
-
-// Register-lean variant of gemm_x3: instead of double-buffering a whole k-step of weight fragments (NT*16
-// registers), a rolling window of L+1 tile pairs (16 registers each) runs L pairs (L * 192 MFMA cycles) ahead of
+// acc[nt] (+)= W(tile nt, k-step ks) x X(k-step ks) for all tiles / k-steps of one matrix, weights from the ring.
+//   SWAP = false: D[feature][sample] (weights = A operand);  SWAP = true: D[sample][feature].
+// Instead of double-buffering a whole k-step of weight fragments (NT*16 registers), a rolling window of L+1 tile pairs (16 registers each) runs L pairs (L * 192 MFMA cycles) ahead of
 // the matrix pipe.  Same ring protocol: acquire(s+1) happens inside k-step s, just before the first read of stage
 // s+1 and after the last read of stage s was issued; each acquire is followed by exactly one refill, one DMA chunk
 // after each of the next NT/2 tile pairs.  acc is accumulated into (initialise it with the bias / residual).
-template <int I>
-struct IC { static constexpr int value = I; };
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(IC<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 #ifdef H3D_EXPERIMENT_TRACE
 __device__ unsigned long long* g_trace;
 __device__ int g_trace_n;
@@ -286,6 +228,9 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
     static_for<0, G>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int s = g / P, p = g % P;
+#ifdef H3D_EXPERIMENT_TRACE_FINE
+        if constexpr (s >= 4 && s < 7) H3D_TRACE(10 + p);
+#endif
         if constexpr (p == P - L && s + 1 < KS) {
             if constexpr (s % 4 == 0) H3D_TRACE(2);
             st[(s + 1) & 1] = ring.acquire();
@@ -313,7 +258,7 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
         // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
         // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()
         constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
-        if constexpr (since >= 0 && since / P + 1 < KS) ring.issue_chunk(since % P);
+        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_chunk<since % P>();
         if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
