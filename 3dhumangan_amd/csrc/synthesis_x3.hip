@@ -72,84 +72,116 @@ __device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
     }
 }
 
-struct Tabs { f32x4 sc, sh; };
-struct TileWords { unsigned Hh[4][2], Ll[4][2]; Tabs tb; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// One sixth of a tile's fragment epilogue, small enough to hide behind one tile-pair section (6 MFMAs) of the GEMM
-// that consumes the fragments: C = 0..3 register group C through val -> packed bf16 halves; 4 / 5 = relayout of
-// the hi / lo plane into the B fragments of k-steps 2*TILE, 2*TILE+1.  val.tabs(tile, rg) reads the LDS tables of
-// a register group, val.apply(tile, rg, tabs) computes its four outputs; the tables are fetched one chunk ahead so
-// that their LDS latency never stalls the (in-order) instruction stream in front of an MFMA.
-template <int NT, int TILE, int C, typename F>
-__device__ __forceinline__ void frag_chunk(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], TileWords& tw, f32x16 (&src)[NT], F& val) {
-    if constexpr (C == 0) pin1(src[TILE]);
-    if constexpr (C < 4) {
-        const f32x4 y = val.apply(IC<TILE>{}, IC<C>{}, tw.tb);
-        if constexpr (C < 3) tw.tb = val.tabs(IC<TILE>{}, IC<C + 1>{});
-        else if constexpr (TILE + 1 < NT) tw.tb = val.tabs(IC<TILE + 1>{}, IC<0>{});
-        tw.Hh[C][0] = split2_bf16(y.x, y.y, tw.Ll[C][0]);
-        tw.Hh[C][1] = split2_bf16(y.z, y.w, tw.Ll[C][1]);
-    } else if constexpr (C == 4) {
-        relayout_tile<BF16>(tw.Hh, xh[2 * TILE], xh[2 * TILE + 1]);
-    } else if constexpr (C == 5) {
-        relayout_tile<BF16>(tw.Ll, xl[2 * TILE], xl[2 * TILE + 1]);
-    }
+// two fp32 -> packed bf16 hi halves (returned) and packed bf16 lo halves; plain VALU only (VOP3P instructions beside
+// MFMAs cost several issue slots on this chip, and hipcc's SLP vectoriser would pack the two subtractions).
+__device__ __forceinline__ unsigned split2_plain(float a, float b, unsigned& lo) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, b2));
+    const float fa = __builtin_bit_cast(float, hb << 16), fb = __builtin_bit_cast(float, hb & 0xffff0000u);
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{la, lb}, b2));
+    return hb;
 }
 
-// conv GEMM dst (+)= W * frags(val(src)) with the fragment epilogue of tile t+1 hidden behind the MFMAs of k-steps
+__device__ __forceinline__ float lrelu_plain(float v) {
+    float t;
+    asm("v_mul_f32 %0, 0x3e4ccccd, %1" : "=v"(t) : "v"(v));      // 0.2 * v, kept out of the SLP vectoriser's reach
+    return fmaxf(v, t);
+}
+
+template <int PR>
+__device__ __forceinline__ bf8 relayout_half(const unsigned (&P)[4][2]) {
+    u32x4 r;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        auto a = __builtin_amdgcn_permlane32_swap(P[2 * PR][c], P[2 * PR + 1][c], false, false);
+        r[c] = a[0];
+        r[2 + c] = a[1];
+    }
+    return __builtin_bit_cast(bf8, r);
+}
+
+// Producer of a conv's B fragments from a feature-major accumulator set, one 32-channel tile in eight chunks of two
+// activations (so that the consuming GEMM hides one chunk behind each tile-pair section of k-steps 2t, 2t+1):
+//   AFFINE  y = lrelu(v * sc + sh)   tables [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1] (constant-style SPADE with the
+//           conv bias of v folded into sh);  otherwise y = lrelu(v) (per-pixel style: v is already modulated)
+//   RGB     also accumulates the ToRGB of v (the previous block's output) into rgb[3]: wr = LDS [3][HdP]
+// Source values are read from the AGPRs eight at a time: a v_accvgpr_read between MFMAs waits for the matrix pipe.
+template <int NT, bool AFFINE, bool RGB>
+struct SpadeProducer {
+    f32x16 (&src)[NT];
+    bf8 (&xh)[2 * NT];
+    bf8 (&xl)[2 * NT];
+    const float* ab;
+    const float* wr;
+    float (&rgb)[3];
+    int h, HdP;
+    unsigned Hh[4][2], Ll[4][2];
+    f32x4 tv;
+    f32x2 w0, w1, w2;
+    float sv[8];
+
+    template <int TILE, int C>
+    __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
+    template <int TILE, int C>
+    __device__ __forceinline__ void fetch() {
+        const int n = chan<TILE, C>();
+        if constexpr (AFFINE) tv = ld4(ab + 2 * n);
+        if constexpr (RGB) {
+            w0 = *reinterpret_cast<const f32x2*>(wr + n);
+            w1 = *reinterpret_cast<const f32x2*>(wr + HdP + n);
+            w2 = *reinterpret_cast<const f32x2*>(wr + 2 * HdP + n);
+        }
+    }
+    __device__ __forceinline__ void prime() { fetch<0, 0>(); }
+    template <int TILE, int C>
+    __device__ __forceinline__ void chunk() {
+        if constexpr (C == 0) pin1(src[TILE]);
+        constexpr int rg = C / 2;
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[i] = src[TILE][(C / 4) * 8 + i];
+        }
+        const float s0 = sv[(C % 4) * 2], s1 = sv[(C % 4) * 2 + 1];
+        float y0 = s0, y1 = s1;
+        if constexpr (AFFINE) { y0 = fmaf(s0, tv.x, tv.z); y1 = fmaf(s1, tv.y, tv.w); }
+        if constexpr (RGB) {
+            rgb[0] = fmaf(s1, w0.y, fmaf(s0, w0.x, rgb[0]));
+            rgb[1] = fmaf(s1, w1.y, fmaf(s0, w1.x, rgb[1]));
+            rgb[2] = fmaf(s1, w2.y, fmaf(s0, w2.x, rgb[2]));
+        }
+        if constexpr (C < 7) fetch<TILE, C + 1>();
+        else if constexpr (TILE + 1 < NT) fetch<TILE + 1, 0>();
+        Hh[rg][C % 2] = split2_plain(lrelu_plain(y0), lrelu_plain(y1), Ll[rg][C % 2]);
+        if constexpr (C == 4) xh[2 * TILE] = relayout_half<0>(Hh);
+        if constexpr (C == 5) xl[2 * TILE] = relayout_half<0>(Ll);
+        if constexpr (C == 7) {
+            xh[2 * TILE + 1] = relayout_half<1>(Hh);
+            xl[2 * TILE + 1] = relayout_half<1>(Ll);
+        }
+    }
+};
+
+// conv GEMM dst (+)= W * frags(producer(src)) with the fragment epilogue of tile t+1 hidden behind the MFMAs of k-steps
 // 2t, 2t+1 (which only need tile t); only tile 0's epilogue is exposed.  src and dst are different register sets.
-template <int NT, bool ZERO, typename RING, typename F>
-__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], f32x16 (&src)[NT], bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT],
-                                                 RING& ring, F val) {
-    TileWords tw;
-    tw.tb = val.tabs(IC<0>{}, IC<0>{});
-    static_for<0, 6>([&](auto c) __attribute__((always_inline)) { frag_chunk<NT, 0, decltype(c)::value>(xh, xl, tw, src, val); });
+template <int NT, bool ZERO, typename RING, typename PROD>
+__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], RING& ring, PROD& prod) {
+    prod.prime();
+    static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
     __builtin_amdgcn_sched_barrier(0);
     constexpr int W = NT, PER = 8 / W;          // sections per 2-k-step window, chunks per section
     gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int t = g / W + 1, j = g % W;
         if constexpr (t < NT) {
-            static_for<0, PER>([&](auto q) __attribute__((always_inline)) {
-                constexpr int c = j * PER + decltype(q)::value;
-                if constexpr (c < 6) frag_chunk<NT, t, c>(xh, xl, tw, src, val);
-            });
+            static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
         }
     });
 }
-
-// y = lrelu(v * sc + sh), tables [2][HdP] in LDS (constant-style SPADE with the conv bias of v folded into sh)
-template <int NT>
-struct AffineLrelu {
-    f32x16 (&v)[NT];
-    const float* ab;
-    int h, HdP;
-    template <typename TI, typename RG>
-    __device__ __forceinline__ Tabs tabs(TI, RG) const {
-        const int n = TI::value * 32 + RG::value * 8 + 4 * h;
-        return Tabs{ld4(ab + n), ld4(ab + HdP + n)};
-    }
-    template <typename TI, typename RG>
-    __device__ __forceinline__ f32x4 apply(TI, RG, const Tabs& t) const {
-        constexpr int nt = TI::value, r = RG::value * 4;
-        f32x4 y = {fmaf(v[nt][r + 0], t.sc.x, t.sh.x), fmaf(v[nt][r + 1], t.sc.y, t.sh.y), fmaf(v[nt][r + 2], t.sc.z, t.sh.z),
-                   fmaf(v[nt][r + 3], t.sc.w, t.sh.w)};
-        return __builtin_elementwise_max(y, y * 0.2f);
-    }
-};
-
-// y = lrelu(v)   (per-pixel-style SPADE: v already holds (x*sc+sh)*(1+gamma) + beta)
-template <int NT>
-struct PlainLrelu {
-    f32x16 (&v)[NT];
-    template <typename TI, typename RG> __device__ __forceinline__ Tabs tabs(TI, RG) const { return Tabs{}; }
-    template <typename TI, typename RG>
-    __device__ __forceinline__ f32x4 apply(TI, RG, const Tabs&) const {
-        constexpr int nt = TI::value, r = RG::value * 4;
-        f32x4 y = {v[nt][r + 0], v[nt][r + 1], v[nt][r + 2], v[nt][r + 3]};
-        return __builtin_elementwise_max(y, y * 0.2f);
-    }
-};
 
 template <int NT, int DEPTH, bool SEG>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
@@ -159,7 +191,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     float* tab0 = smem;                                      // [table_floats] static tables (descriptor offsets)
     float* ab0 = tab0 + ((A.table_floats + 3) & ~3);         // [n_ab][2][HdP] this sample's constant-style affines
     float* cst0 = ab0 + A.n_ab * 2 * HdP;                    // [n_cst][128]   this sample's shared-MLP constants
-    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(cst0 + A.n_cst * kShared);
+    float* zero0 = cst0 + A.n_cst * kShared;                 // [3][HdP] zeros: ToRGB weights of "no ToRGB"
+    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(zero0 + 3 * HdP);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -171,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     for (int i = t; i < A.table_floats; i += 256) tab0[i] = A.tables[i];
     for (int i = t; i < A.n_ab * 2 * HdP; i += 256) ab0[i] = A.ab[(int64_t)b * A.n_ab * 2 * HdP + i];
     for (int i = t; i < A.n_cst * kShared; i += 256) cst0[i] = A.cst[(int64_t)b * A.n_cst * kShared + i];
+    for (int i = t; i < 3 * HdP; i += 256) zero0[i] = 0.f;
     __syncthreads();
 
 #ifdef H3D_EXPERIMENT_TRACE
@@ -257,16 +291,15 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     }
 
     // constant-style SPADE: y = lrelu(v * a + b) -> fragments
-    auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {
+    auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {       // ab: [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]
         make_frags<NT>(xh, xl, v, [&](int nt, int rg) {
             const int n = nt * 32 + rg * 8 + 4 * h;
-            const f32x4 sc = ld4(ab + n);
-            const f32x4 sh = ld4(ab + HdP + n);
+            const f32x4 ta = ld4(ab + 2 * n), tb = ld4(ab + 2 * n + 4);
             float4 y;
-            y.x = lrelu(fmaf(v[nt][rg * 4 + 0], sc.x, sh.x));
-            y.y = lrelu(fmaf(v[nt][rg * 4 + 1], sc.y, sh.y));
-            y.z = lrelu(fmaf(v[nt][rg * 4 + 2], sc.z, sh.z));
-            y.w = lrelu(fmaf(v[nt][rg * 4 + 3], sc.w, sh.w));
+            y.x = lrelu(fmaf(v[nt][rg * 4 + 0], ta.x, ta.z));
+            y.y = lrelu(fmaf(v[nt][rg * 4 + 1], ta.y, ta.w));
+            y.z = lrelu(fmaf(v[nt][rg * 4 + 2], tb.x, tb.z));
+            y.w = lrelu(fmaf(v[nt][rg * 4 + 3], tb.y, tb.w));
             return y;
         });
     };
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         }
     };
     // ToRGB: rgb += Wrgb * x + b, an fp32 dot product over this lane's half of the channels
-    auto to_rgb = [&](const float* wr) {
+    auto to_rgb = [&](const float* wr, bool with_bias) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -302,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (h == 0) { s0 += wr[3 * HdP + 0]; s1 += wr[3 * HdP + 1]; s2 += wr[3 * HdP + 2]; }
+        if (h == 0 && with_bias) { s0 += wr[3 * HdP + 0]; s1 += wr[3 * HdP + 1]; s2 += wr[3 * HdP + 2]; }
         rgb_acc[0] += s0; rgb_acc[1] += s1; rgb_acc[2] += s2;
     };
 
@@ -382,7 +415,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 pin_agpr<NT>(acc);
                 gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
                 pin_agpr<NT>(acc);
-                conv_progressive<NT, true>(x, acc, xh, xl, ring, PlainLrelu<NT>{acc});
+                {
+                    SpadeProducer<NT, false, false> prod{acc, xh, xl, nullptr, nullptr, rgb_acc, h, HdP};
+                    conv_progressive<NT, true>(x, xh, xl, ring, prod);
+                }
                 pin_agpr<NT>(x);
             } else {
                 // constant style before the first skip block: x is both source and destination, so the fragments
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 pin_agpr<NT>(x);
             }
         }
-        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
+        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
     }
 
     // ================= blocks from the first skip connection on (constant style only) ============================
@@ -407,14 +443,25 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         const float* abt = ab0 + opaque;
         f32x16 acc[NT];
         pin_agpr<NT>(x);
-        conv_progressive<NT, true>(acc, x, xh, xl, ring, AffineLrelu<NT>{x, abt + Bk.spade[0].ab_index * 2 * HdP, h, HdP});
+        {   // conv 0, with the ToRGB of the previous skip block's output (this block's input x) riding along
+            const float* wr_prev = (blk > A.first_skip && D.block[blk - 1].to_rgb) ? tab + D.block[blk - 1].w_rgb : zero0 + opaque;
+            SpadeProducer<NT, true, true> prod{x, xh, xl, abt + Bk.spade[0].ab_index * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+            conv_progressive<NT, true>(acc, xh, xl, ring, prod);
+        }
         pin_agpr<NT>(x); pin_agpr<NT>(acc);
-        conv_progressive<NT, false>(x, acc, xh, xl, ring, AffineLrelu<NT>{acc, abt + Bk.spade[1].ab_index * 2 * HdP, h, HdP});
+        {
+            SpadeProducer<NT, true, false> prod{acc, xh, xl, abt + Bk.spade[1].ab_index * 2 * HdP, nullptr, rgb_acc, h, HdP};
+            conv_progressive<NT, false>(x, xh, xl, ring, prod);
+        }
         pin_agpr<NT>(x);
-        H3D_TRACE(5);
-        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb);
-        H3D_TRACE(6);
+        if (Bk.to_rgb && h == 0) {          // bias of this block's ToRGB; its weights ride in the next block's conv 0
+            const float* wb = tab + Bk.w_rgb + 3 * HdP;
+            rgb_acc[0] += wb[0]; rgb_acc[1] += wb[1]; rgb_acc[2] += wb[2];
+        }
     }
+    H3D_TRACE(5);
+    if (D.n_blocks > A.first_skip && D.block[D.n_blocks - 1].to_rgb) to_rgb(tab0 + D.block[D.n_blocks - 1].w_rgb, false);
+    H3D_TRACE(6);
     ring.drain();
     H3D_TRACE(9);
     if (SEG && A.store_state) {
@@ -434,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 }
 
 size_t lds_bytes(const Args& A, int NT, int depth) {
-    return sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared) +
+    return sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared + 3 * (size_t)A.HdP) +
            (size_t)depth * NT * 2048;
 }
 

@@ -306,6 +306,9 @@ class SynthesisPlan:
             G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3["HdP"] if x3 else None)
             if x3 and ab is not None:
                 ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]      # folded conv biases (build_x3)
+                # kernel layout [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]: one 16-byte LDS read per two channels
+                Bq, nq, _, Hq = ab.shape
+                ab = ab.view(Bq, nq, 2, Hq // 2, 2).permute(0, 1, 3, 2, 4).contiguous()
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         with stage(owner, "synthesis"):
             if x3:

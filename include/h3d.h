@@ -183,6 +183,8 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k = 16*kstep + 8*(lane>>5) + e];
  * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
  * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
+ * `ab` for THIS entry point is [B, n_ab, HdP/2, 4] = (scale[n], scale[n+1], shift[n], shift[n+1]) -- one 16-byte read per
+ * two channels -- not the [B, n_ab, 2, HdP] of h3d_synthesis.
  * The conv biases are NOT read by this engine: the caller folds them into the consumers' tables (the activations it
  * carries are the true ones minus a per-channel carry c; SPADE shift sh' = sh + sc*c in `ab` / `vec`, ToRGB bias
  * br' = br + Wr*c -- see SynthesisPlan.build_x3 in lib/generators/synthesis_pack.py).
