@@ -7,14 +7,17 @@
 // planes with wave-uniform (broadcast) ds_read_b128.
 //
 // The search is filter + refine, and bit-exact:
-//   filter  a(v) = |v|^2 - 2 p.v  (= |p - v|^2 - |p|^2) with three packed FMAs per two vertices -- 2 VALU
-//           instructions per (point, vertex) pair instead of the 11 the exact evaluation with index tracking needs.
-//           Per chunk of 64 consecutive vertices only the minimum of a is kept.
+//   filter  a(v) = |v|^2 - 2 p.v  (= |p - v|^2 - |p|^2) on the matrix cores: D[v][p] = A[v][k] * B[k][p] with
+//           A = (vx, vy, vz, |v|^2), B = (-2px, -2py, -2pz, 1), both split into f16 hi + lo, and the three partial
+//           products hi*hi, hi*lo, lo*hi laid side by side along K (12 of the 16 k-slots of one
+//           v_mfma_f32_32x32x16_f16): ONE MFMA evaluates 32 vertices x 32 points to 22 significant bits per operand.
+//           A wave filters its 256 points (eight B fragments, resident) against a 32-vertex tile with 8 MFMAs; only
+//           the minimum of a per chunk of 64 consecutive vertices is kept (v_min3 over the accumulator registers).
 //   refine  the oracle's own arithmetic, d = (dx*dx + dy*dy) + dz*dz with no fused multiply-add and a strict "<" in
 //           ascending vertex order, runs only over candidate chunks.
 // A chunk is a candidate when its filter minimum is within tol of the running filter minimum at the time it is
 // scanned.  With e >= |a(v) + |p|^2 - d_float(v)| for every vertex (rounding of both formulas; e <= 28 eps S,
-// S = |p|^2 + max|v|^2) and tol = 256 eps S >= 2e: the exact winner w has a(w) <= d_w - |p|^2 + e, every vertex has
+// S = |p|^2 + max|v|^2; here e <= 2^-17 S) and tol = 2^-15 S >= 2e: the exact winner w has a(w) <= d_w - |p|^2 + e, every vertex has
 // a >= d_w - |p|^2 - e, so the chunk of w is within 2e of the final -- hence of the running -- minimum.  The last
 // eight candidates are remembered (id + filter minimum) and those still within tol of the FINAL minimum are
 // refined in scan order; a point that overflows the list (pathological ties) is refined over the whole mesh.
@@ -32,6 +35,17 @@ constexpr int kCand = 8;                   // remembered candidate chunks per po
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed f16 hi halves (returned) and packed f16 lo halves (residuals)
+__device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {
+    const half2v h2 = __builtin_convertvector(f2{a, b}, half2v);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a - (float)h2.x, b - (float)h2.y}, half2v));
+    return __builtin_bit_cast(unsigned, h2);
+}
 
 __device__ __forceinline__ float sqdist_exact(float px, float py, float pz, float vx, float vy, float vz) {
     const float dx = __fsub_rn(px, vx), dy = __fsub_rn(py, vy), dz = __fsub_rn(pz, vz);
@@ -62,8 +76,7 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     float* vx = smem;
     float* vy = smem + Vpad;
     float* vz = smem + 2 * Vpad;
-    float* vw = smem + 3 * Vpad;   // |v|^2 (filter only)
-    float* jl = smem + 4 * Vpad;   // 24*3 joints
+    float* jl = smem + 3 * Vpad;   // 24*3 joints
     unsigned* v2max_bits = reinterpret_cast<unsigned*>(jl + kJoints * 3);
     const int b = blockIdx.y;
     const int t = threadIdx.x;
@@ -73,24 +86,24 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     float v2 = 0.f;
     for (int i = t; i < Vpad; i += kThreads) {
         const bool ok = i < V;
-        // padding vertices sit at +inf distance for both the filter and the exact scan and can never win
+        // padding vertices sit at +inf distance for the exact scan and can never win (the filter masks them itself)
         const float x = ok ? vb[i * 3 + 0] : 3.0e18f, y = ok ? vb[i * 3 + 1] : 3.0e18f, z = ok ? vb[i * 3 + 2] : 3.0e18f;
-        const float w = x * x + y * y + z * z;
         vx[i] = x; vy[i] = y; vz[i] = z;
-        vw[i] = ok ? w : 3.0e38f;
-        if (ok) v2 = fmaxf(v2, w);
+        if (ok) v2 = fmaxf(v2, x * x + y * y + z * z);
     }
     atomicMax(v2max_bits, __float_as_uint(v2));      // non-negative floats order like their bit patterns
     if (t < kJoints * 3) jl[t] = joints[(int64_t)b * kJoints * 3 + t];
     __syncthreads();
     const float v2max = __uint_as_float(*v2max_bits);
 
-    const int64_t base = ((int64_t)blockIdx.x * kThreads + t) * kPts;
+    // A wave owns 256 consecutive points as 8 sets of 32: lane (m, hh) owns points (4*hh + k) * 32 + m, k = 0..3.
+    const int lane = t & 63, m = lane & 31, hh = lane >> 5;
+    const int64_t wbase = ((int64_t)blockIdx.x * kThreads + (t & ~63)) * kPts;
     float px[kPts], py[kPts], pz[kPts], best[kPts];
     int bi[kPts];
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        const int64_t n = base + k;
+        const int64_t n = wbase + (4 * hh + k) * 32 + m;
         const bool ok = n < N;
         const float* p = points + ((int64_t)b * N + (ok ? n : 0)) * 3;
         px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
@@ -100,20 +113,28 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     const f4* vx4 = reinterpret_cast<const f4*>(vx);
     const f4* vy4 = reinterpret_cast<const f4*>(vy);
     const f4* vz4 = reinterpret_cast<const f4*>(vz);
-    const f4* vw4 = reinterpret_cast<const f4*>(vw);
 
-    // ---- filter: per-chunk minima of a(v) = |v|^2 - 2 p.v, candidate list per point
-    f2 mx[kPts], my[kPts], mz[kPts];
+    // ---- filter operands: B fragments of the 8 point sets.  Lane (m, hh) holds k-slots 8*hh .. 8*hh+7 of column m:
+    //      hh = 0: [B_hi | B_lo], hh = 1: [B_hi | 0]  against  A: hh = 0: [A_hi | A_hi], hh = 1: [A_lo | 0].
+    half8 bfrag[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = j & 3;
+        const float ox = __shfl_xor(px[k], 32, 64), oy = __shfl_xor(py[k], 32, 64), oz = __shfl_xor(pz[k], 32, 64);
+        const bool own = (j >> 2) == hh;
+        const float x = -2.f * (own ? px[k] : ox), y = -2.f * (own ? py[k] : oy), z = -2.f * (own ? pz[k] : oz);
+        unsigned lo01, lo23;
+        const unsigned hi01 = split2_f16(x, y, lo01), hi23 = split2_f16(z, 1.f, lo23);
+        bfrag[j] = __builtin_bit_cast(half8, u4{hi01, hi23, hh ? 0u : lo01, hh ? 0u : lo23});
+    }
     float run[kPts], tol[kPts], cval[kPts][kCand];
     unsigned long long cid[kPts];
     int ncand[kPts];
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        mx[k] = f2{-2.f * px[k], -2.f * px[k]};
-        my[k] = f2{-2.f * py[k], -2.f * py[k]};
-        mz[k] = f2{-2.f * pz[k], -2.f * pz[k]};
         const float S = px[k] * px[k] + py[k] * py[k] + pz[k] * pz[k] + v2max;
-        tol[k] = 256.f * 5.9604645e-8f * S;
+        // beyond the range the f16 operands cover comfortably every chunk becomes a candidate (-> exact whole-mesh scan)
+        tol[k] = (S < 1.0e4f) ? 3.0517578e-5f * S : 3.0e38f;
         run[k] = 3.0e38f;
         cid[k] = 0ull;
         ncand[k] = 0;
@@ -122,20 +143,34 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     }
     const int n_chunks = Vpad / kChunk;
     for (int c = 0; c < n_chunks; ++c) {
+        float cmv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cmv[j] = 3.4e38f;
+#pragma unroll
+        for (int tile = 0; tile < kChunk / 32; ++tile) {
+            const int v = c * kChunk + tile * 32 + m;             // this lane's A row
+            const bool real = v < V;
+            const float x = real ? vx[v] : 0.f, y = real ? vy[v] : 0.f, z = real ? vz[v] : 0.f;
+            const float w = real ? fmaf(z, z, fmaf(y, y, x * x)) : 6.0e4f;      // padding rows: a = 60000, never minimal
+            unsigned lo01, lo23;
+            const unsigned hi01 = split2_f16(x, y, lo01), hi23 = split2_f16(z, w, lo23);
+            const half8 afrag = __builtin_bit_cast(half8, hh ? u4{lo01, lo23, 0u, 0u} : u4{hi01, hi23, hi01, hi23});
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag[j], zero, 0, 0, 0);
+                float mn = cmv[j];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mn = fminf(fminf(mn, d[r]), d[r + 1]);
+                cmv[j] = mn;
+            }
+        }
         float cm[kPts];
 #pragma unroll
-        for (int k = 0; k < kPts; ++k) cm[k] = 3.4e38f;
-#pragma unroll 4
-        for (int i = 0; i < kChunk / 4; ++i) {
-            const int v4 = c * (kChunk / 4) + i;
-            const f4 X = vx4[v4], Y = vy4[v4], Z = vz4[v4], Wv = vw4[v4];
-#pragma unroll
-            for (int k = 0; k < kPts; ++k) {
-                const f2 a01 = __builtin_elementwise_fma(mx[k], X.xy, __builtin_elementwise_fma(my[k], Y.xy, __builtin_elementwise_fma(mz[k], Z.xy, Wv.xy)));
-                const f2 a23 = __builtin_elementwise_fma(mx[k], X.zw, __builtin_elementwise_fma(my[k], Y.zw, __builtin_elementwise_fma(mz[k], Z.zw, Wv.zw)));
-                cm[k] = fminf(fminf(cm[k], a01.x), a01.y);
-                cm[k] = fminf(fminf(cm[k], a23.x), a23.y);
-            }
+        for (int k = 0; k < kPts; ++k) {
+            const float lo_set = fminf(cmv[k], __shfl_xor(cmv[k], 32, 64));
+            const float hi_set = fminf(cmv[4 + k], __shfl_xor(cmv[4 + k], 32, 64));
+            cm[k] = hh ? hi_set : lo_set;
         }
 #pragma unroll
         for (int k = 0; k < kPts; ++k) {
@@ -172,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
 
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        const int64_t n = base + k;
+        const int64_t n = wbase + (4 * hh + k) * 32 + m;
         if (n >= N) continue;
         const int idx = bi[k];
         const float4* __restrict__ M = reinterpret_cast<const float4*>(vertex_ik + ((int64_t)b * V + idx) * 16);
@@ -209,7 +244,7 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
     H3D_REQUIRE(h3d::aligned16(vertex_ik), "h3d_geo_features: vertex_ik must be 16-byte aligned");
     if (B == 0 || N == 0) return H3D_OK;
     const int Vpad = (V + kChunk - 1) / kChunk * kChunk;
-    const size_t lds = sizeof(float) * (4 * (size_t)Vpad + kJoints * 3 + 4);
+    const size_t lds = sizeof(float) * (3 * (size_t)Vpad + kJoints * 3 + 4);
     H3D_REQUIRE(lds <= 160 * 1024, "h3d_geo_features: mesh with V=%d vertices does not fit the 160 KB LDS", V);
     static bool attr_set = false;
     if (!attr_set) {
