@@ -109,6 +109,7 @@ struct Args {
     float* weights;
     int64_t N;
     int Hd, F, geo_stride, S, clamp_mode, last_back, white_back;
+    int R, log2S;        // fused: rays per batch item; log2(S) when S <= 32 (a power of two), else -1
     float input_scaler;
     LayoutX3 L;
 };
@@ -340,6 +341,9 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int steps = unit / 32;
     const int seglen = FUSED ? (S < 32 ? S : 32) : 32;
     const int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
+    // ray of sample n (fused): no 64-bit division -- S > 32: one ray per wave unit; S <= 32: S is a power of two
+    const int64_t unit_ray = (int64_t)b * A.R + ((int64_t)blockIdx.x * 4 + wave);
+    auto ray_of = [&](int64_t nn) -> int64_t { return A.log2S < 0 ? unit_ray : (int64_t)b * A.R + (nn >> A.log2S); };
 
 #ifdef H3D_EXPERIMENT_TRACE
     if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.out); g_trace_n = 0; }
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             if (ok && h == 0) A.out[gi * (F + 4) + F + 3] = sigma;
         } else {
             // compositing weights of these 32 samples (both lane halves compute identical values)
-            const int s_idx = (int)(n % S);
+            const int s_idx = A.log2S < 0 ? si * 32 + m : (int)(n & (S - 1));
             float alpha = 0.f, f = 1.f, z = 0.f;
             if (ok) {
                 z = A.z_vals[gi];
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             if (last_step) {
                 bg = 1.f - carryW;
                 if (ok && s_idx == S - 1) {
-                    if (h == 0) A.depth[gi / S] = carryD + bg * z_last;
+                    if (h == 0) A.depth[ray_of(n)] = carryD + bg * z_last;
                     if (A.last_back) w += bg;
                 }
             }
@@ -540,53 +544,57 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                     mine = rgbacc;
                 }
                 if (last_step && h == 0 && sl < 3 && ok) {
-                    const int64_t ray = gi / S;
+                    const int64_t ray = ray_of(n);
                     A.feats[ray * C + sl] = mine + (A.white_back ? bg : 0.f);
                 }
             }
             // features: sum over the rows (samples) of each ray held in this lane's accumulator registers
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            float wr[16];
+            // sum_r w_r * (acc_r * inv + bias) = inv * sum_r w_r acc_r + bias * sum_r w_r
+            float wr[16], wsum[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const f32x4 w4 = ld4(wl_lds + rg * 8 + 4 * h);
                 wr[rg * 4 + 0] = w4.x; wr[rg * 4 + 1] = w4.y; wr[rg * 4 + 2] = w4.z; wr[rg * 4 + 3] = w4.w;
+                wsum[rg] = (w4.x + w4.y) + (w4.z + w4.w);
             }
+            const float wtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+            const float back = A.white_back ? wl_lds[32] : 0.f;
+            const int64_t ray0 = ray_of(n0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int nn = nt * 32 + m;
                 const bool okn = nn < F;
                 const float bias = tfeat[okn ? nn : 0];
-                float s8[4];
+                pin1(acc[nt]);
+                float s4[4];
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    float s = fmaf(acc[nt][rg * 4 + 0], inv_f, bias) * wr[rg * 4 + 0];
-                    s = fmaf(fmaf(acc[nt][rg * 4 + 1], inv_f, bias), wr[rg * 4 + 1], s);
-                    s = fmaf(fmaf(acc[nt][rg * 4 + 2], inv_f, bias), wr[rg * 4 + 2], s);
-                    s = fmaf(fmaf(acc[nt][rg * 4 + 3], inv_f, bias), wr[rg * 4 + 3], s);
-                    s8[rg] = s + __shfl_xor(s, 32, 64);
+                    float s = acc[nt][rg * 4 + 0] * wr[rg * 4 + 0];
+                    s = fmaf(acc[nt][rg * 4 + 1], wr[rg * 4 + 1], s);
+                    s = fmaf(acc[nt][rg * 4 + 2], wr[rg * 4 + 2], s);
+                    s4[rg] = fmaf(acc[nt][rg * 4 + 3], wr[rg * 4 + 3], s);
                 }
                 if (S >= 32) {
-                    rayacc[nt] += (s8[0] + s8[1]) + (s8[2] + s8[3]);
-                    if (last_step && okn && h == 0 && n0 < N) {
-                        const int64_t ray = ((int64_t)b * N + n0) / S;
-                        A.feats[ray * C + 3 + nn] = rayacc[nt] + (A.white_back ? wl_lds[32] : 0.f);
-                    }
+                    float tot = fmaf((s4[0] + s4[1]) + (s4[2] + s4[3]), inv_f, bias * wtot);
+                    tot += __shfl_xor(tot, 32, 64);
+                    rayacc[nt] += tot;
+                    if (last_step && okn && h == 0 && n0 < N) A.feats[ray0 * C + 3 + nn] = rayacc[nt] + back;
                 } else {
                     const int g8 = S >> 3;                 // 8-row groups per ray: 1 or 2
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         if (rg % g8 != 0) continue;
-                        float s = s8[rg];
-                        if (g8 == 2) s += s8[rg + 1 < 4 ? rg + 1 : 3];
+                        float sv = fmaf(s4[rg], inv_f, bias * wsum[rg]);
+                        if (g8 == 2) sv += fmaf(s4[rg + 1 < 4 ? rg + 1 : 3], inv_f, bias * wsum[rg + 1 < 4 ? rg + 1 : 3]);
+                        sv += __shfl_xor(sv, 32, 64);
                         const int64_t n_first = n0 + rg * 8;
-                        if (okn && h == 0 && n_first < N) {
-                            const int64_t ray = ((int64_t)b * N + n_first) / S;
-                            A.feats[ray * C + 3 + nn] = s + (A.white_back ? wl_lds[32 + rg * 8] : 0.f);
-                        }
+                        if (okn && h == 0 && n_first < N)
+                            A.feats[ray_of(n_first) * C + 3 + nn] = sv + (A.white_back ? wl_lds[32 + rg * 8] : 0.f);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -818,6 +826,9 @@ extern "C" int h3d_render_fused_x3(const void* packed, const float* points, cons
     A.z_vals = z_vals; A.noise = noise; A.feats = feats; A.depth = depth; A.weights = weights;
     A.N = N; A.Hd = Hd; A.F = F; A.geo_stride = geo_stride; A.S = S; A.input_scaler = input_scaler;
     A.clamp_mode = clamp_mode; A.last_back = last_back; A.white_back = white_back;
+    A.R = R;
+    A.log2S = -1;
+    if (S <= 32) { A.log2S = 0; while ((1 << A.log2S) < S) ++A.log2S; }
     A.L = make_layout(Hd, F);
     const int unit = S > 32 ? S : 32;
     const int64_t units = (N + unit - 1) / unit;
