@@ -53,8 +53,9 @@ __global__ __launch_bounds__(kFieldThreads) void synthesis_kernel(Args A) {
     float* actT = smem;                         // [HdP][MS]   raw activations / conv inputs
     float* aT = actT + HdP * kMS;               // [128][MS]   ReLU'd shared-MLP activations of the current SPADE
     float* abT = aT + kShared * kMS;            // [2][HdP]    per-sample affine of a constant-style SPADE
-    float* part = abT + 2 * HdP;                // [4][3][64]
-    float* ci = part + 4 * 192;                 // [64] pixel coordinate i (rows), then j
+    float* part = aT;                           // [4][3][64]  ToRGB partial sums: aliases aT (only live between the
+                                                //             barriers around a block's ToRGB, when no SPADE is running)
+    float* ci = abT + 2 * HdP;                  // [64] pixel coordinate i (rows), then j
     float* cj = ci + 64;
     int* tap = reinterpret_cast<int*>(cj + 64); // [64][4] low-res tap offsets (pixel index) ; weights follow
     float* tw = reinterpret_cast<float*>(tap + 256);   // [64][2] (ty, tx)
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kFieldThreads) void synthesis_kernel(Args A) {
 }
 
 size_t lds_bytes(int HdP) {
-    return sizeof(float) * ((size_t)HdP * kMS + kShared * kMS + 2 * HdP + 4 * 192 + 128 + 256 + 128);
+    return sizeof(float) * ((size_t)HdP * kMS + kShared * kMS + 2 * HdP + 128 + 256 + 128);
 }
 
 template <int NTW>

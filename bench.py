@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--config", default="MAP3DBN512")
     ap.add_argument("--res", default="512x512", help="output HxW; rays are 3/16 of it per axis (96 for 512)")
+    ap.add_argument("--render", default="", help="rays HxW (default: 3/16 of --res per axis, the MAP3DBN512 ratio)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -213,7 +214,7 @@ def main():
     StageTimer = importlib.import_module("3dhumangan_amd._stages").StageTimer
 
     H, W = [int(v) for v in a.res.split("x")]
-    render = (H * 3 // 16, W * 3 // 16)
+    render = tuple(int(v) for v in a.render.split("x")) if a.render else (H * 3 // 16, W * 3 // 16)
     G, cfg = build_generator(a.config, (H, W), render, a.samples, dev)
     z, cond, jitter = make_inputs(cfg, a.batch, dev, seed=1234 + rank)
     G.stage_timer = StageTimer()

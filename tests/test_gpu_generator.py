@@ -130,9 +130,10 @@ def test_engine_selection_defaults():
     assert G2.synthesis_plan(DEV).engine == "f32"          # per-pixel style after the first skip block
 
 
-@pytest.mark.parametrize("cfg_name", ["MAP3DBN", "MAP3DBN512"])
+@pytest.mark.parametrize("cfg_name", ["MAP3DBN", "MAP3DBN512", "MAP3DBN512L"])
 def test_full_size_forward_vs_oracle(cfg_name):
-    """BASELINE configs 1/2 and 3 geometry at batch 1: the whole HIP path against the CPU oracle."""
+    """BASELINE configs 1/2 and 3 geometry (and the 420-wide legacy / isolated variant) at batch 1: the whole HIP path
+    against the CPU oracle."""
     cfg = {k: v for k, v in getattr(configs, cfg_name).items() if isinstance(k, str)}
     cfg.update(dataset_length=4, last_back=True, nerf_noise=0)
     cfg["neural_field_cls"] = impl.COORDCONCATSIREN
