@@ -204,12 +204,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torchrun always go through RCCL
     torch.cuda.set_device(local)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")          # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))          # RCCL over xGMI
     dev = torch.device("cuda", local)
     StageTimer = importlib.import_module("3dhumangan_amd._stages").StageTimer
 
