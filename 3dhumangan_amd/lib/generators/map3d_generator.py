@@ -316,7 +316,9 @@ class Map3DGenerator(nn.Module):
         ``staged``/``max_points`` chunking is a memory work-around of the reference and is not needed: the field
         tensor never materialises in the fused path."""
         if hierarchical_sample:
-            raise NotImplementedError("hierarchical_sample=True (off in every config, SURVEY 8a) has no HIP path yet")
+            return self._render_hierarchical(freq, phase, conditions, render_width, render_height, ray_start, ray_end,
+                                             int(coarse_steps), int(coarse_steps if fine_steps is None else fine_steps),
+                                             lock_view_dependence, jitter, noise, **kwargs)
         c = conditions
         dev = freq.device
         B, S = freq.shape[0], int(coarse_steps)
@@ -355,6 +357,63 @@ class Map3DGenerator(nn.Module):
                 feats, depths, weights = vr.ray_integration(field.reshape(B, R, S, -1), z_vals, noise_std=0, noise=noise,
                                                             clamp_mode=clamp_mode, last_back=last_back,
                                                             white_back=white_back)
+        rgb_render = (feats[..., :3] * 2 - 1).reshape(B, render_height, render_width, 3).permute(0, 3, 1, 2)
+        return rgb_render, feats[..., 3:], depths, weights, None
+
+    def _render_hierarchical(self, freq, phase, c, render_width, render_height, ray_start, ray_end, S, Sf,
+                             lock_view_dependence, jitter, noise, noise_coarse=None, fine_u=None, **kwargs):
+        """reference :449-516: coarse pass -> compositing weights -> importance samples -> fine pass -> merge by depth ->
+        integration over all samples.  The field tensors materialise here (unfused kernels); random tensors can be
+        injected (jitter, noise_coarse [B,R,S,1], fine_u [B*R,Sf], noise [B,R,S+Sf,1]) or are drawn where the reference
+        draws them."""
+        dev = freq.device
+        B, R = freq.shape[0], render_width * render_height
+        focals, scales = c["intrinsics"][:, 0, 0], c["scales"].float()
+        res = (render_width, render_height)
+        with stage(self, "ray_setup"):
+            pts, z_vals = vr.sample_rays(focals, scales, c["cam2world_matrices"], S, res, ray_start, ray_end, jitter=jitter,
+                                         perturb=True)
+            origins, ray_dirs = vr.ray_frame_world(focals, c["cam2world_matrices"], res)
+        if jitter is None:
+            torch.randn((B, 1), device=dev), torch.randn((B, 1), device=dev)      # sample_camera_positions, result unused
+        nerf_noise = kwargs.get("nerf_noise", 0)
+        clamp_mode = kwargs["clamp_mode"]
+        scaler = 2.0 / self.side_length
+        mesh = (c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"], c["lbs_weights"])
+
+        def dirs_for(n_steps):
+            if lock_view_dependence:
+                return None
+            return ray_dirs.unsqueeze(2).expand(B, R, n_steps, 3).reshape(B, R * n_steps, 3).contiguous()
+
+        with stage(self, "geo_features"):
+            geo = self.get_geo_features(pts, *mesh)
+        with stage(self, "neural_field"):
+            coarse = self.neural_field(pts, freq, phase, geo, dirs_for(S), input_scaler=scaler).reshape(B, R, S, -1)
+        if noise_coarse is None:
+            drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24, first call
+            noise_coarse = drawn * nerf_noise if nerf_noise != 0 else None
+        with stage(self, "ray_integrate"):
+            _, _, w = vr.ray_integration(coarse, z_vals, noise_std=0, noise=noise_coarse, clamp_mode=clamp_mode)
+        with stage(self, "resample"):
+            w = w.reshape(B * R, S) + 1e-5
+            zv = z_vals.reshape(B * R, S)
+            z_mid = 0.5 * (zv[:, :-1] + zv[:, 1:])
+            fine_z = vr.sample_pdf(z_mid, w[:, 1:-1], Sf, det=False, u=fine_u).reshape(B, R, Sf, 1)
+            fine_pts = vr.ray_points(origins, ray_dirs, fine_z)
+        with stage(self, "geo_features"):
+            geo = self.get_geo_features(fine_pts, *mesh)
+        with stage(self, "neural_field"):
+            fine = self.neural_field(fine_pts, freq, phase, geo, dirs_for(Sf), input_scaler=scaler).reshape(B, R, Sf, -1)
+        with stage(self, "resample"):
+            all_out, all_z = vr.merge_samples(fine, coarse, fine_z, z_vals)
+        if noise is None:
+            drawn = torch.randn((B, R, S + Sf, 1), device=dev)                     # volume_rendering.py:24, second call
+            noise = drawn * nerf_noise if nerf_noise != 0 else None
+        with stage(self, "ray_integrate"):
+            feats, depths, weights = vr.ray_integration(all_out, all_z, noise_std=0, noise=noise, clamp_mode=clamp_mode,
+                                                        last_back=kwargs.get("last_back", False),
+                                                        white_back=kwargs.get("white_back", False))
         rgb_render = (feats[..., :3] * 2 - 1).reshape(B, render_height, render_width, 3).permute(0, 3, 1, 2)
         return rgb_render, feats[..., 3:], depths, weights, None
 

@@ -86,3 +86,55 @@ def ray_integration(input, z_vals, device=None, noise_std=0.5, last_back=False, 
                                int(bool(white_back)), _lib.stream_handle())
     _lib.check(rc, "h3d_ray_integrate")
     return feats, depth, weights
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
+    """Inverse-CDF importance sampling, reference volume_rendering.py:261-303 (same arguments).  ``u`` injects the
+    uniform draws [N_rays, N_importance]; otherwise they are drawn here exactly where the reference draws them (:285),
+    or taken as linspace(0, 1) when ``det``.  bins [N_rays, n+1], weights [N_rays, n] -> samples [N_rays, N_importance]."""
+    _need_cuda(bins, weights, u)
+    n_rays, n = weights.shape
+    if u is None:
+        u = (torch.linspace(0, 1, N_importance, device=bins.device).expand(n_rays, N_importance) if det
+             else torch.rand(n_rays, N_importance, device=bins.device))
+    b32, w32, u32 = bins.contiguous().float(), weights.contiguous().float(), u.contiguous().float()
+    out = torch.empty((n_rays, N_importance), device=bins.device, dtype=torch.float32)
+    rc = _lib.load().h3d_sample_pdf(_lib.ptr(b32), _lib.ptr(w32), _lib.ptr(u32), _lib.ptr(out), n_rays, n + 1, N_importance,
+                                    float(eps), _lib.stream_handle())
+    _lib.check(rc, "h3d_sample_pdf")
+    return out
+
+
+def ray_frame_world(focals, cam2world_matrix, resolution):
+    """World-space ray origins [B,3] and unit directions [B,R,3] (transformed_ray_origins / transformed_ray_directions of
+    volume_rendering.py:133-170); a few small torch ops on the device."""
+    W, H = resolution
+    d = ray_directions_world(focals, cam2world_matrix, resolution, 1)
+    return cam2world_matrix[:, :3, 3].float().contiguous(), d
+
+
+def ray_points(origins, dirs, z_vals):
+    """origins [B,3], dirs [B,R,3], z_vals [B,R,S,1] -> points [B,R*S,3] = origin + dir * z (map3d_generator.py:464-466)."""
+    _need_cuda(origins, dirs, z_vals)
+    B, R, S = z_vals.shape[0], z_vals.shape[1], z_vals.shape[2]
+    o, d, z = origins.contiguous().float(), dirs.contiguous().float(), z_vals.contiguous().float()
+    pts = torch.empty((B, R * S, 3), device=z.device, dtype=torch.float32)
+    rc = _lib.load().h3d_ray_points(_lib.ptr(o), _lib.ptr(d), _lib.ptr(z), _lib.ptr(pts), B, R, S, _lib.stream_handle())
+    _lib.check(rc, "h3d_ray_points")
+    return pts
+
+
+def merge_samples(fine_output, coarse_output, fine_z_vals, z_vals):
+    """cat([fine, coarse]) sorted by depth along the sample axis (map3d_generator.py:504-509).
+    fine/coarse_output [B,R,S*,C+1], fine_z_vals / z_vals [B,R,S*,1] -> all_outputs [B,R,Sf+Sc,C+1], all_z_vals [B,R,Sf+Sc,1]."""
+    _need_cuda(fine_output, coarse_output, fine_z_vals, z_vals)
+    B, R, Sf, C1 = fine_output.shape
+    Sc = coarse_output.shape[2]
+    f, c = fine_output.contiguous().float(), coarse_output.contiguous().float()
+    fz, cz = fine_z_vals.contiguous().float(), z_vals.contiguous().float()
+    out = torch.empty((B, R, Sf + Sc, C1), device=f.device, dtype=torch.float32)
+    out_z = torch.empty((B, R, Sf + Sc, 1), device=f.device, dtype=torch.float32)
+    rc = _lib.load().h3d_merge_samples(_lib.ptr(f), _lib.ptr(c), _lib.ptr(fz), _lib.ptr(cz), _lib.ptr(out), _lib.ptr(out_z),
+                                       B * R, Sf, Sc, C1, _lib.stream_handle())
+    _lib.check(rc, "h3d_merge_samples")
+    return out, out_z

@@ -51,6 +51,23 @@ int h3d_ray_integrate(const float* field, const float* z_vals, const float* nois
                       int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Hierarchical (coarse + fine) sampling, hierarchical_sample=True in Map3DGenerator.render
+ *     (lib/generators/map3d_generator.py:449-509; off in every shipped config).
+ * h3d_sample_pdf == sample_pdf (lib/generators/volume_rendering.py:261-303) with the uniform draws passed in:
+ *     bins [n_rays, n_bins], weights [n_rays, n_bins-1], u [n_rays, n_samples] -> samples [n_rays, n_samples]
+ * h3d_ray_points: points[b, r*S+s] = origin[b] + dirs[b, r] * z_vals[b, r, s]   (map3d_generator.py:464-466)
+ * h3d_merge_samples == cat([fine, coarse]) + sort by depth + gather (map3d_generator.py:504-509): fine [n_rays,Sf,C1],
+ *     coarse [n_rays,Sc,C1], fine_z [n_rays,Sf], coarse_z [n_rays,Sc] -> out [n_rays,Sf+Sc,C1], out_z [n_rays,Sf+Sc]
+ *     (stable: equal depths keep the fine-before-coarse order of the concatenation).
+ */
+int h3d_sample_pdf(const float* bins, const float* weights, const float* u, float* samples, int64_t n_rays, int n_bins,
+                   int n_samples, float eps, h3d_stream_t stream);
+int h3d_ray_points(const float* origin, const float* dirs, const float* z_vals, float* points, int B, int64_t R, int S,
+                   h3d_stream_t stream);
+int h3d_merge_samples(const float* fine, const float* coarse, const float* fine_z, const float* coarse_z, float* out,
+                      float* out_z, int64_t n_rays, int Sf, int Sc, int C1, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A3  ray set-up == lib/generators/volume_rendering.py:86-110 (get_initial_rays_weak_perspective),
  *     :124-130 (perturb_points), :133-170 (transform_sampled_points)
  * focals, scales [B]; cam2world [B,4,4] row-major; jitter [B,R,S] U(0,1) or NULL

@@ -390,7 +390,79 @@ def render(state, cfg, freq, phase, cond, jitter, noise):
     return img[:, :3] * 2 - 1, img[:, 3:], depth, w, dict(points=pts, z_vals=z_vals, geo=geo, field=field)
 
 
-def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, return_internal=False):
+def sample_pdf(bins, weights, u, eps=1e-5):
+    """Inverse-CDF sampling of lib/generators/volume_rendering.py:261-303 with the uniform draws `u` [N_rays, N_importance]
+    passed in (the reference draws them with torch.rand at :285).  bins [N_rays, n+1], weights [N_rays, n]."""
+    n = weights.shape[1]
+    weights = weights + eps
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u)
+    below = torch.clamp_min(inds - 1, 0)
+    above = torch.clamp_max(inds, n)
+    sel = torch.stack([below, above], -1).view(u.shape[0], -1)
+    cdf_g = torch.gather(cdf, 1, sel).view(u.shape[0], -1, 2)
+    bins_g = torch.gather(bins, 1, sel).view(u.shape[0], -1, 2)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < eps, torch.ones_like(denom), denom)
+    return bins_g[..., 0] + (u - cdf_g[..., 0]) / denom * (bins_g[..., 1] - bins_g[..., 0])
+
+
+def ray_world_frame(focals, cam2world, render_h, render_w):
+    """World-space ray origins [B,3] and unit directions [B,R,3] of the weak-perspective camera
+    (volume_rendering.py:86-110, 133-170: transformed_ray_origins / transformed_ray_directions)."""
+    B, dt, R = focals.shape[0], focals.dtype, render_h * render_w
+    span = render_w / render_h
+    px = torch.linspace(-span, span, render_w, dtype=dt).repeat(render_h)
+    py = torch.linspace(-1, 1, render_h, dtype=dt).repeat_interleave(render_w)
+    d = torch.stack([px.expand(B, R), py.expand(B, R), focals[:, None].expand(B, R)], dim=-1)
+    d = d / (torch.norm(d, dim=-1, keepdim=True) + 1e-12)
+    wd = torch.bmm(cam2world[:, :3, :3].to(dt), d.transpose(1, 2)).transpose(1, 2)
+    return cam2world[:, :3, 3].to(dt), wd
+
+
+def render_hierarchical(state, cfg, freq, phase, cond, jitter, noise_coarse, u, noise):
+    """Map3DGenerator.render with hierarchical_sample=True (map3d_generator.py:449-516): coarse pass -> weights ->
+    importance samples (sample_pdf) -> fine pass -> merge by depth -> integration over coarse + fine samples.
+    noise_coarse [B,R,S,1] / noise [B,R,2S,1]: the (already scaled) integration noise of the two ray_integration
+    calls, u [B*R, S]: the uniform draws of sample_pdf."""
+    hr, wr, S = cfg["render_height"], cfg["render_width"], cfg["num_steps"]
+    focals = cond["intrinsics"][:, 0, 0]
+    scales = cond["scales"].to(focals.dtype)
+    lock = cfg.get("lock_view_dependence", False)
+    pts, z_vals, dirs = ray_setup(focals, scales, cond["cam2world_matrices"], hr, wr, S, cfg["ray_start"], cfg["ray_end"],
+                                  jitter, lock)
+    B, R = pts.shape[0], hr * wr
+    legacy = cfg.get("legacy_mode", False)
+    mesh = (cond["skeletons_xyz"], cond["vertices"], cond["tpose_vertices"], cond["fk_matrices"], cond["lbs_weights"])
+    nb = cfg.get("neural_field_blocks", 4)
+    scaler = 2.0 / cfg["side_length"]
+    coarse = neural_field(state, pts, freq, phase, geo_features(pts, *mesh, legacy), dirs, input_scaler=scaler,
+                          num_blocks=nb).reshape(B, R, S, -1)
+    _, _, w = ray_integration(coarse, z_vals, noise_coarse, cfg["clamp_mode"], False, False)
+    w = w.reshape(B * R, S) + 1e-5
+    zv = z_vals.reshape(B * R, S)
+    z_mid = 0.5 * (zv[:, :-1] + zv[:, 1:])
+    fine_z = sample_pdf(z_mid, w[:, 1:-1], u).reshape(B, R, S, 1)
+    origin, wd = ray_world_frame(focals, cond["cam2world_matrices"], hr, wr)
+    fine_pts = (origin[:, None, None, :] + wd[:, :, None, :] * fine_z).reshape(B, R * S, 3)
+    fine = neural_field(state, fine_pts, freq, phase, geo_features(fine_pts, *mesh, legacy), dirs, input_scaler=scaler,
+                        num_blocks=nb).reshape(B, R, S, -1)
+    all_out = torch.cat([fine, coarse], dim=-2)
+    all_z = torch.cat([fine_z, z_vals], dim=-2)
+    _, idx = torch.sort(all_z, dim=-2, stable=True)
+    all_z = torch.gather(all_z, -2, idx)
+    all_out = torch.gather(all_out, -2, idx.expand(-1, -1, -1, all_out.shape[-1]))
+    out, depth, wts = ray_integration(all_out, all_z, noise, cfg["clamp_mode"], cfg.get("last_back", False),
+                                      cfg.get("white_back", False))
+    img = out.reshape(B, hr, wr, -1).permute(0, 3, 1, 2)
+    return img[:, :3] * 2 - 1, img[:, 3:], depth, wts, dict(points=pts, z_vals=z_vals, fine_z=fine_z, all_z=all_z,
+                                                          coarse_weights=w, field=all_out)
+
+
+def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, return_internal=False, hier=None):
     """truncation: None or (psi, avg_z, avg_freq, avg_phase, avg_styles) as produced by
     generate_avg_latent (map3d_generator.py:182-194, 295-301)."""
     B = z.shape[0]
@@ -402,7 +474,11 @@ def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, 
         freq = af + psi * (freq - af)
         phase = ap + psi * (phase - ap)
         styles = ast + psi * (styles - ast)
-    rgb_render, fmap, depth, w, inter = render(state, cfg, freq, phase, cond, jitter, noise)
+    if hier is not None:          # hierarchical_sample=True: hier = dict(noise_coarse=..., u=...), noise covers 2S samples
+        rgb_render, fmap, depth, w, inter = render_hierarchical(state, cfg, freq, phase, cond, jitter, hier["noise_coarse"],
+                                                                hier["u"], noise)
+    else:
+        rgb_render, fmap, depth, w, inter = render(state, cfg, freq, phase, cond, jitter, noise)
     H, W = cfg["gen_height"], cfg["gen_width"]
     fmap_up = F.interpolate(fmap, (H, W), mode="bilinear")
     x0 = synthesis_input(state, B, H, W, dtype=z.dtype if z.dtype == torch.float64 else torch.float32)

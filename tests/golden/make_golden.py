@@ -166,6 +166,49 @@ def generator_fixture(name, seed, n_vertices=128, batch=2, nerf_noise=0.3, **ove
          avg=avg)
 
 
+def hierarchical_fixture(name="gen_tiny_hierarchical", seed=5, n_vertices=128, batch=2, nerf_noise=0.3):
+    """forward with hierarchical_sample=True (map3d_generator.py:449-516) + sample_pdf alone (volume_rendering.py:261-303),
+    every random tensor replayed in the reference's consumption order: jitter, two unused randn, the coarse
+    ray_integration's noise, sample_pdf's uniforms, the final ray_integration's noise."""
+    cfg = tiny_cfg(hierarchical_sample=True)
+    torch.manual_seed(seed)
+    G = ref_gen.Map3DGenerator(**cfg).eval()
+    G.set_device("cpu")
+    condition_weights(G, seed)
+    cond = synthetic.make_conditions(batch, n_vertices=n_vertices, seed=seed, pose_scale=0.6)
+    z = torch.randn(batch, cfg["latent_dim"], generator=torch.Generator().manual_seed(seed + 1))
+    run = dict(cfg)
+    run["nerf_noise"] = nerf_noise
+    R, S = cfg["render_height"] * cfg["render_width"], cfg["num_steps"]
+    rs = seed + 7
+    torch.manual_seed(rs)
+    jitter = torch.rand(batch, R, S, 1)
+    torch.randn(batch, 1), torch.randn(batch, 1)
+    noise_coarse = torch.randn(batch, R, S, 1) * nerf_noise
+    u = torch.rand(batch * R, S)
+    noise = torch.randn(batch, R, 2 * S, 1) * nerf_noise
+    torch.manual_seed(rs)
+    with torch.no_grad():
+        out = G.forward(z, cond, **run)
+    # sample_pdf alone: ragged weights incl. exact zeros (bins that can never be sampled) and a degenerate all-zero ray
+    g = torch.Generator().manual_seed(seed + 11)
+    bins = torch.sort(torch.rand(6, 13, generator=g) * 2 + 10, dim=1).values
+    w = torch.rand(6, 12, generator=g)
+    w[1, 3:7] = 0
+    w[2] = 0
+    w[3, :-1] = 0
+    torch.manual_seed(rs + 3)
+    u2 = torch.rand(6, 20)
+    torch.manual_seed(rs + 3)
+    samples = ref_vr.sample_pdf(bins, w, 20, det=False)
+    meta = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool))}
+    meta["mod_blocks"] = list(cfg["mod_blocks"])
+    save(name, state=G.state_dict(), cond=cond, z=z, jitter=jitter, noise_coarse=noise_coarse, u=u, noise=noise,
+         meta_json=np.frombuffer(__import__("json").dumps(meta).encode(), dtype=np.uint8),
+         out=dict(rgbs=out["rgbs"], rgbs_render=out["rgbs_render"]),
+         pdf=dict(bins=bins, weights=w, u=u2, samples=samples))
+
+
 def field_fixture(name, seed, hidden, n_points=96):
     """COORDCONCATSIREN alone at a width that is / is not a multiple of the MFMA tile."""
     torch.manual_seed(seed)
@@ -327,6 +370,7 @@ def harness_fixture():
 if __name__ == "__main__":
     config_fixture()
     harness_fixture()
+    hierarchical_fixture()
     generator_fixture("gen_tiny_mixed", seed=1)
     generator_fixture("gen_tiny_isolated_legacy", seed=2, map3d_mode="isolated", legacy_mode=True,
                       last_back=True, clamp_mode="softplus", hidden_dim=48, latent_dim=48, feature_dim=48,

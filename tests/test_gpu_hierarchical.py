@@ -1,0 +1,106 @@
+"""GPU parity of the hierarchical (coarse + fine) sampling path against vectors from the reference and the CPU oracle."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+DEV = "cuda"
+TOL = 1e-3
+
+
+def test_sample_pdf_golden():
+    g = load_golden("gen_tiny_hierarchical")["pdf"]
+    got = vr.sample_pdf(g["bins"].to(DEV), g["weights"].to(DEV), g["u"].shape[1], u=g["u"].to(DEV))
+    assert rel_err(got.cpu(), g["samples"]) < 1e-5
+
+
+@pytest.mark.parametrize("n_rays,n,ns", [(1, 1, 5), (1000, 62, 64), (37, 126, 128), (5, 254, 3)])
+def test_sample_pdf_vs_oracle(n_rays, n, ns):
+    g = torch.Generator().manual_seed(n_rays + n)
+    bins = torch.sort(torch.rand(n_rays, n + 1, generator=g) * 3 + 9, dim=1).values
+    w = torch.rand(n_rays, n, generator=g) ** 4
+    w[::3, : n // 2] = 0
+    u = torch.rand(n_rays, ns, generator=g)
+    u[0, :2] = torch.tensor([0.0, 1.0])[: min(2, ns)] if ns >= 2 else u[0, :2]
+    ref = O.sample_pdf(bins, w, u)
+    got = vr.sample_pdf(bins.to(DEV), w.to(DEV), ns, u=u.to(DEV))
+    # samples are interpolated depths ~10: compare on the depth scale
+    assert (got.cpu() - ref).abs().max() < 1e-4
+
+
+def test_sample_pdf_det_and_empty():
+    bins = torch.linspace(1, 2, 9).repeat(3, 1)
+    w = torch.ones(3, 8)
+    got = vr.sample_pdf(bins.to(DEV), w.to(DEV), 5, det=True)
+    assert rel_err(got.cpu(), torch.linspace(1, 2, 5).repeat(3, 1)) < 1e-6
+    assert vr.sample_pdf(bins[:0].to(DEV), w[:0].to(DEV), 5).shape == (0, 5)
+
+
+@pytest.mark.parametrize("B,R,Sf,Sc,C1", [(2, 33, 8, 8, 36), (1, 7, 64, 64, 260), (1, 3, 5, 9, 7), (1, 2, 128, 128, 12)])
+def test_merge_samples_vs_torch(B, R, Sf, Sc, C1):
+    g = torch.Generator().manual_seed(Sf * C1)
+    fine, coarse = torch.randn(B, R, Sf, C1, generator=g), torch.randn(B, R, Sc, C1, generator=g)
+    fz = torch.rand(B, R, Sf, 1, generator=g) + 10
+    cz = torch.sort(torch.rand(B, R, Sc, 1, generator=g) + 10, dim=2).values
+    fz[0, 0, 0] = cz[0, 0, Sc // 2]                          # an exact tie: fine sample first (stable)
+    all_out = torch.cat([fine, coarse], dim=-2)
+    all_z = torch.cat([fz, cz], dim=-2)
+    _, idx = torch.sort(all_z, dim=-2, stable=True)
+    ref_z = torch.gather(all_z, -2, idx)
+    ref = torch.gather(all_out, -2, idx.expand(-1, -1, -1, C1))
+    out, out_z = vr.merge_samples(fine.to(DEV), coarse.to(DEV), fz.to(DEV), cz.to(DEV))
+    assert torch.equal(out_z.cpu(), ref_z) and torch.equal(out.cpu(), ref)      # pure data movement: bit-exact
+
+
+def test_ray_points():
+    g = torch.Generator().manual_seed(3)
+    o, d, z = torch.randn(2, 3, generator=g), torch.randn(2, 11, 3, generator=g), torch.rand(2, 11, 6, 1, generator=g) + 10
+    ref = (o[:, None, None, :] + d[:, :, None, :] * z).reshape(2, 66, 3)
+    assert rel_err(vr.ray_points(o.to(DEV), d.to(DEV), z.to(DEV)).cpu(), ref) < 1e-6
+
+
+def _build(meta, state=None):
+    cfg = dict(meta)
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    G = gens.Map3DGenerator(**cfg)
+    if state is not None:
+        G.load_state_dict(state, strict=True)
+    G = G.to(DEV).eval()
+    G.set_device(DEV)
+    return G, cfg
+
+
+def test_hierarchical_forward_golden():
+    g = load_golden("gen_tiny_hierarchical")
+    G, cfg = _build(g["meta"], g["state"])
+    cfg["nerf_noise"] = 0.3
+    out = G.forward(g["z"].to(DEV), {k: v.to(DEV) for k, v in g["cond"].items()}, jitter=g["jitter"].to(DEV),
+                    noise=g["noise"].to(DEV), noise_coarse=g["noise_coarse"].to(DEV), fine_u=g["u"].to(DEV), **cfg)
+    assert rel_err(out["rgbs_render"].cpu(), g["out"]["rgbs_render"]) < TOL
+    assert rel_err(out["rgbs"].cpu(), g["out"]["rgbs"]) < TOL
+
+
+def test_hierarchical_forward_vs_oracle_wide():
+    meta = dict(load_golden("gen_tiny_hierarchical")["meta"])
+    meta.update(hidden_dim=64, latent_dim=64, feature_dim=64, render_height=12, render_width=6, gen_height=64, gen_width=32,
+                num_steps=32, last_back=True, white_back=True)
+    torch.manual_seed(9)
+    G, cfg = _build(meta)
+    sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    cond = synthetic.make_conditions(2, n_vertices=300, seed=4)
+    z = torch.randn(2, 64)
+    R, S = 72, 32
+    jit, u = torch.rand(2, R, S, 1), torch.rand(2 * R, S)
+    ref = O.generator_forward(sd, cfg, z, cond, jit, None, hier=dict(noise_coarse=None, u=u))
+    out = G.forward(z.to(DEV), {k: v.to(DEV) for k, v in cond.items()}, jitter=jit.to(DEV), fine_u=u.to(DEV),
+                    noise=torch.zeros(2, R, 2 * S, 1, device=DEV), noise_coarse=torch.zeros(2, R, S, 1, device=DEV), **cfg)
+    assert rel_err(out["rgbs_render"].cpu(), ref["rgbs_render"]) < TOL
+    assert rel_err(out["rgbs"].cpu(), ref["rgbs"]) < TOL

@@ -137,3 +137,20 @@ def test_plugin_ops():
         out = O.modconv2d_grouped(c["x"], c["style"], st["weight"], st["bias"], st["geo_feature.weight"],
                                   st["geo_feature.bias"])
         assert rel_err(out, c["out"]) < 2e-6
+
+
+def test_sample_pdf_against_reference():
+    g = load_golden("gen_tiny_hierarchical")["pdf"]
+    got = O.sample_pdf(g["bins"], g["weights"], g["u"])
+    assert rel_err(got, g["samples"]) < 1e-6
+
+
+def test_hierarchical_forward():
+    """hierarchical_sample=True: coarse pass, importance re-sampling, merge by depth, integration over 2S samples."""
+    g = load_golden("gen_tiny_hierarchical")
+    cfg = _cfg(g)
+    assert cfg["hierarchical_sample"] is True
+    out = O.generator_forward(g["state"], cfg, g["z"], g["cond"], g["jitter"], g["noise"],
+                              hier=dict(noise_coarse=g["noise_coarse"], u=g["u"]))
+    assert rel_err(out["rgbs_render"], g["out"]["rgbs_render"]) < 2e-5
+    assert rel_err(out["rgbs"], g["out"]["rgbs"]) < 2e-5
