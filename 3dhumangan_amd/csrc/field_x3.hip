@@ -229,15 +229,32 @@ struct FilmProducer {
     }
 };
 
-// One layer: dst (+)= W * frags(producer(src)).  Tile 0 of the producer runs up front, tile t+1 inside the sections of
-// k-steps 2t, 2t+1.  HEAD: the four head rows (sigma, r, g, b) ride along as a ninth tile accumulated in hacc
-// (feature-major: row = head, column = sample), A fragments from LDS, one k-step of look-ahead.
-template <int NT, int KSG, bool ZERO, bool SWAP, bool HEAD, typename RING, typename PROD>
+// Tile-0 work of the NEXT layer's producer (its source is this GEMM's destination): tiles 0 and 1 of dst are final after
+// the first tile-pair section of the last k-step, so the remaining P-1 sections of that k-step carry the eight chunks
+// -- no layer starts with an exposed epilogue.
+template <int P, int S_LAST, int G, typename NEXT>
+__device__ __forceinline__ void next_tile0(NEXT& next) {
+    constexpr int s = G / P, p = G % P;
+    if constexpr (s == S_LAST) {
+        if constexpr (p == 0) next.prime();
+        constexpr int per = (8 + P - 2) / (P - 1);
+        if constexpr (p >= 1) {
+            static_for<0, per>([&](auto q) __attribute__((always_inline)) {
+                constexpr int c = (p - 1) * per + decltype(q)::value;
+                if constexpr (c < 8) next.template chunk<0, c>();
+            });
+        }
+    }
+}
+
+// One layer: dst (+)= W * frags(producer(src)).  Tile 0 of the producer has already run inside the previous GEMM
+// (next_tile0), tile t+1 runs inside the sections of k-steps 2t, 2t+1, and tile 0 of `next` inside the last k-step.
+// HEAD: the four head rows (sigma, r, g, b) ride along as a ninth tile accumulated in hacc (feature-major: row = head,
+// column = sample), A fragments from LDS, one k-step of look-ahead.
+template <int NT, int KSG, bool ZERO, bool SWAP, bool HEAD, typename RING, typename PROD, typename NEXT>
 __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1], half8 (&xl)[2 * NT + 1], RING& ring, PROD& prod,
-                                      f32x16& hacc, const unsigned char* head_lds, int lane) {
+                                      NEXT& next, f32x16& hacc, const unsigned char* head_lds, int lane) {
     constexpr int KS = 2 * NT, P = NT / 2, W = NT, PER = 8 / W;
-    prod.prime();
-    static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
     u32x4 hwh, hwl;
     // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo: [head][plane][KS][half][16 B]
     const unsigned char* hbase = head_lds + ((((lane & 3) * 2) * KS) * 2 + (lane >> 5)) * 16;
@@ -253,6 +270,7 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
         if constexpr (t < NT) {
             static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
         }
+        next_tile0<P, KSG - 1, g>(next);
         if constexpr (HEAD) {
             constexpr int s = g / P, p = g % P;
             if constexpr (p == 0 && s < KS) {
@@ -268,6 +286,15 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
             }
             if constexpr (p == 1 % P && s + 1 < KS) load_head(s + 1);
         }
+    });
+}
+
+// Input GEMM (1 or 2 k-steps, fragments prebuilt) with the tile-0 work of the layer that consumes its result.
+// (its own fragment arrays: the consumer's tile-0 chunks write xh[0], xh[1] while this GEMM is still running)
+template <int NT, int KSG, typename RING, typename NEXT>
+__device__ __forceinline__ void input_layer(f32x16 (&dst)[NT], const half8 (&ih)[2], const half8 (&il)[2], RING& ring, NEXT& next) {
+    gemm_x3_roll<F16, NT, KSG, 2, false, kLookF, kValuF, true>(dst, ih, il, ring, [&](auto gc) __attribute__((always_inline)) {
+        next_tile0<NT / 2, KSG - 1, decltype(gc)::value>(next);
     });
 }
 
@@ -398,41 +425,36 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 split8(v, kSIn, gh[ks], gl[ks]);
             }
         }
-        // ---- coordinate first layer -> Y ; FiLM 0, coordinate half: X = W0a * sin(30 * (Wc p + bc))
-        xh[0] = ch; xl[0] = cl;
-        gemm_x3_roll<F16, NT, 1, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
-        pin_agpr<NT>(Y);
+        // ---- the layer chain.  Producers (FiLM epilogue of a layer's source accumulators) are created up front because the
+        //      tile-0 chunks of producer l+1 run inside the last k-step of GEMM l.
+        FilmProducer<NT> p_coord{Y, xh, xl, tab + ST_COORD * 2 * HdP, h};
+        FilmProducer<NT> p_geo{Y, xh, xl, tab + ST_GEO * 2 * HdP, h};
+        FilmProducer<NT> p_f0{X, xh, xl, tab + ST_FILM0 * 2 * HdP, h};
+        FilmProducer<NT> p_f1{Y, xh, xl, tab + ST_FILM1 * 2 * HdP, h};
+        FilmProducer<NT> p_f2{X, xh, xl, tab + ST_FILM2 * 2 * HdP, h};
+        FilmProducer<NT> p_f3{Y, xh, xl, tab + ST_FILM3 * 2 * HdP, h};
+        FilmProducer<NT> p_col{X, xh, xl, tab + ST_COLOR * 2 * HdP, h};
+        // coordinate first layer -> Y ; FiLM 0, coordinate half: X = W0a * sin(30 * (Wc p + bc))
         {
-            FilmProducer<NT> prod{Y, xh, xl, tab + ST_COORD * 2 * HdP, h};
-            layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
+            const half8 ih[2] = {ch, ch}, il[2] = {cl, cl};
+            input_layer<NT, 1>(Y, ih, il, ring, p_coord);
         }
+        pin_agpr<NT>(Y);
+        layer<NT, KS, true, false, false>(X, xh, xl, ring, p_coord, none, hacc, head_lds, lane);
         pin_agpr<NT>(X);
-        // ---- geometry first layer -> Y ; FiLM 0, geometry half: X += W0b * sin(30 * (Wg g + bg))
-        xh[0] = gh[0]; xl[0] = gl[0]; xh[1] = gh[1]; xl[1] = gl[1];
-        gemm_x3_roll<F16, NT, 2, KS + 1, false, kLookF, 0, true>(Y, xh, xl, ring);
+        // geometry first layer -> Y ; FiLM 0, geometry half: X += W0b * sin(30 * (Wg g + bg))
+        input_layer<NT, 2>(Y, gh, gl, ring, p_geo);
         pin_agpr<NT>(X); pin_agpr<NT>(Y);
-        {
-            FilmProducer<NT> prod{Y, xh, xl, tab + ST_GEO * 2 * HdP, h};
-            layer<NT, KS, false, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
-        }
+        layer<NT, KS, false, false, false>(X, xh, xl, ring, p_geo, p_f0, hacc, head_lds, lane);
         pin_agpr<NT>(X);
-        // ---- FiLM 1..3
-        {
-            FilmProducer<NT> prod{X, xh, xl, tab + ST_FILM0 * 2 * HdP, h};
-            layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
-        }
+        // FiLM 1..3
+        layer<NT, KS, true, false, false>(Y, xh, xl, ring, p_f0, p_f1, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
-        {
-            FilmProducer<NT> prod{Y, xh, xl, tab + ST_FILM1 * 2 * HdP, h};
-            layer<NT, KS, true, false, false>(X, xh, xl, ring, prod, hacc, head_lds, lane);
-        }
+        layer<NT, KS, true, false, false>(X, xh, xl, ring, p_f1, p_f2, hacc, head_lds, lane);
         pin_agpr<NT>(X);
-        {
-            FilmProducer<NT> prod{X, xh, xl, tab + ST_FILM2 * 2 * HdP, h};
-            layer<NT, KS, true, false, false>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
-        }
+        layer<NT, KS, true, false, false>(Y, xh, xl, ring, p_f2, p_f3, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
-        // ---- colour FiLM: X = Wc[:, 3:] * film3(Y) + Wc[:, :3] * dir  (+ density head on film3(Y))
+        // colour FiLM: X = Wc[:, 3:] * film3(Y) + Wc[:, :3] * dir  (+ density head on film3(Y))
         {
             float v[8];
 #pragma unroll
@@ -445,9 +467,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 }
             }
             split8(v, kSA, xh[KS], xl[KS]);
-            FilmProducer<NT> prod{Y, xh, xl, tab + ST_FILM3 * 2 * HdP, h};
-            layer<NT, KS + 1, true, false, true>(X, xh, xl, ring, prod, hacc, head_lds, lane);
         }
+        layer<NT, KS + 1, true, false, true>(X, xh, xl, ring, p_f3, p_col, hacc, head_lds, lane);
         pin_agpr<NT>(X);
         H3D_TRACE(7);
         // density of this lane's sample: head row 0 = accumulator register 0 of the lower lane half
@@ -496,10 +517,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         }
 
         // ---- feature head, sample-major accumulator: Y = film_color(X)^T * Wf^T  (+ colour heads on film_color(X))
-        {
-            FilmProducer<NT> prod{X, xh, xl, tab + ST_COLOR * 2 * HdP, h};
-            layer<NT, KS, true, true, true>(Y, xh, xl, ring, prod, hacc, head_lds, lane);
-        }
+        layer<NT, KS, true, true, true>(Y, xh, xl, ring, p_col, none, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
         float rgb[3];
         {
