@@ -149,17 +149,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& 
     fl = __builtin_bit_cast(half8, u32x4{lw[0], lw[1], lw[2], lw[3]});
 }
 
-// B fragments of k-steps 2*pr and 2*pr+1... of one plane: rows of register groups 2*PR, 2*PR+1 (x3_common.hpp relayout)
-template <int PR>
-__device__ __forceinline__ half8 relayout_half(const unsigned (&P)[4][2]) {
-    u32x4 r;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        auto a = __builtin_amdgcn_permlane32_swap(P[2 * PR][c], P[2 * PR + 1][c], false, false);
-        r[c] = a[0];
-        r[2 + c] = a[1];
-    }
-    return __builtin_bit_cast(half8, r);
+// K order of every GEMM that consumes accumulators ("acc order"): the accumulator registers a lane holds for tile t ARE
+// its B-fragment elements -- register r = 8j + e of tile t is element e of k-step 2t + j -- so no cross-lane relayout is
+// needed; the host packs the weights' K dimension accordingly (k_of below / acc_k in the packer):
+//     feature of k-slot (h, e) of k-step ks:  32*(ks/2) + (e & 3) + 8*(2*(ks & 1) + (e >> 2)) + 4*h
+__device__ __forceinline__ void set_word(half8& f, int w, unsigned v) {
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    t[w] = v;
+    f = __builtin_bit_cast(half8, t);
 }
 
 // Producer of the next layer's B fragments from a feature-major accumulator set: y = v_sin(acc * A1[n] + A0[n])
@@ -173,7 +170,6 @@ struct FilmProducer {
     half8 (&xl)[2 * NT + 1];
     const float* tab;         // LDS [HdP/2][4]: A1[n], A1[n+1], A0[n], A0[n+1]
     int h;
-    unsigned Hh[4][2], Ll[4][2];
     f32x4 tv;
     float sv[8];              // half a tile of the source accumulators, read from the AGPRs in one batch: a
                               // v_accvgpr_read issued between MFMAs waits for the matrix pipe, so 2 batches per tile
@@ -185,47 +181,21 @@ struct FilmProducer {
     template <int TILE, int C>
     __device__ __forceinline__ void chunk() {
         if constexpr (C == 0) pin1(src[TILE]);
-        constexpr int rg = C / 2, q0 = (C % 2) * 2;
+        constexpr int rg = C / 2;
         if constexpr (C % 4 == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) sv[i] = src[TILE][(C / 4) * 8 + i];
         }
-#ifdef H3D_ABL_NOREAD
-        const float s0 = tv.x, s1 = tv.y;
-#else
         const float s0 = sv[(C % 4) * 2], s1 = sv[(C % 4) * 2 + 1];
-#endif
         const float u0 = fmaf(s0, tv.x, tv.z);
         const float u1 = fmaf(s1, tv.y, tv.w);
-#ifndef H3D_ABL_NOTAB
         if constexpr (C < 7) tv = ld4(tab + 2 * chan<TILE, C + 1>());
         else if constexpr (TILE + 1 < NT) tv = ld4(tab + 2 * chan<TILE + 1, 0>());
-#endif
-#ifdef H3D_ABL_NOSIN
-        const float y0 = u0, y1 = u1;
-#else
-        const float y0 = __builtin_amdgcn_sinf(u0), y1 = __builtin_amdgcn_sinf(u1);
-#endif
-#ifdef H3D_ABL_NOSPLIT
-        Hh[rg][C % 2] = __builtin_bit_cast(unsigned, y0); Ll[rg][C % 2] = __builtin_bit_cast(unsigned, y1);
-#else
-        Hh[rg][C % 2] = split2_act(y0, y1, Ll[rg][C % 2]);
-#endif
-#ifdef H3D_ABL_NOPERM
-        if constexpr (C == 4) xh[2 * TILE] = __builtin_bit_cast(half8, u32x4{Hh[0][0], Hh[0][1], Hh[1][0], Hh[1][1]});
-        if constexpr (C == 5) xl[2 * TILE] = __builtin_bit_cast(half8, u32x4{Ll[0][0], Ll[0][1], Ll[1][0], Ll[1][1]});
-        if constexpr (C == 7) {
-            xh[2 * TILE + 1] = __builtin_bit_cast(half8, u32x4{Hh[2][0], Hh[2][1], Hh[3][0], Hh[3][1]});
-            xl[2 * TILE + 1] = __builtin_bit_cast(half8, u32x4{Ll[2][0], Ll[2][1], Ll[3][0], Ll[3][1]});
-        }
-        return;
-#endif
-        if constexpr (C == 4) xh[2 * TILE] = relayout_half<0>(Hh);
-        if constexpr (C == 5) xl[2 * TILE] = relayout_half<0>(Ll);
-        if constexpr (C == 7) {
-            xh[2 * TILE + 1] = relayout_half<1>(Hh);
-            xl[2 * TILE + 1] = relayout_half<1>(Ll);
-        }
+        unsigned lo;
+        const unsigned hi = split2_act(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo);
+        // registers 4*rg + 2*(C%2) + {0, 1} of the tile = k-step 2*TILE + (rg >> 1), word 2*(rg & 1) + C%2
+        set_word(xh[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), hi);
+        set_word(xl[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), lo);
     }
 };
 
@@ -697,13 +667,20 @@ float pow2_scale(const float* w, int64_t n, float target) {
     return exp2f(floorf(log2f(target / mx)));
 }
 
+// input feature of k-slot (half hh, element e) of k-step ks when the consumer's B fragments are accumulator registers
+// (see FilmProducer): tile ks/2, accumulator register r = 8*(ks & 1) + e  ->  row (r & 3) + 8*(r >> 2) + 4*hh
+int acc_k(int ks, int hh, int e) { return 32 * (ks / 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh; }
+
 // W [n_out, ld] row-major; K range [in_begin, in_begin+in_count) -> [KSm][NT][2][64][8] f16, scaled by `scale`.
-void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, uint16_t* dst) {
+// acc_order: K runs in accumulator-register order (the input comes from a previous layer's accumulators) instead of
+// the natural order (inputs assembled from memory: coordinates, geometry features, view direction).
+void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, uint16_t* dst,
+             bool acc_order) {
     for (int ks = 0; ks < KSm; ++ks)
         for (int nt = 0; nt < NT; ++nt)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int k = 16 * ks + 8 * (lane >> 5) + e, nn = 32 * nt + (lane & 31);
+                    const int k = acc_order ? acc_k(ks, lane >> 5, e) : 16 * ks + 8 * (lane >> 5) + e, nn = 32 * nt + (lane & 31);
                     float v = 0.f;
                     if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
                     const uint16_t hi = f32_to_f16_rn(v);
@@ -729,36 +706,36 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
     memset(blob, 0, L.total);
     float* invs = reinterpret_cast<float*>(blob + L.inv_scale);
     const float target = 8192.f;
-    auto mat = [&](int wi, const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, float in_scale) {
+    auto mat = [&](int wi, const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, float in_scale, bool acc_order) {
         // scale taken over the slice actually used
         float mx = 0.f;
         for (int nn = 0; nn < n_out; ++nn)
             for (int k = 0; k < in_count; ++k) mx = fmaxf(mx, fabsf(w[(int64_t)nn * ld + in_begin + k]));
         const float sc = mx > 0.f ? exp2f(floorf(log2f(target / mx))) : 1.f;
-        pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]));
+        pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]), acc_order);
         invs[wi] = 1.f / (sc * in_scale);
         return sc;
     };
-    mat(W_COORD, p->w_coord, 3, 0, 3, Hd, 1, kSIn);
-    mat(W_GEO, p->w_geo, 31, 0, 31, Hd, 2, kSIn);
+    mat(W_COORD, p->w_coord, 3, 0, 3, Hd, 1, kSIn, false);
+    mat(W_GEO, p->w_geo, 31, 0, 31, Hd, 2, kSIn, false);
     // FiLM 0: both halves must share one scale because they accumulate into the same registers
     {
         const float sc = pow2_scale(p->w_film[0], (int64_t)Hd * 2 * Hd, target);
-        pack_x3(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0A]));
-        pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]));
+        pack_x3(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0A]), true);
+        pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]), true);
         invs[W_F0A] = invs[W_F0B] = 1.f / (sc * kSA);
     }
-    for (int l = 1; l < 4; ++l) mat(W_F1 + l - 1, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA);
+    for (int l = 1; l < 4; ++l) mat(W_F1 + l - 1, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA, true);
     // colour layer: KS k-steps over the hidden features (columns 3..) + one k-step over the view direction (columns 0..2),
     // one scale for the whole matrix (same accumulators)
     {
         const float sc = pow2_scale(p->w_color, (int64_t)Hd * (Hd + 3), target);
         uint16_t* dst = reinterpret_cast<uint16_t*>(blob + L.w[W_COLOR]);
-        pack_x3(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, dst);
-        pack_x3(p->w_color, Hd + 3, 0, 3, Hd, 1, L.NT, sc, dst + (int64_t)L.KS * L.NT * 2 * 64 * 8);
+        pack_x3(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, dst, true);
+        pack_x3(p->w_color, Hd + 3, 0, 3, Hd, 1, L.NT, sc, dst + (int64_t)L.KS * L.NT * 2 * 64 * 8, false);
         invs[W_COLOR] = 1.f / (sc * kSA);
     }
-    mat(W_FEAT, p->w_feat, Hd, 0, Hd, F, L.KS, kSA);
+    mat(W_FEAT, p->w_feat, Hd, 0, Hd, F, L.KS, kSA, true);
     float* bias = reinterpret_cast<float*>(blob + L.bias);
     for (int nn = 0; nn < Hd; ++nn) {
         bias[ST_GEO * L.HdP + nn] = p->b_geo[nn];
@@ -778,7 +755,7 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
         for (int ks = 0; ks < L.KS; ++ks)
             for (int hh = 0; hh < 2; ++hh)
                 for (int e = 0; e < 8; ++e) {
-                    const int k = 16 * ks + 8 * hh + e;
+                    const int k = acc_k(ks, hh, e);
                     const float v = k < Hd ? w[k] * sc : 0.f;
                     const uint16_t hi = f32_to_f16_rn(v), lo = f32_to_f16_rn(v - f16_to_f32(hi));
                     hw[((((int64_t)hd * 2 + 0) * L.KS + ks) * 2 + hh) * 8 + e] = hi;
