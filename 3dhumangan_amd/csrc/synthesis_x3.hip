@@ -45,27 +45,33 @@ __device__ __forceinline__ float linspace_pm1(int n, int i) {
     return (i < n / 2) ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
 }
 
-// fp32 values of one accumulator tile set -> bf16 hi/lo B fragments.  val(nt, rg) returns the 4 values of
-// register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
+// K order of every GEMM that consumes accumulators ("acc order", as in field_x3.hip): register r = 8j + e of accumulator
+// tile t IS element e of the lane's B fragment of k-step 2t + j, so fragments are assembled without any cross-lane move;
+// the host packs the K dimension of those weight matrices accordingly (pack_stream_bf16(acc_order=True)):
+//     feature of k-slot (h, e) of k-step ks:  32*(ks/2) + (e & 3) + 8*(2*(ks & 1) + (e >> 2)) + 4*h
+__device__ __forceinline__ void set_word(bf8& f, int w, unsigned v) {
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    t[w] = v;
+    f = __builtin_bit_cast(bf8, t);
+}
+
+// fp32 values of one accumulator tile set -> bf16 hi/lo B fragments (all tiles at once; the progressive variant is
+// SpadeProducer).  val(nt, rg) returns the 4 values of register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
 template <int NT, typename F>
 __device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], f32x16 (&src)[NT], F val) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        unsigned Hh[4][2], Ll[4][2];
         pin1(src[nt]);                       // the source tile sits in AGPRs until this iteration reads it
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const float4 y = val(nt, rg);
-            __bf16 a[4], c[4];
-            split<BF16>(y.x, a[0], c[0]);
-            split<BF16>(y.y, a[1], c[1]);
-            split<BF16>(y.z, a[2], c[2]);
-            split<BF16>(y.w, a[3], c[3]);
-            Hh[rg][0] = pack2<BF16>(a[0], a[1]); Hh[rg][1] = pack2<BF16>(a[2], a[3]);
-            Ll[rg][0] = pack2<BF16>(c[0], c[1]); Ll[rg][1] = pack2<BF16>(c[2], c[3]);
+            unsigned l0, l1;
+            const unsigned h0 = split2_bf16(y.x, y.y, l0), h1 = split2_bf16(y.z, y.w, l1);
+            set_word(xh[2 * nt + (rg >> 1)], 2 * (rg & 1) + 0, h0);
+            set_word(xh[2 * nt + (rg >> 1)], 2 * (rg & 1) + 1, h1);
+            set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 0, l0);
+            set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 1, l1);
         }
-        relayout_tile<BF16>(Hh, xh[2 * nt], xh[2 * nt + 1]);
-        relayout_tile<BF16>(Ll, xl[2 * nt], xl[2 * nt + 1]);
         // bound the scheduler's load hoisting to one tile: the table reads of all tiles at once would cost
         // hundreds of registers on top of the resident activations
         __builtin_amdgcn_sched_barrier(0);
@@ -93,18 +99,6 @@ __device__ __forceinline__ float lrelu_plain(float v) {
     return fmaxf(v, t);
 }
 
-template <int PR>
-__device__ __forceinline__ bf8 relayout_half(const unsigned (&P)[4][2]) {
-    u32x4 r;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        auto a = __builtin_amdgcn_permlane32_swap(P[2 * PR][c], P[2 * PR + 1][c], false, false);
-        r[c] = a[0];
-        r[2 + c] = a[1];
-    }
-    return __builtin_bit_cast(bf8, r);
-}
-
 // Producer of a conv's B fragments from a feature-major accumulator set, one 32-channel tile in eight chunks of two
 // activations (so that the consuming GEMM hides one chunk behind each tile-pair section of k-steps 2t, 2t+1):
 //   AFFINE  y = lrelu(v * sc + sh)   tables [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1] (constant-style SPADE with the
@@ -120,7 +114,6 @@ struct SpadeProducer {
     const float* wr;
     float (&rgb)[3];
     int h, HdP;
-    unsigned Hh[4][2], Ll[4][2];
     f32x4 tv;
     f32x2 w0, w1, w2;
     float sv[8];
@@ -156,13 +149,11 @@ struct SpadeProducer {
         }
         if constexpr (C < 7) fetch<TILE, C + 1>();
         else if constexpr (TILE + 1 < NT) fetch<TILE + 1, 0>();
-        Hh[rg][C % 2] = split2_plain(lrelu_plain(y0), lrelu_plain(y1), Ll[rg][C % 2]);
-        if constexpr (C == 4) xh[2 * TILE] = relayout_half<0>(Hh);
-        if constexpr (C == 5) xl[2 * TILE] = relayout_half<0>(Ll);
-        if constexpr (C == 7) {
-            xh[2 * TILE + 1] = relayout_half<1>(Hh);
-            xl[2 * TILE + 1] = relayout_half<1>(Ll);
-        }
+        unsigned lo;
+        const unsigned hi = split2_plain(lrelu_plain(y0), lrelu_plain(y1), lo);
+        // registers 4*rg + 2*(C%2) + {0, 1} of the tile = k-step 2*TILE + (rg >> 1), word 2*(rg & 1) + C%2
+        set_word(xh[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), hi);
+        set_word(xl[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), lo);
     }
 };
 

@@ -170,15 +170,27 @@ class SynthesisPlan:
         return all(4 * (seg["tables"].numel() + per_sample) + 4 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
 
     @staticmethod
-    def pack_stream_bf16(w_out_in, KS, NT):
-        """[n_out, n_in] -> bf16 hi/lo weight-stream stages [KS][NT][2][64][8] (as int16 bit patterns)."""
+    def pack_stream_bf16(w_out_in, KS, NT, acc_order=True):
+        """[n_out, n_in] -> bf16 hi/lo weight-stream stages [KS][NT][2][64][8] (as int16 bit patterns).
+
+        acc_order (every matrix of the x3 synthesis engine: its inputs are always previous accumulators): the K dimension
+        runs in accumulator-register order, feature of k-slot (h, e) of k-step ks =
+        32*(ks//2) + (e & 3) + 8*(2*(ks & 1) + (e >> 2)) + 4*h, so that a lane's accumulator registers are its B-fragment
+        elements (csrc/synthesis_x3.hip); otherwise the natural order 16*ks + 8*h + e."""
         n_out, n_in = w_out_in.shape
-        wp = torch.zeros(32 * NT, 16 * KS, dtype=torch.float32, device=w_out_in.device)
+        dev = w_out_in.device
+        wp = torch.zeros(32 * NT, 16 * KS, dtype=torch.float32, device=dev)
         wp[:n_out, :n_in] = w_out_in.float()
+        if acc_order:
+            ks = torch.arange(KS, device=dev).view(KS, 1, 1)
+            hh = torch.arange(2, device=dev).view(1, 2, 1)
+            e = torch.arange(8, device=dev).view(1, 1, 8)
+            k = 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh          # [KS, 2, 8]
+            wp = wp[:, k.reshape(-1)]
         hi = wp.to(torch.bfloat16)
         lo = (wp - hi.float()).to(torch.bfloat16)
 
-        def frag(t):        # [N, K] -> [KS, NT, 64 lanes, 8]; lane = 32*h + j, element e: n = 32nt + j, k = 16ks + 8h + e
+        def frag(t):        # [N, K] -> [KS, NT, 64 lanes, 8]; lane = 32*h + j, element e: n = 32nt + j, k-slot (ks, h, e)
             return t.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8)
 
         return torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(torch.int16).flatten()

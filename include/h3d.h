@@ -197,7 +197,9 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
 /* Same network on the bf16 matrix cores with split ("x3") operands (bf16 hi + lo, three partial products, fp32
  * accumulation; ~1e-5 on the image).  `stream`: all conv / gamma / beta matrices of one tile in consumption order
  * (per block, per SPADE: [gamma (8 k-steps), beta (8)] if pixel_style, then conv), each k-step stage
- * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k = 16*kstep + 8*(lane>>5) + e];
+ * [tile][hi|lo][64 lanes][8 bf16] with element (lane, e) = W[n = 32*tile + (lane&31)][k(kstep, lane>>5, e)], K in
+ * accumulator-register order k(ks, h, e) = 32*(ks/2) + (e&3) + 8*(2*(ks&1) + (e>>2)) + 4*h (a lane's accumulator
+ * registers of the producing layer are then its B-fragment elements; every matrix of this engine is fed that way);
  * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
  * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
  * `ab` for THIS entry point is [B, n_ab, HdP/2, 4] = (scale[n], scale[n+1], shift[n], shift[n+1]) -- one 16-byte read per
