@@ -304,6 +304,18 @@ class SynthesisPlan:
             ab[:, :, 1, : self.C] = self.sh_c * gamma1 + beta
         return G, cst, ab
 
+    def x3_forward_tables(self, feature_maps, fixed_style):
+        """per_forward_tables for the x3 engine: the conv biases folded into the constant-style shifts (build_x3) and
+        `ab` in the kernel's layout [B, n_ab, HdP/2, 4] = sc[n], sc[n+1], sh[n], sh[n+1] (one 16-byte LDS read per two
+        channels)."""
+        x3 = self.build_x3()
+        G, cst, ab = self.per_forward_tables(feature_maps, fixed_style, x3["HdP"])
+        if ab is not None:
+            ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]
+            Bq, nq, _, Hq = ab.shape
+            ab = ab.view(Bq, nq, 2, Hq // 2, 2).permute(0, 1, 3, 2, 4).contiguous()
+        return G, cst, ab
+
     def run(self, feature_maps, fixed_style, render_hw, out_hw, owner=None):
         """-> rgb [B,3,H,W]."""
         B = fixed_style.shape[0]
@@ -315,12 +327,10 @@ class SynthesisPlan:
         if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
             x3 = None            # the x3 engine's matrix-core resize does not cover this geometry: fp32 engine
         with stage(owner, "synthesis_tables"):
-            G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3["HdP"] if x3 else None)
-            if x3 and ab is not None:
-                ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]      # folded conv biases (build_x3)
-                # kernel layout [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]: one 16-byte LDS read per two channels
-                Bq, nq, _, Hq = ab.shape
-                ab = ab.view(Bq, nq, 2, Hq // 2, 2).permute(0, 1, 3, 2, 4).contiguous()
+            if x3:
+                G, cst, ab = self.x3_forward_tables(feature_maps.float(), fixed_style.float())
+            else:
+                G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float())
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         with stage(owner, "synthesis"):
             if x3:

@@ -1,0 +1,110 @@
+"""Host logic of the split-bf16 synthesis plan (lib/generators/synthesis_pack.py: build_x3 / x3_forward_tables) checked on
+the CPU: the packed weight stream (consumption order, accumulator-order K permutation, hi + lo halves), the folded conv
+biases / ToRGB biases and the per-forward tables are decoded and run through a plain float64 restatement of what
+csrc/synthesis_x3.hip computes, and the image must match the oracle's SynthesisNetwork.  No HIP call is made."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import load_golden, rel_err
+
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+sp = importlib.import_module("3dhumangan_amd.lib.generators.synthesis_pack")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+
+
+def acc_k(ks, h, e):
+    return 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * h
+
+
+def decode_matrix(stream_i16, stage0, KS, NT):
+    """stages [KS][NT][2][64][8] of bf16 bit patterns -> dense W [32*NT, 16*KS] (hi + lo), K back in natural order."""
+    n = KS * NT * 2 * 64 * 8
+    t = stream_i16[stage0 * NT * 2 * 64 * 8: stage0 * NT * 2 * 64 * 8 + n].view(torch.bfloat16).double().view(KS, NT, 2, 64, 8)
+    t = t[:, :, 0] + t[:, :, 1]                                       # [KS, NT, 64, 8]
+    W = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+    for ks in range(KS):
+        for h in range(2):
+            for e in range(8):
+                W[:, acc_k(ks, h, e)] = t[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
+    return W
+
+
+def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W):
+    """float64 restatement of synthesis_x3_kernel on the plan's own tables / stream."""
+    x3 = plan.build_x3()
+    assert len(x3["segments"]) == 1
+    seg, NT, HdP = x3["segments"][0], x3["NT"], x3["HdP"]
+    desc, tab = seg["desc"], seg["tables"].double()
+    stream = seg["stream"]
+    G, cst, ab = plan.x3_forward_tables(fmap_lowres.float(), fixed_style.float())
+    B = fixed_style.shape[0]
+    vec = lambda off, n=HdP: tab[off: off + n]
+    ii = torch.linspace(-1, 1, H, dtype=torch.float64).view(H, 1).expand(H, W).reshape(-1)
+    jj = torch.linspace(-1, 1, W, dtype=torch.float64).view(1, W).expand(H, W).reshape(-1)
+    x = torch.sin(ii[:, None] * vec(desc.w_in) + jj[:, None] * vec(desc.w_in + HdP) + vec(desc.b_in))   # [HW, HdP]
+    x = x.unsqueeze(0).repeat(B, 1, 1)
+    if G is not None:
+        Gmap = G.double().view(B, Hr, Wr, -1).permute(0, 3, 1, 2)
+        Gup = torch.nn.functional.interpolate(Gmap, (H, W), mode="bilinear").permute(0, 2, 3, 1).reshape(B, H * W, -1)
+    rgb = torch.zeros(B, H * W, 3, dtype=torch.float64)
+    stage = 0
+    lrelu = lambda v: torch.maximum(v, 0.2 * v)
+    for k in range(desc.n_blocks):
+        bk = desc.block[k]
+        x_in = x
+        for s in range(2):
+            d = bk.spade[s]
+            if d.pixel_style:
+                a = torch.relu(Gup[:, :, d.g_offset: d.g_offset + 128] + cst[:, d.cst_index].double()[:, None, :])
+                Wg = decode_matrix(stream, stage, 8, NT); stage += 8
+                Wb = decode_matrix(stream, stage, 8, NT); stage += 8
+                g1 = vec(d.vec) + a @ Wg.t()
+                y = lrelu((x * vec(d.vec + 2 * HdP) + vec(d.vec + 3 * HdP)) * g1 + vec(d.vec + HdP) + a @ Wb.t())
+            else:
+                t4 = ab[:, d.ab_index].double()                       # [B, HdP/2, 2 (sc | sh), 2 (channel pair)]
+                sc = t4[:, :, 0, :].reshape(B, 1, HdP)
+                sh = t4[:, :, 1, :].reshape(B, 1, HdP)
+                y = lrelu(x * sc + sh)
+            Wc = decode_matrix(stream, stage, 2 * NT, NT); stage += 2 * NT
+            x = y @ Wc.t() + (x_in if (s == 1 and bk.skip) else 0.0)
+        if bk.to_rgb:
+            wr = torch.stack([vec(bk.w_rgb), vec(bk.w_rgb + HdP), vec(bk.w_rgb + 2 * HdP)])          # [3, HdP]
+            rgb = rgb + x @ wr.t() + vec(bk.w_rgb + 3 * HdP, 3)
+    assert stage == seg["stages"]
+    return rgb.view(B, H, W, 3).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("mode,width", [("mixed", 32), ("isolated", 40)])
+def test_x3_plan_matches_oracle(mode, width):
+    meta = dict(load_golden("gen_tiny_mixed")["meta"])
+    meta.update(map3d_mode=mode, hidden_dim=width, latent_dim=width, feature_dim=width, gen_height=12, gen_width=8,
+                render_height=5, render_width=4)
+    meta["neural_field_cls"] = impl.COORDCONCATSIREN
+    torch.manual_seed(3 + width)
+    Gn = gens.Map3DGenerator(**meta).eval()
+    with torch.no_grad():                                             # non-trivial BN statistics, biases, spectral u/v
+        for n, p in Gn.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+        for n, b in Gn.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.2 * torch.randn_like(b))
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand_like(b))
+    sd = {k: v.detach().clone() for k, v in Gn.state_dict().items()}
+    plan = sp.SynthesisPlan(sd, "synthesis_network", "synthesis_input", meta["synthesis_blocks"], tuple(meta["mod_blocks"]), mode,
+                            torch.device("cpu"))
+    assert plan.x3_supported()
+    B, Hr, Wr, H, W = 2, 5, 4, 12, 8
+    fmap = torch.randn(B, Hr * Wr, width)
+    style = torch.randn(B, width)
+    got = emulate(plan, fmap, style, Hr, Wr, H, W)
+    fm = fmap.view(B, Hr, Wr, width).permute(0, 3, 1, 2)
+    fm_up = torch.nn.functional.interpolate(fm, (H, W), mode="bilinear")
+    x0 = O.synthesis_input(sd, B, H, W)
+    ref = O.synthesis_network(sd, x0, fm_up, style.view(B, 1, width), mode, tuple(meta["mod_blocks"]), meta["synthesis_blocks"])["final"]
+    # bf16 hi + lo carries 16 significant bits of every weight: 1e-4 covers it comfortably
+    assert rel_err(got.float(), ref) < 1e-4
