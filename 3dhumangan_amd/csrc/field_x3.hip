@@ -693,6 +693,18 @@ void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int 
 
 }  // namespace
 
+extern "C" int h3d_field_x3_layout(int Hd, int F, int64_t* out, int n_out) {
+    H3D_REQUIRE(out && n_out >= 20, "h3d_field_x3_layout: need room for 20 values");
+    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_x3_layout: widths up to 256 (got %d, %d)", Hd, F);
+    const LayoutX3 L = make_layout(Hd, F);
+    int i = 0;
+    out[i++] = L.NT; out[i++] = L.KS; out[i++] = L.HdP; out[i++] = L.stages;
+    for (int w = 0; w < W_COUNT; ++w) out[i++] = L.w[w];
+    out[i++] = L.inv_scale; out[i++] = L.bias; out[i++] = L.b_feat; out[i++] = L.head_w; out[i++] = L.head_inv;
+    out[i++] = L.head_b; out[i++] = L.total;
+    return H3D_OK;
+}
+
 extern "C" int64_t h3d_field_pack_x3_size(int Hd, int F) {
     if (Hd < 1 || F < 1 || Hd > 256 || F > 256) return -1;
     return make_layout(Hd, F).total;

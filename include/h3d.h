@@ -142,6 +142,16 @@ int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w,
  */
 int64_t h3d_field_pack_x3_size(int Hd, int F);
 int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+/* Layout of the blob h3d_field_pack_x3 writes (HOST helper, for tools and tests).  out[0..19] = tiles, k-steps per
+ * hidden GEMM, padded width, weight-stream stages per 32-sample step, then BYTE offsets of the nine stream matrices in
+ * consumption order (coord [1 k-step], film0 coord half, geo [2], film0 geo half, film1, film2, film3, colour [k-steps
+ * + 1: the view direction], feature head), of inv_scale float[9], bias float[7][HdP] (coord, geo, film0..3, colour),
+ * b_feat float[HdP], head_w f16 [4][2][k-steps][2][8], head_inv float[4], head_b float[4], and the total size.
+ * A stage is [tile][hi|lo][64 lanes][8 f16]; element (lane, e) = s * W[n = 32*tile + (lane&31)][k], s the matrix's
+ * power-of-two scale (inv_scale = 1 / (s * input scale)), K in accumulator-register order
+ * k = 32*(ks/2) + (e&3) + 8*(2*(ks&1) + (e>>2)) + 4*(lane>>5) for the matrices fed by accumulators and in natural order
+ * 16*ks + 8*(lane>>5) + e for coord, geo and the view-direction stage. */
+int h3d_field_x3_layout(int Hd, int F, int64_t* out, int n_out);
 int h3d_neural_field_x3(const void* packed, const float* points, const float* geo, const float* dirs,
                         const float* freq, const float* phase, float* out,
                         int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler,
