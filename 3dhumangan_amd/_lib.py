@@ -89,10 +89,25 @@ def ptr(t):
 
 
 def need_cuda(*tensors):
-    """The product has no CPU path: refuse CPU tensors loudly."""
+    """The product has no CPU path: refuse CPU tensors loudly.  All tensors of a call must live on ONE device and that
+    device must be the current one: the kernels launch on the current device's current stream (stream_handle), so a
+    tensor from another GPU would be read through a foreign pointer with no ordering against the torch ops that
+    produced it.  Map3DGenerator.forward enters ``torch.cuda.device(latent.device)`` itself; direct callers of the op
+    wrappers do the same."""
+    import torch
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise H3DError("3dhumangan_amd ops run on a ROCm device only (got a CPU tensor); there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise H3DError(f"3dhumangan_amd op called with tensors on {dev} and {t.device}: all operands must share a device")
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        raise H3DError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                       f"wrap the call in `with torch.cuda.device({dev.index}):`")
 
 
 def stream_handle():

@@ -21,40 +21,48 @@ from ..lib import generators as lib_generators
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-@torch.no_grad()
-def generate_frames(generator, preprocessor, config, seed, conditions, n_angles, angle_range_h, angle_range_v, back_and_forth):
-    """-> (frames uint8 [n_angles,H,W,3], rasterized_semantics uint8 [n_angles,H,W,3])."""
+def latent_for_seed(seed, latent_dim):
+    """Seed -> latent convention of the reference app (:26-29): both RNGs seeded, one N(0,1) row drawn on the app device
+    (so a CUDA run consumes the device RNG, as the reference does)."""
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed(seed)
-    dev = generator.device
-    z = torch.randn((1, config["latent_dim"]), device=device).repeat_interleave(n_angles, dim=0).to(dev)
-    conditions = {k: v.repeat_interleave(n_angles, dim=0).to(dev) for k, v in conditions.items()}
+    return torch.randn((1, latent_dim), device=device)
+
+
+def camera_sweep(n_angles, range_h, range_v, back_and_forth):
+    """Angle schedule of the reference app (:35-43) as two float32 lists [n_angles]: a linear pan across
+    [-range, +range], or (back_and_forth) one period of a (sin, cos) loop."""
     if back_and_forth:
-        sweep = torch.linspace(-np.pi, np.pi, n_angles).to(dev)
-        angles_h = angle_range_h * torch.sin(sweep).unsqueeze(-1)
-        angles_v = angle_range_v * torch.cos(sweep).unsqueeze(-1)
-    else:
-        angles_h = torch.linspace(-angle_range_h, angle_range_h, n_angles).to(dev).unsqueeze(-1)
-        angles_v = torch.linspace(-angle_range_v, angle_range_v, n_angles).to(dev).unsqueeze(-1)
-    angles_r = torch.zeros_like(angles_h)
-    H, W = config["gen_height"], config["gen_width"]
-    frames = torch.zeros(n_angles, 3, H, W, device=dev)
-    semantics = torch.zeros(n_angles, 3, H, W, device=dev)
-    for i in range(n_angles):
-        one = {k: v[i:i + 1] for k, v in conditions.items()}
-        one = preprocessor.forward_with_rotation(one, angles_h[i:i + 1], angles_v[i:i + 1], angles_r[i:i + 1], **config)
-        smpl = torch.clamp(one["rasterized_semantics"], -1, 1)
-        bg = torch.all(smpl == 0, dim=1, keepdim=True)
-        smpl[bg.repeat(1, 3, 1, 1)] = 1
-        semantics[i:i + 1] = smpl
-        out = generator.staged_forward(z[i:i + 1], one, **config)
-        frames[i:i + 1] = torch.clamp(out["rgbs"], -1, 1)
+        phase = torch.linspace(-np.pi, np.pi, n_angles)
+        return range_h * torch.sin(phase), range_v * torch.cos(phase)
+    return torch.linspace(-range_h, range_h, n_angles), torch.linspace(-range_v, range_v, n_angles)
 
-    def to_u8(t):
-        return torch.clamp((t * 0.5 + 0.5) * 255, 0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
 
-    return to_u8(frames), to_u8(semantics)
+def to_uint8_nhwc(images):
+    """[-1, 1] NCHW float -> uint8 NHWC numpy, the reference's conversion (:59-62): *0.5+0.5, *255, clamp, truncate."""
+    return (images * 0.5 + 0.5).mul(255).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+
+
+@torch.no_grad()
+def generate_frames(generator, preprocessor, config, seed, conditions, n_angles, angle_range_h, angle_range_v, back_and_forth):
+    """One frame per camera angle for the latent of `seed` -> (frames, rasterized_semantics), both uint8
+    [n_angles,H,W,3].  Same behaviour as the reference's generate_frames (apps/sample_from_generator.py:24-67; pinned by
+    tests/test_app.py against frames the reference function produced); the batch-1 conditions are reused per angle
+    instead of being replicated n_angles times up front."""
+    dev = generator.device
+    z = latent_for_seed(seed, config["latent_dim"]).to(dev)
+    base = {k: v[:1].to(dev) for k, v in conditions.items()}
+    pan, tilt = camera_sweep(n_angles, angle_range_h, angle_range_v, back_and_forth)
+    frames, semantics = [], []
+    for a_h, a_v in zip(pan.to(dev), tilt.to(dev)):
+        a_h, a_v = a_h.reshape(1, 1), a_v.reshape(1, 1)
+        view = preprocessor.forward_with_rotation(dict(base), a_h, a_v, torch.zeros_like(a_h), **config)
+        sem = view["rasterized_semantics"].clamp(-1, 1)
+        sem = torch.where((sem == 0).all(dim=1, keepdim=True), torch.ones_like(sem), sem)      # empty pixels -> white
+        semantics.append(sem)
+        frames.append(generator.staged_forward(z, view, **config)["rgbs"].clamp(-1, 1))
+    return to_uint8_nhwc(torch.cat(frames).float()), to_uint8_nhwc(torch.cat(semantics).float())
 
 
 def _save(path_stem, frames, mode):

@@ -14,15 +14,13 @@ void set_error(const char* fmt, ...) {
 }
 
 int compute_units() {
-    static int cached = 0;
-    if (cached) return cached;
+    static int cached[64] = {0};
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        cached = n;
-    else
-        cached = 256;
-    return cached;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c) return c;
+    c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return c;
 }
 
 }  // namespace h3d

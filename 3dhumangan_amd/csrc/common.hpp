@@ -34,7 +34,22 @@ constexpr int kWave = 64;   // CDNA wavefront
 
 __host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Number of CUs of the current device (cached per process; falls back to the MI355X value).
+// Number of CUs of the current device (cached per device; falls back to the MI355X value).
 int compute_units();
+
+// Function attributes are per device: raise the dynamic-LDS limit of `kernel` to the full 160 KB once per
+// (expansion site = kernel instantiation, device).  Idempotent, so a race between two host threads is harmless.
+#define H3D_ALLOW_MAX_LDS(kernel)                                                                         \
+    do {                                                                                                  \
+        static unsigned long long done_ = 0;                                                              \
+        int dev_ = 0;                                                                                     \
+        (void)hipGetDevice(&dev_);                                                                        \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                              \
+        if (!(done_ & bit_)) {                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+            done_ |= bit_;                                                                                \
+        }                                                                                                 \
+    } while (0)
 
 }  // namespace h3d

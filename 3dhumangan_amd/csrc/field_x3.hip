@@ -598,12 +598,7 @@ size_t lds_bytes(const LayoutX3& L) {
 
 template <int NT, bool FUSED>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(field_x3_kernel<NT, FUSED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED>));
     h3d::pre_launch();
     hipLaunchKernelGGL((field_x3_kernel<NT, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
     return h3d::launch_status(FUSED ? "h3d_render_fused_x3" : "h3d_neural_field_x3");

@@ -246,12 +246,7 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
     const int Vpad = (V + kChunk - 1) / kChunk * kChunk;
     const size_t lds = sizeof(float) * (3 * (size_t)Vpad + kJoints * 3 + 4);
     H3D_REQUIRE(lds <= 160 * 1024, "h3d_geo_features: mesh with V=%d vertices does not fit the 160 KB LDS", V);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(geo_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-        attr_set = true;
-    }
+    H3D_ALLOW_MAX_LDS(geo_features_kernel);
     const int64_t per_block = (int64_t)kThreads * kPts;
     const int64_t gx = (N + per_block - 1) / per_block;
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_geo_features: N too large");

@@ -87,10 +87,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* __restrict__ fi
     __syncthreads();
     for (int i = t; i < n; i += 256) {
         const float zi = zs[i];
+        const bool ni = zi != zi;
         int rank = 0;
+        // total order: by value, NaN after every number (as torch.sort), ties and NaNs by index -> ranks are always a
+        // permutation, so every output row is written even for NaN depths
         for (int j = 0; j < n; ++j) {
             const float zj = zs[j];
-            rank += (zj < zi || (zj == zi && j < i)) ? 1 : 0;
+            const bool nj = zj != zj;
+            const bool before = ni ? (!nj || j < i) : (!nj && (zj < zi || (zj == zi && j < i)));
+            rank += before ? 1 : 0;
         }
         src[rank] = i;
         out_z[ray * n + rank] = zi;

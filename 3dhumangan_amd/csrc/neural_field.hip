@@ -381,12 +381,7 @@ size_t lds_bytes(const Layout& L) {
 template <int NTW, bool FUSED>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
     const size_t lds = lds_bytes(A.L);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(field_kernel<NTW, FUSED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    H3D_ALLOW_MAX_LDS((field_kernel<NTW, FUSED>));
     h3d::pre_launch();
     hipLaunchKernelGGL((field_kernel<NTW, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(kFieldThreads), lds, st, A);
     return h3d::launch_status(FUSED ? "h3d_render_fused" : "h3d_neural_field");

@@ -263,12 +263,7 @@ size_t lds_bytes(int HdP) {
 
 template <int NTW>
 int launch_one(const Args& A, int B, int64_t tiles, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_kernel<NTW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    H3D_ALLOW_MAX_LDS((synthesis_kernel<NTW>));
     h3d::pre_launch();
     hipLaunchKernelGGL((synthesis_kernel<NTW>), dim3((unsigned)tiles, (unsigned)B), dim3(kFieldThreads), lds_bytes(A.HdP), st, A);
     return h3d::launch_status("h3d_synthesis");

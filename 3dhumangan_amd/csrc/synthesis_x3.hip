@@ -478,12 +478,7 @@ size_t lds_bytes(const Args& A, int NT, int depth) {
 
 template <int NT, int DEPTH, bool SEG>
 int launch_seg(const Args& A, int B, int64_t groups, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(synthesis_x3_kernel<NT, DEPTH, SEG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG>));
     h3d::pre_launch();
     hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG>), dim3((unsigned)groups, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH), st, A);

@@ -19,19 +19,23 @@ def get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, l
     """Same arguments and result as the reference function: points [B,N,3] -> [B,N,31].
 
     ``vertex_ik`` lets a caller that evaluates many point sets for one pose reuse the blended transforms."""
-    _lib.need_cuda(points, skeletons, vertices, tpose_vertices)
+    _lib.need_cuda(points, skeletons, vertices, tpose_vertices, fk_matrices, lbs_weights, vertex_ik)
     B, N, _ = points.shape
     V = vertices.shape[1]
     if vertex_ik is None:
         vertex_ik = vertex_inverse_transforms(fk_matrices, lbs_weights)
+    # every converted tensor is bound to a local: ptr() keeps only the address, so a temporary would be freed (and its
+    # block reused by the next same-sized temporary) before the kernel launches
     pts = points.contiguous().float()
+    sk = skeletons.contiguous().float()
+    vt = vertices.contiguous().float()
+    tv = tpose_vertices.contiguous().float()
+    vertex_ik = vertex_ik.contiguous().float()
     geo = torch.empty((B, N, out_stride), device=pts.device, dtype=torch.float32)
     if out_stride > GEO_DIM:
         geo[..., GEO_DIM:].zero_()
     idx = torch.empty((B, N), device=pts.device, dtype=torch.int32) if return_index else None
-    rc = _lib.load().h3d_geo_features(_lib.ptr(pts), _lib.ptr(skeletons.contiguous().float()),
-                                      _lib.ptr(vertices.contiguous().float()),
-                                      _lib.ptr(tpose_vertices.contiguous().float()), _lib.ptr(vertex_ik),
+    rc = _lib.load().h3d_geo_features(_lib.ptr(pts), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vertex_ik),
                                       _lib.ptr(geo), _lib.ptr(idx), B, N, V, out_stride, int(bool(legacy_mode)),
                                       _lib.stream_handle())
     _lib.check(rc, "h3d_geo_features")

@@ -29,6 +29,28 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
+def _consume_camera_rng(sample_dist, batch, device):
+    """The reference samples a camera position inside transform_sampled_points and throws it away (the camera comes
+    from the conditions): volume_rendering.py:141-143 -> sample_camera_positions (:182-221).  Only the RNG draws
+    survive, and they depend on ``sample_dist``; they are mirrored here so that the integration noise drawn afterwards
+    comes from the same place of the device RNG stream for every mode:
+      'uniform', 'spherical_uniform'   two rand  [B,1]
+      'normal', 'gaussian'             two randn [B,1]
+      'truncated_gaussian'             two normal_ [B,1,4]   (truncated_normal_, :173-180)
+      'hybrid'                         python's random.random() picks the rand or the randn pair
+      anything else (None)             no draw"""
+    if sample_dist in ("uniform", "spherical_uniform"):
+        torch.rand((batch, 1), device=device), torch.rand((batch, 1), device=device)
+    elif sample_dist in ("normal", "gaussian"):
+        torch.randn((batch, 1), device=device), torch.randn((batch, 1), device=device)
+    elif sample_dist == "hybrid":
+        import random
+        draw = torch.rand if random.random() < 0.5 else torch.randn
+        draw((batch, 1), device=device), draw((batch, 1), device=device)
+    elif sample_dist == "truncated_gaussian":
+        torch.empty((batch, 1, 4), device=device).normal_(), torch.empty((batch, 1, 4), device=device).normal_()
+
+
 class LatentPool(nn.Module):
     """reference lib/components/util.py:16-29."""
 
@@ -66,26 +88,36 @@ class MappingNetwork(nn.Module):
 
 
 class FullyConnectedLayer(nn.Module):
-    """StyleGAN equalised-lr FC layer (reference mapping_networks.py:92-121); bias+activation on the HIP op."""
+    """Equalised-learning-rate dense layer holding the parameters of the reference's FullyConnectedLayer
+    (mapping_networks.py:92-121: weight stored divided by lr_multiplier, raw bias; same state_dict keys).  Inference
+    form: the runtime gains are folded into an effective (W^T, b) pair once per weight version, the product is one
+    library GEMM and bias + activation go through the HIP bias_act op."""
 
     def __init__(self, in_features, out_features, bias=True, activation="linear", lr_multiplier=1, bias_init=0):
         super().__init__()
         self.activation = activation
-        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
-        self.bias = nn.Parameter(torch.full([out_features], float(bias_init))) if bias else None
-        self.weight_gain = lr_multiplier / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.randn(out_features, in_features) * (1.0 / lr_multiplier))
+        self.bias = nn.Parameter(torch.full((out_features,), float(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / math.sqrt(in_features)      # callers may rescale it (implicit branch: x0.2)
         self.bias_gain = lr_multiplier
+        self._folded = (None, None, None)
+
+    def folded(self):
+        """(W^T * weight_gain [in, out], b * bias_gain or None), rebuilt when a parameter or a gain changes."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight_gain, self.bias_gain,
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        if self._folded[0] != key:
+            wt = (self.weight.detach().float() * self.weight_gain).t().contiguous()
+            b = None if self.bias is None else self.bias.detach().float() * self.bias_gain
+            self._folded = (key, wt, b)
+        return self._folded[1], self._folded[2]
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == "linear" and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
-        return bias_act(x.matmul(w.t()), b, act=self.activation)
+        wt, b = self.folded()
+        y = x.float() @ wt
+        if self.activation == "linear":
+            return y if b is None else y + b
+        return bias_act(y, b, act=self.activation)
 
 
 class TwoPartMappingNetwork(nn.Module):
@@ -256,6 +288,7 @@ class Map3DGenerator(nn.Module):
         self.latent_pool = LatentPool(k["dataset_length"], k["latent_dim"])
         self.device = None
         self.avg_latent = None
+        self._avg_latent_key = None
         self._plan = None
         self._plan_key = None
         self.stage_timer = None          # set to _stages.StageTimer() to collect per-stage HIP-event timings
@@ -265,6 +298,11 @@ class Map3DGenerator(nn.Module):
         self.device = device
         self.neural_field.device = device
 
+    def _mapping_key(self):
+        """Identity + version of every mapping-network tensor: a cached avg_latent is only valid for these weights."""
+        return tuple((p.data_ptr(), p._version) for net in (self.neural_field_mapping_network, self.synthesis_mapping_network)
+                     for p in net.parameters())
+
     def generate_avg_latent(self):
         """Mean freq / phase / styles over 10 000 random latents (reference :182-194)."""
         z = torch.randn((10000, self.latent_dim), device=self.neural_field.device)
@@ -272,7 +310,15 @@ class Map3DGenerator(nn.Module):
         _, st = self.synthesis_mapping_network(z)
         self.avg_latent = (z.mean(dim=0, keepdim=True), fr.mean(dim=0, keepdim=True), ph.mean(dim=0, keepdim=True),
                            st.mean(dim=0, keepdim=True))
+        self._avg_latent_key = self._mapping_key()
         return self.avg_latent
+
+    def cached_avg_latent(self):
+        """The cached avg_latent if it was computed from the CURRENT mapping-network weights (load_state_dict, .to() or an
+        optimizer step invalidate it), else None."""
+        if self.avg_latent is not None and getattr(self, "_avg_latent_key", None) == self._mapping_key():
+            return self.avg_latent
+        return None
 
     @torch.no_grad()
     def get_geo_features(self, points, skeletons, vertices, tpose_vertices, fk_matrices, lbs_weights, **kw):
@@ -318,19 +364,18 @@ class Map3DGenerator(nn.Module):
         if hierarchical_sample:
             return self._render_hierarchical(freq, phase, conditions, render_width, render_height, ray_start, ray_end,
                                              int(coarse_steps), int(coarse_steps if fine_steps is None else fine_steps),
-                                             lock_view_dependence, jitter, noise, **kwargs)
+                                             lock_view_dependence, jitter, noise, sample_dist=sample_dist, **kwargs)
         c = conditions
         dev = freq.device
         B, S = freq.shape[0], int(coarse_steps)
         R = render_width * render_height
         focals = c["intrinsics"][:, 0, 0]
         scales = c["scales"].float()
-        # RNG order of the reference: jitter U(0,1) [B,R,S,1]; two unused randn [B,1]; integration noise randn
+        # RNG order of the reference: jitter U(0,1) [B,R,S,1]; the discarded camera sample; integration noise randn
         with stage(self, "ray_setup"):
             pts, z_vals = vr.sample_rays(focals, scales, c["cam2world_matrices"], S, (render_width, render_height),
                                          ray_start, ray_end, jitter=jitter, perturb=True)
-        if jitter is None:
-            torch.randn((B, 1), device=dev), torch.randn((B, 1), device=dev)      # sample_camera_positions, result unused
+        _consume_camera_rng(sample_dist, B, dev)
         nerf_noise = kwargs.get("nerf_noise", 0)
         if noise is None:
             drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24
@@ -361,7 +406,8 @@ class Map3DGenerator(nn.Module):
         return rgb_render, feats[..., 3:], depths, weights, None
 
     def _render_hierarchical(self, freq, phase, c, render_width, render_height, ray_start, ray_end, S, Sf,
-                             lock_view_dependence, jitter, noise, noise_coarse=None, fine_u=None, **kwargs):
+                             lock_view_dependence, jitter, noise, noise_coarse=None, fine_u=None, sample_dist=None,
+                             **kwargs):
         """reference :449-516: coarse pass -> compositing weights -> importance samples -> fine pass -> merge by depth ->
         integration over all samples.  The field tensors materialise here (unfused kernels); random tensors can be
         injected (jitter, noise_coarse [B,R,S,1], fine_u [B*R,Sf], noise [B,R,S+Sf,1]) or are drawn where the reference
@@ -374,8 +420,7 @@ class Map3DGenerator(nn.Module):
             pts, z_vals = vr.sample_rays(focals, scales, c["cam2world_matrices"], S, res, ray_start, ray_end, jitter=jitter,
                                          perturb=True)
             origins, ray_dirs = vr.ray_frame_world(focals, c["cam2world_matrices"], res)
-        if jitter is None:
-            torch.randn((B, 1), device=dev), torch.randn((B, 1), device=dev)      # sample_camera_positions, result unused
+        _consume_camera_rng(sample_dist, B, dev)
         nerf_noise = kwargs.get("nerf_noise", 0)
         clamp_mode = kwargs["clamp_mode"]
         scaler = 2.0 / self.side_length
@@ -425,7 +470,12 @@ class Map3DGenerator(nn.Module):
     @torch.no_grad()
     def forward(self, latent, conditions, render_height, render_width, latent_indices=None, **kwargs):
         """reference :208-280 -> {"rgbs", "rgbs_render"}"""
-        _lib.need_cuda(latent)
+        if not latent.is_cuda:
+            _lib.need_cuda(latent)
+        with torch.cuda.device(latent.device):          # kernels launch on the current device's stream
+            return self._forward(latent, conditions, render_height, render_width, latent_indices, **kwargs)
+
+    def _forward(self, latent, conditions, render_height, render_width, latent_indices=None, **kwargs):
         if kwargs.get("disable_render", False):
             raise NotImplementedError("disable_render=True is not set by any config and has no HIP path")
         num_steps = kwargs.get("num_steps", 24)
@@ -444,7 +494,12 @@ class Map3DGenerator(nn.Module):
     def staged_forward(self, latent, conditions, render_height, render_width, truncation_psi, **kwargs):
         """reference :282-378 -> {"rgbs", "rgbs_render", "depths" (CPU, as the reference), "skeletons"}.
         ``avg_latent=`` kwarg (or a cached self.avg_latent with cache_avg_latent=True) skips the 10 000-sample pass."""
-        _lib.need_cuda(latent)
+        if not latent.is_cuda:
+            _lib.need_cuda(latent)
+        with torch.cuda.device(latent.device):
+            return self._staged_forward(latent, conditions, render_height, render_width, truncation_psi, **kwargs)
+
+    def _staged_forward(self, latent, conditions, render_height, render_width, truncation_psi, **kwargs):
         if kwargs.get("disable_render", False):
             raise NotImplementedError("disable_render=True is not set by any config and has no HIP path")
         num_steps = kwargs.get("num_steps", 24)
@@ -453,8 +508,9 @@ class Map3DGenerator(nn.Module):
         if truncation_psi < 1.0:
             avg = kwargs.get("avg_latent")
             if avg is None:
-                avg = self.avg_latent if (kwargs.get("cache_avg_latent", False) and self.avg_latent is not None) \
-                    else self.generate_avg_latent()
+                avg = self.cached_avg_latent() if kwargs.get("cache_avg_latent", False) else None
+                if avg is None:
+                    avg = self.generate_avg_latent()
             az, af, ap, ast = avg
             fr = af + truncation_psi * (fr - af)
             ph = ap + truncation_psi * (ph - ap)

@@ -118,9 +118,12 @@ def style_mapping(state, z, prefix="synthesis_mapping_network", trunk_layers=7, 
 
 
 def ray_setup(focals, scales, cam2world, render_h, render_w, num_steps, ray_start, ray_end,
-              jitter=None, lock_view_dependence=True):
+              jitter=None, lock_view_dependence=True, ray_subset=None):
     """jitter: U(0,1) tensor [B,R,S,1] (the reference draws it at
     volume_rendering.py:126) or None for no perturbation.
+    ray_subset: optional LongTensor of ray indices r = y*render_w + x; only those rays are set up (every ray is
+    independent of the others, so this is the full computation restricted to rows of the result; the jitter tensor is
+    still the full-size one and is indexed here).  R below is then len(ray_subset).
     Returns points [B,R*S,3] (world), z_vals [B,R,S,1], dirs [B,R*S,3]."""
     B = focals.shape[0]
     dt = focals.dtype
@@ -131,6 +134,10 @@ def ray_setup(focals, scales, cam2world, render_h, render_w, num_steps, ray_star
     # row-major over (y, x): pixel r = y*W + x
     px = xs.repeat(render_h)                      # x varies fastest
     py = ys.repeat_interleave(render_w)
+    if ray_subset is not None:
+        px, py, R = px[ray_subset], py[ray_subset], int(ray_subset.numel())
+        if jitter is not None:
+            jitter = jitter[:, ray_subset]
     d = torch.stack([px.expand(B, R), py.expand(B, R), focals[:, None].expand(B, R)], dim=-1)
     d = d / (torch.norm(d, dim=-1, keepdim=True) + 1e-12)
     z = torch.linspace(ray_start, ray_end, num_steps, dtype=dt).view(1, 1, num_steps, 1)
@@ -371,13 +378,19 @@ def synthesis_network(state, x, feature_maps, fixed_style, map3d_mode="mixed", m
 # (lib/generators/map3d_generator.py:208-280, 282-378, 381-523)
 
 
-def render(state, cfg, freq, phase, cond, jitter, noise):
+def render(state, cfg, freq, phase, cond, jitter, noise, ray_subset=None):
+    """ray_subset: LongTensor of ray indices -> the same computation for those rays only; the image-shaped outputs
+    then come back as [B, C, 1, len(ray_subset)] (a one-row "image" over the chosen rays)."""
     hr, wr, S = cfg["render_height"], cfg["render_width"], cfg["num_steps"]
     focals = cond["intrinsics"][:, 0, 0]
     scales = cond["scales"].to(focals.dtype)
     pts, z_vals, dirs = ray_setup(focals, scales, cond["cam2world_matrices"], hr, wr, S,
                                   cfg["ray_start"], cfg["ray_end"], jitter,
-                                  cfg.get("lock_view_dependence", False))
+                                  cfg.get("lock_view_dependence", False), ray_subset)
+    if ray_subset is not None:
+        if noise is not None:
+            noise = noise[:, ray_subset]
+        hr, wr = 1, int(ray_subset.numel())
     geo = geo_features(pts, cond["skeletons_xyz"], cond["vertices"], cond["tpose_vertices"],
                        cond["fk_matrices"], cond["lbs_weights"], cfg.get("legacy_mode", False))
     field = neural_field(state, pts, freq, phase, geo, dirs, input_scaler=2.0 / cfg["side_length"],
@@ -495,6 +508,74 @@ def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, 
     if return_internal:
         out.update({k: v for k, v in syn.items() if k != "final"})
     return out
+
+
+def _resize_axis(n_in, n_out, dtype=torch.float32):
+    """Source taps of F.interpolate(mode='bilinear', align_corners=False) along one axis (same formula as
+    bilinear_resize above): i0, i1, t per destination index."""
+    dst = torch.arange(n_out, dtype=dtype)
+    src = ((dst + 0.5) * (n_in / n_out) - 0.5).clamp(min=0)
+    i0 = src.floor().long().clamp(max=n_in - 1)
+    i1 = (i0 + 1).clamp(max=n_in - 1)
+    return i0, i1, src - i0.to(dtype)
+
+
+def pixels_of_cells(cells, gen_hw, render_hw):
+    """Output pixels whose upper-left bilinear tap is one of the low-resolution cells [(cy, cx), ...] -> sorted
+    LongTensor of pixel indices p = Y*W + X.  Used to pick subsets that need only 4 rays per cell."""
+    (H, W), (Hr, Wr) = gen_hw, render_hw
+    y0, _, _ = _resize_axis(Hr, H)
+    x0, _, _ = _resize_axis(Wr, W)
+    pix = []
+    for cy, cx in cells:
+        ys = torch.nonzero(y0 == cy).flatten()
+        xs = torch.nonzero(x0 == cx).flatten()
+        if len(ys) and len(xs):
+            pix.append((ys[:, None] * W + xs[None, :]).flatten())
+    return torch.unique(torch.cat(pix)) if pix else torch.zeros(0, dtype=torch.long)
+
+
+def generator_forward_subset(state, cfg, z, cond, jitter, pixel_subset, noise=None, truncation=None):
+    """generator_forward restricted to the output pixels `pixel_subset` (LongTensor of p = Y*W + X, the same set for
+    every batch item).  The path is per-ray up to the rendered feature maps and per-pixel after the bilinear resize, so
+    this is the full computation on the rays / pixels the subset touches -- nothing is approximated; it exists so that
+    BASELINE-size workloads (B=16, 512^2, 96x96 rays x 64 samples ...) can be checked in seconds.  jitter / noise are the
+    FULL-size tensors.  -> dict(rgbs [B,3,P], rgbs_render [B,3,Rs], ray_subset [Rs] (sorted ray indices the pixels
+    need), raw_depth [B,Rs,1], weights [B,Rs,S,1], feature_maps [B,F,Rs])."""
+    B = z.shape[0]
+    H, W = cfg["gen_height"], cfg["gen_width"]
+    Hr, Wr = cfg["render_height"], cfg["render_width"]
+    dt = z.dtype if z.dtype == torch.float64 else torch.float32
+    Y, X = pixel_subset // W, pixel_subset % W
+    y0, y1, ty = _resize_axis(Hr, H, dt)
+    x0, x1, tx = _resize_axis(Wr, W, dt)
+    taps = torch.stack([y0[Y] * Wr + x0[X], y0[Y] * Wr + x1[X], y1[Y] * Wr + x0[X], y1[Y] * Wr + x1[X]])   # [4,P]
+    rays = torch.unique(taps)
+    pos = torch.searchsorted(rays, taps)                                                                      # [4,P]
+    zin = z if cfg.get("neural_field_latent_input", True) else torch.zeros_like(z)
+    freq, phase = film_mapping(state, zin)
+    _, styles = style_mapping(state, z)
+    if truncation is not None:
+        psi, _, af, ap, ast = truncation
+        freq = af + psi * (freq - af)
+        phase = ap + psi * (phase - ap)
+        styles = ast + psi * (styles - ast)
+    rgb_render, fmap, depth, w, _ = render(state, cfg, freq, phase, cond, jitter, noise, ray_subset=rays)
+    fm = fmap[:, :, 0, :]                                                                                     # [B,F,Rs]
+    txp, typ = tx[X], ty[Y]
+    top = fm[:, :, pos[0]] * (1 - txp) + fm[:, :, pos[1]] * txp
+    bot = fm[:, :, pos[2]] * (1 - txp) + fm[:, :, pos[3]] * txp
+    fmap_up = (top * (1 - typ) + bot * typ).unsqueeze(-1)                                                     # [B,F,P,1]
+    # A8 at the chosen pixels (synthesis_input restricted to rows of the coordinate grid)
+    ii = torch.linspace(-1, 1, H, dtype=dt)[Y]
+    jj = torch.linspace(-1, 1, W, dtype=dt)[X]
+    coords = torch.stack([ii, jj], dim=0)[None, :, :, None].expand(B, 2, len(pixel_subset), 1)
+    x0in = torch.sin(F.conv2d(coords, state["synthesis_input.network.0.weight"].to(dt),
+                              state["synthesis_input.network.0.bias"].to(dt)))
+    syn = synthesis_network(state, x0in, fmap_up, styles, cfg.get("map3d_mode", "isolated"),
+                            tuple(cfg["mod_blocks"]), cfg["synthesis_blocks"])
+    return dict(rgbs=syn["final"][..., 0], rgbs_render=rgb_render[:, :, 0, :], ray_subset=rays, raw_depth=depth,
+                weights=w, feature_maps=fm, styles=styles, freq=freq, phase=phase)
 
 
 # --------------------------------------------------------------------------

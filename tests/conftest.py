@@ -53,3 +53,15 @@ def h3d():
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_err_channels(a, b, dim=1):
+    """max over channels (dimension `dim`) of max|a-b| / max|b| within the channel: a low-magnitude channel cannot hide
+    behind a large one, unlike the single max-norm of rel_err."""
+    a, b = a.double().transpose(0, dim).flatten(1), b.double().transpose(0, dim).flatten(1)
+    return float(((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).max())
+
+
+def rel_err_rms(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).square().mean().sqrt() / b.square().mean().sqrt().clamp_min(1e-30))

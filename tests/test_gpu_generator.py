@@ -163,3 +163,41 @@ def test_rng_is_consumed_like_the_reference():
     a2 = G.forward(z, c, **cfg)["rgbs"]
     assert not torch.equal(a, b)
     assert torch.equal(a, a2)
+
+
+@pytest.mark.parametrize("dist,draws", [("gaussian", "randn"), ("uniform", "rand"), (None, "none"), ("truncated_gaussian", "normal4")])
+def test_camera_rng_draws_follow_sample_dist(dist, draws):
+    """The integration noise must come from the same place of the device RNG stream as in the reference, whose discarded
+    camera sample draws differently per sample_dist (volume_rendering.py:182-221)."""
+    g = load_golden("gen_tiny_mixed")
+    G, cfg = build(g["meta"], g["state"])
+    cfg = dict(cfg, nerf_noise=1.0, sample_dist=dist)
+    z, c = g["z"].to(DEV), cond_to(g["cond"])
+    B, R, S = z.shape[0], cfg["render_height"] * cfg["render_width"], cfg["num_steps"]
+    torch.manual_seed(7)
+    got = G.forward(z, c, **cfg)["rgbs_render"]
+    torch.manual_seed(7)
+    jit = torch.rand((B, R, S, 1), device=DEV)
+    if draws == "randn":
+        torch.randn((B, 1), device=DEV), torch.randn((B, 1), device=DEV)
+    elif draws == "rand":
+        torch.rand((B, 1), device=DEV), torch.rand((B, 1), device=DEV)
+    elif draws == "normal4":
+        torch.empty((B, 1, 4), device=DEV).normal_(), torch.empty((B, 1, 4), device=DEV).normal_()
+    noise = torch.randn((B, R, S, 1), device=DEV) * 1.0
+    want = G.forward(z, c, jitter=jit, noise=noise, **cfg)["rgbs_render"]
+    assert torch.equal(got, want)
+
+
+def test_avg_latent_cache_is_invalidated_by_new_weights():
+    g = load_golden("gen_tiny_mixed")
+    G, cfg = build(g["meta"], g["state"])
+    torch.manual_seed(1)
+    a = G.generate_avg_latent()
+    assert G.cached_avg_latent() is a
+    with torch.no_grad():
+        G.neural_field_mapping_network.network[0].weight.mul_(1.5)
+    assert G.cached_avg_latent() is None
+    G.generate_avg_latent()
+    G.load_state_dict(g["state"], strict=True)
+    assert G.cached_avg_latent() is None

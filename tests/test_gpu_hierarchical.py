@@ -60,6 +60,21 @@ def test_merge_samples_vs_torch(B, R, Sf, Sc, C1):
     assert torch.equal(out_z.cpu(), ref_z) and torch.equal(out.cpu(), ref)      # pure data movement: bit-exact
 
 
+def test_merge_samples_with_nan_depths_is_a_permutation():
+    """NaN depths (e.g. from NaN weights reaching sample_pdf) sort last, by index, exactly like torch.sort(stable=True):
+    every output row is written."""
+    g = torch.Generator().manual_seed(9)
+    fine, coarse = torch.randn(1, 4, 8, 12, generator=g), torch.randn(1, 4, 8, 12, generator=g)
+    fz, cz = torch.rand(1, 4, 8, 1, generator=g) + 10, torch.rand(1, 4, 8, 1, generator=g) + 10
+    fz[0, 1, 2] = float("nan"); fz[0, 1, 5] = float("nan"); cz[0, 1, 0] = float("nan"); cz[0, 3, :] = float("nan")
+    all_out, all_z = torch.cat([fine, coarse], dim=-2), torch.cat([fz, cz], dim=-2)
+    _, idx = torch.sort(all_z, dim=-2, stable=True)
+    ref = torch.gather(all_out, -2, idx.expand(-1, -1, -1, 12))
+    out, out_z = vr.merge_samples(fine.to(DEV), coarse.to(DEV), fz.to(DEV), cz.to(DEV))
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(torch.isnan(out_z.cpu()), torch.isnan(torch.gather(all_z, -2, idx)))
+
+
 def test_ray_points():
     g = torch.Generator().manual_seed(3)
     o, d, z = torch.randn(2, 3, generator=g), torch.randn(2, 11, 3, generator=g), torch.rand(2, 11, 6, 1, generator=g) + 10

@@ -136,6 +136,23 @@ def test_geo_features_vs_oracle(V, N):
     _geo_check(pts, cond, False)
 
 
+def test_geo_features_fp64_and_non_contiguous_conditions():
+    """Conditions that need a conversion (fp64, expanded / strided views): the converted copies must outlive the launch
+    (round-1 advisor finding: temporaries freed before the kernel ran could alias each other)."""
+    cond = synthetic.make_conditions(2, n_vertices=777, seed=4)
+    pts = (torch.rand(2, 300, 3, generator=torch.Generator().manual_seed(1)) - 0.5) * torch.tensor([1.8, 2.4, 1.0])
+    ref = O.geo_features(pts, cond["skeletons_xyz"], cond["vertices"], cond["tpose_vertices"], cond["fk_matrices"],
+                         cond["lbs_weights"])
+    c = dev_dict(cond)
+    # same-sized temporaries: vertices and tpose_vertices both fp64, skeletons a strided view, points transposed storage
+    wide = torch.zeros(2, 24, 6, device=DEV)
+    wide[..., ::2] = c["skeletons_xyz"]
+    got = smpl.get_geo_features(dev(pts).transpose(1, 2).contiguous().transpose(1, 2), wide[..., ::2],
+                                c["vertices"].double(), c["tpose_vertices"].double(), c["fk_matrices"].double(),
+                                c["lbs_weights"].double())
+    assert rel_err(got.cpu(), ref) < 1e-5
+
+
 def test_geo_features_exact_ties_pick_first_vertex():
     cond = synthetic.make_conditions(1, n_vertices=64, seed=0, pose_scale=0.0)
     cond["vertices"][0, 10] = cond["vertices"][0, 3]          # duplicate vertex: 3 must win

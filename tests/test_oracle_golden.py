@@ -154,3 +154,28 @@ def test_hierarchical_forward():
                               hier=dict(noise_coarse=g["noise_coarse"], u=g["u"]))
     assert rel_err(out["rgbs_render"], g["out"]["rgbs_render"]) < 2e-5
     assert rel_err(out["rgbs"], g["out"]["rgbs"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", GEN_FIXTURES)
+def test_subset_oracle_matches_reference_vectors(name):
+    """generator_forward_subset (the restriction used to check BASELINE-size workloads in seconds) against the SAME
+    vectors captured from the reference, at the pixels / rays it selects -- so the subset path is pinned, not just the
+    full one."""
+    g = load_golden(name)
+    cfg = _cfg(g)
+    H, W, Hr, Wr = cfg["gen_height"], cfg["gen_width"], cfg["render_height"], cfg["render_width"]
+    cells = [(0, 0), (Hr - 1, Wr - 1), (Hr // 2, Wr // 2), (0, Wr - 1), (Hr - 1, 0)]       # corners: clamped taps
+    pix = O.pixels_of_cells(cells, (H, W), (Hr, Wr))
+    assert 0 < len(pix) < H * W
+    sub = O.generator_forward_subset(g["state"], cfg, g["z"], g["cond"], g["jitter"], pix, g["noise"])
+    ref_rgb = g["out"]["rgbs"].flatten(2)[:, :, pix]
+    ref_ren = g["out"]["rgbs_render"].flatten(2)[:, :, sub["ray_subset"]]
+    assert rel_err(sub["rgbs"], ref_rgb) < 5e-5
+    assert rel_err(sub["rgbs_render"], ref_ren) < 5e-5
+    # and every pixel of the image, in two halves, reproduces the full oracle to rounding
+    full = O.generator_forward(g["state"], cfg, g["z"], g["cond"], g["jitter"], g["noise"])
+    allpix = torch.arange(H * W)
+    for part in (allpix[: H * W // 2], allpix[H * W // 2:]):
+        s2 = O.generator_forward_subset(g["state"], cfg, g["z"], g["cond"], g["jitter"], part, g["noise"])
+        assert rel_err(s2["rgbs"], full["rgbs"].flatten(2)[:, :, part]) < 2e-6
+        assert rel_err(s2["raw_depth"], full["raw_depth"][:, s2["ray_subset"]]) < 1e-6
