@@ -1,0 +1,242 @@
+// Split-operand ("x3") matrix-core engine with the activations of a 64-sample tile resident in LDS ("x3t"), gfx950.
+//
+// Why a second x3 engine: x3_common.hpp keeps a sample's activations in the registers of ONE lane (a wave owns 32
+// samples and all channels), which needs 2 x C accumulator registers per lane and stops at C = 256.  Here the N
+// (output feature) dimension is split over the four waves of a workgroup instead, so the width is bounded by LDS, not
+// by registers (C <= 448 with 64 samples per workgroup): MAP3DBN (384) and MAP3DBN512L (420, the released checkpoint's
+// architecture) run on the f16/bf16 matrix cores instead of the 16x slower fp32 ones.
+//
+//   arithmetic   x = hi + lo (f16 for the field, bf16 for the synthesis network), product = hi*hi + hi*lo + lo*hi on
+//                v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulation -- identical to x3_common.hpp.
+//   dataflow     D[feature][sample] = W[feature][k] * X[k][sample]: weights are the A operand and come straight from
+//                L2 in A-fragment order (each wave streams only the tiles it owns, four k-steps ahead, in registers);
+//                activations are the B operand and live in LDS as ready-made hi / lo B fragments
+//                    actT[mt][ks][plane][64 lanes][8 x 16 bit]          (2 KB per sample tile mt and k-step ks)
+//                shared by the four waves (one ds_read_b128 per fragment, conflict-free).
+//   K order      the accumulator registers a lane holds for feature tile t are, in order, the B-fragment elements of
+//                k-steps 2t and 2t+1 ("accumulator order", the same permutation as x3_common.hpp):
+//                    feature(ks, h, e) = 32*(ks/2) + (e & 3) + 8*(2*(ks & 1) + (e >> 2)) + 4*h
+//                so the epilogue of a unit writes its fragments with two lane-local ds_write_b128 per plane, no
+//                transposition; the host packs the K dimension of every matrix fed that way accordingly.  Matrices
+//                fed from memory (coordinates, geometry features, view direction, shared-MLP activations) use the
+//                natural order k = 16*ks + 8*h + e.
+//   work split   a *unit* is (feature tile nt, sample tile mt).  Wave w owns the full tiles nt = w, w+4, .. (< 4*NTF)
+//                for both sample tiles and, when the tile count is 4*NTF + 2, one extra unit
+//                (nt = 4*NTF + (w >> 1), mt = w & 1): 2*NTF + NX accumulator tiles per wave, perfectly balanced for the
+//                even tile counts the hosts pad to (12 for width 384, 14 for 420).
+#pragma once
+#include "x3_common.hpp"
+#include <string.h>
+
+namespace h3d {
+
+constexpr int kX3tMT = 2;            // sample tiles (of 32) per workgroup
+constexpr int kX3tDepth = 4;         // weight k-steps in flight per wave (register ring)
+
+// byte offset of fragment plane (mt, ks, plane) inside an activation tile with KS k-steps per sample tile
+__device__ __forceinline__ int x3t_frag(int KS, int mt, int ks, int plane) { return ((mt * KS + ks) * 2 + plane) * 1024; }
+
+__host__ __device__ inline int x3t_acc_k(int ks, int hh, int e) { return 32 * (ks / 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh; }
+
+// Which units a wave owns.
+template <int NTF, int NX>
+struct X3tUnits {
+    static constexpr int NU = 2 * NTF + NX;       // accumulator tiles per wave
+    static constexpr int NA = NTF + NX;           // weight tiles per wave and k-step
+    int nt[NA];                                   // feature tile of weight slot i (slot NTF = the extra unit's)
+    int xmt;                                      // sample tile of the extra unit
+    __device__ __forceinline__ void init(int wave) {
+#pragma unroll
+        for (int i = 0; i < NTF; ++i) nt[i] = wave + 4 * i;
+        if (NX) nt[NTF] = 4 * NTF + (wave >> 1);
+        xmt = wave & 1;
+    }
+    // unit u -> (weight slot, sample tile): u = 2*i + mt for the full tiles, u = 2*NTF for the extra unit
+    static __device__ __forceinline__ constexpr int slot(int u) { return u < 2 * NTF ? u / 2 : NTF; }
+    __device__ __forceinline__ int tile(int u) const { return nt[slot(u)]; }
+    __device__ __forceinline__ int mt(int u) const { return u < 2 * NTF ? (u & 1) : xmt; }
+};
+
+// acc[u] += W(tile(u), ks) x X(mt(u), ks), ks = 0 .. KS-1 (KS a multiple of kX3tDepth, or <= kX3tDepth).
+//   bT     LDS: fragment plane (mt 0, first k-step of this phase, hi); sample tiles are mt_stride bytes apart
+//   W      global: A fragments [tile][KStot][plane][64][16 B]; this phase uses k-steps ks0 .. ks0+KS-1 of every tile
+//   SWAP   D[sample][feature] instead (activations as the A operand): used by the feature head of the fused render,
+//          where the weighted sum over the samples of a ray becomes a sum over accumulator registers.
+// Register ring: the A fragments of k-step s+3 are requested before the MFMAs of k-step s (four k-steps in flight,
+// ~2000 matrix-pipe cycles: an L2 miss served by the Infinity Cache is covered), B fragments one k-step ahead.
+// GUARD: the phase may be shorter than the ring (input layers with 1 or 2 k-steps): every slot is predicated.
+template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false>
+__device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsigned char* bT, int mt_stride,
+                                         const unsigned char* __restrict__ W, int KStot, int ks0, int KS,
+                                         const X3tUnits<NTF, NX>& U, int lane) {
+    constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
+    struct AF { u32x4 h[NA], l[NA]; };
+    struct BF { u32x4 h[2], l[2], xh, xl; };
+    const u32x4* wp[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+        wp[i] = reinterpret_cast<const u32x4*>(W + ((int64_t)U.nt[i] * KStot + ks0) * 2048) + lane;
+    const unsigned char* bp = bT + lane * 16;
+    const unsigned char* bx = bp + U.xmt * mt_stride;
+    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f.h[i] = wp[i][(ks * 2 + 0) * 64];
+            f.l[i] = wp[i][(ks * 2 + 1) * 64];
+        }
+    };
+    auto loadB = [&](BF& f, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (NTF > 0) {
+                f.h[mt] = *reinterpret_cast<const u32x4*>(bp + mt * mt_stride + ks * 2048);
+                f.l[mt] = *reinterpret_cast<const u32x4*>(bp + mt * mt_stride + ks * 2048 + 1024);
+            }
+        }
+        if (NX) {
+            f.xh = *reinterpret_cast<const u32x4*>(bx + ks * 2048);
+            f.xl = *reinterpret_cast<const u32x4*>(bx + ks * 2048 + 1024);
+        }
+    };
+    auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {
+        // three passes (hi*hi, hi*lo, lo*hi) over all units: consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int s = u < 2 * NTF ? u / 2 : NTF;
+                const u32x4 wv = p == 2 ? a.l[s] : a.h[s];
+                const u32x4 xv = u < 2 * NTF ? (p == 1 ? b.l[u & 1] : b.h[u & 1]) : (p == 1 ? b.xl : b.xh);
+                acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
+            }
+        }
+    };
+    AF a[D];
+    BF b[2];
+    const int last = KS - 1;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) loadA(a[d], d < last ? d : last);
+    loadB(b[0], 0);
+    for (int ks = 0; ks < KS; ks += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (!GUARD || ks + d < KS) {             // uniform; full phases have KS % D == 0 and no branch at all
+                const int ka = ks + d + D - 1, kb = ks + d + 1;
+                loadA(a[(d + D - 1) % D], ka < last ? ka : last);      // beyond the end: a harmless re-read
+                loadB(b[(d + 1) & 1], kb < last ? kb : last);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a[d], b[d & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// Epilogue of one unit: y = f(rg, values of register group rg) for the four register groups of the accumulator tile
+// (rg -> features 32*nt + 8*rg + 4*h + 0..3 of this lane's sample), split into hi / lo and written as the B fragments of
+// k-steps 2*nt, 2*nt+1 of sample tile mt.  SPLIT(a, b, lo) -> packed hi halves.
+template <typename SPLIT, typename F>
+__device__ __forceinline__ void x3t_store_unit(const f32x16& v, unsigned char* actT, int KS, int nt, int mt, int lane, SPLIT split, F f) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rg = 2 * j + q;
+            const f32x4 y = f(rg, f32x4{v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]});
+            unsigned l0, l1;
+            hi[2 * q + 0] = split(y[0], y[1], l0);
+            hi[2 * q + 1] = split(y[2], y[3], l1);
+            lo[2 * q + 0] = l0;
+            lo[2 * q + 1] = l1;
+        }
+        unsigned char* p = actT + x3t_frag(KS, mt, 2 * nt + j, 0) + lane * 16;
+        *reinterpret_cast<u32x4*>(p) = hi;
+        *reinterpret_cast<u32x4*>(p + 1024) = lo;
+    }
+}
+
+struct SplitF16 {
+    __device__ __forceinline__ unsigned operator()(float a, float b, unsigned& lo) const {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const h2 hv = __builtin_convertvector(f2{a, b}, h2);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a - (float)hv.x, b - (float)hv.y}, h2));
+        return __builtin_bit_cast(unsigned, hv);
+    }
+};
+struct SplitBF16 {
+    __device__ __forceinline__ unsigned operator()(float a, float b, unsigned& lo) const { return split2_bf16(a, b, lo); }
+};
+
+// value of element e of a fragment word pair (hi + lo), as fp32
+__device__ __forceinline__ float x3t_f16_sum(unsigned hw, unsigned lw, int half) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, hw), b = __builtin_bit_cast(h2, lw);
+    return half ? (float)a.y + (float)b.y : (float)a.x + (float)b.x;
+}
+__device__ __forceinline__ float x3t_bf16_sum(unsigned hw, unsigned lw, int half) {
+    const unsigned a = half ? (hw & 0xffff0000u) : (hw << 16), b = half ? (lw & 0xffff0000u) : (lw << 16);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
+// ---- host-side packing (shared by field_x3t.hip; the synthesis side packs with torch, same layout) ------------------
+
+inline uint16_t x3t_f32_to_f16_rn(float f) {            // round-to-nearest-even, handles subnormals; inputs are finite
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7bffu);
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - (int)(x >> 23);
+        uint32_t r = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+inline float x3t_f16_to_f32(uint16_t v) {
+    const uint32_t sign = (uint32_t)(v & 0x8000u) << 16;
+    uint32_t e = (v >> 10) & 0x1f, m = v & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int s = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++s; }
+            x = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// W [n_out, ld] row-major, K range [in_begin, in_begin + in_count) -> A fragments [NT][KStot][2][64][8] f16 (scaled),
+// written into k-steps ks0 .. ks0+KSm-1 of every tile.
+inline void x3t_pack_f16(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int KStot, int ks0, int KSm,
+                         float scale, uint16_t* dst, bool acc_order) {
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KSm; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int k = acc_order ? x3t_acc_k(ks, lane >> 5, e) : 16 * ks + 8 * (lane >> 5) + e;
+                    const int nn = 32 * nt + (lane & 31);
+                    float v = 0.f;
+                    if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+                    const uint16_t hi = x3t_f32_to_f16_rn(v);
+                    const uint16_t lo = x3t_f32_to_f16_rn(v - x3t_f16_to_f32(hi));
+                    const int64_t base = (((int64_t)nt * KStot + ks0 + ks) * 2) * 64 * 8;
+                    dst[base + lane * 8 + e] = hi;
+                    dst[base + 64 * 8 + lane * 8 + e] = lo;
+                }
+}
+
+}  // namespace h3d

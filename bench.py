@@ -106,7 +106,10 @@ def kernel_rooflines(G, cfg, batch, stage_ms):
                                           dict(reference_formulation_TFLOPs=reference_form / ms / 1e9))
     if "geo_features" in stage_ms:
         ms = stage_ms["geo_features"][0]
-        out["h3d_geo_features"] = dict(bound="valu", ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3)
+        by = pts * (3 + 31) * 4.0 + batch * 6890 * (3 + 3 + 16) * 4.0            # points in, features out, mesh once
+        out["h3d_geo_features"] = dict(bound="valu+mfma (6890 point-vertex pairs per sample); HBM figures for reference",
+                                       ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3, bytes=by,
+                                       hbm_achieved_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS)
     return out
 
 
@@ -148,7 +151,7 @@ def ray_integrate_roofline(cfg, batch, iters=10):
 def load_traffic(workload_key):
     """{kernel: HBM bytes per launch} from the newest profiles/*_hbm_traffic.json measured on this workload."""
     import glob
-    best = {}
+    best, src = {}, None
     for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic.json"))):
         try:
             d = json.load(open(f))
@@ -156,35 +159,147 @@ def load_traffic(workload_key):
             continue
         if d.get("workload") == workload_key:
             best = {k: v["bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
-    return best
+            src = "profiles/" + os.path.basename(f)
+    return best, src
 
 
-def cpu_baseline(cfg, sd, seed=1234, shrink=2):
-    """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores.
-    Bounded sample: ONE image at 1/shrink of the height and width (output pixels, rays) with the same samples per
-    ray, widths and weights -- per-ray and per-pixel work is identical and the total is linear in both counts, so
-    the full-size rate is the measured one divided by shrink^2."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_run(cfg, sd, batch, seed, runs):
+    """1 warm-up + `runs` timed oracle forwards of `batch` images -> [seconds]."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import h3d_oracle as O
     synthetic = importlib.import_module("3dhumangan_amd.synthetic")
-    torch.set_num_threads(min(64, os.cpu_count() or 1))      # more threads than this only adds contention
     g = torch.Generator().manual_seed(seed)
+    cond = synthetic.make_conditions(batch, 6890, seed=seed % 1000)
+    z = torch.randn(batch, cfg["latent_dim"], generator=g)
+    jit = torch.rand(batch, cfg["render_height"] * cfg["render_width"], cfg["num_steps"], 1, generator=g)
+    times = []
+    with torch.no_grad():
+        for i in range(runs + 1):
+            t0 = time.perf_counter()
+            O.generator_forward(sd, cfg, z, cond, jit, None)
+            if i:
+                times.append(time.perf_counter() - t0)
+    return times
+
+
+def cpu_baseline(cfg, sd, seed=1234, shrink=2, runs=3):
+    """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores.
+    Bounded sample of the SAME workload: one image at 1/shrink of the height and width (output pixels, rays) with the
+    same samples per ray, widths and weights -- per-ray and per-pixel work is identical and the total is linear in
+    both counts, so the full-size rate is the measured one divided by shrink^2.  1 warm-up + `runs` timed runs, median."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))      # more threads than this only adds contention
     ocfg = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
     for k in ("gen_height", "gen_width", "render_height", "render_width"):
         ocfg[k] = max(1, cfg[k] // shrink)
-    cond = synthetic.make_conditions(1, 6890, seed=seed % 1000)
-    z = torch.randn(1, cfg["latent_dim"], generator=g)
-    jit = torch.rand(1, ocfg["render_height"] * ocfg["render_width"], cfg["num_steps"], 1, generator=g)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        O.generator_forward(sd, ocfg, z, cond, jit, None)
-    dt = time.perf_counter() - t0
+    times = sorted(_oracle_run(ocfg, sd, 1, seed, runs))
+    dt = times[len(times) // 2]
     full = dt * shrink * shrink
-    return dict(value=1.0 / full, unit="images/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=1.0 / full, unit="images/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+                host_cores=os.cpu_count(), torch=torch.__version__, runs=[round(t, 2) for t in times],
                 sample=f"1 image at 1/{shrink} linear size ({ocfg['gen_height']}x{ocfg['gen_width']} px, "
-                       f"{ocfg['render_height']}x{ocfg['render_width']} rays x {cfg['num_steps']} samples, same widths) "
-                       f"took {dt:.1f} s -> {full:.0f} s per full-size image (work is linear in rays and pixels); "
-                       "pure-PyTorch CPU oracle, brute-force nearest-vertex search")
+                       f"{ocfg['render_height']}x{ocfg['render_width']} rays x {cfg['num_steps']} samples, same widths): "
+                       f"1 warm-up + {runs} timed runs, median {dt:.1f} s -> {full:.0f} s per full-size image (work is "
+                       "linear in rays and pixels); pure-PyTorch CPU oracle, brute-force nearest-vertex search")
+
+
+def cpu_baseline_cfg1(runs=3):
+    """BASELINE config 1 on the host cores, FULL size: MAP3DBN (hidden 384), one 256x128 image from 64x32 rays x 32
+    samples (the reference-native '256^2'); 1 warm-up + `runs` timed runs of the oracle, images/s = 1 / median."""
+    configs = importlib.import_module("3dhumangan_amd.configs")
+    gens = importlib.import_module("3dhumangan_amd.lib.generators")
+    impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+    cfg = {k: v for k, v in configs.MAP3DBN.items() if isinstance(k, str)}
+    cfg.update(dataset_length=4, nerf_noise=0, last_back=cfg["eval_last_back"])
+    torch.manual_seed(1234)
+    G = gens.Map3DGenerator(**dict(cfg, neural_field_cls=impl.COORDCONCATSIREN)).eval()
+    sd = {k: v.detach() for k, v in G.state_dict().items()}
+    cfg.pop("neural_field_cls", None)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    times = sorted(_oracle_run(cfg, sd, 1, 1234, runs))
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit="images/s", cores=torch.get_num_threads(), kind="port", runs=[round(t, 2) for t in times],
+                sample=f"MAP3DBN 256x128, 64x32 rays x 32, batch 1, full size: 1 warm-up + {runs} timed runs")
+
+
+def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
+    """Correctness of what was timed: one more forward of the SAME batch, compared with the CPU oracle restricted to a
+    subset of pixels / rays (oracle/h3d_oracle.py: generator_forward_subset) for a few batch items."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import h3d_oracle as O
+    out = G.forward(z, cond, jitter=jitter, **cfg)
+    rgb, ren = out["rgbs"].cpu(), out["rgbs_render"].cpu()
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    ocfg = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+    Hr, Wr = cfg["render_height"], cfg["render_width"]
+    g = torch.Generator().manual_seed(seed)
+    cells = [(0, 0), (Hr - 1, Wr - 1), (Hr // 2, Wr // 2)] + list(zip(torch.randint(0, Hr, (n_cells,), generator=g).tolist(),
+                                                                      torch.randint(0, Wr, (n_cells,), generator=g).tolist()))
+    pix = O.pixels_of_cells(cells, (cfg["gen_height"], cfg["gen_width"]), (Hr, Wr))
+    worst, worst_r, rays = 0.0, 0.0, 0
+    zc, jc = z.cpu(), jitter.cpu()
+    for i in items:
+        ci = {k: v[i:i + 1].cpu() for k, v in cond.items()}
+        ref = O.generator_forward_subset(sd, ocfg, zc[i:i + 1], ci, jc[i:i + 1], pix)
+        got = rgb[i:i + 1].flatten(2)[:, :, pix]
+        got_r = ren[i:i + 1].flatten(2)[:, :, ref["ray_subset"]]
+        for c in range(3):
+            worst = max(worst, float((got[:, c] - ref["rgbs"][:, c]).abs().max() / ref["rgbs"][:, c].abs().max()))
+            worst_r = max(worst_r, float((got_r[:, c] - ref["rgbs_render"][:, c]).abs().max() / ref["rgbs_render"][:, c].abs().max()))
+        rays = len(ref["ray_subset"])
+    return dict(max_rel_err=worst, max_rel_err_render=worst_r, tolerance=1e-3, ok=bool(worst < 1e-3 and worst_r < 1e-3),
+                batch_items=list(items), pixels=int(len(pix)), rays=int(rays),
+                against="CPU oracle on a pixel/ray subset (per-channel max-norm); oracle pinned to the reference's vectors")
+
+
+def op_rooflines():
+    """HBM rooflines of the stand-alone HBM-bound ops: algorithmic bytes (inputs + outputs once) / time."""
+    L = importlib.import_module("3dhumangan_amd._lib")
+    ba = importlib.import_module("3dhumangan_amd.lib.components.ops.bias_act")
+    uf = importlib.import_module("3dhumangan_amd.lib.components.ops.upfirdn2d")
+    rs = importlib.import_module("3dhumangan_amd.lib.components.resample")
+
+    def timeit(fn, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    def entry(by, ms, shape):
+        return dict(bound="hbm", achieved=by / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / ms / 1e6 / HBM_PEAK_GBS,
+                    ms=ms, bytes=by, shape=shape, note="time includes the wrapper's output allocation")
+
+    out = {}
+    x = torch.randn(8, 256, 512, 256, device="cuda")
+    b = torch.randn(256, device="cuda")
+    out["h3d_bias_act"] = entry(2.0 * x.numel() * 4, timeit(lambda: ba.bias_act(x, b, act="lrelu")), "lrelu [8,256,512,256] f32")
+    del x
+    x = torch.randn(8, 64, 256, 256, device="cuda")
+    f = uf.setup_filter([1, 3, 3, 1], device="cuda")
+    y = uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)
+    out["h3d_upfirdn2d"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)),
+                                 "2x up, [1,3,3,1], [8,64,256,256] -> [8,64,512,512] f32")
+    del x, y
+    x = torch.randn(4, 256, 96, 96, device="cuda")
+    y = rs.bilinear_resize(x, (512, 512))
+    out["h3d_bilinear_resize"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: rs.bilinear_resize(x, (512, 512))),
+                                       "[4,256,96,96] -> [4,256,512,512] f32")
+    return out
 
 
 def main():
@@ -199,6 +314,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -243,8 +359,10 @@ def main():
     roof["kernel"] = dominant
     # HBM traffic per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate passes,
     # corrected as MI355X_MICROARCH.md prescribes); only valid for the workload it was measured on.
-    traffic = load_traffic(f"{a.config}_{H}x{W}_b{a.batch}_s{a.samples}")
+    traffic, traffic_file = load_traffic(f"{a.config}_{H}x{W}_b{a.batch}_s{a.samples}")
     roof["traffic"] = traffic.get(dominant)
+    roof["traffic_source"] = (f"{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a builder run "
+                              "(tools/profile_round.sh), NOT measured in this run") if traffic else None
     kernels["h3d_ray_integrate"]["traffic"] = traffic.get("h3d_ray_integrate")
     for k, v in traffic.items():
         if k in kernels:
@@ -252,11 +370,26 @@ def main():
 
     extra = {}
     if not a.no_extra and world == 1 and (H, W) == (512, 512):
-        G2, cfg2 = build_generator(a.config, (512, 256), (96, 48), a.samples, dev)
-        z2, cond2, jit2 = make_inputs(cfg2, a.batch, dev)
-        dt2 = timed_steps(G2, cfg2, z2, cond2, jit2, max(3, a.steps // 2), 1, False)
-        extra["native_512x256_images_per_s"] = a.batch * max(3, a.steps // 2) / dt2
-        del G2
+        def side_run(config, gen_hw, render_hw, samples, batch, steps, engines=None):
+            G2, cfg2 = build_generator(config, gen_hw, render_hw, samples, dev)
+            if engines:
+                G2.neural_field.precision = engines[0]
+                G2.synthesis_plan(dev).engine = engines[1]
+            z2, cond2, jit2 = make_inputs(cfg2, batch, dev)
+            dt2 = timed_steps(G2, cfg2, z2, cond2, jit2, steps, 1, False)
+            eng = (G2.neural_field.precision, G2.synthesis_plan(dev).engine)
+            del G2
+            torch.cuda.empty_cache()
+            return dict(images_per_s=batch * steps / dt2, ms_per_step=dt2 / steps * 1e3, batch=batch, engines=eng)
+
+        n2 = max(3, a.steps // 2)
+        extra["native_512x256_images_per_s"] = side_run(a.config, (512, 256), (96, 48), a.samples, a.batch, n2)["images_per_s"]
+        extra["cfg2_MAP3DBN_256x256_64x64rays_s32"] = side_run("MAP3DBN", (256, 256), (64, 64), 32, 8, n2)
+        extra["cfg3L_MAP3DBN512L_512x512_96x96rays_s64"] = side_run("MAP3DBN512L", (512, 512), (96, 96), 64, a.batch, 3)
+        extra["cfg5_MAP3DBN512_1024x1024_192x192rays_s128"] = side_run("MAP3DBN512", (1024, 1024), (192, 192), 128, 4, 3)
+        extra["headline_workload_on_strict_fp32_mfma_engines"] = side_run(a.config, (H, W), render, a.samples, a.batch, 2,
+                                                                        engines=("f32", "f32"))
+        extra["op_rooflines"] = op_rooflines()
 
     out = {
         "metric": "generator images/sec at 512^2", "value": value, "unit": "images/s", "n_gpus": world,
@@ -276,9 +409,12 @@ def main():
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "extra": extra,
     }
+    out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, sorted({0, a.batch - 1}))
     if world == 1 and not a.no_cpu:
         sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        if not a.no_extra:
+            out["extra"]["cpu_baseline_cfg1"] = cpu_baseline_cfg1()
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -163,6 +163,33 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
                         int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A5 / A5+A6, split-operand arithmetic as the _x3 entry points, for hidden widths up to 448 ("x3t": the activations of
+ * a 64-sample tile live in LDS as ready-made MFMA fragments and the output features are split over the four waves, so
+ * the width is bounded by LDS instead of registers; csrc/x3t_common.hpp).  Covers MAP3DBN (384) and MAP3DBN512L (420).
+ * Same arguments and results as h3d_neural_field / h3d_render_fused; the fused variant takes S in {8,16,32,64} or a
+ * multiple of 64.  Weights are packed by h3d_field_pack_x3t (its own blob format, see h3d_field_x3t_layout).
+ */
+int64_t h3d_field_pack_x3t_size(int Hd, int F);
+int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+/* HOST helper: out[0..16] = tiles NT (even, >= 4), k-steps KS = 2*NT, padded width 32*NT, then BYTE offsets of the eight
+ * weight matrices (coord [1 k-step], geo [2], film0 [2*KS: coordinate half, geometry half], film1..3 [KS], colour
+ * [KS + 1: the last k-step carries the view direction], feature head [KS]), of inv_scale float[8], bias float[7][HdP],
+ * b_feat float[HdP], head_w float[4][HdP] (sigma, r, g, b in fragment order) , head_b float[4] and the total size.
+ * A matrix is [tile][k-step][hi|lo][64 lanes][8 f16], element (lane, e) = s * W[n = 32*tile + (lane&31)][k], K in
+ * accumulator-register order for matrices fed by accumulators, natural order 16*ks + 8*(lane>>5) + e for coord, geo and
+ * the view-direction k-step. */
+int h3d_field_x3t_layout(int Hd, int F, int64_t* out, int n_out);
+int h3d_neural_field_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
+                         const float* freq, const float* phase, float* out,
+                         int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler,
+                         h3d_stream_t stream);
+int h3d_render_fused_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
+                         const float* freq, const float* phase, const float* z_vals, const float* noise,
+                         float* feats, float* depth, float* weights,
+                         int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
+                         int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A7+A8+A9  SPADE synthesis network, eval mode == SynthesisNetwork.forward
  *     (lib/generators/map3d_generator.py:58-97) over SPADEBlock (lib/components/map3d_layers.py:218-238),
  *     fed by SynthesisInput (:260-275) and the bilinear F.interpolate of map3d_generator.py:244-245.
