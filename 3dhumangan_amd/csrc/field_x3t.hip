@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     float* rgbv = bgl + 64;                                            // [64][3]
     float* xsum = rgbv + 64 * 3;                                       // [4 waves][32] extra-unit ray sums
 
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane0 = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int m = lane & 31, h = lane >> 5;
+    const int m = lane0 & 31, h = lane0 >> 5;
     const int b = blockIdx.y;
     const int64_t N = A.N;
     const int Hd = A.Hd, F = A.F, S = A.S;
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     const float* __restrict__ bfeat = reinterpret_cast<const float*>(blob + L.b_feat);
     const float* __restrict__ headw = reinterpret_cast<const float*>(blob + L.head_w);
     const float* __restrict__ headb = reinterpret_cast<const float*>(blob + L.head_b);
-    X3tUnits<NTF, NX> U;
-    U.init(wave);
+    X3tUnits<NTF, NX> U0;
+    U0.init(wave);
 
     // ---- per-sample-of-the-batch activation tables, once per workgroup:
     //      y = sin(f * (acc*inv + bias) + p) = v_sin(acc * A1 + A0),  A1 = inv*f/2pi,  A0 = (bias*f + p)/2pi
@@ -154,40 +154,46 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     for (int u = 0; u < NU; ++u) rayacc[u] = 0.f;
 
     SplitF16 split;
-    // FiLM epilogue of an accumulator set -> fragments of actT
-    auto store_film = [&](f32x16 (&acc)[NU], int st) __attribute__((always_inline)) {
-        const float* a1 = tab + (st * 2 + 0) * HdP + 4 * h;
-        const float* a0 = tab + (st * 2 + 1) * HdP + 4 * h;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int nt = U.tile(u);
-            x3t_store_unit(acc[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
-                const f32x4 s1 = ld4(a1 + nt * 32 + rg * 8), s0 = ld4(a0 + nt * 32 + rg * 8);
-                f32x4 y;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_sinf(fmaf(v[i], s1[i], s0[i]));
-                return y;
-            });
-            // bound the scheduler's hoisting of the table loads to one unit (all units at once cost > 200 registers)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto zero = [&](f32x16 (&acc)[NU]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
-    };
-
     for (int ti = 0; ti < tiles; ++ti) {
         const int64_t n0 = g0 + (int64_t)ti * 64;
         const bool last_tile = ti == tiles - 1;
         // The weights do not depend on the tile: launder an opaque zero offset so that the compiler does not hoist the
         // first k-steps' fragment loads of every GEMM out of the tile loop (LICM) and spill hundreds of registers.
+        // (The same goes for every per-phase fragment address derived from the lane and the wave's tiles.)
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         const unsigned char* wblob = blob + opaque;
         auto wmat = [&](int wi) { return wblob + L.w[wi]; };
+        X3tUnits<NTF, NX> U = U0;
+#pragma unroll
+        for (int i = 0; i < NTF + NX; ++i) asm volatile("" : "+s"(U.nt[i]));
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        // FiLM epilogue of an accumulator set -> fragments of actT
+        auto store_film = [&](f32x16 (&acc)[NU], int st) __attribute__((always_inline)) {
+            const float* a1 = tab + (st * 2 + 0) * HdP + 4 * h;
+            const float* a0 = tab + (st * 2 + 1) * HdP + 4 * h;
+    #pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int nt = U.tile(u);
+                x3t_store_unit(acc[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
+                    const f32x4 s1 = ld4(a1 + nt * 32 + rg * 8), s0 = ld4(a0 + nt * 32 + rg * 8);
+                    f32x4 y;
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_sinf(fmaf(v[i], s1[i], s0[i]));
+                    return y;
+                });
+                // bound the scheduler's hoisting of the table loads to one unit (all units at once cost > 200 registers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto zero = [&](f32x16 (&acc)[NU]) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int u = 0; u < NU; ++u)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        };
+
 
         // ---- stage the inputs as B fragments (natural K order): thread -> (sample tile, slot lane, k-step)
         {

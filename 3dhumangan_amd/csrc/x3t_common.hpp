@@ -31,7 +31,10 @@
 namespace h3d {
 
 constexpr int kX3tMT = 2;            // sample tiles (of 32) per workgroup
-constexpr int kX3tDepth = 4;         // weight k-steps in flight per wave (register ring)
+#ifndef H3D_X3T_DEPTH
+#define H3D_X3T_DEPTH 4
+#endif
+constexpr int kX3tDepth = H3D_X3T_DEPTH;        // weight k-steps in flight per wave (register ring)
 
 // byte offset of fragment plane (mt, ks, plane) inside an activation tile with KS k-steps per sample tile
 __device__ __forceinline__ int x3t_frag(int KS, int mt, int ks, int plane) { return ((mt * KS + ks) * 2 + plane) * 1024; }

@@ -55,9 +55,12 @@ class COORDCONCATSIREN(nn.Module):
         for lin in (self.first_layer_coord.layer, self.first_layer_mod.layer):
             _uniform_(lin, 1.0 / lin.weight.shape[1])
         self._packed = {}
-        # Arithmetic engine: "f16x3" = split-operand f16 matrix cores (fp32-class results, widths <= 256),
-        # "f32" = fp32 matrix cores (any width <= 512).  Both meet the 1e-3 parity budget; see DESIGN.md 4.1.
-        default = "f16x3" if max(hidden_dim, feature_dim) <= 256 else "f32"
+        # Arithmetic engine (all meet the 1e-3 parity budget):
+        #   "f16x3"   split-operand f16 matrix cores, activations register-resident (widths <= 256)
+        #   "f16x3t"  split-operand f16 matrix cores, activations LDS-resident, any width <= 448 (MAP3DBN 384, MAP3DBN512L 420)
+        #   "f32"     fp32 matrix cores (any width <= 512)
+        widest = max(hidden_dim, feature_dim)
+        default = "f16x3" if widest <= 256 else "f16x3t" if widest <= 448 else "f32"
         self.precision = os.environ.get("H3D_FIELD_PRECISION", default)
 
     # ---- weight packing (host, once per weight version)
@@ -65,23 +68,29 @@ class COORDCONCATSIREN(nn.Module):
         return [self.first_layer_coord.layer, self.first_layer_mod.layer] + [d.layer for d in self.network] + \
                [self.sigma_layer, self.color_layer_sine.layer, self.color_layer_linear, self.feature_layer_linear]
 
-    def _x3(self):
-        if self.precision not in ("f16x3", "f32"):
+    # engine -> (pack-size, pack, field, fused-render) entry points of the C ABI and the sample tile of the fused kernel
+    _ENGINES = {
+        "f16x3": ("h3d_field_pack_x3_size", "h3d_field_pack_x3", "h3d_neural_field_x3", "h3d_render_fused_x3", 32),
+        "f16x3t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t", "h3d_render_fused_x3t", 64),
+        "f32": ("h3d_field_pack_size", "h3d_field_pack", "h3d_neural_field", "h3d_render_fused", 64),
+    }
+
+    def _engine(self):
+        if self.precision not in self._ENGINES:
             raise ValueError(f"unknown precision {self.precision!r}")
-        return self.precision == "f16x3"
+        return self._ENGINES[self.precision]
 
     def fused_supported(self, num_steps):
         """Sample counts the fused field+integration kernel of the active engine accepts."""
-        S = int(num_steps)
-        if self._x3():
-            return (8 <= S <= 32 and S & (S - 1) == 0) or (S > 32 and S % 32 == 0)
-        return (8 <= S <= 64 and S & (S - 1) == 0) or (S > 64 and S % 64 == 0)
+        S, tile = int(num_steps), self._engine()[4]
+        return (8 <= S <= tile and S & (S - 1) == 0) or (S > tile and S % tile == 0)
 
     def packed_weights(self, device):
         """Device blob in MFMA fragment order (csrc/field_common.hpp, csrc/field_x3.hip); cached until a
         parameter changes."""
         lins = self._params_for_pack()
-        x3 = self._x3()
+        x3 = self.precision
+        size_name, pack_name = self._engine()[:2]
         key = (str(device), x3) + tuple((p.data_ptr(), p._version) for l in lins for p in (l.weight, l.bias))
         hit = self._packed.get(x3)
         if hit is not None and hit[0] == key:
@@ -99,8 +108,7 @@ class COORDCONCATSIREN(nn.Module):
         P.w_color, P.b_color = vp(host[7][0]), vp(host[7][1])
         P.w_rgb, P.b_rgb = vp(host[8][0]), vp(host[8][1])
         P.w_feat, P.b_feat = vp(host[9][0]), vp(host[9][1])
-        size_fn, pack_fn = (lib.h3d_field_pack_x3_size, lib.h3d_field_pack_x3) if x3 else \
-                           (lib.h3d_field_pack_size, lib.h3d_field_pack)
+        size_fn, pack_fn = getattr(lib, size_name), getattr(lib, pack_name)
         nbytes = size_fn(H, F)
         if nbytes <= 0:
             raise _lib.H3DError(f"field engine {self.precision} does not support widths {H}/{F}")
@@ -130,7 +138,7 @@ class COORDCONCATSIREN(nn.Module):
         assert fr.shape == (B, 4 * H) and ph.shape == (B, 4 * H)
         out = torch.empty((B, N, F + 4), device=pts.device, dtype=torch.float32)
         blob = self.packed_weights(pts.device)
-        fn = _lib.load().h3d_neural_field_x3 if self._x3() else _lib.load().h3d_neural_field
+        fn = getattr(_lib.load(), self._engine()[2])
         rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
                                           _lib.ptr(ph), _lib.ptr(out), B, N, H, F, geo.shape[-1], float(input_scaler),
                                           _lib.stream_handle())
@@ -159,7 +167,7 @@ class COORDCONCATSIREN(nn.Module):
         weights = torch.empty((B, R, S, 1), device=pts.device, dtype=torch.float32)
         blob = self.packed_weights(pts.device)
         mode = {"relu": 0, "softplus": 1}[clamp_mode]
-        fn = _lib.load().h3d_render_fused_x3 if self._x3() else _lib.load().h3d_render_fused
+        fn = getattr(_lib.load(), self._engine()[3])
         rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
                                           _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(feats), _lib.ptr(depth),
                                           _lib.ptr(weights), B, R, S, H, F, geo.shape[-1], float(input_scaler), mode,

@@ -13,7 +13,7 @@ DEV = "cuda"
 FIELD_TOL = 1e-3      # north_star: within 1e-3 relative fp32; measured errors are ~1e-5
 
 
-ENGINES = ["f16x3", "f32"]
+ENGINES = ["f16x3", "f16x3t", "f32"]
 
 
 def make_field(state, hidden, feature, prefix="neural_field.", precision=None):
@@ -73,7 +73,10 @@ def test_field_in_generator_fixture(name, engine):
 
 @pytest.mark.parametrize("hidden,feature,N,engine", [(256, 256, 200, "f32"), (256, 256, 200, "f16x3"), (384, 384, 130, "f32"),
                                                      (420, 420, 64, "f32"), (32, 32, 1, "f32"), (32, 32, 1, "f16x3"),
-                                                     (128, 96, 77, "f32"), (128, 96, 77, "f16x3"), (200, 256, 333, "f16x3")])
+                                                     (128, 96, 77, "f32"), (128, 96, 77, "f16x3"), (200, 256, 333, "f16x3"),
+                                                     (384, 384, 130, "f16x3t"), (420, 420, 200, "f16x3t"), (256, 256, 65, "f16x3t"),
+                                                     (32, 32, 1, "f16x3t"), (128, 96, 77, "f16x3t"), (200, 300, 333, "f16x3t"),
+                                                     (448, 448, 64, "f16x3t"), (170, 170, 100, "f16x3t")])
 def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
     state, net = random_state(hidden, feature, seed=hidden, precision=engine)
     g = torch.Generator().manual_seed(N)
@@ -93,7 +96,10 @@ def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
 @pytest.mark.parametrize("S,R,hidden,engine", [(8, 20, 32, "f32"), (16, 30, 48, "f32"), (32, 9, 64, "f32"), (64, 5, 256, "f32"),
                                                 (128, 3, 64, "f32"), (32, 7, 384, "f32"), (8, 20, 32, "f16x3"),
                                                 (16, 30, 48, "f16x3"), (32, 9, 64, "f16x3"), (64, 5, 256, "f16x3"),
-                                                (128, 3, 64, "f16x3"), (32, 7, 256, "f16x3"), (96, 3, 128, "f16x3")])
+                                                (128, 3, 64, "f16x3"), (32, 7, 256, "f16x3"), (96, 3, 128, "f16x3"),
+                                                (8, 20, 32, "f16x3t"), (16, 30, 48, "f16x3t"), (32, 9, 64, "f16x3t"),
+                                                (64, 5, 420, "f16x3t"), (128, 3, 200, "f16x3t"), (32, 7, 384, "f16x3t"),
+                                                (64, 6, 384, "f16x3t"), (192, 2, 300, "f16x3t"), (16, 11, 420, "f16x3t")])
 @pytest.mark.parametrize("last_back,white_back,clamp", [(False, True, "relu"), (True, False, "softplus")])
 def test_fused_render_vs_oracle(S, R, hidden, engine, last_back, white_back, clamp):
     state, net = random_state(hidden, hidden, seed=S + hidden, precision=engine)
