@@ -149,7 +149,12 @@ class SynthesisPlan:
         self.g_channels = SHARED * len(self.pixel_ids)
         self.device = device
         self._x3 = None
-        self.engine = os.environ.get("H3D_SYNTH_PRECISION", "bf16x3" if self.x3_supported() else "f32")
+        self._x3t = None
+        # Arithmetic engine: "bf16x3" split-bf16 matrix cores, register-resident activations (C <= 256);
+        # "bf16x3t" split-bf16 matrix cores, LDS-resident activations (C <= 448: MAP3DBN 384, MAP3DBN512L 420);
+        # "f32" fp32 matrix cores (anything else).
+        default = "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
+        self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
     def x3_supported(self):
@@ -194,6 +199,75 @@ class SynthesisPlan:
             return t.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8)
 
         return torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(torch.int16).flatten()
+
+    # ------------------------------------------------------------------ split-bf16 engine with LDS-resident activations
+    def x3t_supported(self):
+        """C <= 448, per-pixel styles only in blocks without skip connection, no plain block after the first skip block
+        (csrc/synthesis_x3t.hip)."""
+        if _lib.load().h3d_synthesis_x3t_tiles(self.C) < 0:
+            return False
+        seen_skip = False
+        for k in range(self.n_blocks):
+            blk = self.desc.block[k]
+            if seen_skip and not blk.skip:
+                return False
+            seen_skip = seen_skip or bool(blk.skip)
+            if blk.skip and (blk.spade[0].pixel_style or blk.spade[1].pixel_style):
+                return False
+        return True
+
+    def build_x3t(self):
+        """Weights as bf16 hi/lo MFMA A fragments, tile-major [tile][k-step][hi|lo][64 lanes][8] (conv matrices with K in
+        accumulator-register order, gamma / beta in natural order: their input is assembled from memory), fp32 tables
+        padded to the engine's width 32 * tiles, and a descriptor whose w_* offsets are BYTES into the fragment blob and
+        whose vec / b_conv / w_rgb / w_in / b_in offsets are FLOATS into the tables."""
+        if self._x3t is not None:
+            return self._x3t
+        C = self.C
+        NT = _lib.load().h3d_synthesis_x3t_tiles(C)
+        HdP, KS = 32 * NT, 2 * NT
+        wchunks, woff, tchunks, toff = [], [0], [], [0]
+
+        def add_w(w_out_in, ks, acc_order):
+            frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order).view(ks, NT, 2 * 64 * 8)
+            o = woff[0]
+            wchunks.append(frag.transpose(0, 1).contiguous().flatten())          # [NT][ks][2][64][8]
+            woff[0] += wchunks[-1].numel() * 2
+            return o
+
+        def add_t(t):
+            o = toff[0]
+            t = t.flatten().float()
+            pad = (-t.numel()) % 4
+            if pad:
+                t = torch.cat([t, t.new_zeros(pad)])
+            tchunks.append(t)
+            toff[0] += t.numel()
+            return o
+
+        desc = SynthDesc()
+        desc.n_blocks, desc.C = self.n_blocks, C
+        desc.w_in = add_t(torch.cat([_pad(self._w_in[:, 0], HdP), _pad(self._w_in[:, 1], HdP)]))
+        desc.b_in = add_t(_pad(self._b_in, HdP))
+        for k in range(self.n_blocks):
+            src, dst = self.desc.block[k], desc.block[k]
+            dst.skip, dst.to_rgb = src.skip, src.to_rgb
+            for s in range(2):
+                raw = self._raw[2 * k + s]
+                d, so = dst.spade[s], src.spade[s]
+                d.pixel_style, d.g_offset, d.cst_index, d.ab_index = so.pixel_style, so.g_offset, so.cst_index, so.ab_index
+                if raw["pixel"]:
+                    d.w_gamma = add_w(raw["wgam"], SHARED // 16, False)
+                    d.w_beta = add_w(raw["wbet"], SHARED // 16, False)
+                    d.vec = add_t(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), _pad(raw["sc"], HdP),
+                                             _pad(raw["sh"], HdP)]))
+                d.w_conv = add_w(raw["conv_w"], KS, True)
+                d.b_conv = add_t(_pad(raw["conv_b"], HdP))
+            if dst.to_rgb:
+                wr, br = self._rgb[k]
+                dst.w_rgb = add_t(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
+        self._x3t = dict(desc=desc, wblob=torch.cat(wchunks).contiguous(), tables=torch.cat(tchunks).contiguous(), NT=NT, HdP=HdP)
+        return self._x3t
 
     # Optional split of the network into several launches whose weight streams each fit the 4 MB L2 of an XCD
     # (H3D_SYNTH_SEGMENT_BYTES=2359296).  Measured on MI355X: the single-launch stream (6.3 MB, 63 % L2 hit rate) is
@@ -321,19 +395,27 @@ class SynthesisPlan:
         B = fixed_style.shape[0]
         Hr, Wr = render_hw
         H, W = out_hw
-        if self.engine not in ("bf16x3", "f32"):
+        if self.engine not in ("bf16x3", "bf16x3t", "f32"):
             raise ValueError(f"unknown synthesis engine {self.engine!r}")
         x3 = self.build_x3() if self.engine == "bf16x3" else None
+        x3t = self.build_x3t() if self.engine == "bf16x3t" else None
         if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
-            x3 = None            # the x3 engine's matrix-core resize does not cover this geometry: fp32 engine
+            # the x3 engine's matrix-core resize does not cover this geometry: the LDS-resident engine does
+            x3, x3t = None, (self.build_x3t() if self.x3t_supported() else None)
         with stage(owner, "synthesis_tables"):
             if x3:
                 G, cst, ab = self.x3_forward_tables(feature_maps.float(), fixed_style.float())
             else:
-                G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float())
+                G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3t["HdP"] if x3t else None)
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
+        what = "h3d_synthesis_x3" if x3 else "h3d_synthesis_x3t" if x3t else "h3d_synthesis"
         with stage(owner, "synthesis"):
-            if x3:
+            if x3t:
+                rc = _lib.load().h3d_synthesis_x3t(_lib.ptr(x3t["wblob"]), _lib.ptr(x3t["tables"]), ctypes.byref(x3t["desc"]),
+                                                 _lib.ptr(G), self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids),
+                                                 _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
+                                                 _lib.stream_handle())
+            elif x3:
                 segs = x3["segments"]
                 state = None
                 if len(segs) > 1:
@@ -355,7 +437,7 @@ class SynthesisPlan:
                         break
             else:
                 rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
-        _lib.check(rc, "h3d_synthesis_x3" if x3 else "h3d_synthesis")
+        _lib.check(rc, what)
         return rgb
 
     def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):

@@ -262,6 +262,22 @@ int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tabl
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                      float* state, int load_state, int store_state, h3d_stream_t stream_handle);
 
+/* Same network, split-bf16 arithmetic as h3d_synthesis_x3, for widths up to 448 ("x3t": the activations of a 64-pixel
+ * tile live in LDS as ready-made MFMA fragments, the channels are split over the four waves; csrc/x3t_common.hpp).
+ * tiles = h3d_synthesis_x3t_tiles(C) (even, >= 4; -1 when C > 448), HdP = 32*tiles.
+ * `wblob`: every matrix as bf16 hi/lo A fragments [tile][k-step][hi|lo][64 lanes][8], element (lane, e) =
+ * W[n = 32*tile + (lane&31)][k]; conv matrices (2*tiles k-steps) with K in accumulator-register order
+ * k = 32*(ks/2) + (e&3) + 8*(2*(ks&1) + (e>>2)) + 4*(lane>>5), gamma / beta (8 k-steps) in natural order
+ * 16*ks + 8*(lane>>5) + e.  The descriptor's w_gamma / w_beta / w_conv are BYTE offsets into wblob; vec / b_conv / w_rgb
+ * / w_in / b_in are FLOAT offsets into `tables` (vectors HdP long, zero padded; conv biases are read, nothing is folded).
+ * G, cst as h3d_synthesis; ab [B, n_ab, 2, HdP].  Any resize geometry.  Returns H3D_EUNSUPPORTED (use h3d_synthesis)
+ * for C > 448, a per-pixel-style SPADE inside a skip block, or a block without skip connection after the first one
+ * that has it. */
+int h3d_synthesis_x3t_tiles(int C);
+int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G, int g_channels,
+                      int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H,
+                      int W, h3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * P3a per-pixel modulated 1x1 convolution == SpatialStyleModLayer.forward (lib/components/map3d_layers.py:60-80)
  *     m = style * Wa^T + ba + 1 ;  out = (x*m) W * rsqrt((m*m) (W*W) + eps) + bias        (demodulate != 0)

@@ -1,0 +1,118 @@
+"""Host logic of the LDS-resident split-bf16 synthesis plan (lib/generators/synthesis_pack.py: build_x3t) checked on the
+CPU: the tile-major fragment blob (accumulator-order K for the convs, natural order for gamma / beta, hi + lo halves), the
+fp32 tables and the per-forward tables are decoded and run through a plain float64 restatement of what
+csrc/synthesis_x3t.hip computes; the image must match the oracle's SynthesisNetwork.  Widths 384 / 420 are the ones the
+engine exists for (here at a tiny image).  No kernel launch (only the HOST helper h3d_synthesis_x3t_tiles)."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import load_golden, rel_err
+
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+sp = importlib.import_module("3dhumangan_amd.lib.generators.synthesis_pack")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+
+
+def acc_k(ks, h, e):
+    return 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * h
+
+
+def decode_matrix(wblob_i16, byte_off, KS, NT, acc_order):
+    """A fragments [NT][KS][2][64][8] of bf16 bit patterns -> dense W [32*NT, 16*KS] (hi + lo), K back in natural order."""
+    n = NT * KS * 2 * 64 * 8
+    assert byte_off % 16 == 0
+    t = wblob_i16[byte_off // 2: byte_off // 2 + n].view(torch.bfloat16).double().view(NT, KS, 2, 64, 8)
+    t = t[:, :, 0] + t[:, :, 1]                                       # [NT, KS, 64, 8]
+    W = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+    for ks in range(KS):
+        for h in range(2):
+            for e in range(8):
+                k = acc_k(ks, h, e) if acc_order else 16 * ks + 8 * h + e
+                W[:, k] = t[:, ks, 32 * h: 32 * h + 32, e].reshape(-1)
+    return W
+
+
+def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W):
+    x3t = plan.build_x3t()
+    NT, HdP = x3t["NT"], x3t["HdP"]
+    desc, tab, wb = x3t["desc"], x3t["tables"].double(), x3t["wblob"]
+    G, cst, ab = plan.per_forward_tables(fmap_lowres.float(), fixed_style.float(), HdP)
+    B = fixed_style.shape[0]
+    vec = lambda off, n=HdP: tab[off: off + n]
+    ii = torch.linspace(-1, 1, H, dtype=torch.float64).view(H, 1).expand(H, W).reshape(-1)
+    jj = torch.linspace(-1, 1, W, dtype=torch.float64).view(1, W).expand(H, W).reshape(-1)
+    x = torch.sin(ii[:, None] * vec(desc.w_in) + jj[:, None] * vec(desc.w_in + HdP) + vec(desc.b_in))   # [HW, HdP]
+    x = x.unsqueeze(0).repeat(B, 1, 1)
+    if G is not None:
+        Gmap = G.double().view(B, Hr, Wr, -1).permute(0, 3, 1, 2)
+        Gup = torch.nn.functional.interpolate(Gmap, (H, W), mode="bilinear").permute(0, 2, 3, 1).reshape(B, H * W, -1)
+    rgb = torch.zeros(B, H * W, 3, dtype=torch.float64)
+    lrelu = lambda v: torch.maximum(v, 0.2 * v)
+    for k in range(desc.n_blocks):
+        bk = desc.block[k]
+        x_in = x
+        for s in range(2):
+            d = bk.spade[s]
+            if d.pixel_style:
+                assert not bk.skip
+                a = torch.relu(Gup[:, :, d.g_offset: d.g_offset + 128] + cst[:, d.cst_index].double()[:, None, :])
+                Wg = decode_matrix(wb, d.w_gamma, 8, NT, False)
+                Wb = decode_matrix(wb, d.w_beta, 8, NT, False)
+                g1 = vec(d.vec) + a @ Wg.t()
+                y = lrelu((x * vec(d.vec + 2 * HdP) + vec(d.vec + 3 * HdP)) * g1 + vec(d.vec + HdP) + a @ Wb.t())
+            else:
+                t2 = ab[:, d.ab_index].double()                       # [B, 2, HdP]
+                y = lrelu(x * t2[:, 0:1] + t2[:, 1:2])
+            Wc = decode_matrix(wb, d.w_conv, 2 * NT, NT, True)
+            x = y @ Wc.t() + vec(d.b_conv) + (x_in if (s == 1 and bk.skip) else 0.0)
+        if bk.to_rgb:
+            wr = torch.stack([vec(bk.w_rgb), vec(bk.w_rgb + HdP), vec(bk.w_rgb + 2 * HdP)])          # [3, HdP]
+            rgb = rgb + x @ wr.t() + vec(bk.w_rgb + 3 * HdP, 3)
+    return rgb.view(B, H, W, 3).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("mode,width", [("mixed", 40), ("isolated", 384), ("mixed", 420)])
+def test_x3t_plan_matches_oracle(mode, width):
+    meta = dict(load_golden("gen_tiny_mixed")["meta"])
+    meta.update(map3d_mode=mode, hidden_dim=width, latent_dim=width, feature_dim=width, gen_height=6, gen_width=4,
+                render_height=3, render_width=2)
+    meta["neural_field_cls"] = impl.COORDCONCATSIREN
+    torch.manual_seed(3 + width)
+    Gn = gens.Map3DGenerator(**meta).eval()
+    with torch.no_grad():                                             # non-trivial BN statistics, biases, spectral u/v
+        for n, p in Gn.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.1 * torch.randn_like(p))
+        for n, b in Gn.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.2 * torch.randn_like(b))
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand_like(b))
+    sd = {k: v.detach().clone() for k, v in Gn.state_dict().items()}
+    plan = sp.SynthesisPlan(sd, "synthesis_network", "synthesis_input", meta["synthesis_blocks"], tuple(meta["mod_blocks"]), mode,
+                            torch.device("cpu"))
+    assert plan.x3t_supported()
+    assert plan.engine == ("bf16x3" if width <= 256 else "bf16x3t")
+    B, Hr, Wr, H, W = 2, 3, 2, 6, 4
+    fmap = torch.randn(B, Hr * Wr, width)
+    style = torch.randn(B, width)
+    got = emulate(plan, fmap, style, Hr, Wr, H, W)
+    fm = fmap.view(B, Hr, Wr, width).permute(0, 3, 1, 2)
+    fm_up = torch.nn.functional.interpolate(fm, (H, W), mode="bilinear")
+    x0 = O.synthesis_input(sd, B, H, W)
+    ref = O.synthesis_network(sd, x0, fm_up, style.view(B, 1, width), mode, tuple(meta["mod_blocks"]), meta["synthesis_blocks"])["final"]
+    # bf16 hi + lo carries 16 significant bits of every weight: 1e-4 covers it comfortably
+    assert rel_err(got.float(), ref) < 1e-4
+
+
+def test_x3t_plan_refuses_what_the_kernel_cannot_run():
+    meta = dict(load_golden("gen_tiny_mixed")["meta"])
+    meta.update(map3d_mode="all", hidden_dim=300, latent_dim=300, feature_dim=300)        # per-pixel styles in skip blocks
+    meta["neural_field_cls"] = impl.COORDCONCATSIREN
+    Gn = gens.Map3DGenerator(**meta).eval()
+    plan = sp.SynthesisPlan(Gn.state_dict(), "synthesis_network", "synthesis_input", meta["synthesis_blocks"],
+                            tuple(meta["mod_blocks"]), "all", torch.device("cpu"))
+    assert not plan.x3t_supported() and plan.engine == "f32"
