@@ -15,6 +15,8 @@
 // exists in HBM.  MFMA-bound: 2*(7*Hd^2 + 41*Hd) flop per sample (x3 products issued).
 #include "x3t_common.hpp"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 using namespace h3d;
 
@@ -141,6 +143,11 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         }
     }
 
+#ifdef H3D_EXPERIMENT_TRACE
+    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.out); g_trace_n = 0; }
+    __syncthreads();
+    H3D_TRACE(0);
+#endif
     const int group_pts = FUSED ? (S > 64 ? S : 64) : 64;
     const int tiles = group_pts / 64;
     const int64_t g0 = (int64_t)blockIdx.x * group_pts;
@@ -171,6 +178,10 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         asm volatile("" : "+v"(lane));
         // FiLM epilogue of an accumulator set -> fragments of actT
         auto store_film = [&](f32x16 (&acc)[NU], int st) __attribute__((always_inline)) {
+            // fresh copies of the lane id / lane half: the fragment and table addresses below are the same in every layer
+            // and would otherwise be kept alive (dozens of registers) across the GEMMs instead of being recomputed
+            int lane = lane0, h = lane0 >> 5;
+            asm volatile("" : "+v"(lane), "+v"(h));
             const float* a1 = tab + (st * 2 + 0) * HdP + 4 * h;
             const float* a0 = tab + (st * 2 + 1) * HdP + 4 * h;
     #pragma unroll
@@ -249,33 +260,56 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             }
         }
         __syncthreads();          // inputs (and, first tile, the tables) visible; previous tile's readers are done
+        H3D_TRACE(1);
 
         f32x16 acc[NU], acc2[NU];
+        X3tRing<NTF + NX> ring;     // weight fragments in flight; the next GEMM's first k-steps are requested before the
+                                    // epilogue and barriers in front of it (x3t_prefetch)
         // ---- coordinate layer (K = 3) -> sine -> FiLM 0, coordinate half
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_COORD * 2048, in_stride, wmat(W_COORD), 1, 0, 1, U, lane);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_COORD * 2048, in_stride, wmat(W_COORD), 1, 0, 1, U, lane, ring);
+        x3t_prefetch(ring, wmat(W_F0), 2 * KS, 0, U, lane);
+        H3D_TRACE(2);
         store_film(acc, ST_COORD);
+        H3D_TRACE(3);
         __syncthreads();
+        H3D_TRACE(4);
         zero(acc2);
-        gemm_x3t<F16, NTF, NX, false>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, 0, KS, U, lane);
+        gemm_x3t<F16, NTF, NX, false, false, true>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, 0, KS, U, lane, ring);
+        H3D_TRACE(5);
         // ---- geometry layer (K = 31) -> sine -> FiLM 0, geometry half (same accumulators)
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_GEO * 2048, in_stride, wmat(W_GEO), 2, 0, 2, U, lane);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_GEO * 2048, in_stride, wmat(W_GEO), 2, 0, 2, U, lane, ring);
+        x3t_prefetch(ring, wmat(W_F0), 2 * KS, KS, U, lane);
+        H3D_TRACE(6);
         __syncthreads();          // every wave has finished reading the coordinate activations
+        H3D_TRACE(7);
         store_film(acc, ST_GEO);
+        H3D_TRACE(8);
         __syncthreads();
-        gemm_x3t<F16, NTF, NX, false>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, KS, KS, U, lane);
+        H3D_TRACE(9);
+        gemm_x3t<F16, NTF, NX, false, false, true>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, KS, KS, U, lane, ring);
+        x3t_prefetch(ring, wmat(W_F1), KS, 0, U, lane);
+        H3D_TRACE(10);
         __syncthreads();
+        H3D_TRACE(11);
         store_film(acc2, ST_FILM0);
+        H3D_TRACE(12);
         __syncthreads();
+        H3D_TRACE(13);
         // ---- FiLM 1..3
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
             zero(acc);
-            gemm_x3t<F16, NTF, NX, false>(acc, actT, act_stride, wmat(W_F0 + l), KS, 0, KS, U, lane);
+            gemm_x3t<F16, NTF, NX, false, false, true>(acc, actT, act_stride, wmat(W_F0 + l), KS, 0, KS, U, lane, ring);
+            x3t_prefetch(ring, wmat(W_F0 + l + 1), l == 3 ? KS + 1 : KS, 0, U, lane);      // FiLM l+1, or the colour layer
+            H3D_TRACE(14);
             __syncthreads();
+            H3D_TRACE(15);
             store_film(acc, ST_FILM0 + l);
+            H3D_TRACE(16);
             __syncthreads();
+            H3D_TRACE(17);
         }
 
         // ---- density head: fp32 dot product over the fragments; wave w covers k-steps w, w+4, ..; lane = sample
@@ -294,7 +328,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             }
             part[wave * 192 + lane] = s;
         }
+        H3D_TRACE(18);
         __syncthreads();
+        H3D_TRACE(19);
         if (t < 64) {
             const float sigma = (part[t] + part[192 + t]) + (part[384 + t] + part[576 + t]) + headb[0];
             const int64_t n = n0 + t;
@@ -345,13 +381,19 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             }
         }
 
+        H3D_TRACE(20);
         // ---- colour FiLM on [x, dir]: KS k-steps over the hidden features + one k-step carrying the view direction
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false>(acc, actT, act_stride, wmat(W_COLOR), KS + 1, 0, KS, U, lane);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_DIR * 2048, in_stride, wmat(W_COLOR), KS + 1, KS, 1, U, lane);
+        gemm_x3t<F16, NTF, NX, false, false, true>(acc, actT, act_stride, wmat(W_COLOR), KS + 1, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_DIR * 2048, in_stride, wmat(W_COLOR), KS + 1, KS, 1, U, lane, ring);
+        x3t_prefetch(ring, wmat(W_FEAT), KS, 0, U, lane);
+        H3D_TRACE(21);
         __syncthreads();
+        H3D_TRACE(22);
         store_film(acc, ST_COLOR);
+        H3D_TRACE(23);
         __syncthreads();
+        H3D_TRACE(24);
 
         // ---- colour heads (fp32 dot products) and feature head (matrix cores, operands swapped: rows = samples)
         {
@@ -376,10 +418,13 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             part[wave * 192 + 64 + lane] = s1;
             part[wave * 192 + 128 + lane] = s2;
         }
+        H3D_TRACE(25);
         f32x16 (&accF)[NU] = acc2;
         zero(accF);
-        gemm_x3t<F16, NTF, NX, true>(accF, actT, act_stride, wmat(W_FEAT), KS, 0, KS, U, lane);
+        gemm_x3t<F16, NTF, NX, true, false, true>(accF, actT, act_stride, wmat(W_FEAT), KS, 0, KS, U, lane, ring);
+        H3D_TRACE(26);
         __syncthreads();
+        H3D_TRACE(27);
         if (t < 192) {
             const int c = t >> 6, mm_ = t & 63;
             const float v = (part[c * 64 + mm_] + part[192 + c * 64 + mm_]) + (part[384 + c * 64 + mm_] + part[576 + c * 64 + mm_]) +
@@ -474,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                 if (h == 0) xsum[wave * 32 + m] = xs_last;
                 __syncthreads();
                 if ((wave & 1) == 0 && h == 0) {
-                    const int n = U.nt[NTF] * 32 + m;
+                    const int n = U.nt[NTF + NX - 1] * 32 + m;
                     if (n < F && n0 < N) {
                         const int64_t ray = ((int64_t)b * N + n0) / S;
                         A.feats[ray * C + 3 + n] = (xsum[wave * 32 + m] + xsum[(wave + 1) * 32 + m]) + (A.white_back ? bgl[0] : 0.f);
@@ -482,7 +527,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                 }
             }
         }
+        H3D_TRACE(28);
         __syncthreads();     // actT / inT / part / wgt are rewritten by the next tile
+        H3D_TRACE(29);
     }
 }
 
@@ -669,5 +716,29 @@ extern "C" int h3d_render_fused_x3t(const void* packed, const float* points, con
     const int group = S > 64 ? S : 64;
     const int64_t groups = (N + group - 1) / group;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_render_fused_x3t: too many rays");
+#ifdef H3D_EXPERIMENT_TRACE
+    {   // development build: dump the cycle trace of workgroup (1000, 3) to $H3D_TRACE_FILE after every launch
+        static unsigned long long* tb = nullptr;
+        if (!tb) (void)hipMalloc(&tb, 4096 * 8);
+        (void)hipMemset(tb, 0, 4096 * 8);
+        A.out = reinterpret_cast<float*>(tb);
+        const int rc2 = launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[4096];
+        (void)hipMemcpy(host, tb, sizeof(host), hipMemcpyDeviceToHost);
+        if (const char* f = getenv("H3D_TRACE_FILE")) {
+            if (FILE* fp = fopen(f, "w")) {
+                unsigned long long t0 = host[0] >> 8, prev = t0;
+                for (int i = 0; i < 4096 && host[i]; ++i) {
+                    const unsigned long long tt = host[i] >> 8;
+                    fprintf(fp, "%llu %llu +%llu\n", host[i] & 255ull, tt - t0, tt - prev);
+                    prev = tt;
+                }
+                fclose(fp);
+            }
+        }
+        return rc2;
+    }
+#endif
     return launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
 }

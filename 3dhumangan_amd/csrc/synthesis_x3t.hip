@@ -56,6 +56,7 @@ struct Block {
     int* tap;
     int lane, m, h, wave, b, t, KS, HdP, act_stride;
     SplitBF16 split;
+    X3tRing<NTF + NX>& ring;            // weight fragments in flight (x3t_common.hpp)
 
     // constant-style SPADE of `src`: y = lrelu(x * a + b) (per-(sample, channel) affine from the host) -> actT
     __device__ __forceinline__ void store_const(f32x16 (&src)[NU], const h3d_spade_desc& Sp) const {
@@ -95,7 +96,7 @@ struct Block {
     template <bool ADD>
     __device__ __forceinline__ void conv(f32x16 (&dst)[NU], const h3d_spade_desc& Sp) const {
         add_vec<ADD>(dst, tables + Sp.b_conv);
-        gemm_x3t<BF16, NTF, NX, false>(dst, actT, act_stride, wblob + Sp.w_conv, KS, 0, KS, U, lane);
+        gemm_x3t<BF16, NTF, NX, false>(dst, actT, act_stride, wblob + Sp.w_conv, KS, 0, KS, U, lane, ring);
     }
     // per-pixel-style SPADE: fragments of lrelu((x*sc + sh) * (1 + gamma) + beta) -> actT; g is the gamma / beta scratch
     __device__ __forceinline__ void store_pixel(f32x16 (&x)[NU], f32x16 (&g)[NU], const h3d_spade_desc& Sp) const {
@@ -138,7 +139,7 @@ struct Block {
         const float* __restrict__ vec = tables + Sp.vec;
         constexpr int a_stride = kKSA * 2048;
         add_vec<false>(g, vec);
-        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane);
+        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int nt = U.tile(u);
@@ -153,7 +154,7 @@ struct Block {
             pin1(g[u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane);
+        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             pin1(g[u]);
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
     __syncthreads();
 
     f32x16 cur[NU];                     // raw activations of this wave's units (lane = pixel, registers = channels)
+    X3tRing<NTF + NX> ring;
     float rgb_acc = 0.f;                // threads < 192: (channel t>>6, pixel t&63)
 
     // ---- A8: x0[n][p] = sin(w0[n]*i + w1[n]*j + b[n]) straight into the accumulator layout
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         return Block<NTF, NX>{A, U, A.wblob + opaque, A.tables + opaque, actT, aT, part, tw, tap,
-                              lane, m, h, wave, b, t, KS, HdP, act_stride, SplitBF16()};
+                              lane, m, h, wave, b, t, KS, HdP, act_stride, SplitBF16(), ring};
     };
 
     // ================= blocks before the first skip connection (either style) =======================================

@@ -51,7 +51,7 @@ struct X3tUnits {
     __device__ __forceinline__ void init(int wave) {
 #pragma unroll
         for (int i = 0; i < NTF; ++i) nt[i] = wave + 4 * i;
-        if (NX) nt[NTF] = 4 * NTF + (wave >> 1);
+        if constexpr (NX > 0) nt[NA - 1] = 4 * NTF + (wave >> 1);
         xmt = wave & 1;
     }
     // unit u -> (weight slot, sample tile): u = 2*i + mt for the full tiles, u = 2*NTF for the extra unit
@@ -60,32 +60,84 @@ struct X3tUnits {
     __device__ __forceinline__ int mt(int u) const { return u < 2 * NTF ? (u & 1) : xmt; }
 };
 
-// acc[u] += W(tile(u), ks) x X(mt(u), ks), ks = 0 .. KS-1 (KS a multiple of kX3tDepth, or <= kX3tDepth).
+// One 16-byte weight-fragment load, issued through inline asm on purpose.  With compiler-visible loads hipcc's waitcnt
+// pass loses count at the loop back-edge of the register ring below and, once per trip, waits for everything but the
+// newest k-step (s_waitcnt vmcnt(6) where vmcnt(18) is right): the prefetch distance collapses from three k-steps to
+// one.  The ring is synchronised by hand instead (x3t_wait_frags): loads retire in order, so "at most N outstanding"
+// is exact by construction, and loads the compiler issues on its own only make the wait stricter, never weaker.
+// Address = uniform base (SGPR pair: the tile's k-step) + per-lane byte offset (one VGPR shared by every load) + OFF.
+template <int OFF>
+__device__ __forceinline__ void x3t_gload(u32x4& dst, const unsigned char* base, unsigned lane_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(lane_off), "s"(base), "n"(OFF) : "memory");
+}
+// s_waitcnt vmcnt(N), tied to the fragments about to be consumed: their users read the post-wait values, so the
+// scheduler cannot move an MFMA above the wait.
+template <int N, int NA>
+__device__ __forceinline__ void x3t_wait_frags(u32x4 (&h)[NA], u32x4 (&l)[NA]) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(h[0]) : "n"(N) : "memory");
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        if (i) asm volatile("" : "+v"(h[i]));
+        asm volatile("" : "+v"(l[i]));
+    }
+}
+
+// The weight-fragment ring of one wave: kX3tDepth k-steps of (hi, lo) A fragments for its NA tiles.  Owned by the caller
+// so that the first D-1 k-steps of the NEXT GEMM can be requested (x3t_prefetch) before the epilogue / barriers that
+// separate two GEMMs: their L2 latency then hides behind that work instead of stalling the GEMM's first MFMA.
+template <int NA>
+struct X3tRing {
+    struct AF { u32x4 h[NA], l[NA]; };
+    AF a[kX3tDepth];
+};
+
+// Request k-steps ks0 .. ks0+D-2 of the wave's tiles of matrix W into ring slots 0 .. D-2 (2*NA*(D-1) loads).  Between
+// this call and the GEMM that consumes it (PRE = true) the caller must not start another GEMM on the same ring.
+template <int NTF, int NX>
+__device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigned char* __restrict__ W, int KStot, int ks0,
+                                             const X3tUnits<NTF, NX>& U, int lane) {
+    constexpr int NA = NTF + NX;
+    const unsigned lane_off = (unsigned)lane * 16u;
+#pragma unroll
+    for (int d = 0; d < kX3tDepth - 1; ++d)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned char* q = W + ((int64_t)U.nt[i] * KStot + ks0 + d) * 2048;
+            x3t_gload<0>(R.a[d].h[i], q, lane_off);
+            x3t_gload<1024>(R.a[d].l[i], q, lane_off);
+        }
+}
+
+// acc[u] += W(tile(u), ks) x X(mt(u), ks), ks = 0 .. KS-1 (KS a multiple of kX3tDepth unless GUARD).
 //   bT     LDS: fragment plane (mt 0, first k-step of this phase, hi); sample tiles are mt_stride bytes apart
 //   W      global: A fragments [tile][KStot][plane][64][16 B]; this phase uses k-steps ks0 .. ks0+KS-1 of every tile
 //   SWAP   D[sample][feature] instead (activations as the A operand): used by the feature head of the fused render,
 //          where the weighted sum over the samples of a ray becomes a sum over accumulator registers.
 // Register ring: the A fragments of k-step s+3 are requested before the MFMAs of k-step s (four k-steps in flight,
 // ~2000 matrix-pipe cycles: an L2 miss served by the Infinity Cache is covered), B fragments one k-step ahead.
-// GUARD: the phase may be shorter than the ring (input layers with 1 or 2 k-steps): every slot is predicated.
-template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false>
+// GUARD: a short phase (input layers with KS = 1 or 2 k-steps); otherwise KS is a multiple of the ring depth, >= depth.
+// PRE: the ring already holds the requests of x3t_prefetch(R, W, KStot, ks0, ..) (full phases only).
+template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false, bool PRE = false>
 __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsigned char* bT, int mt_stride,
                                          const unsigned char* __restrict__ W, int KStot, int ks0, int KS,
-                                         const X3tUnits<NTF, NX>& U, int lane) {
+                                         const X3tUnits<NTF, NX>& U, int lane, X3tRing<NTF + NX>& R) {
     constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
-    struct AF { u32x4 h[NA], l[NA]; };
+    static_assert(!(GUARD && PRE), "short phases load everything themselves");
+    typedef typename X3tRing<NA>::AF AF;
     struct BF { u32x4 h[2], l[2], xh, xl; };
-    const u32x4* wp[NA];
+    AF (&a)[D] = R.a;
+    const unsigned char* wp[NA];              // uniform: first k-step of this phase of the wave's tiles
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-        wp[i] = reinterpret_cast<const u32x4*>(W + ((int64_t)U.nt[i] * KStot + ks0) * 2048) + lane;
+    for (int i = 0; i < NA; ++i) wp[i] = W + ((int64_t)U.nt[i] * KStot + ks0) * 2048;
+    const unsigned lane_off = (unsigned)lane * 16u;
     const unsigned char* bp = bT + lane * 16;
     const unsigned char* bx = bp + U.xmt * mt_stride;
-    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {
+    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {      // 2*NA loads, always all of them
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            f.h[i] = wp[i][(ks * 2 + 0) * 64];
-            f.l[i] = wp[i][(ks * 2 + 1) * 64];
+            const unsigned char* q = wp[i] + ks * 2048;     // one scalar address per tile and k-step; lo plane 1 KB further
+            x3t_gload<0>(f.h[i], q, lane_off);
+            x3t_gload<1024>(f.l[i], q, lane_off);
         }
     };
     auto loadB = [&](BF& f, int ks) __attribute__((always_inline)) {
@@ -101,37 +153,95 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
             f.xl = *reinterpret_cast<const u32x4*>(bx + ks * 2048 + 1024);
         }
     };
-    auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {
-        // three passes (hi*hi, hi*lo, lo*hi) over all units: consecutive MFMAs never share an accumulator
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int s = u < 2 * NTF ? u / 2 : NTF;
-                const u32x4 wv = p == 2 ? a.l[s] : a.h[s];
-                const u32x4 xv = u < 2 * NTF ? (p == 1 ? b.l[u & 1] : b.h[u & 1]) : (p == 1 ? b.xl : b.xh);
-                acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
-            }
-        }
+    // MFMA j of a k-step, j = 0 .. 3*NU-1: pass p = j / NU (hi*hi, hi*lo, lo*hi) over all units -- consecutive MFMAs never
+    // share an accumulator
+    auto mfma1 = [&](auto jc, const AF& a, const BF& b) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, p = j / NU, u = j % NU, sl = u < 2 * NTF ? u / 2 : NTF;
+        const u32x4 wv = p == 2 ? a.l[sl] : a.h[sl];
+        const u32x4 xv = u < 2 * NTF ? (p == 1 ? b.l[u & 1] : b.h[u & 1]) : (p == 1 ? b.xl : b.xh);
+        acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
     };
-    AF a[D];
+    auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {
+        static_for<0, 3 * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, a, b); });
+    };
+    // One k-step with its memory traffic in the shadow of the matrix pipe (one wave per SIMD: whatever is issued between
+    // two MFMAs is free, whatever is issued before the first one leaves the pipe idle): after MFMA j comes weight load j
+    // (tile j/2, plane j%2) of k-step `ka`, then the LDS reads of k-step `kb`, one per MFMA.  Every position is pinned.
+    // (LA / LB: whether this k-step still requests weights / fragments; references, never pointers: taking the address of a
+    // ring element would move the whole ring to scratch memory)
+    auto kstep = [&](auto la, auto lb, const AF& a_cur, const BF& b_cur, AF& a_nxt, int ka, BF& b_nxt, int kb) __attribute__((always_inline)) {
+        constexpr bool LA = decltype(la)::value != 0, LB = decltype(lb)::value != 0;
+        constexpr int NB = (NTF > 0 ? 4 : 0) + (NX ? 2 : 0), NOPS = 2 * NA + NB, NM = 3 * NU;
+        // memory operation i = 0 .. NOPS-1: the 2*NA weight loads first, then the NB fragment reads
+        auto memop = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < 2 * NA) {
+                if constexpr (LA) {
+                    const unsigned char* q = wp[i / 2] + ka * 2048;
+                    if constexpr (i % 2 == 0) x3t_gload<0>(a_nxt.h[i / 2], q, lane_off);
+                    else x3t_gload<1024>(a_nxt.l[i / 2], q, lane_off);
+                }
+            } else if constexpr (LB) {
+                constexpr int r = i - 2 * NA;
+                if constexpr (NTF > 0 && r < 4) {
+                    const unsigned char* q = bp + (r >> 1) * mt_stride + kb * 2048 + (r & 1) * 1024;
+                    if constexpr ((r & 1) == 0) b_nxt.h[r >> 1] = *reinterpret_cast<const u32x4*>(q);
+                    else b_nxt.l[r >> 1] = *reinterpret_cast<const u32x4*>(q);
+                } else {
+                    constexpr int k = r - (NTF > 0 ? 4 : 0);
+                    if constexpr (k == 0) b_nxt.xh = *reinterpret_cast<const u32x4*>(bx + kb * 2048);
+                    else b_nxt.xl = *reinterpret_cast<const u32x4*>(bx + kb * 2048 + 1024);
+                }
+            }
+        };
+        static_for<0, NM>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            mfma1(jc, a_cur, b_cur);
+            __builtin_amdgcn_sched_barrier(0);
+            // operations [j*NOPS/NM, (j+1)*NOPS/NM) ride behind MFMA j: spread evenly over the k-step
+            static_for<j * NOPS / NM, (j + 1) * NOPS / NM>([&](auto ic) __attribute__((always_inline)) {
+                memop(ic);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
     BF b[2];
-    const int last = KS - 1;
+    // (every load the caller issued before this point is older than the ring's loads: it cannot weaken the waits)
+    if constexpr (GUARD) {
+        // short phase (KS = 1 or 2 <= D-1): everything up front, one wait
+        static_assert(D >= 3, "short phases keep all their k-steps in the ring");
+        loadA(a[0], 0);
+        loadB(b[0], 0);
+        if (KS > 1) { loadA(a[1], 1); loadB(b[1], 1); }
+        x3t_wait_frags<0, NA>(a[0].h, a[0].l);
+        mfmas(a[0], b[0]);
+        if (KS > 1) {
+            x3t_wait_frags<0, NA>(a[1].h, a[1].l);
+            mfmas(a[1], b[1]);
+        }
+    } else {
+        if constexpr (!PRE) {
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) loadA(a[d], d < last ? d : last);
-    loadB(b[0], 0);
-    for (int ks = 0; ks < KS; ks += D) {
+            for (int d = 0; d < D - 1; ++d) loadA(a[d], d);
+        }
+        loadB(b[0], 0);
+        // slot d of a trip: the fragments of its k-step were requested D-1 slots ago; the requests of the D-2 slots in
+        // between -- (D-2) * 2*NA loads -- may stay in flight.  Its own requests (k-step +D-1) follow inside kstep.
+        for (int ks = 0; ks < KS - D; ks += D) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (!GUARD || ks + d < KS) {             // uniform; full phases have KS % D == 0 and no branch at all
-                const int ka = ks + d + D - 1, kb = ks + d + 1;
-                loadA(a[(d + D - 1) % D], ka < last ? ka : last);      // beyond the end: a harmless re-read
-                loadB(b[(d + 1) & 1], kb < last ? kb : last);
+            for (int d = 0; d < D; ++d) {
+                x3t_wait_frags<(D - 2) * 2 * NA, NA>(a[d].h, a[d].l);
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas(a[d], b[d & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                kstep(IC<1>{}, IC<1>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
             }
         }
+        // the last D k-steps: one more request, then the ring drains
+        static_for<0, D>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int d = decltype(dc)::value;
+            x3t_wait_frags<(d == 0 ? D - 2 : D - 1 - d) * 2 * NA, NA>(a[d].h, a[d].l);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(IC<(d == 0)>{}, IC<(d < D - 1)>{}, a[d], b[d & 1], a[D - 1], KS - 1, b[(d + 1) & 1], KS - D + d + 1);
+        });
     }
 }
 

@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 L = importlib.import_module("3dhumangan_amd._lib")
 impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
 dev = "cuda"
-B, R, S, H = 16, 9216, 64, 256
+B, R, S = 8, 9216, 64
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 256        # width: 256 -> field_x3, > 256 -> field_x3t (or H3D_FIELD_PRECISION)
 net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=H, hidden_dim=H, geo_feature_dim=31, output_dim=H + 4, feature_dim=H,
                             num_blocks=4).to(dev)
 N = R * S

@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc $CTRS -d $OUT -o p -- python "$@" > $OUT/run.log 2> $OUT/run.err
 cd $REPO
 DB=$(find $OUT -name '*.db' | head -1)
-python tools/pmc_dump.py $DB 'x3_kernel|geo_features' | tee $OUT/pmc.txt
+python tools/pmc_dump.py $DB 'x3_kernel|x3t_kernel|geo_features' | tee $OUT/pmc.txt
 rm -f $DB
