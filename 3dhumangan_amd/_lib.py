@@ -49,11 +49,15 @@ _SIGNATURES = {
     "h3d_neural_field_x3t": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),
     "h3d_render_fused_x3t": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i,
                                        _i, _i, _p]),
+    "h3d_neural_field_x3t_tier": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _i, _p]),
+    "h3d_render_fused_x3t_tier": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i,
+                                            _i, _i, _i, _p]),
     "h3d_pack_matrix": (C.c_int, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_synthesis": (C.c_int, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "h3d_synthesis_x3": (C.c_int, [_p, _l, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p]),
     "h3d_synthesis_x3t_tiles": (C.c_int, [_i]),
     "h3d_synthesis_x3t": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "h3d_synthesis_x3t_tier": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "h3d_modconv1x1": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _f, _p]),
     "h3d_modconv2d": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_synthesis_x3_geometry_ok": (C.c_int, [_i, _i, _i, _i]),

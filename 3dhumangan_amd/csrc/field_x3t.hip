@@ -86,9 +86,12 @@ __device__ __forceinline__ float density(float x, int clamp_mode) {
     return fmaxf(x, 0.f);
 }
 
-template <int NTF, int NX, bool FUSED>
+// P: partial products per operand pair of the hidden GEMMs (x3t_common.hpp): 3 = fp32-class (the default engine), 1 = plain
+// f16 matrix-core arithmetic (the "f16 MFMA" tier of BASELINE config 5; the K=3 / K=31 input layers always run with 3).
+template <int NTF, int NX, bool FUSED, int P>
 __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     constexpr int NU = 2 * NTF + NX;
+    constexpr bool LO = P == 3;            // activations carry a lo half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const LayoutT& L = A.L;
     const int KS = L.KS, HdP = L.HdP;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int nt = U.tile(u);
-                x3t_store_unit(acc[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
+                x3t_store_unit<LO>(acc[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
                     const f32x4 s1 = ld4(a1 + nt * 32 + rg * 8), s0 = ld4(a0 + nt * 32 + rg * 8);
                     f32x4 y;
     #pragma unroll
@@ -268,19 +271,19 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         // ---- coordinate layer (K = 3) -> sine -> FiLM 0, coordinate half
         zero(acc);
         gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_COORD * 2048, in_stride, wmat(W_COORD), 1, 0, 1, U, lane, ring);
-        x3t_prefetch(ring, wmat(W_F0), 2 * KS, 0, U, lane);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), 2 * KS, 0, U, lane);
         H3D_TRACE(2);
         store_film(acc, ST_COORD);
         H3D_TRACE(3);
         __syncthreads();
         H3D_TRACE(4);
         zero(acc2);
-        gemm_x3t<F16, NTF, NX, false, false, true>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, 0, KS, U, lane, ring);
         H3D_TRACE(5);
         // ---- geometry layer (K = 31) -> sine -> FiLM 0, geometry half (same accumulators)
         zero(acc);
         gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_GEO * 2048, in_stride, wmat(W_GEO), 2, 0, 2, U, lane, ring);
-        x3t_prefetch(ring, wmat(W_F0), 2 * KS, KS, U, lane);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), 2 * KS, KS, U, lane);
         H3D_TRACE(6);
         __syncthreads();          // every wave has finished reading the coordinate activations
         H3D_TRACE(7);
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(8);
         __syncthreads();
         H3D_TRACE(9);
-        gemm_x3t<F16, NTF, NX, false, false, true>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, KS, KS, U, lane, ring);
-        x3t_prefetch(ring, wmat(W_F1), KS, 0, U, lane);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, KS, KS, U, lane, ring);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F1), KS, 0, U, lane);
         H3D_TRACE(10);
         __syncthreads();
         H3D_TRACE(11);
@@ -301,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
             zero(acc);
-            gemm_x3t<F16, NTF, NX, false, false, true>(acc, actT, act_stride, wmat(W_F0 + l), KS, 0, KS, U, lane, ring);
-            x3t_prefetch(ring, wmat(W_F0 + l + 1), l == 3 ? KS + 1 : KS, 0, U, lane);      // FiLM l+1, or the colour layer
+            gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_F0 + l), KS, 0, KS, U, lane, ring);
+            x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0 + l + 1), l == 3 ? KS + 1 : KS, 0, U, lane);      // FiLM l+1, or the colour layer
             H3D_TRACE(14);
             __syncthreads();
             H3D_TRACE(15);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                     const u32x4 hv = *reinterpret_cast<const u32x4*>(p), lv = *reinterpret_cast<const u32x4*>(p + 1024);
                     const float* w = headw + ks * 16 + hh * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s = fmaf(x3t_f16_sum(hv[e >> 1], lv[e >> 1], e & 1), w[e], s);
+                    for (int e = 0; e < 8; ++e) s = fmaf(x3t_f16_sum(hv[e >> 1], LO ? lv[e >> 1] : 0u, e & 1), w[e], s);
                 }
             }
             part[wave * 192 + lane] = s;
@@ -384,9 +387,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(20);
         // ---- colour FiLM on [x, dir]: KS k-steps over the hidden features + one k-step carrying the view direction
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, false, true>(acc, actT, act_stride, wmat(W_COLOR), KS + 1, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_COLOR), KS + 1, 0, KS, U, lane, ring);
         gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_DIR * 2048, in_stride, wmat(W_COLOR), KS + 1, KS, 1, U, lane, ring);
-        x3t_prefetch(ring, wmat(W_FEAT), KS, 0, U, lane);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_FEAT), KS, 0, U, lane);
         H3D_TRACE(21);
         __syncthreads();
         H3D_TRACE(22);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                     const float* w = headw + HdP + ks * 16 + hh * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float x = x3t_f16_sum(hv[e >> 1], lv[e >> 1], e & 1);
+                        const float x = x3t_f16_sum(hv[e >> 1], LO ? lv[e >> 1] : 0u, e & 1);
                         s0 = fmaf(x, w[e], s0);
                         s1 = fmaf(x, w[HdP + e], s1);
                         s2 = fmaf(x, w[2 * HdP + e], s2);
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(25);
         f32x16 (&accF)[NU] = acc2;
         zero(accF);
-        gemm_x3t<F16, NTF, NX, true, false, true>(accF, actT, act_stride, wmat(W_FEAT), KS, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, true, false, true, P>(accF, actT, act_stride, wmat(W_FEAT), KS, 0, KS, U, lane, ring);
         H3D_TRACE(26);
         __syncthreads();
         H3D_TRACE(27);
@@ -538,23 +541,23 @@ size_t lds_bytes(const LayoutT& L) {
            sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + 4 * 3 * 64 + 64 + 64 + 64 * 3 + 4 * 32);
 }
 
-template <int NTF, int NX, bool FUSED>
+template <int NTF, int NX, bool FUSED, int P>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((field_x3t_kernel<NTF, NX, FUSED>));
+    H3D_ALLOW_MAX_LDS((field_x3t_kernel<NTF, NX, FUSED, P>));
     h3d::pre_launch();
-    hipLaunchKernelGGL((field_x3t_kernel<NTF, NX, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    hipLaunchKernelGGL((field_x3t_kernel<NTF, NX, FUSED, P>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
     return h3d::launch_status(FUSED ? "h3d_render_fused_x3t" : "h3d_neural_field_x3t");
 }
 
-template <bool FUSED>
+template <bool FUSED, int P>
 int launch(const Args& A, int B, int64_t groups, hipStream_t st) {
     switch (A.L.NT) {
-        case 4: return launch_one<1, 0, FUSED>(A, B, groups, st);
-        case 6: return launch_one<1, 1, FUSED>(A, B, groups, st);
-        case 8: return launch_one<2, 0, FUSED>(A, B, groups, st);
-        case 10: return launch_one<2, 1, FUSED>(A, B, groups, st);
-        case 12: return launch_one<3, 0, FUSED>(A, B, groups, st);
-        case 14: return launch_one<3, 1, FUSED>(A, B, groups, st);
+        case 4: return launch_one<1, 0, FUSED, P>(A, B, groups, st);
+        case 6: return launch_one<1, 1, FUSED, P>(A, B, groups, st);
+        case 8: return launch_one<2, 0, FUSED, P>(A, B, groups, st);
+        case 10: return launch_one<2, 1, FUSED, P>(A, B, groups, st);
+        case 12: return launch_one<3, 0, FUSED, P>(A, B, groups, st);
+        case 14: return launch_one<3, 1, FUSED, P>(A, B, groups, st);
         default:
             h3d::set_error("x3t field kernel: width %d exceeds the 448 its LDS tile holds (use the fp32 engine)", A.L.HdP);
             return H3D_EUNSUPPORTED;
@@ -671,11 +674,12 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     return H3D_OK;
 }
 
-extern "C" int h3d_neural_field_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
-                                    const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
-                                    int geo_stride, float input_scaler, h3d_stream_t stream) {
+extern "C" int h3d_neural_field_x3t_tier(const void* packed, const float* points, const float* geo, const float* dirs,
+                                         const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                                         int geo_stride, float input_scaler, int products, h3d_stream_t stream) {
     int rc = check_x3t(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
+    H3D_REQUIRE(products == 1 || products == 3, "h3d_neural_field_x3t_tier: products must be 1 (plain f16) or 3 (split f16)");
     H3D_REQUIRE(out, "h3d_neural_field_x3t: null output");
     if (B == 0 || N == 0) return H3D_OK;
     Args A{};
@@ -685,17 +689,25 @@ extern "C" int h3d_neural_field_x3t(const void* packed, const float* points, con
     A.L = make_layout(Hd, F);
     const int64_t groups = (N + 63) / 64;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_neural_field_x3t: N too large");
-    return launch<false>(A, B, groups, static_cast<hipStream_t>(stream));
+    return products == 3 ? launch<false, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+                         : launch<false, 1>(A, B, groups, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int h3d_render_fused_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
-                                    const float* freq, const float* phase, const float* z_vals, const float* noise,
-                                    float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
-                                    int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
-                                    h3d_stream_t stream) {
+extern "C" int h3d_neural_field_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
+                                    const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                                    int geo_stride, float input_scaler, h3d_stream_t stream) {
+    return h3d_neural_field_x3t_tier(packed, points, geo, dirs, freq, phase, out, B, N, Hd, F, geo_stride, input_scaler, 3, stream);
+}
+
+extern "C" int h3d_render_fused_x3t_tier(const void* packed, const float* points, const float* geo, const float* dirs,
+                                         const float* freq, const float* phase, const float* z_vals, const float* noise,
+                                         float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                                         int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                                         int products, h3d_stream_t stream) {
     const int64_t N = (int64_t)R * S;
     int rc = check_x3t(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
+    H3D_REQUIRE(products == 1 || products == 3, "h3d_render_fused_x3t_tier: products must be 1 (plain f16) or 3 (split f16)");
     H3D_REQUIRE(z_vals && feats && depth && weights, "h3d_render_fused_x3t: null pointer");
     H3D_REQUIRE(clamp_mode == 0 || clamp_mode == 1, "h3d_render_fused_x3t: clamp_mode must be 0 (relu) or 1 (softplus)");
     H3D_REQUIRE(R >= 0 && S >= 1, "h3d_render_fused_x3t: bad R=%d S=%d", R, S);
@@ -722,7 +734,8 @@ extern "C" int h3d_render_fused_x3t(const void* packed, const float* points, con
         if (!tb) (void)hipMalloc(&tb, 4096 * 8);
         (void)hipMemset(tb, 0, 4096 * 8);
         A.out = reinterpret_cast<float*>(tb);
-        const int rc2 = launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+        const int rc2 = products == 3 ? launch<true, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+                                      : launch<true, 1>(A, B, groups, static_cast<hipStream_t>(stream));
         (void)hipDeviceSynchronize();
         static unsigned long long host[4096];
         (void)hipMemcpy(host, tb, sizeof(host), hipMemcpyDeviceToHost);
@@ -740,5 +753,15 @@ extern "C" int h3d_render_fused_x3t(const void* packed, const float* points, con
         return rc2;
     }
 #endif
-    return launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+    return products == 3 ? launch<true, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+                         : launch<true, 1>(A, B, groups, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int h3d_render_fused_x3t(const void* packed, const float* points, const float* geo, const float* dirs,
+                                    const float* freq, const float* phase, const float* z_vals, const float* noise,
+                                    float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                                    int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                                    h3d_stream_t stream) {
+    return h3d_render_fused_x3t_tier(packed, points, geo, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S,
+                                     Hd, F, geo_stride, input_scaler, clamp_mode, last_back, white_back, 3, stream);
 }

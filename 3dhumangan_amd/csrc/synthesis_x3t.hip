@@ -13,6 +13,7 @@
 // accumulator-order K), every conv / gamma / beta is a GEMM over those fragments with its weights streamed from L2 in
 // A-fragment order.  Only the 3-channel image reaches HBM.
 #include "x3t_common.hpp"
+#include <type_traits>
 
 using namespace h3d;
 
@@ -44,9 +45,14 @@ __device__ __forceinline__ float linspace_pm1(int n, int i) {   // torch.linspac
 // table pointers, the wave's tile ids and the lane id: none of the per-phase fragment addresses is then loop-invariant
 // for the compiler, which would otherwise hoist the first k-steps' weight loads of every GEMM (and their addresses) out
 // of the block loop and spill hundreds of registers (LICM).
-template <int NTF, int NX>
+// T / P: operand type and partial products per operand pair (x3t_common.hpp): BF16 / 3 is the fp32-class default; F16 / 2
+// (weights hi + lo, activations one f16 value) and F16 / 1 (plain f16 matrix-core arithmetic) are the reduced-precision
+// tiers of BASELINE config 5 -- f16 because one bf16 value (8 significant bits) per activation is too coarse.
+template <int NTF, int NX, typename T, int P>
 struct Block {
     static constexpr int NU = 2 * NTF + NX;
+    static constexpr bool LO = P == 3;          // activations carry a lo half
+    typedef typename std::conditional<std::is_same<T, F16>::value, SplitF16, SplitBF16>::type Split;
     const Args& A;
     X3tUnits<NTF, NX> U;
     const unsigned char* wblob;
@@ -55,7 +61,7 @@ struct Block {
     float *part, *tw;
     int* tap;
     int lane, m, h, wave, b, t, KS, HdP, act_stride;
-    SplitBF16 split;
+    Split split;
     X3tRing<NTF + NX>& ring;            // weight fragments in flight (x3t_common.hpp)
 
     // constant-style SPADE of `src`: y = lrelu(x * a + b) (per-(sample, channel) affine from the host) -> actT
@@ -65,7 +71,7 @@ struct Block {
         for (int u = 0; u < NU; ++u) {
             const int nt = U.tile(u);
             pin1(src[u]);           // accumulator sets live in AGPRs; VALU code reads / writes them one unit at a time
-            x3t_store_unit(src[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
+            x3t_store_unit<LO>(src[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
                 const f32x4 sa = ld4(abg + nt * 32 + rg * 8), sb = ld4(abg + HdP + nt * 32 + rg * 8);
                 f32x4 y;
 #pragma unroll
@@ -96,7 +102,7 @@ struct Block {
     template <bool ADD>
     __device__ __forceinline__ void conv(f32x16 (&dst)[NU], const h3d_spade_desc& Sp) const {
         add_vec<ADD>(dst, tables + Sp.b_conv);
-        gemm_x3t<BF16, NTF, NX, false>(dst, actT, act_stride, wblob + Sp.w_conv, KS, 0, KS, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, false, P>(dst, actT, act_stride, wblob + Sp.w_conv, KS, 0, KS, U, lane, ring);
     }
     // per-pixel-style SPADE: fragments of lrelu((x*sc + sh) * (1 + gamma) + beta) -> actT; g is the gamma / beta scratch
     __device__ __forceinline__ void store_pixel(f32x16 (&x)[NU], f32x16 (&g)[NU], const h3d_spade_desc& Sp) const {
@@ -139,7 +145,7 @@ struct Block {
         const float* __restrict__ vec = tables + Sp.vec;
         constexpr int a_stride = kKSA * 2048;
         add_vec<false>(g, vec);
-        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int nt = U.tile(u);
@@ -154,11 +160,11 @@ struct Block {
             pin1(g[u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        gemm_x3t<BF16, NTF, NX, false>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             pin1(g[u]);
-            x3t_store_unit(g[u], actT, KS, U.tile(u), U.mt(u), lane, split, [&](int, f32x4 v) {
+            x3t_store_unit<LO>(g[u], actT, KS, U.tile(u), U.mt(u), lane, split, [&](int, f32x4 v) {
                 f32x4 y;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = lrelu(v[i]);
@@ -211,7 +217,7 @@ struct Block {
     }
 };
 
-template <int NTF, int NX>
+template <int NTF, int NX, typename T, int P>
 __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
     constexpr int NU = 2 * NTF + NX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         for (int i = 0; i < NTF + NX; ++i) asm volatile("" : "+s"(U.nt[i]));
         int lane = lane0;
         asm volatile("" : "+v"(lane));
-        return Block<NTF, NX>{A, U, A.wblob + opaque, A.tables + opaque, actT, aT, part, tw, tap,
-                              lane, m, h, wave, b, t, KS, HdP, act_stride, SplitBF16(), ring};
+        return Block<NTF, NX, T, P>{A, U, A.wblob + opaque, A.tables + opaque, actT, aT, part, tw, tap,
+                              lane, m, h, wave, b, t, KS, HdP, act_stride, {}, ring};
     };
 
     // ================= blocks before the first skip connection (either style) =======================================
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
 #pragma unroll 1
     for (int blk = 0; blk < A.first_skip; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
-        const Block<NTF, NX> K = block_view();
+        const Block<NTF, NX, T, P> K = block_view();
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
             const h3d_spade_desc& Sp = Bk.spade[s];
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
 #pragma unroll 1
     for (int blk = A.first_skip; blk < D.n_blocks; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
-        const Block<NTF, NX> K = block_view();
+        const Block<NTF, NX, T, P> K = block_view();
         f32x16 acc[NU];
         K.store_const(cur, Bk.spade[0]);
         __syncthreads();
@@ -344,12 +350,27 @@ size_t lds_bytes(int NT) {
     return (size_t)2 * (2 * NT) * 2048 + 2 * kKSA * 2048 + sizeof(float) * (4 * 3 * 64 + 64 + 64 + 256 + 128);
 }
 
-template <int NTF, int NX>
+template <int NTF, int NX, typename T, int P>
 int launch_one(const Args& A, int B, int64_t tiles, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((synthesis_x3t_kernel<NTF, NX>));
+    H3D_ALLOW_MAX_LDS((synthesis_x3t_kernel<NTF, NX, T, P>));
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3t_kernel<NTF, NX>), dim3((unsigned)tiles, (unsigned)B), dim3(256), lds_bytes(A.NT), st, A);
+    hipLaunchKernelGGL((synthesis_x3t_kernel<NTF, NX, T, P>), dim3((unsigned)tiles, (unsigned)B), dim3(256), lds_bytes(A.NT), st, A);
     return h3d::launch_status("h3d_synthesis_x3t");
+}
+
+template <typename T, int P>
+int launch(const Args& A, int B, int64_t tiles, hipStream_t st) {
+    switch (A.NT) {
+        case 4: return launch_one<1, 0, T, P>(A, B, tiles, st);
+        case 6: return launch_one<1, 1, T, P>(A, B, tiles, st);
+        case 8: return launch_one<2, 0, T, P>(A, B, tiles, st);
+        case 10: return launch_one<2, 1, T, P>(A, B, tiles, st);
+        case 12: return launch_one<3, 0, T, P>(A, B, tiles, st);
+        case 14: return launch_one<3, 1, T, P>(A, B, tiles, st);
+        default:
+            h3d::set_error("h3d_synthesis_x3t: unsupported tile count %d", A.NT);
+            return H3D_EUNSUPPORTED;
+    }
 }
 
 }  // namespace
@@ -361,10 +382,12 @@ extern "C" int h3d_synthesis_x3t_tiles(int C) {
     return nt + (nt & 1);
 }
 
-extern "C" int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
-                                 int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
-                                 float* rgb, int B, int H, int W, h3d_stream_t stream) {
+extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                                      int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
+                                      float* rgb, int B, int H, int W, int dtype, int products, h3d_stream_t stream) {
     H3D_REQUIRE(wblob && tables && desc && rgb, "h3d_synthesis_x3t: null pointer");
+    H3D_REQUIRE((dtype == 0 && products == 3) || (dtype == 1 && (products == 1 || products == 2)),
+                "h3d_synthesis_x3t_tier: (dtype, products) must be (0 bf16, 3), (1 f16, 2) or (1 f16, 1)");
     H3D_REQUIRE(h3d::aligned16(wblob) && h3d::aligned16(tables), "h3d_synthesis_x3t: weights / tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3t: n_blocks=%d", desc->n_blocks);
     H3D_REQUIRE(B >= 0 && B <= 65535 && H >= 1 && W >= 1, "h3d_synthesis_x3t: bad output shape");
@@ -420,15 +443,12 @@ extern "C" int h3d_synthesis_x3t(const void* wblob, const float* tables, const h
     H3D_REQUIRE(tiles < (int64_t(1) << 31), "h3d_synthesis_x3t: image too large");
     H3D_REQUIRE(lds_bytes(NT) <= 160 * 1024, "h3d_synthesis_x3t: width %d does not fit the 160 KB LDS", desc->C);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (NT) {
-        case 4: return launch_one<1, 0>(A, B, tiles, st);
-        case 6: return launch_one<1, 1>(A, B, tiles, st);
-        case 8: return launch_one<2, 0>(A, B, tiles, st);
-        case 10: return launch_one<2, 1>(A, B, tiles, st);
-        case 12: return launch_one<3, 0>(A, B, tiles, st);
-        case 14: return launch_one<3, 1>(A, B, tiles, st);
-        default:
-            h3d::set_error("h3d_synthesis_x3t: unsupported tile count %d", NT);
-            return H3D_EUNSUPPORTED;
-    }
+    if (dtype == 0) return launch<BF16, 3>(A, B, tiles, st);
+    return products == 2 ? launch<F16, 2>(A, B, tiles, st) : launch<F16, 1>(A, B, tiles, st);
+}
+
+extern "C" int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                                 int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
+                                 float* rgb, int B, int H, int W, h3d_stream_t stream) {
+    return h3d_synthesis_x3t_tier(wblob, tables, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W, 0, 3, stream);
 }

@@ -72,13 +72,13 @@ __device__ __forceinline__ void x3t_gload(u32x4& dst, const unsigned char* base,
 }
 // s_waitcnt vmcnt(N), tied to the fragments about to be consumed: their users read the post-wait values, so the
 // scheduler cannot move an MFMA above the wait.
-template <int N, int NA>
+template <int N, int NA, bool LO = true>
 __device__ __forceinline__ void x3t_wait_frags(u32x4 (&h)[NA], u32x4 (&l)[NA]) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(h[0]) : "n"(N) : "memory");
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         if (i) asm volatile("" : "+v"(h[i]));
-        asm volatile("" : "+v"(l[i]));
+        if (LO) asm volatile("" : "+v"(l[i]));
     }
 }
 
@@ -93,7 +93,7 @@ struct X3tRing {
 
 // Request k-steps ks0 .. ks0+D-2 of the wave's tiles of matrix W into ring slots 0 .. D-2 (2*NA*(D-1) loads).  Between
 // this call and the GEMM that consumes it (PRE = true) the caller must not start another GEMM on the same ring.
-template <int NTF, int NX>
+template <int NTF, int NX, int P = 3>
 __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigned char* __restrict__ W, int KStot, int ks0,
                                              const X3tUnits<NTF, NX>& U, int lane) {
     constexpr int NA = NTF + NX;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigne
         for (int i = 0; i < NA; ++i) {
             const unsigned char* q = W + ((int64_t)U.nt[i] * KStot + ks0 + d) * 2048;
             x3t_gload<0>(R.a[d].h[i], q, lane_off);
-            x3t_gload<1024>(R.a[d].l[i], q, lane_off);
+            if constexpr (P >= 2) x3t_gload<1024>(R.a[d].l[i], q, lane_off);
         }
 }
 
@@ -117,11 +117,18 @@ __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigne
 // ~2000 matrix-pipe cycles: an L2 miss served by the Infinity Cache is covered), B fragments one k-step ahead.
 // GUARD: a short phase (input layers with KS = 1 or 2 k-steps); otherwise KS is a multiple of the ring depth, >= depth.
 // PRE: the ring already holds the requests of x3t_prefetch(R, W, KStot, ks0, ..) (full phases only).
-template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false, bool PRE = false>
+// P: partial products per operand pair -- the precision tier (same data layout, fewer planes touched):
+//      3  hi*hi + hi*lo + lo*hi   fp32-class (22 / 16 significant bits per operand with f16 / bf16 halves)
+//      2  hi*hi + lo*hi           weights to full precision, activations rounded to ONE 16-bit value
+//      1  hi*hi                   plain f16 / bf16 matrix-core arithmetic
+template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false, bool PRE = false, int P = 3>
 __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsigned char* bT, int mt_stride,
                                          const unsigned char* __restrict__ W, int KStot, int ks0, int KS,
                                          const X3tUnits<NTF, NX>& U, int lane, X3tRing<NTF + NX>& R) {
     constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
+    constexpr bool WLO = P >= 2, XLO = P == 3;       // which lo planes are read
+    constexpr int NLA = (WLO ? 2 : 1) * NA;          // weight loads per k-step
+    static_assert(P >= 1 && P <= 3, "1, 2 or 3 partial products");
     static_assert(!(GUARD && PRE), "short phases load everything themselves");
     typedef typename X3tRing<NA>::AF AF;
     struct BF { u32x4 h[2], l[2], xh, xl; };
@@ -132,12 +139,12 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
     const unsigned lane_off = (unsigned)lane * 16u;
     const unsigned char* bp = bT + lane * 16;
     const unsigned char* bx = bp + U.xmt * mt_stride;
-    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {      // 2*NA loads, always all of them
+    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {      // NLA loads, always all of them
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const unsigned char* q = wp[i] + ks * 2048;     // one scalar address per tile and k-step; lo plane 1 KB further
             x3t_gload<0>(f.h[i], q, lane_off);
-            x3t_gload<1024>(f.l[i], q, lane_off);
+            if constexpr (WLO) x3t_gload<1024>(f.l[i], q, lane_off);
         }
     };
     auto loadB = [&](BF& f, int ks) __attribute__((always_inline)) {
@@ -145,24 +152,24 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         for (int mt = 0; mt < 2; ++mt) {
             if (NTF > 0) {
                 f.h[mt] = *reinterpret_cast<const u32x4*>(bp + mt * mt_stride + ks * 2048);
-                f.l[mt] = *reinterpret_cast<const u32x4*>(bp + mt * mt_stride + ks * 2048 + 1024);
+                if constexpr (XLO) f.l[mt] = *reinterpret_cast<const u32x4*>(bp + mt * mt_stride + ks * 2048 + 1024);
             }
         }
         if (NX) {
             f.xh = *reinterpret_cast<const u32x4*>(bx + ks * 2048);
-            f.xl = *reinterpret_cast<const u32x4*>(bx + ks * 2048 + 1024);
+            if constexpr (XLO) f.xl = *reinterpret_cast<const u32x4*>(bx + ks * 2048 + 1024);
         }
     };
-    // MFMA j of a k-step, j = 0 .. 3*NU-1: pass p = j / NU (hi*hi, hi*lo, lo*hi) over all units -- consecutive MFMAs never
-    // share an accumulator
+    // MFMA j of a k-step, j = 0 .. P*NU-1: pass j / NU (hi*hi, then lo*hi, then hi*lo) over all units -- consecutive MFMAs
+    // never share an accumulator
     auto mfma1 = [&](auto jc, const AF& a, const BF& b) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value, p = j / NU, u = j % NU, sl = u < 2 * NTF ? u / 2 : NTF;
-        const u32x4 wv = p == 2 ? a.l[sl] : a.h[sl];
-        const u32x4 xv = u < 2 * NTF ? (p == 1 ? b.l[u & 1] : b.h[u & 1]) : (p == 1 ? b.xl : b.xh);
+        const u32x4 wv = p == 1 ? a.l[sl] : a.h[sl];
+        const u32x4 xv = u < 2 * NTF ? (p == 2 ? b.l[u & 1] : b.h[u & 1]) : (p == 2 ? b.xl : b.xh);
         acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
     };
     auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {
-        static_for<0, 3 * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, a, b); });
+        static_for<0, P * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, a, b); });
     };
     // One k-step with its memory traffic in the shadow of the matrix pipe (one wave per SIMD: whatever is issued between
     // two MFMAs is free, whatever is issued before the first one leaves the pipe idle): after MFMA j comes weight load j
@@ -171,24 +178,27 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
     // ring element would move the whole ring to scratch memory)
     auto kstep = [&](auto la, auto lb, const AF& a_cur, const BF& b_cur, AF& a_nxt, int ka, BF& b_nxt, int kb) __attribute__((always_inline)) {
         constexpr bool LA = decltype(la)::value != 0, LB = decltype(lb)::value != 0;
-        constexpr int NB = (NTF > 0 ? 4 : 0) + (NX ? 2 : 0), NOPS = 2 * NA + NB, NM = 3 * NU;
-        // memory operation i = 0 .. NOPS-1: the 2*NA weight loads first, then the NB fragment reads
+        constexpr int XP = XLO ? 2 : 1;                            // fragment planes read per sample tile
+        constexpr int NBF = NTF > 0 ? 2 * XP : 0, NB = NBF + (NX ? XP : 0), NOPS = NLA + NB, NM = P * NU;
+        // memory operation i = 0 .. NOPS-1: the NLA weight loads first (tile-major, hi then lo), then the NB fragment reads
         auto memop = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (i < 2 * NA) {
+            if constexpr (i < NLA) {
                 if constexpr (LA) {
-                    const unsigned char* q = wp[i / 2] + ka * 2048;
-                    if constexpr (i % 2 == 0) x3t_gload<0>(a_nxt.h[i / 2], q, lane_off);
-                    else x3t_gload<1024>(a_nxt.l[i / 2], q, lane_off);
+                    constexpr int tile = WLO ? i / 2 : i, plane = WLO ? i % 2 : 0;
+                    const unsigned char* q = wp[tile] + ka * 2048;
+                    if constexpr (plane == 0) x3t_gload<0>(a_nxt.h[tile], q, lane_off);
+                    else x3t_gload<1024>(a_nxt.l[tile], q, lane_off);
                 }
             } else if constexpr (LB) {
-                constexpr int r = i - 2 * NA;
-                if constexpr (NTF > 0 && r < 4) {
-                    const unsigned char* q = bp + (r >> 1) * mt_stride + kb * 2048 + (r & 1) * 1024;
-                    if constexpr ((r & 1) == 0) b_nxt.h[r >> 1] = *reinterpret_cast<const u32x4*>(q);
-                    else b_nxt.l[r >> 1] = *reinterpret_cast<const u32x4*>(q);
+                constexpr int r = i - NLA;
+                if constexpr (r < NBF) {
+                    constexpr int mt = r / XP, plane = r % XP;
+                    const unsigned char* q = bp + mt * mt_stride + kb * 2048 + plane * 1024;
+                    if constexpr (plane == 0) b_nxt.h[mt] = *reinterpret_cast<const u32x4*>(q);
+                    else b_nxt.l[mt] = *reinterpret_cast<const u32x4*>(q);
                 } else {
-                    constexpr int k = r - (NTF > 0 ? 4 : 0);
+                    constexpr int k = r - NBF;
                     if constexpr (k == 0) b_nxt.xh = *reinterpret_cast<const u32x4*>(bx + kb * 2048);
                     else b_nxt.xl = *reinterpret_cast<const u32x4*>(bx + kb * 2048 + 1024);
                 }
@@ -198,7 +208,8 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
             constexpr int j = decltype(jc)::value;
             mfma1(jc, a_cur, b_cur);
             __builtin_amdgcn_sched_barrier(0);
-            // operations [j*NOPS/NM, (j+1)*NOPS/NM) ride behind MFMA j: spread evenly over the k-step
+            // operations [j*NOPS/NM, (j+1)*NOPS/NM) ride behind MFMA j: spread evenly over the k-step (with one product
+            // per operand pair there are more memory operations than MFMAs: some gaps carry two)
             static_for<j * NOPS / NM, (j + 1) * NOPS / NM>([&](auto ic) __attribute__((always_inline)) {
                 memop(ic);
                 __builtin_amdgcn_sched_barrier(0);
@@ -213,10 +224,10 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         loadA(a[0], 0);
         loadB(b[0], 0);
         if (KS > 1) { loadA(a[1], 1); loadB(b[1], 1); }
-        x3t_wait_frags<0, NA>(a[0].h, a[0].l);
+        x3t_wait_frags<0, NA, WLO>(a[0].h, a[0].l);
         mfmas(a[0], b[0]);
         if (KS > 1) {
-            x3t_wait_frags<0, NA>(a[1].h, a[1].l);
+            x3t_wait_frags<0, NA, WLO>(a[1].h, a[1].l);
             mfmas(a[1], b[1]);
         }
     } else {
@@ -226,11 +237,11 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         }
         loadB(b[0], 0);
         // slot d of a trip: the fragments of its k-step were requested D-1 slots ago; the requests of the D-2 slots in
-        // between -- (D-2) * 2*NA loads -- may stay in flight.  Its own requests (k-step +D-1) follow inside kstep.
+        // between -- (D-2) * NLA loads -- may stay in flight.  Its own requests (k-step +D-1) follow inside kstep.
         for (int ks = 0; ks < KS - D; ks += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                x3t_wait_frags<(D - 2) * 2 * NA, NA>(a[d].h, a[d].l);
+                x3t_wait_frags<(D - 2) * NLA, NA, WLO>(a[d].h, a[d].l);
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(IC<1>{}, IC<1>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
             }
@@ -238,7 +249,7 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         // the last D k-steps: one more request, then the ring drains
         static_for<0, D>([&](auto dc) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
-            x3t_wait_frags<(d == 0 ? D - 2 : D - 1 - d) * 2 * NA, NA>(a[d].h, a[d].l);
+            x3t_wait_frags<(d == 0 ? D - 2 : D - 1 - d) * NLA, NA, WLO>(a[d].h, a[d].l);
             __builtin_amdgcn_sched_barrier(0);
             kstep(IC<(d == 0)>{}, IC<(d < D - 1)>{}, a[d], b[d & 1], a[D - 1], KS - 1, b[(d + 1) & 1], KS - D + d + 1);
         });
@@ -248,7 +259,8 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
 // Epilogue of one unit: y = f(rg, values of register group rg) for the four register groups of the accumulator tile
 // (rg -> features 32*nt + 8*rg + 4*h + 0..3 of this lane's sample), split into hi / lo and written as the B fragments of
 // k-steps 2*nt, 2*nt+1 of sample tile mt.  SPLIT(a, b, lo) -> packed hi halves.
-template <typename SPLIT, typename F>
+// LO = false (precision tiers with ONE 16-bit value per activation): only the hi plane is written.
+template <bool LO = true, typename SPLIT, typename F>
 __device__ __forceinline__ void x3t_store_unit(const f32x16& v, unsigned char* actT, int KS, int nt, int mt, int lane, SPLIT split, F f) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -265,7 +277,7 @@ __device__ __forceinline__ void x3t_store_unit(const f32x16& v, unsigned char* a
         }
         unsigned char* p = actT + x3t_frag(KS, mt, 2 * nt + j, 0) + lane * 16;
         *reinterpret_cast<u32x4*>(p) = hi;
-        *reinterpret_cast<u32x4*>(p + 1024) = lo;
+        if constexpr (LO) *reinterpret_cast<u32x4*>(p + 1024) = lo;
     }
 }
 

@@ -329,6 +329,11 @@ class Map3DGenerator(nn.Module):
 
     # ------------------------------------------------------------------ synthesis plan (static packing)
     def synthesis_plan(self, device):
+        """Packed synthesis weights for `device` ("cuda", "cuda:0" and torch.device("cuda", 0) name the same plan: an
+        engine override set through one spelling must be seen by forward(), which asks with the tensors' device)."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         sd = self.state_dict()
         key = (str(device),) + tuple((v.data_ptr(), v._version) for n, v in sd.items()
                                      if n.startswith(("synthesis_network", "synthesis_input")))

@@ -152,7 +152,9 @@ class SynthesisPlan:
         self._x3t = None
         # Arithmetic engine: "bf16x3" split-bf16 matrix cores, register-resident activations (C <= 256);
         # "bf16x3t" split-bf16 matrix cores, LDS-resident activations (C <= 448: MAP3DBN 384, MAP3DBN512L 420);
-        # "f32" fp32 matrix cores (anything else).
+        # "f32" fp32 matrix cores (anything else).  Opt-in reduced-precision tiers on the bf16x3t kernel (NOT within the
+        # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16x2t" weights f16 hi + lo, activations one f16 value (two
+        # products); "f16x1t" plain f16 products.
         default = "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
@@ -175,8 +177,8 @@ class SynthesisPlan:
         return all(4 * (seg["tables"].numel() + per_sample) + 4 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
 
     @staticmethod
-    def pack_stream_bf16(w_out_in, KS, NT, acc_order=True):
-        """[n_out, n_in] -> bf16 hi/lo weight-stream stages [KS][NT][2][64][8] (as int16 bit patterns).
+    def pack_stream_bf16(w_out_in, KS, NT, acc_order=True, dtype=torch.bfloat16):
+        """[n_out, n_in] -> bf16 (or `dtype`) hi/lo weight-stream stages [KS][NT][2][64][8] (as int16 bit patterns).
 
         acc_order (every matrix of the x3 synthesis engine: its inputs are always previous accumulators): the K dimension
         runs in accumulator-register order, feature of k-slot (h, e) of k-step ks =
@@ -192,8 +194,8 @@ class SynthesisPlan:
             e = torch.arange(8, device=dev).view(1, 1, 8)
             k = 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh          # [KS, 2, 8]
             wp = wp[:, k.reshape(-1)]
-        hi = wp.to(torch.bfloat16)
-        lo = (wp - hi.float()).to(torch.bfloat16)
+        hi = wp.to(dtype)
+        lo = (wp - hi.float()).to(dtype)
 
         def frag(t):        # [N, K] -> [KS, NT, 64 lanes, 8]; lane = 32*h + j, element e: n = 32nt + j, k-slot (ks, h, e)
             return t.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8)
@@ -216,20 +218,24 @@ class SynthesisPlan:
                 return False
         return True
 
-    def build_x3t(self):
-        """Weights as bf16 hi/lo MFMA A fragments, tile-major [tile][k-step][hi|lo][64 lanes][8] (conv matrices with K in
+    X3T_TIERS = {"bf16x3t": (torch.bfloat16, 0, 3), "f16x2t": (torch.float16, 1, 2), "f16x1t": (torch.float16, 1, 1)}
+
+    def build_x3t(self, dtype=torch.bfloat16):
+        """Weights as bf16 (f16 for the reduced-precision tiers) hi/lo MFMA A fragments, tile-major [tile][k-step][hi|lo][64 lanes][8] (conv matrices with K in
         accumulator-register order, gamma / beta in natural order: their input is assembled from memory), fp32 tables
         padded to the engine's width 32 * tiles, and a descriptor whose w_* offsets are BYTES into the fragment blob and
         whose vec / b_conv / w_rgb / w_in / b_in offsets are FLOATS into the tables."""
-        if self._x3t is not None:
-            return self._x3t
+        if self._x3t is None:
+            self._x3t = {}
+        if dtype in self._x3t:
+            return self._x3t[dtype]
         C = self.C
         NT = _lib.load().h3d_synthesis_x3t_tiles(C)
         HdP, KS = 32 * NT, 2 * NT
         wchunks, woff, tchunks, toff = [], [0], [], [0]
 
         def add_w(w_out_in, ks, acc_order):
-            frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order).view(ks, NT, 2 * 64 * 8)
+            frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order, dtype=dtype).view(ks, NT, 2 * 64 * 8)
             o = woff[0]
             wchunks.append(frag.transpose(0, 1).contiguous().flatten())          # [NT][ks][2][64][8]
             woff[0] += wchunks[-1].numel() * 2
@@ -266,8 +272,9 @@ class SynthesisPlan:
             if dst.to_rgb:
                 wr, br = self._rgb[k]
                 dst.w_rgb = add_t(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
-        self._x3t = dict(desc=desc, wblob=torch.cat(wchunks).contiguous(), tables=torch.cat(tchunks).contiguous(), NT=NT, HdP=HdP)
-        return self._x3t
+        self._x3t[dtype] = dict(desc=desc, wblob=torch.cat(wchunks).contiguous(), tables=torch.cat(tchunks).contiguous(),
+                                NT=NT, HdP=HdP)
+        return self._x3t[dtype]
 
     # Optional split of the network into several launches whose weight streams each fit the 4 MB L2 of an XCD
     # (H3D_SYNTH_SEGMENT_BYTES=2359296).  Measured on MI355X: the single-launch stream (6.3 MB, 63 % L2 hit rate) is
@@ -395,10 +402,11 @@ class SynthesisPlan:
         B = fixed_style.shape[0]
         Hr, Wr = render_hw
         H, W = out_hw
-        if self.engine not in ("bf16x3", "bf16x3t", "f32"):
+        if self.engine not in ("bf16x3", "f32") and self.engine not in self.X3T_TIERS:
             raise ValueError(f"unknown synthesis engine {self.engine!r}")
         x3 = self.build_x3() if self.engine == "bf16x3" else None
-        x3t = self.build_x3t() if self.engine == "bf16x3t" else None
+        tier = self.X3T_TIERS.get(self.engine, self.X3T_TIERS["bf16x3t"])
+        x3t = self.build_x3t(tier[0]) if self.engine in self.X3T_TIERS else None
         if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
             # the x3 engine's matrix-core resize does not cover this geometry: the LDS-resident engine does
             x3, x3t = None, (self.build_x3t() if self.x3t_supported() else None)
@@ -411,10 +419,10 @@ class SynthesisPlan:
         what = "h3d_synthesis_x3" if x3 else "h3d_synthesis_x3t" if x3t else "h3d_synthesis"
         with stage(owner, "synthesis"):
             if x3t:
-                rc = _lib.load().h3d_synthesis_x3t(_lib.ptr(x3t["wblob"]), _lib.ptr(x3t["tables"]), ctypes.byref(x3t["desc"]),
-                                                 _lib.ptr(G), self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids),
-                                                 _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
-                                                 _lib.stream_handle())
+                rc = _lib.load().h3d_synthesis_x3t_tier(_lib.ptr(x3t["wblob"]), _lib.ptr(x3t["tables"]),
+                                                      ctypes.byref(x3t["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr,
+                                                      _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids),
+                                                      _lib.ptr(rgb), B, H, W, tier[1], tier[2], _lib.stream_handle())
             elif x3:
                 segs = x3["segments"]
                 state = None

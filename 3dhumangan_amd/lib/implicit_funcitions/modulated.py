@@ -59,6 +59,8 @@ class COORDCONCATSIREN(nn.Module):
         #   "f16x3"   split-operand f16 matrix cores, activations register-resident (widths <= 256)
         #   "f16x3t"  split-operand f16 matrix cores, activations LDS-resident, any width <= 448 (MAP3DBN 384, MAP3DBN512L 420)
         #   "f32"     fp32 matrix cores (any width <= 512)
+        # and, NOT within the 1e-3 budget (the "fp16 MFMA path" tier of BASELINE config 5, ~1e-2 on the render; opt-in):
+        #   "f16x1t"  plain f16 matrix-core products on the f16x3t engine (one product instead of three)
         widest = max(hidden_dim, feature_dim)
         default = "f16x3" if widest <= 256 else "f16x3t" if widest <= 448 else "f32"
         self.precision = os.environ.get("H3D_FIELD_PRECISION", default)
@@ -68,11 +70,14 @@ class COORDCONCATSIREN(nn.Module):
         return [self.first_layer_coord.layer, self.first_layer_mod.layer] + [d.layer for d in self.network] + \
                [self.sigma_layer, self.color_layer_sine.layer, self.color_layer_linear, self.feature_layer_linear]
 
-    # engine -> (pack-size, pack, field, fused-render) entry points of the C ABI and the sample tile of the fused kernel
+    # engine -> (pack-size, pack, field, fused-render) entry points of the C ABI, the sample tile of the fused kernel and
+    # the extra trailing arguments (before the stream) of the field / render entry points
     _ENGINES = {
-        "f16x3": ("h3d_field_pack_x3_size", "h3d_field_pack_x3", "h3d_neural_field_x3", "h3d_render_fused_x3", 32),
-        "f16x3t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t", "h3d_render_fused_x3t", 64),
-        "f32": ("h3d_field_pack_size", "h3d_field_pack", "h3d_neural_field", "h3d_render_fused", 64),
+        "f16x3": ("h3d_field_pack_x3_size", "h3d_field_pack_x3", "h3d_neural_field_x3", "h3d_render_fused_x3", 32, ()),
+        "f16x3t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t", "h3d_render_fused_x3t", 64, ()),
+        "f16x1t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t_tier", "h3d_render_fused_x3t_tier",
+                   64, (1,)),
+        "f32": ("h3d_field_pack_size", "h3d_field_pack", "h3d_neural_field", "h3d_render_fused", 64, ()),
     }
 
     def _engine(self):
@@ -88,9 +93,12 @@ class COORDCONCATSIREN(nn.Module):
     def packed_weights(self, device):
         """Device blob in MFMA fragment order (csrc/field_common.hpp, csrc/field_x3.hip); cached until a
         parameter changes."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         lins = self._params_for_pack()
-        x3 = self.precision
         size_name, pack_name = self._engine()[:2]
+        x3 = pack_name                       # engines that share a packer share the blob
         key = (str(device), x3) + tuple((p.data_ptr(), p._version) for l in lins for p in (l.weight, l.bias))
         hit = self._packed.get(x3)
         if hit is not None and hit[0] == key:
@@ -141,7 +149,7 @@ class COORDCONCATSIREN(nn.Module):
         fn = getattr(_lib.load(), self._engine()[2])
         rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
                                           _lib.ptr(ph), _lib.ptr(out), B, N, H, F, geo.shape[-1], float(input_scaler),
-                                          _lib.stream_handle())
+                                          *self._engine()[5], _lib.stream_handle())
         _lib.check(rc, "h3d_neural_field")
         return out.squeeze(1) if unsq else out
 
@@ -171,6 +179,6 @@ class COORDCONCATSIREN(nn.Module):
         rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(geo), _lib.ptr(dirs), _lib.ptr(fr),
                                           _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(feats), _lib.ptr(depth),
                                           _lib.ptr(weights), B, R, S, H, F, geo.shape[-1], float(input_scaler), mode,
-                                          int(bool(last_back)), int(bool(white_back)), _lib.stream_handle())
+                                          int(bool(last_back)), int(bool(white_back)), *self._engine()[5], _lib.stream_handle())
         _lib.check(rc, "h3d_render_fused")
         return feats, depth, weights

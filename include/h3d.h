@@ -188,6 +188,20 @@ int h3d_render_fused_x3t(const void* packed, const float* points, const float* g
                          float* feats, float* depth, float* weights,
                          int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
                          int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+/* Precision tiers of the same kernels (same blob): products = 3 is the entry point above (hi*hi + hi*lo + lo*hi, fp32
+ * class); products = 1 evaluates the hidden GEMMs with ONE f16 product per operand pair -- plain f16 matrix-core
+ * arithmetic, ~3x less matrix work, ~1e-2 relative on the render (the freq ~ 45 sines amplify the 2^-11 operand rounding):
+ * outside the 1e-3 parity budget, provided as BASELINE config 5's "fp16 MFMA path".  The K=3 / K=31 input layers always
+ * run with 3 products. */
+int h3d_neural_field_x3t_tier(const void* packed, const float* points, const float* geo, const float* dirs,
+                              const float* freq, const float* phase, float* out,
+                              int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler, int products,
+                              h3d_stream_t stream);
+int h3d_render_fused_x3t_tier(const void* packed, const float* points, const float* geo, const float* dirs,
+                              const float* freq, const float* phase, const float* z_vals, const float* noise,
+                              float* feats, float* depth, float* weights,
+                              int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
+                              int clamp_mode, int last_back, int white_back, int products, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A7+A8+A9  SPADE synthesis network, eval mode == SynthesisNetwork.forward
@@ -277,6 +291,13 @@ int h3d_synthesis_x3t_tiles(int C);
 int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G, int g_channels,
                       int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H,
                       int W, h3d_stream_t stream);
+/* Precision tiers: (dtype 0 = bf16, products 3) is the entry point above.  (dtype 1 = f16, products 2): wblob holds f16
+ * hi/lo fragments, activations are rounded to ONE f16 value (products hi*hi + lo*hi); (1, 1): plain f16 products.  Both
+ * are outside the 1e-3 parity budget (BASELINE config 5's "fp16 MFMA path"); f16 because one bf16 value per activation
+ * (8 significant bits) is too coarse. */
+int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G, int g_channels,
+                           int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H,
+                           int W, int dtype, int products, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P3a per-pixel modulated 1x1 convolution == SpatialStyleModLayer.forward (lib/components/map3d_layers.py:60-80)

@@ -158,6 +158,29 @@ def test_wide_configs_default_to_the_x3t_engines():
         assert G.neural_field.precision == "f16x3t" and G.synthesis_plan(DEV).engine == "bf16x3t", name
 
 
+def test_engine_override_is_seen_by_forward_under_any_device_spelling():
+    """plan.engine set through synthesis_plan("cuda") must be the engine forward() runs (it asks with cuda:0): the stage
+    timer names the kernel that actually ran."""
+    g = load_golden("gen_tiny_mixed")
+    G, cfg = build(g["meta"], g["state"])
+    assert G.synthesis_plan("cuda") is G.synthesis_plan(torch.device("cuda", torch.cuda.current_device()))
+    ran = []
+    L = importlib.import_module("3dhumangan_amd._lib")
+    lib = L.load()
+    for eng, fn in (("bf16x3", "h3d_synthesis_x3"), ("bf16x3t", "h3d_synthesis_x3t_tier"), ("f32", "h3d_synthesis")):
+        G.synthesis_plan("cuda").engine = eng
+        real = getattr(lib, fn)
+        called = []
+        wrapper = lambda *a, _r=real, _c=called: (_c.append(1), _r(*a))[1]
+        setattr(lib, fn, wrapper)
+        try:
+            G.forward(g["z"].to(DEV), cond_to(g["cond"]), jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV), **cfg)
+        finally:
+            setattr(lib, fn, real)
+        ran.append(len(called))
+    assert ran == [1, 1, 1], ran
+
+
 def test_engine_selection_defaults():
     g = load_golden("gen_tiny_mixed")
     G, cfg = build(g["meta"], g["state"])

@@ -1,0 +1,65 @@
+"""Stress test of the LDS weight ring of the register-resident x3 engines (csrc/x3_common.hpp: WeightRing::acquire).
+
+The ring's write-after-read hazard (a refill landing in a buffer whose last fragment reads are still in flight) is closed
+by a distance argument, not by a wait: the refill of stage t-1's buffer is issued >= 192 MFMA cycles after the barrier that
+every wave passes only after ISSUING its last reads of that buffer, and lands an L2 round trip later, while an LDS read
+retires within ~130 cycles.  A violation would show up as a corrupted weight fragment in some workgroup, i.e. as a
+different image.  Here the two kernels run 200 times back to back on the bench geometry (small batch), alone and next to a
+second stream that thrashes HBM / L2 (which stretches LDS-DMA latencies and perturbs the relative timing of the waves), and
+every output must be BIT-identical to the first one; the result is also checked against the strict fp32-MFMA engines, which
+have no ring."""
+import importlib
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+configs = importlib.import_module("3dhumangan_amd.configs")
+DEV = "cuda"
+
+
+def _setup(B=2):
+    cfg = {k: v for k, v in configs.MAP3DBN512.items() if isinstance(k, str)}
+    cfg.update(gen_height=512, gen_width=512, render_height=96, render_width=96, num_steps=64, dataset_length=4, nerf_noise=0,
+               last_back=True)
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    torch.manual_seed(77)
+    G = gens.Map3DGenerator(**cfg).to(DEV).eval()
+    G.set_device(DEV)
+    g = torch.Generator().manual_seed(77)
+    cond = {k: v.to(DEV) for k, v in synthetic.make_conditions(B, 6890, seed=77).items()}
+    z = torch.randn(B, cfg["latent_dim"], generator=g).to(DEV)
+    jit = torch.rand(B, 96 * 96, 64, 1, generator=g).to(DEV)
+    return G, cfg, z, cond, jit
+
+
+@pytest.mark.parametrize("thrash", [False, True])
+def test_x3_kernels_are_bit_reproducible_over_200_launches(thrash):
+    G, cfg, z, cond, jit = _setup()
+    assert G.neural_field.precision == "f16x3" and G.synthesis_plan(DEV).engine == "bf16x3"
+    first = G.forward(z, cond, jitter=jit, **cfg)
+    ref_rgb, ref_ren = first["rgbs"].clone(), first["rgbs_render"].clone()
+    side = torch.cuda.Stream()
+    junk = torch.empty(2, 1 << 28, dtype=torch.uint8, device=DEV) if thrash else None       # 2 x 256 MB: beyond the caches
+    bad = 0
+    for it in range(200):
+        if thrash:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    junk[1].copy_(junk[0], non_blocking=True)
+                    junk[0].add_(1)
+        out = G.forward(z, cond, jitter=jit, **cfg)
+        bad += int(not torch.equal(out["rgbs"], ref_rgb)) + int(not torch.equal(out["rgbs_render"], ref_ren))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 400 outputs differ from the first launch"
+    # and the ring-less fp32-MFMA engines agree with it to rounding
+    G.neural_field.precision = "f32"
+    G.synthesis_plan(DEV).engine = "f32"
+    strict = G.forward(z, cond, jitter=jit, **cfg)
+    assert rel_err(ref_rgb.cpu(), strict["rgbs"].cpu()) < 2e-4
+    assert rel_err(ref_ren.cpu(), strict["rgbs_render"].cpu()) < 2e-4
