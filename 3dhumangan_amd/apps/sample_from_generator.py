@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from .. import configs, synthetic
+from .. import checkpoints, configs, synthetic
 from ..lib import generators as lib_generators
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -87,7 +87,9 @@ def main(argv=None):
     ap.add_argument("--config", type=str, default="MAP3DBN")
     ap.add_argument("--tune", type=str, default="")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--checkpoint", type=str)
+    ap.add_argument("--checkpoint", type=str, help="a *_state_dict.pth file or the trainer's pickled <step>_generator.pth")
+    ap.add_argument("--ema", type=str, default=None, help="the trainer's pickled <step>_ema.pth: its shadow parameters "
+                    "replace the trainable parameters (what the reference evaluates with)")
     ap.add_argument("--seeds", nargs="+", type=int, default=list(range(1, 10)))
     ap.add_argument("--dataroot", type=str, default=None)
     ap.add_argument("--dataset_length", type=int, default=10)
@@ -119,11 +121,7 @@ def main(argv=None):
 
     generator = getattr(lib_generators, config["generator"])(**config).to(device)
     if opt.checkpoint:
-        ckpt = torch.load(opt.checkpoint, map_location=device)
-        if not isinstance(ckpt, dict):
-            raise NotImplementedError("pickled-module checkpoints of the reference trainer are not supported; "
-                                      "pass the *_generator_ema_state_dict.pth file")
-        generator.load_state_dict(ckpt)
+        checkpoints.load_generator(generator, opt.checkpoint, ema_path=opt.ema, map_location=device)
     generator.set_device(device)
     generator.eval()
     preprocessor = synthetic.SyntheticPreprocessor(device)

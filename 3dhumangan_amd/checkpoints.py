@@ -1,0 +1,97 @@
+"""Reading the checkpoint files the reference's trainer writes (lib/trainers/base_trainer.py:183-202):
+
+    <step>_generator.pth / _discriminator.pth   torch.save(module)   -- a PICKLED nn.Module of the reference's classes
+    <step>_ema.pth                              torch.save(ema)      -- a pickled ExponentialMovingAverage object
+    <step>_optimizer_{G,D}.pth, _scaler.pth     plain state dicts
+    *_state_dict.pth                            plain state dicts (what the released checkpoint ships)
+
+The pickled objects name classes under the reference's import paths (`lib.generators.map3d_generator.Map3DGenerator`,
+`lib.components.ema.ExponentialMovingAverage`, ...), which do not exist here.  They are restored WITHOUT the reference on
+the path: an unpickler maps every class under `lib.` / `configs` to a stand-in built on the fly (an nn.Module subclass when
+the pickled state has module dictionaries), which is all `state_dict()` needs; torch's own classes (spectral-norm hooks,
+parameters, tensors) resolve normally.  Only data is taken from the file.
+"""
+import io
+import pickle
+
+import torch
+import torch.nn as nn
+
+from .lib.components.ema import ExponentialMovingAverage
+
+_REF_PREFIXES = ("lib.", "configs", "lib")
+
+
+class _Bag:
+    """Stand-in for a non-module reference class: attribute bag."""
+
+
+class _StubModule(nn.Module):
+    """Stand-in for any reference nn.Module class: carries _parameters / _buffers / _modules, never runs forward."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def forward(self, *a, **k):
+        raise RuntimeError("stand-in for a reference module: only its state_dict() is meaningful")
+
+
+_module_stubs = {}
+
+
+def _stub_for(module, name):
+    if module.startswith("lib.components.ema") and name == "ExponentialMovingAverage":
+        return ExponentialMovingAverage
+    key = (module, name)
+    if key not in _module_stubs:
+        # nn.Module subclass: pickle restores __dict__ through nn.Module.__setstate__, plain objects through __dict__.update;
+        # a Module stand-in works for both kinds because an attribute bag is all a non-module needs
+        _module_stubs[key] = type(name, (_StubModule,), {"__module__": "3dhumangan_amd.checkpoints", "_ref_path": f"{module}.{name}"})
+    return _module_stubs[key]
+
+
+class _RefUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == "lib" or module.startswith("lib.") or module.startswith("configs"):
+            return _stub_for(module, name)
+        return super().find_class(module, name)
+
+
+class _RefPickleModule:
+    """The `pickle_module` torch.load expects: same surface as pickle, with our Unpickler."""
+    __name__ = "pickle"
+    Unpickler = _RefUnpickler
+    load = staticmethod(lambda f, **kw: _RefUnpickler(f, **kw).load())
+    loads = staticmethod(lambda b, **kw: _RefUnpickler(io.BytesIO(b), **kw).load())
+    dumps, dump, HIGHEST_PROTOCOL, PickleError, UnpicklingError = (pickle.dumps, pickle.dump, pickle.HIGHEST_PROTOCOL,
+                                                                   pickle.PickleError, pickle.UnpicklingError)
+
+
+def load_reference_pickle(path, map_location="cpu"):
+    """torch.load of a file written by the reference's trainer, reference classes replaced by stand-ins."""
+    return torch.load(path, map_location=map_location, pickle_module=_RefPickleModule, weights_only=False)
+
+
+def state_dict_of(obj):
+    """state dict from whatever a checkpoint file holds: a dict of tensors, or a (stand-in) module."""
+    if isinstance(obj, dict):
+        return obj
+    if isinstance(obj, nn.Module):
+        return obj.state_dict()
+    raise TypeError(f"cannot take a state dict from {type(obj).__name__}")
+
+
+def load_generator(generator, path, ema_path=None, map_location="cpu", strict=True):
+    """Load generator weights from any of the reference's formats into `generator` (this build's Map3DGenerator):
+    `path` a state-dict file or a pickled module; `ema_path` (optional) a pickled ExponentialMovingAverage whose shadow
+    parameters are then copied over the trainable parameters -- what the reference's apps evaluate with."""
+    generator.load_state_dict(state_dict_of(load_reference_pickle(path, map_location)), strict=strict)
+    if ema_path is not None:
+        ema = load_reference_pickle(ema_path, map_location)
+        if not isinstance(ema, ExponentialMovingAverage):
+            raise TypeError(f"{ema_path} does not hold an ExponentialMovingAverage")
+        live = [p for p in generator.parameters() if p.requires_grad]
+        if len(live) != len(ema.shadow_params) or any(p.shape != s.shape for p, s in zip(live, ema.shadow_params)):
+            raise ValueError("EMA shadow list does not match the generator's parameters (count / shapes / order)")
+        ema.copy_to(generator.parameters())
+    return generator

@@ -1,0 +1,128 @@
+"""UNetDiscriminator -- counterpart of the reference's lib/discriminators/unet_discriminators.py:82-160 (ResBlock :8-72).
+
+Same constructor kwargs (the whole config dict is splatted in), same state_dict schema (spectral-norm convs store
+bias / weight_orig / weight_u / weight_v under the reference's module paths, so `*_discriminator` checkpoints load with
+strict=True) and the same output dict.  SURVEY 8f.1 ranks this row "next" with library convolutions first: the 3x3 / 1x1
+convolutions go through torch (MIOpen / rocBLAS on the device) so that autograd -- including the double backward the R1
+penalty needs -- is available; nothing here is on the generator hot path.
+
+Module layout note: the reference wraps its convs in nn.Sequential(LeakyReLU, [Upsample,] conv), which fixes the state_dict
+index of the conv (conv1.1 / conv1.2 / conv2.1).  Here the activations and resampling are plain functional calls and a
+`_Slot` holds the conv under that same index, so only parameters live in modules.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Slot(nn.Module):
+    """Holds one sub-module under a numeric name (`<parent>.<index>.*` state_dict keys) and forwards to it."""
+
+    def __init__(self, index, module):
+        super().__init__()
+        self.index = str(index)
+        self.add_module(self.index, module)
+
+    def forward(self, x):
+        return getattr(self, self.index)(x)
+
+
+def _conv(cin, cout, k, spectral):
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2)
+    return nn.utils.spectral_norm(conv) if spectral else conv
+
+
+class ResBlock(nn.Module):
+    """dx = conv2(lrelu(conv1([up](lrelu(x)))))  (+ average pooling when going down), shortcut = [resample +] [1x1 conv]."""
+
+    def __init__(self, fin, fout, up_or_down, first=False, **kwargs):
+        super().__init__()
+        self.up_or_down, self.first = up_or_down, first
+        sn = not kwargs.get("disable_spectral_norm", False)
+        if first:
+            self.conv1 = _conv(fin, fout, 3, sn)                       # no activation in front of the very first conv
+        else:
+            self.conv1 = _Slot(2 if up_or_down > 0 else 1, _conv(fin, fout, 3, sn))
+        self.conv2 = _Slot(1, _conv(fout, fout, 3, sn))
+        self.conv_s = _conv(fin, fout, 1, sn) if fin != fout else None
+
+    def _resample(self, x):
+        if self.up_or_down > 0:
+            return F.interpolate(x, scale_factor=2, mode="nearest")
+        if self.up_or_down < 0:
+            return F.avg_pool2d(x, 2)
+        return x
+
+    def forward(self, x):
+        # shortcut: the first block pools BEFORE its 1x1 conv, later down blocks after it; up blocks upsample first
+        s = x
+        if self.first or self.up_or_down > 0:
+            s = self._resample(s)
+        if self.conv_s is not None:
+            s = self.conv_s(s)
+        if not self.first and self.up_or_down < 0:
+            s = self._resample(s)
+        # residual branch
+        d = x
+        if not self.first:
+            d = F.leaky_relu(d, 0.2)
+            if self.up_or_down > 0:
+                d = self._resample(d)
+        d = self.conv2(F.leaky_relu(self.conv1(d), 0.2))
+        if self.up_or_down < 0:
+            d = self._resample(d)
+        return s + d
+
+
+class UNetDiscriminator(nn.Module):
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.epoch = 0
+        self.step = 0
+        self.semantic_dim = kwargs.get("semantic_dim", 0)
+        self.label_dim = kwargs.get("label_dim", 0)
+        self.latent_dim = kwargs["latent_dim"]
+        self.output_dim = self.semantic_dim + self.label_dim
+        H, W = kwargs["gen_height"], kwargs["gen_width"]
+        n = min(kwargs.get("discriminator_blocks", 6), int(math.log2(max(H, W))) - 1)
+        self.num_blocks = n
+        ch = [6 if kwargs.get("dual_discrimination", False) else 3, 128, 128, 256, 256, 512, 512, 512, 512]
+        self.channels = ch
+        self.body_down = nn.ModuleList(ResBlock(ch[i], ch[i + 1], -1, first=(i == 0), **kwargs) for i in range(n))
+        ups = [ResBlock(ch[n], ch[n - 1], 1, **kwargs)]
+        ups += [ResBlock(2 * ch[n - i], ch[n - i - 1], 1, **kwargs) for i in range(1, n - 1)]
+        ups.append(ResBlock(2 * ch[1], 64, 1, **kwargs))
+        self.body_up = nn.ModuleList(ups)
+        self.layer_up_last = nn.Conv2d(64, 1, 1)
+        self.output_layer = nn.Conv2d(64, self.output_dim, 1)
+        self.latent_layer = nn.Conv2d(ch[n], self.latent_dim, (H // 2 ** n, W // 2 ** n))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                w = m.weight_orig if hasattr(m, "weight_orig") else m.weight
+                nn.init.kaiming_normal_(w, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+        with torch.no_grad():
+            self.output_layer.weight *= 0.25
+
+    def forward(self, images, conditions, alpha, **kwargs):
+        """images [B, 3|6, H, W] -> {"prediction" [B,1,H,W], "latents" [B,latent_dim], "segments" [B,label_dim,H,W]
+        (, "semantics" [B,semantic_dim,H,W])}.  `conditions` and `alpha` are accepted and unused, as in the reference."""
+        x, skips = images, []
+        for blk in self.body_down:
+            x = blk(x)
+            skips.append(x)
+        if min(x.shape[2:4]) > 1:
+            latents = self.latent_layer(x).view(x.shape[0], self.latent_dim)
+        else:
+            latents = x.new_zeros((x.shape[0], self.latent_dim))
+        x = self.body_up[0](x)
+        for i in range(1, len(self.body_up)):
+            x = self.body_up[i](torch.cat((skips[-i - 1], x), dim=1))
+        prediction = self.layer_up_last(x)
+        y = self.output_layer(x)
+        out = {"prediction": prediction, "latents": latents, "segments": y[:, self.semantic_dim:]}
+        if self.semantic_dim > 0:
+            out["semantics"] = y[:, :self.semantic_dim]
+        return out

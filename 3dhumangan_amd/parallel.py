@@ -41,6 +41,56 @@ def gather_images(local, total, group=None):
     return torch.cat(parts, dim=0)
 
 
+def r1_allgather(local_stat, group=None):
+    """The one data-path collective of the training step (BASELINE north_star: "RCCL all-gather over xGMI for the
+    discriminator R1 step only"): all-gather of the per-sample R1 statistics ||grad_x D(x_i)||^2 [b] of every rank's batch
+    shard -> [world * b], identical on every rank, so that every rank applies the SAME global-batch penalty
+    0.5 * r1_lambda * mean(...) (the reference gets a mean over ranks implicitly, through DDP's gradient averaging of
+    per-rank penalties: lib/trainers/phase_trainer.py:259-294, 392).  b floats per rank: latency-bound, one small RCCL
+    all-gather per step.
+
+    Autograd: this rank's slice of the result keeps its graph (the double-backward through D), the other ranks' slices are
+    constants -- backward of mean(result) therefore yields exactly this rank's share of the global-batch gradient."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_stat
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.empty_like(local_stat) for _ in range(world)]
+    dist.all_gather(parts, local_stat.detach().contiguous(), group=group)
+    parts[rank] = local_stat
+    return torch.cat(parts, dim=0)
+
+
+def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=64 << 20):
+    """Sum (or average) the .grad of `parameters` over the ranks with a few large flat all-reduces (RCCL ring all-reduce is
+    per-link bound on xGMI: fewer, larger messages -- 64 MB buckets -- instead of one collective per tensor)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    grads = [p.grad for p in parameters if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
+        bucket.clear()
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+            size = 0
+    flush()
+
+
 def max_over_ranks(seconds, device=None):
     """The bench's timing reduction: the job is as slow as its slowest rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -54,22 +54,85 @@ def make_inputs(cfg, batch, device, seed=1234):
     return z, cond, jitter
 
 
-def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on):
+def dist_env():
+    """(rank, world, local_rank, dist_on) from the torchrun environment; under torchrun always go through the collective
+    backend, even with one rank."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, world, int(os.environ.get("LOCAL_RANK", "0")), world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+
+
+def init_distributed(local, backend="nccl"):
+    """One process per GPU; backend "nccl" IS RCCL on ROCm (gloo in the CPU test of this plumbing)."""
     import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+
+
+def timed_loop(step, steps, warmup, dist_on, device="cuda"):
+    """W untimed warm-up steps, then EXACTLY `steps` timed ones bracketed by a barrier + device synchronise on both sides;
+    returns the MAX over ranks of the elapsed seconds (the job is as slow as its slowest rank)."""
+    import torch.distributed as dist
+    sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
     for _ in range(warmup):
-        G.forward(z, cond, jitter=jitter, **cfg)
+        step()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        G.forward(z, cond, jitter=jitter, **cfg)
-    torch.cuda.synchronize()
+        step()
+    sync()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     par = importlib.import_module("3dhumangan_amd.parallel")
-    return par.max_over_ranks(dt, device="cuda")       # the job is as slow as its slowest rank
+    return par.max_over_ranks(dt, device=device if device == "cuda" else None)
+
+
+def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on):
+    return timed_loop(lambda: G.forward(z, cond, jitter=jitter, **cfg), steps, warmup, dist_on)
+
+
+def discriminator_step_bench(a, rank, world, dist_on, dev):
+    """BASELINE config 4, the discriminator half (the generator has no backward in this build): per rank `--batch` images of
+    the reference-native 512x256 geometry (96x48 rays x 32 samples, hidden 256); a step = generator forward under no_grad
+    (HIP kernels) + UNetDiscriminator forward on real and fake + R1 double backward + the all-gather of the R1 statistics +
+    gradient all-reduce + Adam.  Prints its own JSON line."""
+    trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+    disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+    G, cfg = build_generator(a.config, (512, 256), (96, 48), 32, dev)
+    z, cond, jitter = make_inputs(cfg, a.batch, dev, seed=1234 + rank)
+    torch.manual_seed(99)
+    D = disc.UNetDiscriminator(**{k: v for k, v in cfg.items() if k != "neural_field_cls"}).to(dev)
+    opt = torch.optim.Adam(D.parameters(), lr=cfg.get("disc_lr", 2e-4), betas=(0.0, 0.9))
+    g = torch.Generator().manual_seed(7 + rank)
+    real = torch.randn(a.batch, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
+    gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (a.batch, 512, 256), generator=g).to(dev)
+    # every loss term on (the shipped configs switch them per training phase): logistic GAN + segmentation head + R1
+    meta = dict(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, label_dim=cfg.get("label_dim", 0))
+    last = {}
+
+    def step():
+        with torch.no_grad():
+            fake = G.forward(z, cond, jitter=jitter, **cfg)["rgbs"]
+        last.update(trainers.discriminator_step(D, opt, real, fake, gt, meta, do_r1=True, distributed=dist_on,
+                                                grad_clip=cfg.get("grad_clip", 10.0)))
+
+    dt = timed_loop(step, a.steps, a.warmup, dist_on)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "discriminator-step images/sec at 512x256 (G forward + D fwd/bwd + R1)", "value": a.batch * world * a.steps / dt,
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "generator: split f16/bf16 (fp32-class); discriminator: fp32 (torch / MIOpen convolutions)", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4, discriminator half: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; "
+                                   "UNetDiscriminator 6 blocks; R1 every step; generator backward NOT included (not built)",
+                       "global_batch": a.batch * world,
+                       "parallelism": f"batch-sharded x{world}: RCCL all-gather of the R1 statistics + gradient all-reduce"},
+            "loss": {k: float(v) for k, v in last.items()}}))
 
 
 def kernel_rooflines(G, cfg, batch, stage_ms):
@@ -312,21 +375,23 @@ def main():
     ap.add_argument("--res", default="512x512", help="output HxW; rays are 3/16 of it per axis (96 for 512)")
     ap.add_argument("--render", default="", help="rays HxW (default: 3/16 of --res per axis, the MAP3DBN512 ratio)")
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--mode", default="generator", choices=["generator", "dstep"],
+                    help="generator: the headline forward benchmark; dstep: BASELINE config 4's discriminator step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torchrun always go through RCCL
+    rank, world, local, dist_on = dist_env()
     torch.cuda.set_device(local)
     if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))          # RCCL over xGMI
+        init_distributed(local)                                       # RCCL over xGMI
     dev = torch.device("cuda", local)
+    if a.mode == "dstep":
+        discriminator_step_bench(a, rank, world, dist_on, dev)
+        if dist_on:
+            torch.distributed.destroy_process_group()
+        return
     StageTimer = importlib.import_module("3dhumangan_amd._stages").StageTimer
 
     H, W = [int(v) for v in a.res.split("x")]

@@ -1,0 +1,138 @@
+"""Golden fixtures for the training-side rows from the real Python reference.
+
+BUILD CONTAINER ONLY (imports /root/reference through _ref_import.py).  Stores data only:
+  disc_tiny.npz         UNetDiscriminator (2 blocks) weights (fp16-exact), images, eval-mode outputs, the reference's
+                        logistic GAN loss, balanced segmentation loss and R1 penalty on those outputs
+  ema_tiny.npz          ExponentialMovingAverage: parameters before / after three updates, shadow parameters
+  ref_ckpt_tiny_*.pth   the files BaseTrainer.save_model writes (pickled generator module, pickled EMA object, optimizer
+                        state dict) for a tiny generator -- to pin the checkpoint loader
+  param_order.json      named_parameters() order of the three shipped generator configs (EMA shadow lists are positional)
+Run:  python tests/golden/make_golden_train.py
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+for name in ("tensorboardX", "torch.utils.tensorboard"):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.SummaryWriter = object
+        sys.modules[name] = m
+
+import configs as ref_configs  # noqa: E402
+import lib.generators.map3d_generator as ref_gen  # noqa: E402
+from lib import implicit_funcitions as ref_impl  # noqa: E402
+from lib.components.ema import ExponentialMovingAverage  # noqa: E402
+from lib.discriminators.unet_discriminators import UNetDiscriminator  # noqa: E402
+
+from make_golden import save, tiny_cfg  # noqa: E402
+
+
+def disc_fixture():
+    torch.manual_seed(11)
+    kw = dict(latent_dim=16, gen_height=32, gen_width=16, semantic_dim=0, label_dim=3, discriminator_blocks=2)
+    D = UNetDiscriminator(**kw).eval()
+    sd = D.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.is_floating_point():
+                v.copy_(v.half().float())                      # fp16-exact weights: the fixture stores them as fp16
+            if k.endswith("bias"):
+                v.copy_((0.1 * torch.randn(v.shape)).half().float())
+        for k, v in sd.items():                                # exact spectral-norm vectors (eval mode uses them as stored)
+            if k.endswith("weight_orig"):
+                U, S, Vh = torch.linalg.svd(v.flatten(1), full_matrices=False)
+                sd[k.replace("weight_orig", "weight_u")].copy_(U[:, 0])
+                sd[k.replace("weight_orig", "weight_v")].copy_(Vh[0])
+    D.load_state_dict(sd)
+    g = torch.Generator().manual_seed(12)
+    real = torch.randn(3, 3, 32, 16, generator=g).clamp(-1, 1)
+    fake = torch.randn(3, 3, 32, 16, generator=g).clamp(-1, 1)
+    real.requires_grad_(True)
+    out_real = D(real, None, 1.0)
+    out_fake = D(fake, None, 1.0)
+    # the trainer's loss functions, called unbound on a minimal stand-in for `self` (CPU: GradScaler disabled => scale 1)
+    import lib.trainers.phase_trainer as pt
+    me = types.SimpleNamespace(device="cpu", amp=False, scaler=torch.cuda.amp.GradScaler(enabled=False))
+    meta = dict(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, label_dim=3)
+    r1 = pt.PhaseTrainer._calculate_r1_regularization(me, real, out_real, {"name": "p"}, meta)
+    gt = torch.randint(0, 3, (3, 32, 16), generator=g)
+    seg_real, acc_real, prob_real = pt.PhaseTrainer._calculate_segmentation_loss(me, out_real["segments"], gt, meta)
+    seg_gen, _, prob_gen = pt.PhaseTrainer._calculate_segmentation_loss(me, out_fake["segments"], torch.zeros_like(gt), meta)
+    gan = torch.nn.functional.softplus(out_fake["prediction"]).mean() + torch.nn.functional.softplus(-out_real["prediction"]).mean()
+    # gradient of the reference's D loss (gan + 4 * r1 + segmentation) w.r.t. one weight: pins the whole D step's backward
+    D.zero_grad()
+    loss = gan + 4 * r1 + (seg_real + seg_gen)
+    loss.backward()
+    gkey = "body_down.0.conv2.1.weight_orig"
+    state16 = {k: (v.half() if v.is_floating_point() and not k.endswith(("weight_u", "weight_v")) else v) for k, v in sd.items()}
+    save("disc_tiny", state=state16, real=real.detach(), fake=fake, gt_segments=gt,
+         out_real={k: v.detach() for k, v in out_real.items()}, out_fake={k: v.detach() for k, v in out_fake.items()},
+         loss=dict(r1=r1.detach(), gan=gan.detach(), seg_real=seg_real.detach(), seg_gen=seg_gen.detach(), acc_real=acc_real,
+                   prob_real=prob_real.detach(), prob_gen=prob_gen.detach(), total=loss.detach()),
+         grad={gkey: dict(D.named_parameters())[gkey].grad})
+    json.dump(dict(kwargs=kw, meta=meta, grad_key=gkey), open(os.path.join(HERE, "disc_tiny.json"), "w"))
+
+
+def ema_and_checkpoint_fixture():
+    cfg = tiny_cfg()
+    torch.manual_seed(21)
+    G = ref_gen.Map3DGenerator(**cfg)
+    ema = ExponentialMovingAverage(G.parameters(), decay=0.999)
+    before = [p.detach().clone() for p in G.parameters() if p.requires_grad]
+    g = torch.Generator().manual_seed(22)
+    for _ in range(3):
+        with torch.no_grad():
+            for p in G.parameters():
+                p.add_(0.01 * torch.randn(p.shape, generator=g))
+        ema.update(G.parameters())
+    after = [p.detach().clone() for p in G.parameters() if p.requires_grad]
+    names = [n for n, p in G.named_parameters() if p.requires_grad]
+    pick = [0, 5, len(names) // 2, len(names) - 1]
+    save("ema_tiny", **{f"before/{i}": before[i] for i in pick}, **{f"after/{i}": after[i] for i in pick},
+         **{f"shadow/{i}": ema.shadow_params[i] for i in pick}, num_updates=np.asarray(ema.num_updates),
+         decay=np.asarray(ema.decay))
+    # the trainer's files (BaseTrainer.save_model: torch.save of the module / the EMA object / optimizer state dicts)
+    G.neural_field_cls = None
+    torch.save(G, os.path.join(HERE, "ref_ckpt_tiny_generator.pth"))
+    torch.save(ema, os.path.join(HERE, "ref_ckpt_tiny_ema.pth"))
+    opt = torch.optim.Adam(G.parameters(), lr=1e-3, betas=(0.0, 0.9))
+    torch.save(opt.state_dict(), os.path.join(HERE, "ref_ckpt_tiny_optimizer_G.pth"))
+    torch.save({k: v.clone() for k, v in G.state_dict().items()}, os.path.join(HERE, "ref_ckpt_tiny_generator_state_dict.pth"))
+    json.dump(dict(meta={k: v for k, v in cfg.items() if k != "neural_field_cls" and isinstance(v, (int, float, str, bool, list, type(None)))},
+                   names=names, pick=pick), open(os.path.join(HERE, "ref_ckpt_tiny.json"), "w"))
+    for f in sorted(os.listdir(HERE)):
+        if f.startswith("ref_ckpt_tiny"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")
+
+
+def param_order_fixture():
+    out = {}
+    for name in ("MAP3DBN", "MAP3DBN512", "MAP3DBN512L"):
+        cfg = {k: v for k, v in getattr(ref_configs, name).items() if isinstance(k, str)}
+        cfg.update(dataset_length=4)
+        cfg["neural_field_cls"] = ref_impl.COORDCONCATSIREN
+        G = ref_gen.Map3DGenerator(**cfg)
+        out[name] = [[n, list(p.shape)] for n, p in G.named_parameters() if p.requires_grad]
+    json.dump(out, open(os.path.join(HERE, "param_order.json"), "w"))
+    print("param_order.json", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    disc_fixture()
+    ema_and_checkpoint_fixture()
+    param_order_fixture()

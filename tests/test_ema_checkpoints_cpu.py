@@ -1,0 +1,93 @@
+"""EMA and the trainer's checkpoint formats against files / vectors the reference produced
+(tests/golden/make_golden_train.py): the pickled generator module and the pickled ExponentialMovingAverage object that
+BaseTrainer.save_model writes are read WITHOUT the reference on the import path."""
+import importlib
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_err
+
+ck = importlib.import_module("3dhumangan_amd.checkpoints")
+ema_mod = importlib.import_module("3dhumangan_amd.lib.components.ema")
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+configs = importlib.import_module("3dhumangan_amd.configs")
+
+
+def _tiny():
+    info = json.load(open(os.path.join(GOLDEN, "ref_ckpt_tiny.json")))
+    meta = dict(info["meta"])
+    meta["neural_field_cls"] = impl.COORDCONCATSIREN
+    return info, gens.Map3DGenerator(**meta)
+
+
+def test_reference_is_not_importable_here():
+    assert not any(p.rstrip("/").endswith("/root/reference") for p in sys.path)
+    assert "lib.generators.map3d_generator" not in sys.modules
+
+
+@pytest.mark.parametrize("name", ["MAP3DBN", "MAP3DBN512", "MAP3DBN512L"])
+def test_parameter_order_is_the_reference_order(name):
+    """EMA shadow lists are positional: parameters() must enumerate in the reference's order."""
+    want = json.load(open(os.path.join(GOLDEN, "param_order.json")))[name]
+    cfg = {k: v for k, v in getattr(configs, name).items() if isinstance(k, str)}
+    cfg.update(dataset_length=4)
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    G = gens.Map3DGenerator(**cfg)
+    got = [[n, list(p.shape)] for n, p in G.named_parameters() if p.requires_grad]
+    assert got == want
+
+
+def test_pickled_generator_module_loads():
+    info, G = _tiny()
+    obj = ck.load_reference_pickle(os.path.join(GOLDEN, "ref_ckpt_tiny_generator.pth"))
+    assert type(obj).__name__ == "Map3DGenerator" and type(obj).__module__ == "3dhumangan_amd.checkpoints"     # a stand-in
+    sd = ck.state_dict_of(obj)
+    assert len(sd) == 343
+    G.load_state_dict(sd, strict=True)
+    assert [n for n, p in G.named_parameters() if p.requires_grad] == info["names"]
+    ck.load_generator(G, os.path.join(GOLDEN, "ref_ckpt_tiny_generator.pth"))                                   # one-call form
+    opt = ck.load_reference_pickle(os.path.join(GOLDEN, "ref_ckpt_tiny_optimizer_G.pth"))
+    assert isinstance(opt, dict) and "param_groups" in opt
+
+
+def test_pickled_ema_restores_and_applies():
+    info, G = _tiny()
+    g = load_golden("ema_tiny")
+    ema = ck.load_reference_pickle(os.path.join(GOLDEN, "ref_ckpt_tiny_ema.pth"))
+    assert isinstance(ema, ema_mod.ExponentialMovingAverage)
+    assert ema.num_updates == int(g["num_updates"]) and ema.decay == float(g["decay"])
+    for i in info["pick"]:
+        assert torch.equal(ema.shadow_params[i], g["shadow"][str(i)])
+    ck.load_generator(G, os.path.join(GOLDEN, "ref_ckpt_tiny_generator.pth"), ema_path=os.path.join(GOLDEN, "ref_ckpt_tiny_ema.pth"))
+    live = [p for p in G.parameters() if p.requires_grad]
+    for i in info["pick"]:
+        assert torch.equal(live[i].detach(), g["shadow"][str(i)])
+
+
+def test_ema_update_rule():
+    """Three updates from the captured parameter trajectory endpoints: shadow = s - (1-d_n)(s - p) with the warm-up decay
+    min(decay, (1+n)/(10+n)) -- checked against a closed form on a scalar, and store / restore / copy_to round trips."""
+    p = torch.nn.Parameter(torch.tensor([1.0, 2.0]))
+    frozen = torch.nn.Parameter(torch.tensor([5.0]), requires_grad=False)
+    ema = ema_mod.ExponentialMovingAverage([p, frozen], decay=0.999)
+    assert len(ema.shadow_params) == 1
+    s = p.detach().clone()
+    for n in range(1, 4):
+        with torch.no_grad():
+            p.add_(1.0)
+        ema.update([p, frozen])
+        d = min(0.999, (1 + n) / (10 + n))
+        s = s - (1 - d) * (s - p.detach())
+        assert torch.allclose(ema.shadow_params[0], s, atol=0, rtol=0)
+    ema.store([p, frozen])
+    ema.copy_to([p, frozen])
+    assert torch.equal(p.detach(), s)
+    ema.restore([p, frozen])
+    assert torch.equal(p.detach(), torch.tensor([4.0, 5.0]))
+    with pytest.raises(ValueError):
+        ema_mod.ExponentialMovingAverage([p], decay=1.5)

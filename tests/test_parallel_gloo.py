@@ -62,3 +62,111 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------- R1 all-gather + discriminator step, world size 2
+
+def _r1_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+        trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+        torch.manual_seed(3)                                   # same weights and same global batch on every rank
+        D = disc.UNetDiscriminator(latent_dim=8, gen_height=16, gen_width=8, label_dim=2, discriminator_blocks=2).eval()
+        g = torch.Generator().manual_seed(4)
+        total = 4
+        real, fake = torch.randn(total, 3, 16, 8, generator=g), torch.randn(total, 3, 16, 8, generator=g)
+        gt = torch.zeros(total, 16, 8, dtype=torch.long)
+        meta = dict(gan_lambda=1.0, segmentation_lambda=0.0, r1_lambda=10.0, label_dim=2)
+        # single-process truth on the whole batch
+        ref = disc.UNetDiscriminator(latent_dim=8, gen_height=16, gen_width=8, label_dim=2, discriminator_blocks=2).eval()
+        ref.load_state_dict(D.state_dict())
+        r_ref = trainers.discriminator_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), real, fake, gt, meta)
+        # sharded step: gathered statistics identical on both ranks, gradients equal to the whole-batch ones
+        lo, hi = par.shard_bounds(total, rank, world)
+        stat = torch.arange(lo, hi, dtype=torch.float32, requires_grad=True) * 1.0
+        gathered = par.r1_allgather(stat)
+        assert torch.equal(gathered.detach(), torch.arange(total, dtype=torch.float32))
+        gathered.mean().backward()                              # only the local slice carries a graph
+        r_loc = trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real[lo:hi], fake[lo:hi], gt[lo:hi], meta,
+                                            distributed=True)
+        assert abs(float(r_loc["r1"]) - float(r_ref["r1"])) <= 1e-5 * abs(float(r_ref["r1"])), (r_loc["r1"], r_ref["r1"])
+        worst = 0.0
+        checked = 0
+        for (n, a), (_, b) in zip(D.named_parameters(), ref.named_parameters()):
+            assert (a.grad is None) == (b.grad is None), n
+            if b.grad is not None:                              # heads that do not feed this loss have no gradient
+                worst = max(worst, float((a.grad - b.grad).abs().max() / b.grad.abs().max().clamp_min(1e-12)))
+                checked += 1
+        assert checked > 20 and worst < 1e-4, (checked, worst)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_r1_allgather_and_sharded_discriminator_step_world2():
+    """north_star: batch-dim sharding with an all-gather for the discriminator R1 step.  Two ranks, half the batch each: the
+    gathered per-sample statistics are the global ones on both ranks, the penalty equals the whole-batch penalty, and after
+    the gradient all-reduce every discriminator gradient equals the single-process whole-batch gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_r1_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+# ---------------------------------------------------------------- bench.py's distributed plumbing, world size 2 (gloo)
+
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        import sys
+        import time
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        r, w, local, dist_on = bench.dist_env()
+        assert (r, w, local, dist_on) == (rank, world, rank, True)
+        bench.init_distributed(local, backend="gloo")
+        calls = []
+
+        def step():
+            calls.append(1)
+            time.sleep(0.01 * (1 + rank))                      # rank 1 is the slow one
+
+        dt = bench.timed_loop(step, steps=5, warmup=2, dist_on=True, device="cpu")
+        assert len(calls) == 7                                  # warm-up steps are run, but only `steps` are timed
+        assert 0.09 < dt < 1.0, dt                              # the MAX over ranks: >= 5 * 0.02 s, the slow rank's time
+        dts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(dts, torch.tensor([dt], dtype=torch.float64))
+        assert all(float(t) == dt for t in dts)                 # every rank reports the same (max) time
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_bench_distributed_plumbing_world2():
+    """bench.py's N > 1 path (rendezvous from the torchrun environment, barrier-bracketed timed loop, MAX over ranks) with the
+    gloo backend: the first multi-GPU run of the driver must not fail on plumbing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
