@@ -143,42 +143,5 @@ def make_conditions(batch, n_vertices=6890, seed=0, pose_scale=0.5, scale=0.8, h
     return cond
 
 
-def euler_xyz_to_matrix(euler):
-    """pytorch3d.transforms.euler_angles_to_matrix(euler, "XYZ") == Rx(a) @ Ry(b) @ Rz(c); euler [B,3]."""
-    a, b, c = euler[:, 0], euler[:, 1], euler[:, 2]
-    one, zero = torch.ones_like(a), torch.zeros_like(a)
-    rx = torch.stack([one, zero, zero, zero, a.cos(), -a.sin(), zero, a.sin(), a.cos()], -1).view(-1, 3, 3)
-    ry = torch.stack([b.cos(), zero, b.sin(), zero, one, zero, -b.sin(), zero, b.cos()], -1).view(-1, 3, 3)
-    rz = torch.stack([c.cos(), -c.sin(), zero, c.sin(), c.cos(), zero, zero, zero, one], -1).view(-1, 3, 3)
-    return rx @ ry @ rz
-
-
-class SyntheticPreprocessor:
-    """Stand-in for lib/data/preprocessor.py: the camera math of `_forward_fix_body` (:72-97) in plain torch;
-    the pytorch3d mesh rasteriser (:138-176) is not reproduced -- `rasterized_semantics` is an all-zero map."""
-
-    def __init__(self, device="cpu"):
-        self.device = device
-
-    def to(self, device):
-        self.device = device
-        return self
-
-    @torch.no_grad()
-    def forward_with_rotation(self, data, h_rotation, v_rotation, r_rotation, **kwargs):
-        data = dict(data)
-        B = data["scales"].shape[0]
-        dev = data["scales"].device
-        euler = torch.zeros([B, 3], device=dev)
-        euler[:, 1] = -h_rotation.reshape(B)
-        euler[:, 0] = math.pi - v_rotation.reshape(B)
-        euler[:, 2] = -r_rotation.reshape(B)
-        R = data["full_pose"][:, 0] @ euler_xyz_to_matrix(euler)
-        body = torch.zeros(B, 4, 4, device=dev)
-        body[:, :3, :3] = R
-        body[:, 3, 3] = 1.0
-        world2cam = torch.bmm(torch.bmm(data["R"], data["T"]), body)
-        data["cam2world_matrices"] = torch.inverse(world2cam.float())
-        h, w = kwargs.get("gen_height", 1), kwargs.get("gen_width", 1)
-        data["rasterized_semantics"] = torch.zeros(B, 3, h, w, device=dev)
-        return data
+# The camera front-end lives in lib/data/conditions.py (pinned to the reference's preprocessor); the old names stay importable.
+from .lib.data.conditions import CameraPreprocessor as SyntheticPreprocessor, euler_xyz_to_matrix  # noqa: E402,F401

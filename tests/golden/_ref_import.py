@@ -56,6 +56,19 @@ def _knn_gather(x, idx):
                         idx[..., None].expand(B, P, K, C))
 
 
+def _euler_angles_to_matrix(euler_angles, convention):
+    """Stand-in for pytorch3d.transforms.euler_angles_to_matrix (pinned 0.6.2; call sites lib/data/preprocessor.py:85,
+    107, 114), following its published definition: the product of the per-axis rotations in the order of `convention`
+    (intrinsic), e.g. "XYZ" -> Rx(a0) @ Ry(a1) @ Rz(a2).  Like the kNN stand-in this boundary is unpinned by the reference."""
+    def axis(ax, a):
+        c, s, one, zero = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+        rows = {"X": (one, zero, zero, zero, c, -s, zero, s, c), "Y": (c, zero, s, zero, one, zero, -s, zero, c),
+                "Z": (c, -s, zero, s, c, zero, zero, zero, one)}[ax]
+        return torch.stack(rows, -1).reshape(a.shape + (3, 3))
+    mats = [axis(c, e) for c, e in zip(convention, torch.unbind(euler_angles, -1))]
+    return mats[0] @ mats[1] @ mats[2]
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -88,7 +101,7 @@ def install():
     p3d.renderer = _mod("pytorch3d.renderer", PerspectiveCameras=_Stub,
                         MeshRasterizer=_Stub, RasterizationSettings=_Stub)
     p3d.structures = _mod("pytorch3d.structures", Meshes=_Stub)
-    p3d.transforms = _mod("pytorch3d.transforms", euler_angles_to_matrix=_nf)
+    p3d.transforms = _mod("pytorch3d.transforms", euler_angles_to_matrix=_euler_angles_to_matrix)
 
     tv = _mod("torchvision")
     tv.transforms = _mod("torchvision.transforms")

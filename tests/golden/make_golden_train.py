@@ -120,6 +120,44 @@ def ema_and_checkpoint_fixture():
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KB")
 
 
+def frontend_fixture():
+    """the dataset's SMPL -> conditions conversion (lib/data/datasets.py:117-181, _preprocess_smpl_fix_body)
+    and the preprocessor's camera math (lib/data/preprocessor.py:72-97, _forward_fix_body), both called UNBOUND on stand-in
+    `self` objects (the classes' constructors need the licensed SMPL file / pytorch3d rasteriser) with a synthetic SMPL
+    prediction record."""
+    import lib.data.datasets as ds
+    import lib.data.preprocessor as pp
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(5)
+    V, J = 60, 24
+    joints_idx = list(rng.permutation(49)[:J])
+    pred = {
+        "orig_cam": rng.uniform(0.6, 1.2, (1, 4)).astype(np.float64) * np.array([1, 1, 0.1, 0.1]),
+        "joints": rng.randn(1, 49, 3),
+        "full_pose": Rotation.random(J, random_state=6).as_matrix()[None],
+        "tpose_vertices": rng.randn(1, V, 3) * 0.5,
+        "fk_matrices": np.concatenate([np.concatenate([Rotation.random(J, random_state=7).as_matrix(), rng.randn(J, 3, 1) * 0.3], 2),
+                                       np.tile(np.array([[[0, 0, 0, 1.0]]]), (J, 1, 1))], 1)[None],
+        "lbs_weights": (lambda w: w / w.sum(1, keepdims=True))(rng.rand(V, J) ** 4),
+        "betas": rng.randn(1, 10),
+    }
+    me = types.SimpleNamespace(coodinate_mode="fix_body", joints=joints_idx, smpl_tpose_vertices=rng.randn(V, 3).astype(np.float64),
+                               inference=True)
+    out = ds.SHHQDataset._preprocess_smpl_fix_body(me, pred)
+    # batch of 3 identical records with different camera rotations through the preprocessor
+    B = 3
+    data = {k: torch.from_numpy(np.asarray(v)).float()[None].repeat(B, *([1] * np.asarray(v).ndim)) for k, v in out.items()}
+    data["scales"] = data["scales"].reshape(B)
+    h = torch.tensor([0.3, -0.5, 0.0])
+    v = torch.tensor([0.1, 0.0, -0.2])
+    r = torch.tensor([0.0, 0.05, 0.0])
+    pself = types.SimpleNamespace(device="cpu")
+    res, R_raster = pp.SHHQPreprocessor._forward_fix_body(pself, dict(data), h, v, r)
+    save("frontend", pred={k: np.asarray(v) for k, v in pred.items()}, joints_index=np.asarray(joints_idx),
+         smpl_tpose_vertices=me.smpl_tpose_vertices, conditions={k: np.asarray(v) for k, v in out.items()},
+         angles=dict(h=h, v=v, r=r), cam2world=res["cam2world_matrices"], R_raster=R_raster)
+
+
 def param_order_fixture():
     out = {}
     for name in ("MAP3DBN", "MAP3DBN512", "MAP3DBN512L"):
@@ -133,6 +171,7 @@ def param_order_fixture():
 
 
 if __name__ == "__main__":
+    frontend_fixture()
     disc_fixture()
     ema_and_checkpoint_fixture()
     param_order_fixture()
