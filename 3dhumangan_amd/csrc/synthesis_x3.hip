@@ -32,7 +32,7 @@ struct Args {
     const float* cst;
     const float* ab;
     float* rgb;
-    int table_floats, total_stages, g_channels, Hr, Wr, n_cst, n_ab, H, W, HdP, C, first_skip;
+    int table_floats, total_stages, g_channels, Hr, Wr, n_cst, n_ab, H, W, HdP, C, first_skip, n_pixel_blocks;
     float* state;          // [wave tiles][NT*4 + 1][64 lanes] float4: activations (+ rgb partial sums) between segments
     int load_state, store_state;
 };
@@ -332,92 +332,109 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 
     // Register roles: every SPADE+conv stage takes its input in x and leaves its output in x (the conv accumulates
     // onto x = bias); acc is the scratch accumulator of the gamma / beta GEMMs and of the first conv of a skip block.
-    // ================= blocks before the first skip connection (either style) ===================================
+    // ================= blocks before the first skip connection ===================================================
+    // Per-pixel-style blocks first, then constant-style ones, in two loops without a per-SPADE branch (the host checks
+    // that the styles are laid out that way, as mod_blocks = [0, 1, 2] is): at the control-flow merge of the two kinds of
+    // SPADE hipcc could not keep both accumulator sets in the 256 AGPRs and spilled three tiles (48 registers, 5 GB of
+    // scratch stores per launch at 512^2 x 16) at every SPADE.
 #pragma unroll 1
-    for (int blk = 0; blk < A.first_skip; ++blk) {
+    for (int blk = 0; blk < A.n_pixel_blocks; ++blk) {
         const h3d_block_desc& Bk = D.block[blk];
         int opaque = 0;                       // keeps the loop-invariant LDS table loads inside the body
         asm volatile("" : "+s"(opaque));
         const float* tab = tab0 + opaque;
         const float* abt = ab0 + opaque;
         const float* cstt = cst0 + opaque;
+        (void)abt;
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
             const h3d_spade_desc& Sp = Bk.spade[s];
-            if (Sp.pixel_style) {
-                f32x16 acc[NT];
-                // ---- shared-MLP activations a = relu(resize(G) + cst) of this lane's pixel as B fragments
-                bf8 ah[8], al[8];
-                const float* cs = cstt + Sp.cst_index * kShared;
-                {
-                    float tq[4][8];
+            f32x16 acc[NT];
+            // ---- shared-MLP activations a = relu(resize(G) + cst) of this lane's pixel as B fragments
+            bf8 ah[8], al[8];
+            const float* cs = cstt + Sp.cst_index * kShared;
+            {
+                float tq[4][8];
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
+                for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            tq[tt][e] = trow[(int64_t)min(xa + e, A.Wr - 1) * A.g_channels + Sp.g_offset + 32 * tt];
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    f32x16 (&d)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
+                    for (int e = 0; e < 8; ++e)
+                        tq[tt][e] = trow[(int64_t)min(xa + e, A.Wr - 1) * A.g_channels + Sp.g_offset + 32 * tt];
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 (&d)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        unsigned hw[4], lw[4];
+                for (int tt = 0; tt < 4; ++tt) {
+                    unsigned hw[4], lw[4];
 #pragma unroll
-                        for (int e = 0; e < 8; e += 2) hw[e / 2] = split2_bf16(tq[tt][e], tq[tt][e + 1], lw[e / 2]);
-                        const bf8 th = __builtin_bit_cast(bf8, u32x4{hw[0], hw[1], hw[2], hw[3]});
-                        const bf8 tl = __builtin_bit_cast(bf8, u32x4{lw[0], lw[1], lw[2], lw[3]});
-                        d[tt] = BF16::mfma(th, wih, zero);
-                        d[tt] = BF16::mfma(th, wil, d[tt]);
-                        d[tt] = BF16::mfma(tl, wih, d[tt]);
-                    }
-                    make_frags<4>(ah, al, d, [&](int nt, int rg) {
-                        const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
-                        float4 y;
-                        y.x = fmaxf(d[nt][rg * 4 + 0] + k4.x, 0.f);
-                        y.y = fmaxf(d[nt][rg * 4 + 1] + k4.y, 0.f);
-                        y.z = fmaxf(d[nt][rg * 4 + 2] + k4.z, 0.f);
-                        y.w = fmaxf(d[nt][rg * 4 + 3] + k4.w, 0.f);
-                        return y;
-                    });
+                    for (int e = 0; e < 8; e += 2) hw[e / 2] = split2_bf16(tq[tt][e], tq[tt][e + 1], lw[e / 2]);
+                    const bf8 th = __builtin_bit_cast(bf8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+                    const bf8 tl = __builtin_bit_cast(bf8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+                    d[tt] = BF16::mfma(th, wih, zero);
+                    d[tt] = BF16::mfma(th, wil, d[tt]);
+                    d[tt] = BF16::mfma(tl, wih, d[tt]);
                 }
-                const float* vec = tab + Sp.vec;
-                // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
-                set_bias(acc, vec);
-                pin_agpr<NT>(x); pin_agpr<NT>(acc);
-                gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
-                pin_agpr<NT>(x); pin_agpr<NT>(acc);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    pin1(x[nt]); pin1(acc[nt]);
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int n = nt * 32 + rg * 8 + 4 * h;
-                        const f32x4 bt = ld4(vec + HdP + n);
-                        const f32x4 sc = ld4(vec + 2 * HdP + n);
-                        const f32x4 sh = ld4(vec + 3 * HdP + n);
-                        acc[nt][rg * 4 + 0] = fmaf(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x), acc[nt][rg * 4 + 0], bt.x);
-                        acc[nt][rg * 4 + 1] = fmaf(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y), acc[nt][rg * 4 + 1], bt.y);
-                        acc[nt][rg * 4 + 2] = fmaf(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z), acc[nt][rg * 4 + 2], bt.z);
-                        acc[nt][rg * 4 + 3] = fmaf(fmaf(x[nt][rg * 4 + 3], sc.w, sh.w), acc[nt][rg * 4 + 3], bt.w);
-                    }
-                    pin1(acc[nt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // beta:   y = lrelu(acc + beta)
-                pin_agpr<NT>(acc);
-                gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
-                pin_agpr<NT>(acc);
-                {
-                    SpadeProducer<NT, false, false> prod{acc, xh, xl, nullptr, nullptr, rgb_acc, h, HdP};
-                    conv_progressive<NT, true>(x, xh, xl, ring, prod);
-                }
-                pin_agpr<NT>(x);
-            } else {
-                // constant style before the first skip block: x is both source and destination, so the fragments
-                // are completed before the conv starts
-                const_frags(x, abt + Sp.ab_index * 2 * HdP);
-                gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
-                pin_agpr<NT>(x);
+                make_frags<4>(ah, al, d, [&](int nt, int rg) {
+                    const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
+                    float4 y;
+                    y.x = fmaxf(d[nt][rg * 4 + 0] + k4.x, 0.f);
+                    y.y = fmaxf(d[nt][rg * 4 + 1] + k4.y, 0.f);
+                    y.z = fmaxf(d[nt][rg * 4 + 2] + k4.z, 0.f);
+                    y.w = fmaxf(d[nt][rg * 4 + 3] + k4.w, 0.f);
+                    return y;
+                });
             }
+            const float* vec = tab + Sp.vec;
+            // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
+            set_bias(acc, vec);
+            pin_agpr<NT>(x); pin_agpr<NT>(acc);
+            gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+            pin_agpr<NT>(x); pin_agpr<NT>(acc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                pin1(x[nt]); pin1(acc[nt]);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = nt * 32 + rg * 8 + 4 * h;
+                    const f32x4 bt = ld4(vec + HdP + n);
+                    const f32x4 sc = ld4(vec + 2 * HdP + n);
+                    const f32x4 sh = ld4(vec + 3 * HdP + n);
+                    acc[nt][rg * 4 + 0] = fmaf(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x), acc[nt][rg * 4 + 0], bt.x);
+                    acc[nt][rg * 4 + 1] = fmaf(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y), acc[nt][rg * 4 + 1], bt.y);
+                    acc[nt][rg * 4 + 2] = fmaf(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z), acc[nt][rg * 4 + 2], bt.z);
+                    acc[nt][rg * 4 + 3] = fmaf(fmaf(x[nt][rg * 4 + 3], sc.w, sh.w), acc[nt][rg * 4 + 3], bt.w);
+                }
+                pin1(acc[nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // beta:   y = lrelu(acc + beta)
+            pin_agpr<NT>(acc);
+            gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+            pin_agpr<NT>(acc);
+            {
+                SpadeProducer<NT, false, false> prod{acc, xh, xl, nullptr, nullptr, rgb_acc, h, HdP};
+                conv_progressive<NT, true>(x, xh, xl, ring, prod);
+            }
+            pin_agpr<NT>(x);
+        }
+        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
+    }
+#pragma unroll 1
+    for (int blk = A.n_pixel_blocks; blk < A.first_skip; ++blk) {
+        const h3d_block_desc& Bk = D.block[blk];
+        int opaque = 0;                       // keeps the loop-invariant LDS table loads inside the body
+        asm volatile("" : "+s"(opaque));
+        const float* tab = tab0 + opaque;
+        const float* abt = ab0 + opaque;
+        const float* cstt = cst0 + opaque;
+        (void)cstt;
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const h3d_spade_desc& Sp = Bk.spade[s];
+            // constant style before the first skip block: x is both source and destination, so the fragments
+            // are completed before the conv starts
+            const_frags(x, abt + Sp.ab_index * 2 * HdP);
+            gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+            pin_agpr<NT>(x);
         }
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
     }
@@ -543,6 +560,17 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
             want += 2 * NT;
         }
     }
+    // per-pixel styles must form a leading run of whole blocks (both SPADEs), everything after it constant style
+    int n_pixel_blocks = 0;
+    while (n_pixel_blocks < desc->n_blocks && desc->block[n_pixel_blocks].spade[0].pixel_style &&
+           desc->block[n_pixel_blocks].spade[1].pixel_style)
+        ++n_pixel_blocks;
+    for (int k = n_pixel_blocks; k < desc->n_blocks; ++k)
+        if (desc->block[k].spade[0].pixel_style || desc->block[k].spade[1].pixel_style) {
+            h3d::set_error("h3d_synthesis_x3: per-pixel-style SPADEs must be the leading whole blocks (block %d breaks that); "
+                           "use h3d_synthesis_x3t / h3d_synthesis", k);
+            return H3D_EUNSUPPORTED;
+        }
     H3D_REQUIRE(want == total_stages, "h3d_synthesis_x3: stream has %lld stages, descriptor needs %lld",
                 (long long)total_stages, (long long)want);
     H3D_REQUIRE(!any_pixel || (G && cst && (g_channels & 3) == 0 && h3d::aligned16(G)), "h3d_synthesis_x3: G/cst missing");
@@ -561,7 +589,7 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
     if (!any_pixel) A.g_channels = 0;
-    A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip;
+    A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip; A.n_pixel_blocks = n_pixel_blocks;
     const bool deep = lds_bytes(A, NT, 6) <= 160 * 1024;      // deepest weight ring the tables leave room for
     if (lds_bytes(A, NT, kRingDepth) > 160 * 1024) {
         h3d::set_error("h3d_synthesis_x3: tables (%d floats) + ring do not fit the 160 KB LDS; use h3d_synthesis", table_floats);

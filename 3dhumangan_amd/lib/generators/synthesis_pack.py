@@ -160,17 +160,21 @@ class SynthesisPlan:
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
     def x3_supported(self):
-        """C <= 256, no per-pixel-style block at or after the first skip block, every block after the first skip block
-        has a skip connection too (csrc/synthesis_x3.hip)."""
+        """C <= 256, per-pixel styles only in a leading run of whole blocks before the first skip block, every block after
+        the first skip block has a skip connection too (csrc/synthesis_x3.hip)."""
         if self.C > 256:
             return False
-        seen_skip = False
+        seen_skip, seen_const = False, False
         for k in range(self.n_blocks):
             if seen_skip and not self.desc.block[k].skip:
                 return False
             seen_skip = seen_skip or bool(self.desc.block[k].skip)
-            if seen_skip and (self.desc.block[k].spade[0].pixel_style or self.desc.block[k].spade[1].pixel_style):
+            px = [bool(self.desc.block[k].spade[s].pixel_style) for s in range(2)]
+            if seen_skip and any(px):
                 return False
+            if any(px) and (seen_const or not all(px)):          # per-pixel styles: a leading run of whole blocks
+                return False
+            seen_const = seen_const or not any(px)
         # LDS budget of csrc/synthesis_x3.hip: static tables + per-sample tables + 4-deep weight ring <= 160 KB
         x3 = self.build_x3()
         per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED

@@ -1,24 +1,29 @@
 #!/bin/bash
-# Round profile: bench line, rocprofv3 kernel stats of the same command, and separate PMC passes for HBM traffic.
-# usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r1
+# Round profile: bench line, rocprofv3 kernel stats of the same command, separate PMC passes for HBM traffic and for the SQ
+# counters, the same for the wide (x3t) workload.  usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r2
 set -u
-R=${1:-r1}
+R=${1:-r2}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 REPO=$PWD
+KERN='x3_kernel|x3t_kernel|geo_features|ray_integrate'
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $REPO/bench.py --no-cpu --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $REPO/bench.py --no-cpu --no-extra --no-check > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c -d $OUT/pmc_$c -o p -- python $REPO/bench.py --no-cpu --no-extra --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
+  timeout 600 rocprofv3 --pmc $c -d $OUT/pmc_$c -o p -- python $REPO/bench.py --no-cpu --no-extra --no-check --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
 done
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o p -- python $REPO/bench.py --no-cpu --no-extra --no-check --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq1.err
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq2 -o p -- python $REPO/bench.py --no-cpu --no-extra --no-check --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq2.err
+# the wide workload (MAP3DBN512L, hidden 420: the x3t engines)
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_wide -o k -- python $REPO/bench.py --config MAP3DBN512L --no-cpu --no-extra --no-check --steps 5 > $OUT/bench_wide_under_rocprof.json 2> $OUT/stats_wide.err
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $OUT/pmc_wide -o p -- python $REPO/bench.py --config MAP3DBN512L --no-cpu --no-extra --no-check --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_wide.err
 cd $REPO
-DB=$(find $OUT/stats -name '*.db' | head -1)
-python tools/rocprof_summary.py $DB $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  DB=$(find $OUT/pmc_$c -name '*.db' | head -1)
-  python tools/pmc_dump.py $DB 'x3_kernel|geo_features|ray_integrate' > $OUT/pmc_$c.txt
+python tools/rocprof_summary.py $(find $OUT/stats -name '*.db' | head -1) $OUT/kernel_stats.csv
+python tools/rocprof_summary.py $(find $OUT/stats_wide -name '*.db' | head -1) $OUT/wide_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE sq1 sq2 wide; do
+  python tools/pmc_dump.py $(find $OUT/pmc_$c -name '*.db' | head -1) "$KERN" > $OUT/pmc_$c.txt
 done
 python tools/traffic_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt MAP3DBN512_512x512_b16_s64 $OUT/hbm_traffic.json
-find $OUT -name '*.db' -size +12M -delete; ls -la $OUT/*/*/* 2>/dev/null | head
-tail -c 600 $OUT/bench.json
+find $OUT -name '*.db' -delete
+tail -c 400 $OUT/bench.json
