@@ -22,6 +22,8 @@ using namespace h3d;
 
 namespace {
 
+typedef F16::vec8 half8;
+
 enum { ST_COORD = 0, ST_GEO, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, ST_COUNT };
 enum { W_COORD = 0, W_GEO, W_F0, W_F1, W_F2, W_F3, W_COLOR, W_FEAT, W_COUNT };
 enum { IN_COORD = 0, IN_GEO = 1, IN_DIR = 3, IN_SLOTS = 4 };      // k-step slots of the input tile
@@ -34,7 +36,9 @@ struct LayoutT {           // offsets in BYTES into the blob (all multiples of 1
     int64_t inv_scale;     // float[W_COUNT]   1 / (weight scale * input scale)
     int64_t bias;          // float[ST_COUNT][HdP]
     int64_t b_feat;        // float[HdP]
-    int64_t head_w;        // float[4][HdP]    sigma, r, g, b weights in FRAGMENT order: [ks*16 + h*8 + e] = w[acc_k(ks,h,e)]
+    int64_t head_w;        // f16 [KS][hi|lo][64 lanes][8]: A fragments of the head tile, rows 0..3 = sigma, r, g, b (each scaled
+                           //   by its own power of two), rows 4..31 zero; K in accumulator order
+    int64_t head_inv;      // float[4]   1 / head scale
     int64_t head_b;        // float[4]
     int64_t total;
 };
@@ -56,7 +60,8 @@ LayoutT make_layout(int Hd, int F) {
     L.inv_scale = take(4 * W_COUNT);
     L.bias = take(4 * (int64_t)ST_COUNT * L.HdP);
     L.b_feat = take(4 * (int64_t)L.HdP);
-    L.head_w = take(4 * (int64_t)4 * L.HdP);
+    L.head_w = take((int64_t)L.KS * 2048);
+    L.head_inv = take(16);
     L.head_b = take(16);
     L.total = o;
     return L;
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     unsigned char* inT = actT + 2 * act_stride;                        // [2][IN_SLOTS][2][1 KB]
     constexpr int in_stride = IN_SLOTS * 2048;
     float* tab = reinterpret_cast<float*>(inT + 2 * in_stride);        // [ST_COUNT][2][HdP]: A1 row, A0 row per step
-    float* part = tab + ST_COUNT * 2 * HdP;                            // [4 waves][3][64]
-    float* wgt = part + 4 * 3 * 64;                                    // [64] compositing weights
+    float* part = tab + ST_COUNT * 2 * HdP;                            // [4 waves][4 heads][64] partial head sums
+    float* wgt = part + 4 * 4 * 64;                                    // [64] compositing weights
     float* bgl = wgt + 64;                                             // [64] background term of the row's ray
     float* rgbv = bgl + 64;                                            // [64][3]
     float* xsum = rgbv + 64 * 3;                                       // [4 waves][32] extra-unit ray sums
@@ -115,7 +120,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     const unsigned char* __restrict__ blob = A.blob;
     const float* __restrict__ invs = reinterpret_cast<const float*>(blob + L.inv_scale);
     const float* __restrict__ bfeat = reinterpret_cast<const float*>(blob + L.b_feat);
-    const float* __restrict__ headw = reinterpret_cast<const float*>(blob + L.head_w);
+    const unsigned char* __restrict__ headw = blob + L.head_w;
+    const float* __restrict__ headinv = reinterpret_cast<const float*>(blob + L.head_inv);
     const float* __restrict__ headb = reinterpret_cast<const float*>(blob + L.head_b);
     X3tUnits<NTF, NX> U0;
     U0.init(wave);
@@ -187,19 +193,86 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             asm volatile("" : "+v"(lane), "+v"(h));
             const float* a1 = tab + (st * 2 + 0) * HdP + 4 * h;
             const float* a0 = tab + (st * 2 + 1) * HdP + 4 * h;
-    #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int nt = U.tile(u);
-                x3t_store_unit<LO>(acc[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
-                    const f32x4 s1 = ld4(a1 + nt * 32 + rg * 8), s0 = ld4(a0 + nt * 32 + rg * 8);
+            // the two units of a tile (sample tiles 0 / 1) share the tile's table values: one fetch per tile, one tile ahead
+            f32x4 t1[2][4], t0[2][4];
+            auto fetch = [&](int slot, int nt) __attribute__((always_inline)) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    t1[slot][rg] = ld4(a1 + nt * 32 + rg * 8);
+                    t0[slot][rg] = ld4(a0 + nt * 32 + rg * 8);
+                }
+            };
+            fetch(0, U.nt[0]);
+            static_for<0, NTF + NX>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, sl = i & 1;
+                if constexpr (i + 1 < NTF + NX) fetch(sl ^ 1, U.nt[i + 1]);
+                auto film = [&](int rg, f32x4 v) {
                     f32x4 y;
-    #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_sinf(fmaf(v[i], s1[i], s0[i]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_sinf(fmaf(v[q], t1[sl][rg][q], t0[sl][rg][q]));
                     return y;
-                });
-                // bound the scheduler's hoisting of the table loads to one unit (all units at once cost > 200 registers)
+                };
+                if constexpr (i < NTF) {
+                    pin1(acc[2 * i]);
+                    x3t_store_unit<LO>(acc[2 * i], actT, KS, U.nt[i], 0, lane, split, film);
+                    pin1(acc[2 * i + 1]);
+                    x3t_store_unit<LO>(acc[2 * i + 1], actT, KS, U.nt[i], 1, lane, split, film);
+                } else {
+                    pin1(acc[2 * NTF]);
+                    x3t_store_unit<LO>(acc[2 * NTF], actT, KS, U.nt[i], U.xmt, lane, split, film);
+                }
+                // bound the scheduler's hoisting to one tile (all tiles at once cost > 200 registers)
                 __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // The four 1-row heads (density, r, g, b) of the activations in actT on the matrix cores: D[head][sample] with the
+        // head tile's A fragments (4 real rows) from L2; wave w contracts k-steps w, w+4, .. and leaves its partial sums in
+        // part[w][head][sample] (rows 0..3 of the tile are registers 0..3 of the lanes with h == 0).  All weight fragments
+        // of the wave are requested up front (<= 7 k-steps), so their latency overlaps instead of adding up.
+        auto heads = [&]() __attribute__((always_inline)) {
+            constexpr int MAXK = 7;                                     // KS <= 28
+            u32x4 wh[MAXK], wl[MAXK];
+            const unsigned char* wsrc = headw + opaque + lane * 16;
+#pragma unroll
+            for (int i = 0; i < MAXK; ++i) {
+                const int ks = wave + 4 * i;
+                if (ks < KS) {
+                    wh[i] = *reinterpret_cast<const u32x4*>(wsrc + ks * 2048);
+                    if (LO) wl[i] = *reinterpret_cast<const u32x4*>(wsrc + ks * 2048 + 1024);
+                }
             }
+            f32x16 ha[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ha[mt][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXK; ++i) {
+                const int ks = wave + 4 * i;
+                if (ks < KS) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const unsigned char* q = actT + x3t_frag(KS, mt, ks, 0) + lane * 16;
+                        const half8 xh_ = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(q));
+                        ha[mt] = F16::mfma(__builtin_bit_cast(half8, wh[i]), xh_, ha[mt]);
+                        if (LO) {
+                            const half8 xl_ = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(q + 1024));
+                            ha[mt] = F16::mfma(__builtin_bit_cast(half8, wl[i]), xh_, ha[mt]);
+                            ha[mt] = F16::mfma(__builtin_bit_cast(half8, wh[i]), xl_, ha[mt]);
+                        }
+                    }
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int hd = 0; hd < 4; ++hd) part[(wave * 4 + hd) * 64 + mt * 32 + m] = ha[mt][hd];
+            }
+        };
+        auto head_value = [&](int hd, int sample) {                    // after a barrier: sum over the waves, de-scale, bias
+            const float* q = part + hd * 64 + sample;
+            return ((q[0] + q[256]) + (q[512] + q[768])) * headinv[hd] + headb[hd];
         };
         auto zero = [&](f32x16 (&acc)[NU]) __attribute__((always_inline)) {
     #pragma unroll
@@ -315,27 +388,13 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
             H3D_TRACE(17);
         }
 
-        // ---- density head: fp32 dot product over the fragments; wave w covers k-steps w, w+4, ..; lane = sample
-        {
-            const int mt = lane >> 5;
-            float s = 0.f;
-            for (int ks = wave; ks < KS; ks += 4) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const unsigned char* p = actT + x3t_frag(KS, mt, ks, 0) + (32 * hh + m) * 16;
-                    const u32x4 hv = *reinterpret_cast<const u32x4*>(p), lv = *reinterpret_cast<const u32x4*>(p + 1024);
-                    const float* w = headw + ks * 16 + hh * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s = fmaf(x3t_f16_sum(hv[e >> 1], LO ? lv[e >> 1] : 0u, e & 1), w[e], s);
-                }
-            }
-            part[wave * 192 + lane] = s;
-        }
+        // ---- density head (and, unused here, the colour heads of the same tile) on the matrix cores
+        heads();
         H3D_TRACE(18);
         __syncthreads();
         H3D_TRACE(19);
         if (t < 64) {
-            const float sigma = (part[t] + part[192 + t]) + (part[384 + t] + part[576 + t]) + headb[0];
+            const float sigma = head_value(0, t);
             const int64_t n = n0 + t;
             const bool ok = n < N;
             if (!FUSED) {
@@ -398,29 +457,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         __syncthreads();
         H3D_TRACE(24);
 
-        // ---- colour heads (fp32 dot products) and feature head (matrix cores, operands swapped: rows = samples)
-        {
-            const int mt = lane >> 5;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            for (int ks = wave; ks < KS; ks += 4) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const unsigned char* p = actT + x3t_frag(KS, mt, ks, 0) + (32 * hh + m) * 16;
-                    const u32x4 hv = *reinterpret_cast<const u32x4*>(p), lv = *reinterpret_cast<const u32x4*>(p + 1024);
-                    const float* w = headw + HdP + ks * 16 + hh * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = x3t_f16_sum(hv[e >> 1], LO ? lv[e >> 1] : 0u, e & 1);
-                        s0 = fmaf(x, w[e], s0);
-                        s1 = fmaf(x, w[HdP + e], s1);
-                        s2 = fmaf(x, w[2 * HdP + e], s2);
-                    }
-                }
-            }
-            part[wave * 192 + lane] = s0;
-            part[wave * 192 + 64 + lane] = s1;
-            part[wave * 192 + 128 + lane] = s2;
-        }
+        // ---- colour heads (rows 1..3 of the head tile) and feature head (operands swapped: rows = samples)
+        heads();
         H3D_TRACE(25);
         f32x16 (&accF)[NU] = acc2;
         zero(accF);
@@ -430,8 +468,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(27);
         if (t < 192) {
             const int c = t >> 6, mm_ = t & 63;
-            const float v = (part[c * 64 + mm_] + part[192 + c * 64 + mm_]) + (part[384 + c * 64 + mm_] + part[576 + c * 64 + mm_]) +
-                            headb[1 + c];
+            const float v = head_value(1 + c, mm_);
             const float rgb = 1.f / (1.f + expf(-v));
             const int64_t n = n0 + mm_;
             if (!FUSED) {
@@ -538,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
 
 size_t lds_bytes(const LayoutT& L) {
     return (size_t)2 * L.KS * 2048 + 2 * IN_SLOTS * 2048 +
-           sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + 4 * 3 * 64 + 64 + 64 + 64 * 3 + 4 * 32);
+           sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + 4 * 4 * 64 + 64 + 64 + 64 * 3 + 4 * 32);
 }
 
 template <int NTF, int NX, bool FUSED, int P>
@@ -595,13 +632,14 @@ extern "C" int64_t h3d_field_pack_x3t_size(int Hd, int F) {
 }
 
 extern "C" int h3d_field_x3t_layout(int Hd, int F, int64_t* out, int n_out) {
-    H3D_REQUIRE(out && n_out >= 3 + W_COUNT + 6, "h3d_field_x3t_layout: need room for %d values", 3 + W_COUNT + 6);
+    H3D_REQUIRE(out && n_out >= 3 + W_COUNT + 7, "h3d_field_x3t_layout: need room for %d values", 3 + W_COUNT + 7);
     H3D_REQUIRE(widths_ok(Hd, F), "h3d_field_x3t_layout: widths up to 448 (got %d, %d)", Hd, F);
     const LayoutT L = make_layout(Hd, F);
     int i = 0;
     out[i++] = L.NT; out[i++] = L.KS; out[i++] = L.HdP;
     for (int w = 0; w < W_COUNT; ++w) out[i++] = L.w[w];
-    out[i++] = L.inv_scale; out[i++] = L.bias; out[i++] = L.b_feat; out[i++] = L.head_w; out[i++] = L.head_b; out[i++] = L.total;
+    out[i++] = L.inv_scale; out[i++] = L.bias; out[i++] = L.b_feat; out[i++] = L.head_w; out[i++] = L.head_inv; out[i++] = L.head_b;
+    out[i++] = L.total;
     return H3D_OK;
 }
 
@@ -659,16 +697,24 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     }
     float* bf = reinterpret_cast<float*>(blob + L.b_feat);
     for (int nn = 0; nn < F; ++nn) bf[nn] = p->b_feat[nn];
-    float* hw = reinterpret_cast<float*>(blob + L.head_w);
+    // heads: one 32-row A tile whose rows 0..3 are sigma, r, g, b (own power-of-two scale each), K in accumulator order
+    uint16_t* hw = reinterpret_cast<uint16_t*>(blob + L.head_w);
+    float* hinv = reinterpret_cast<float*>(blob + L.head_inv);
     float* hb = reinterpret_cast<float*>(blob + L.head_b);
     for (int hd = 0; hd < 4; ++hd) {
         const float* w = hd == 0 ? p->w_sigma : p->w_rgb + (int64_t)(hd - 1) * Hd;
+        const float sc = pow2_scale(w, Hd, target);
         for (int ks = 0; ks < L.KS; ++ks)
             for (int hh = 0; hh < 2; ++hh)
                 for (int e = 0; e < 8; ++e) {
                     const int k = x3t_acc_k(ks, hh, e);
-                    hw[(int64_t)hd * L.HdP + ks * 16 + hh * 8 + e] = k < Hd ? w[k] : 0.f;
+                    const float v = k < Hd ? w[k] * sc : 0.f;
+                    const uint16_t hi = x3t_f32_to_f16_rn(v), lo = x3t_f32_to_f16_rn(v - x3t_f16_to_f32(hi));
+                    const int64_t base = ((int64_t)ks * 2) * 64 * 8 + (32 * hh + hd) * 8 + e;      // lane = 32*hh + row
+                    hw[base] = hi;
+                    hw[base + 64 * 8] = lo;
                 }
+        hinv[hd] = 1.f / sc;
         hb[hd] = hd == 0 ? p->b_sigma[0] : p->b_rgb[hd - 1];
     }
     return H3D_OK;

@@ -64,39 +64,68 @@ struct Block {
     Split split;
     X3tRing<NTF + NX>& ring;            // weight fragments in flight (x3t_common.hpp)
 
+    // Visit the wave's tiles; fn(slot constant, tile, first unit, number of units (2 sample tiles, or 1 for the extra
+    // unit)).  The two units of a full tile share every per-channel table value: tables are fetched once per TILE.
+    template <typename FN>
+    __device__ __forceinline__ void for_tiles(FN fn) const {
+        static_for<0, NTF + NX>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            fn(ic, U.nt[i], i < NTF ? 2 * i : 2 * NTF, i < NTF ? 2 : 1);
+            __builtin_amdgcn_sched_barrier(0);      // bound the hoisting of table loads to one tile
+        });
+    }
+    __device__ __forceinline__ int unit_mt(int u) const { return U.mt(u); }
+
     // constant-style SPADE of `src`: y = lrelu(x * a + b) (per-(sample, channel) affine from the host) -> actT
     __device__ __forceinline__ void store_const(f32x16 (&src)[NU], const h3d_spade_desc& Sp) const {
         const float* __restrict__ abg = A.ab + ((int64_t)b * A.n_ab + Sp.ab_index) * 2 * HdP + 4 * h;
+        f32x4 sa[2][4], sb[2][4];                  // the tile's affine, fetched one tile ahead (global memory: L2 latency)
+        auto fetch = [&](int slot, int nt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int nt = U.tile(u);
-            pin1(src[u]);           // accumulator sets live in AGPRs; VALU code reads / writes them one unit at a time
-            x3t_store_unit<LO>(src[u], actT, KS, nt, U.mt(u), lane, split, [&](int rg, f32x4 v) {
-                const f32x4 sa = ld4(abg + nt * 32 + rg * 8), sb = ld4(abg + HdP + nt * 32 + rg * 8);
-                f32x4 y;
+            for (int rg = 0; rg < 4; ++rg) {
+                sa[slot][rg] = ld4(abg + nt * 32 + rg * 8);
+                sb[slot][rg] = ld4(abg + HdP + nt * 32 + rg * 8);
+            }
+        };
+        fetch(0, U.nt[0]);
+        for_tiles([&](auto ic, int nt, int u0, int nu) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value, sl = i & 1;
+            if constexpr (i + 1 < NTF + NX) fetch(sl ^ 1, U.nt[i + 1]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = lrelu(fmaf(v[i], sa[i], sb[i]));
-                return y;
-            });
-            __builtin_amdgcn_sched_barrier(0);      // bound the hoisting of the table loads to one unit
-        }
+            for (int k = 0; k < 2; ++k) {
+                if (k < nu) {
+                    const int u = u0 + k;
+                    pin1(src[u]);       // accumulator sets live in AGPRs; VALU code reads / writes them one unit at a time
+                    x3t_store_unit<LO>(src[u], actT, KS, nt, unit_mt(u), lane, split, [&](int rg, f32x4 v) {
+                        f32x4 y;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = lrelu(fmaf(v[q], sa[sl][rg][q], sb[sl][rg][q]));
+                        return y;
+                    });
+                }
+            }
+        });
     }
     // dst = vec (ADD = false) or dst += vec (ADD = true), vec a per-channel vector of the tables
     template <bool ADD>
     __device__ __forceinline__ void add_vec(f32x16 (&dst)[NU], const float* __restrict__ vecp) const {
+        for_tiles([&](auto, int nt, int u0, int nu) __attribute__((always_inline)) {
+            f32x4 bb[4];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int nt = U.tile(u);
-            if (ADD) pin1(dst[u]);
+            for (int rg = 0; rg < 4; ++rg) bb[rg] = ld4(vecp + nt * 32 + rg * 8 + 4 * h);
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 bb = ld4(vecp + nt * 32 + rg * 8 + 4 * h);
+            for (int k = 0; k < 2; ++k) {
+                if (k < nu) {
+                    const int u = u0 + k;
+                    if (ADD) pin1(dst[u]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[u][rg * 4 + i] = ADD ? dst[u][rg * 4 + i] + bb[i] : bb[i];
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[u][rg * 4 + q] = ADD ? dst[u][rg * 4 + q] + bb[rg][q] : bb[rg][q];
+                    pin1(dst[u]);
+                }
             }
-            pin1(dst[u]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     }
     // dst (+)= bias + Wconv * actT
     template <bool ADD>
@@ -146,20 +175,27 @@ struct Block {
         constexpr int a_stride = kKSA * 2048;
         add_vec<false>(g, vec);
         gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int nt = U.tile(u);
-            pin1(x[u]); pin1(g[u]);
+        for_tiles([&](auto, int nt, int u0, int nu) __attribute__((always_inline)) {
+            f32x4 bt[4], sc[4], sh[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
-                const f32x4 bt = ld4(vec + HdP + n), sc = ld4(vec + 2 * HdP + n), sh = ld4(vec + 3 * HdP + n);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g[u][rg * 4 + i] = fmaf(fmaf(x[u][rg * 4 + i], sc[i], sh[i]), g[u][rg * 4 + i], bt[i]);
+                bt[rg] = ld4(vec + HdP + n); sc[rg] = ld4(vec + 2 * HdP + n); sh[rg] = ld4(vec + 3 * HdP + n);
             }
-            pin1(g[u]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k < nu) {
+                    const int u = u0 + k;
+                    pin1(x[u]); pin1(g[u]);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            g[u][rg * 4 + q] = fmaf(fmaf(x[u][rg * 4 + q], sc[rg][q], sh[rg][q]), g[u][rg * 4 + q], bt[rg][q]);
+                    pin1(g[u]);
+                }
+            }
+        });
         gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -178,32 +214,38 @@ struct Block {
     __device__ __forceinline__ void to_rgb(f32x16 (&x)[NU], const h3d_block_desc& Bk, float& rgb_acc) const {
         const float* __restrict__ wr = tables + Bk.w_rgb;
         float pr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int nt = U.tile(u);
-            pin1(x[u]);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for_tiles([&](auto, int nt, int u0, int nu) __attribute__((always_inline)) {
+            f32x4 w0[4], w1[4], w2[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = nt * 32 + rg * 8 + 4 * h;
-                const f32x4 w0 = ld4(wr + n), w1 = ld4(wr + HdP + n), w2 = ld4(wr + 2 * HdP + n);
+                w0[rg] = ld4(wr + n); w1[rg] = ld4(wr + HdP + n); w2[rg] = ld4(wr + 2 * HdP + n);
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = x[u][rg * 4 + i];
-                    s0 = fmaf(v, w0[i], s0);
-                    s1 = fmaf(v, w1[i], s1);
-                    s2 = fmaf(v, w2[i], s2);
+            for (int k = 0; k < 2; ++k) {
+                if (k < nu) {
+                    const int u = u0 + k;
+                    pin1(x[u]);
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = x[u][rg * 4 + q];
+                            s0 = fmaf(v, w0[rg][q], s0);
+                            s1 = fmaf(v, w1[rg][q], s1);
+                            s2 = fmaf(v, w2[rg][q], s2);
+                        }
+                    if (u < 2 * NTF) {
+                        pr[k][0] += s0; pr[k][1] += s1; pr[k][2] += s2;          // unit 2i + k covers sample tile k
+                    } else {                          // the extra unit covers sample tile xmt only
+                        const float f0 = U.xmt == 0 ? 1.f : 0.f, f1 = 1.f - f0;
+                        pr[0][0] = fmaf(s0, f0, pr[0][0]); pr[0][1] = fmaf(s1, f0, pr[0][1]); pr[0][2] = fmaf(s2, f0, pr[0][2]);
+                        pr[1][0] = fmaf(s0, f1, pr[1][0]); pr[1][1] = fmaf(s1, f1, pr[1][1]); pr[1][2] = fmaf(s2, f1, pr[1][2]);
+                    }
                 }
             }
-            if (u < 2 * NTF) {
-                pr[u & 1][0] += s0; pr[u & 1][1] += s1; pr[u & 1][2] += s2;
-            } else {                          // the extra unit covers sample tile xmt only
-                const float f0 = U.xmt == 0 ? 1.f : 0.f, f1 = 1.f - f0;
-                pr[0][0] = fmaf(s0, f0, pr[0][0]); pr[0][1] = fmaf(s1, f0, pr[0][1]); pr[0][2] = fmaf(s2, f0, pr[0][2]);
-                pr[1][0] = fmaf(s0, f1, pr[1][0]); pr[1][1] = fmaf(s1, f1, pr[1][1]); pr[1][2] = fmaf(s2, f1, pr[1][2]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        });
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

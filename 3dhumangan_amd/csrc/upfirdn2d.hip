@@ -3,6 +3,13 @@
 // form of lib/components/ops/upfirdn2d.cu:29-92: for output (ox, oy) only the taps that land on a real input
 // sample of the zero-stuffed signal are visited, so the cost is ceil(fw/upx)*ceil(fh/upy) MACs per output.
 // Strides are explicit (NCHW or channels_last).  The filter (<= 1 K taps) is staged in LDS once per workgroup.
+//
+// Two kernels:
+//   upfirdn2d_tiled    dense NCHW planes (the usual case): a workgroup owns a 64 x 16 output tile of one (b, c) plane, stages
+//                      the input samples the tile touches in LDS once (zero-filled outside the image: the padding) and every
+//                      thread gathers its taps from there -- each input sample is read from HBM once per tile instead of
+//                      once per tap, with 32-bit index arithmetic only.  HBM-bound: bytes = input + output once.
+//   upfirdn2d_kernel   any strides / very large resampling footprints: one thread per output element, global gathers.
 #include "common.hpp"
 #include <hip/hip_fp16.h>
 
@@ -27,7 +34,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const T* __restrict__ x,
         // store in "correlation order": sf[ky][kx] multiplies padded sample (oy*down + ky, ox*down + kx)
         const int ky = i / p.fw, kx = i % p.fw;
         const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
-        sf[i] = f[sy * p.fw + sx] * p.gain;
+        sf[i] = f[sy * p.fw + sx];
     }
     __syncthreads();
     const int64_t total = (int64_t)p.B * p.C * p.outH * p.outW;
@@ -53,12 +60,95 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const T* __restrict__ x,
                 acc += (A)xb[iy * p.xs[2] + ix * p.xs[3]] * (A)sf[ky * p.fw + kx];
             }
         }
-        y[b * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3]] = (T)acc;
+        y[b * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3]] = (T)(acc * (A)p.gain);     // gain last, as upfirdn2d.cu
     }
+}
+
+constexpr int kTileW = 64, kTileH = 16;          // output tile of the tiled kernel (256 threads x 4 rows each)
+constexpr size_t kMaxTileLds = 60 * 1024;        // staged input tile + filter must fit the default dynamic-LDS limit
+
+struct TileGeom { int in_w, in_h; };
+
+// input footprint of a kTileW x kTileH output tile (independent of the tile's position up to +1)
+__host__ __device__ inline TileGeom tile_geom(const Params& p) {
+    TileGeom g;
+    g.in_w = ((kTileW - 1) * p.downx + p.fw - 1) / p.upx + 2;
+    g.in_h = ((kTileH - 1) * p.downy + p.fh - 1) / p.upy + 2;
+    return g;
+}
+
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
+                                                       Params p, TileGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    A* tile = reinterpret_cast<A*>(smem);                                         // [in_h][in_w]
+    float* sf = reinterpret_cast<float*>(smem + sizeof(A) * g.in_w * g.in_h);      // [fh][fw] in correlation order
+    const int t = threadIdx.x;
+    for (int i = t; i < p.fh * p.fw; i += 256) {
+        const int ky = i / p.fw, kx = i % p.fw;
+        const int sy = p.flip ? ky : p.fh - 1 - ky, sx = p.flip ? kx : p.fw - 1 - kx;
+        sf[i] = f[sy * p.fw + sx];
+    }
+    const int ox0 = blockIdx.x * kTileW, oy0 = blockIdx.y * kTileH;
+    const int plane = blockIdx.z;                                                  // b * C + c, dense NCHW
+    // first input sample any tap of this tile can touch
+    const int ix0 = floor_div(ox0 * p.downx - p.padx0, p.upx), iy0 = floor_div(oy0 * p.downy - p.pady0, p.upy);
+    const T* __restrict__ xb = x + (int64_t)plane * p.H * p.W;
+    for (int i = t; i < g.in_w * g.in_h; i += 256) {
+        const int ly = i / g.in_w, lx = i - ly * g.in_w;
+        const int iy = iy0 + ly, ix = ix0 + lx;
+        tile[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (A)xb[iy * p.W + ix] : (A)0;
+    }
+    __syncthreads();
+    const int tx = t & (kTileW - 1), ty0 = t / kTileW;                             // 4 thread rows, 4 output rows each
+    const int ox = ox0 + tx;
+    if (ox >= p.outW) return;
+    const int bx = ox * p.downx - p.padx0;
+    const int kx0 = ((-bx) % p.upx + p.upx) % p.upx;                               // first tap that lands on a real sample
+    // taps kx0, kx0 + upx, .. read CONSECUTIVE input samples starting at (bx + kx0) / upx (an exact division): the only
+    // integer divisions of a thread are these two per axis, none inside the tap loops
+    const int lx0 = (bx + kx0) / p.upx - ix0;
+    const A gain = (A)p.gain;
+    T* __restrict__ yb = y + (int64_t)plane * p.outH * p.outW;
+#pragma unroll
+    for (int r = 0; r < kTileH / 4; ++r) {
+        const int oy = oy0 + ty0 + 4 * r;
+        if (oy >= p.outH) break;
+        const int by = oy * p.downy - p.pady0;
+        const int ky0 = ((-by) % p.upy + p.upy) % p.upy;
+        const A* row = tile + ((by + ky0) / p.upy - iy0) * g.in_w + lx0;
+        A acc = 0;
+        for (int ky = ky0; ky < p.fh; ky += p.upy, row += g.in_w) {
+            const float* fr = sf + ky * p.fw + kx0;
+            const A* px = row;
+            for (int kx = kx0; kx < p.fw; kx += p.upx, fr += p.upx, ++px) acc += *px * (A)*fr;
+        }
+        yb[oy * p.outW + ox] = (T)(acc * gain);                                     // gain last, as upfirdn2d.cu
+    }
+}
+
+bool dense_nchw(const Params& p) {
+    return p.xs[3] == 1 && p.xs[2] == p.W && p.xs[1] == (int64_t)p.H * p.W && p.xs[0] == (int64_t)p.C * p.H * p.W &&
+           p.ys[3] == 1 && p.ys[2] == p.outW && p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
 }
 
 template <typename T, typename A>
 int launch(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    const TileGeom g = tile_geom(p);
+    const int64_t planes = (int64_t)p.B * p.C;
+    const size_t lds = sizeof(A) * g.in_w * g.in_h + sizeof(float) * p.fh * p.fw;
+    if (dense_nchw(p) && lds <= kMaxTileLds && (int64_t)p.H * p.W < (1ll << 31) && (int64_t)p.outH * p.outW < (1ll << 31)) {
+        // blockIdx.z is limited to 65535: fold the planes over several launches if ever needed
+        for (int64_t z0 = 0; z0 < planes; z0 += 65535) {
+            const unsigned nz = (unsigned)((planes - z0) < 65535 ? (planes - z0) : 65535);
+            h3d::pre_launch();
+            hipLaunchKernelGGL((upfirdn2d_tiled<T, A>), dim3((p.outW + kTileW - 1) / kTileW, (p.outH + kTileH - 1) / kTileH, nz),
+                               dim3(256), lds, st, (const T*)x + z0 * p.H * p.W, f, (T*)y + z0 * p.outH * p.outW, p, g);
+            const int rc = h3d::launch_status("h3d_upfirdn2d");
+            if (rc) return rc;
+        }
+        return H3D_OK;
+    }
     const int64_t total = (int64_t)p.B * p.C * p.outH * p.outW;
     const int64_t want = (total + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 32 ? (want < 1 ? 1 : want) : 256 * 32);

@@ -353,10 +353,10 @@ def op_rooflines():
     out["h3d_bias_act"] = entry(2.0 * x.numel() * 4, timeit(lambda: ba.bias_act(x, b, act="lrelu")), "lrelu [8,256,512,256] f32")
     del x
     x = torch.randn(8, 64, 256, 256, device="cuda")
-    f = uf.setup_filter([1, 3, 3, 1], device="cuda")
+    f = uf.setup_filter([1, 3, 3, 1], device="cuda", separable=False)          # 4x4 taps: one pass
     y = uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)
     out["h3d_upfirdn2d"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)),
-                                 "2x up, [1,3,3,1], [8,64,256,256] -> [8,64,512,512] f32")
+                                 "2x up, 4x4 [1,3,3,1] filter, [8,64,256,256] -> [8,64,512,512] f32")
     del x, y
     x = torch.randn(4, 256, 96, 96, device="cuda")
     y = rs.bilinear_resize(x, (512, 512))

@@ -171,10 +171,11 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
  */
 int64_t h3d_field_pack_x3t_size(int Hd, int F);
 int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
-/* HOST helper: out[0..16] = tiles NT (even, >= 4), k-steps KS = 2*NT, padded width 32*NT, then BYTE offsets of the eight
+/* HOST helper: out[0..17] = tiles NT (even, >= 4), k-steps KS = 2*NT, padded width 32*NT, then BYTE offsets of the eight
  * weight matrices (coord [1 k-step], geo [2], film0 [2*KS: coordinate half, geometry half], film1..3 [KS], colour
  * [KS + 1: the last k-step carries the view direction], feature head [KS]), of inv_scale float[8], bias float[7][HdP],
- * b_feat float[HdP], head_w float[4][HdP] (sigma, r, g, b in fragment order) , head_b float[4] and the total size.
+ * b_feat float[HdP], head_w (f16 [KS][hi|lo][64][8]: ONE tile whose rows 0..3 are the sigma, r, g, b heads, each with its own
+ * power-of-two scale), head_inv float[4] (1 / scale), head_b float[4] and the total size.
  * A matrix is [tile][k-step][hi|lo][64 lanes][8 f16], element (lane, e) = s * W[n = 32*tile + (lane&31)][k], K in
  * accumulator-register order for matrices fed by accumulators, natural order 16*ks + 8*(lane>>5) + e for coord, geo and
  * the view-direction k-step. */

@@ -167,7 +167,8 @@ def test_engine_override_is_seen_by_forward_under_any_device_spelling():
     ran = []
     L = importlib.import_module("3dhumangan_amd._lib")
     lib = L.load()
-    for eng, fn in (("bf16x3", "h3d_synthesis_x3"), ("bf16x3t", "h3d_synthesis_x3t_tier"), ("f32", "h3d_synthesis")):
+    # (this fixture's 16x8 image is outside the register-resident engine's resize geometry: "bf16x3" hands over to x3t)
+    for eng, fn in (("bf16x3", "h3d_synthesis_x3t_tier"), ("bf16x3t", "h3d_synthesis_x3t_tier"), ("f32", "h3d_synthesis")):
         G.synthesis_plan("cuda").engine = eng
         real = getattr(lib, fn)
         called = []

@@ -266,3 +266,21 @@ def test_upfirdn2d_helpers_and_layouts():
     assert f12.ndim == 1
     assert rel_err(upfirdn_mod.upsample2d(dev(x), dev(f12), up=2).cpu(),
                    O.upfirdn2d(x, f12, up=2, padding=[6, 5, 6, 5], gain=4)) < 3e-6
+
+
+@pytest.mark.parametrize("up,down,pad,taps", [(2, 1, (2, 1, 2, 1), 4), (1, 2, (1, 1, 1, 1), 4), (3, 2, (4, 3, 2, 5), 6), (1, 1, (-3, 2, 1, -2), 5),
+                                                (2, 3, (0, 0, 7, 1), 12), (4, 1, (0, 0, 0, 0), 1)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float64, 1e-12), (torch.float16, 2e-3)])
+def test_upfirdn2d_tiled_kernel_vs_oracle(up, down, pad, taps, dtype, tol):
+    """The LDS-tiled kernel (dense NCHW) on sizes that are not multiples of its 64 x 16 tile, every resampling
+    combination, negative padding, and against the per-element kernel (channels_last input takes that one)."""
+    g = torch.Generator().manual_seed(up * 10 + down)
+    x = torch.randn(2, 3, 37, 70, generator=g, dtype=torch.float64)
+    f = torch.randn(taps, taps, generator=g)
+    ref = O.upfirdn2d(x, f.double(), up=up, down=down, padding=pad, gain=1.5)
+    got = upfirdn_mod.upfirdn2d(dev(x.to(dtype)), dev(f), up=up, down=down, padding=pad, gain=1.5)
+    assert got.shape == ref.shape
+    assert rel_err(got.cpu(), ref) < tol
+    cl = upfirdn_mod.upfirdn2d(dev(x.to(dtype)).contiguous(memory_format=torch.channels_last), dev(f), up=up, down=down, padding=pad,
+                               gain=1.5)
+    assert rel_err(cl.cpu(), ref) < tol

@@ -40,8 +40,8 @@ def pack(net, Hd, F):
     nbytes = lib.h3d_field_pack_x3t_size(Hd, F)
     blob = torch.zeros(nbytes, dtype=torch.uint8)
     L.check(lib.h3d_field_pack_x3t(ctypes.byref(P), Hd, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack_x3t")
-    lay = (ctypes.c_int64 * 17)()
-    L.check(lib.h3d_field_x3t_layout(Hd, F, lay, 17), "h3d_field_x3t_layout")
+    lay = (ctypes.c_int64 * 18)()
+    L.check(lib.h3d_field_x3t_layout(Hd, F, lay, 18), "h3d_field_x3t_layout")
     return blob, list(lay)
 
 
@@ -73,7 +73,7 @@ def test_field_x3t_pack_decodes_to_the_reference_network(Hd):
     NT, KS, HdP = lay[0:3]
     assert NT % 2 == 0 and NT >= 4 and KS == 2 * NT and HdP == 32 * NT and HdP >= Hd
     woff = dict(zip(W_NAMES, lay[3:11]))
-    inv_off, bias_off, bfeat_off, headw_off, headb_off, total = lay[11:17]
+    inv_off, bias_off, bfeat_off, headw_off, headinv_off, headb_off, total = lay[11:18]
     assert total == blob.numel()
     f32 = lambda off, n: blob[off: off + 4 * n].view(torch.float32).double()
     inv = dict(zip(W_NAMES, f32(inv_off, 8)))
@@ -110,16 +110,17 @@ def test_field_x3t_pack_decodes_to_the_reference_network(Hd):
     for l in (1, 2, 3):
         x = film(x @ Wl[l].t(), inv[f"f{l}"], bias[2 + l], f[l], ph[l])
     c = film(x @ Wcol.t() + padk(dirs[0].double(), 16) @ Wdir.t(), inv["color"], bias[6], f[3], ph[3])
-    # heads: fp32 [4][HdP] in FRAGMENT order [ks*16 + h*8 + e] -> natural order
-    hw = f32(headw_off, 4 * HdP).view(4, HdP)
+    # heads: one A tile [KS][hi|lo][64 lanes][8] f16 whose rows 0..3 are sigma, r, g, b (rows 4..31 zero), accumulator-order K
+    ht = blob[headw_off: headw_off + KS * 2048].view(torch.float16).double().view(KS, 2, 64, 8).sum(1)      # hi + lo
+    assert float(ht.view(KS, 2, 32, 8)[:, :, 4:].abs().max()) == 0.0
     hv = torch.zeros(4, HdP, dtype=torch.float64)
     for ks in range(KS):
         for h in range(2):
             for e in range(8):
-                hv[:, acc_k(ks, h, e)] = hw[:, ks * 16 + h * 8 + e]
-    hb = f32(headb_off, 4)
-    sigma = x @ hv[0] + hb[0]
-    rgb = torch.sigmoid(c @ hv[1:4].t() + hb[1:4])
+                hv[:, acc_k(ks, h, e)] = ht[ks, 32 * h: 32 * h + 4, e]
+    hinv, hb = f32(headinv_off, 4), f32(headb_off, 4)
+    sigma = x @ hv[0] * hinv[0] + hb[0]
+    rgb = torch.sigmoid(c @ hv[1:4].t() * hinv[1:4] + hb[1:4])
     feat = (c @ Wf.t() * inv["feat"])[:, :F] + f32(bfeat_off, HdP)[:F]
     got = torch.cat([rgb, feat, sigma[:, None]], dim=1)
 
