@@ -304,13 +304,22 @@ def synthesis_input(state, batch, height, width, dtype=torch.float32, prefix="sy
 # lib/components/map3d_layers.py:176-190, 218-238, 346-352), eval mode.
 
 
-def spectral_weight(state, prefix):
-    """weight_orig / sigma with the *stored* u, v (no power iteration in eval;
-    torch.nn.utils.spectral_norm hook)."""
+def spectral_weight(state, prefix, training=False, buffers_out=None):
+    """weight_orig / sigma.  eval: the *stored* u, v (no power iteration; torch.nn.utils.spectral_norm hook).
+    training: one power iteration first (v <- normalize(W^T u), u <- normalize(W v), both without gradient, eps 1e-12),
+    sigma = u . (W v) differentiable through W only; the new u, v are reported in buffers_out."""
     w = state[prefix + ".weight_orig"]
     u = state[prefix + ".weight_u"]
     v = state[prefix + ".weight_v"]
-    sigma = torch.dot(u, torch.mv(w.flatten(1), v))
+    wm = w.flatten(1)
+    if training:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+        if buffers_out is not None:
+            buffers_out[prefix + ".weight_u"] = u
+            buffers_out[prefix + ".weight_v"] = v
+    sigma = torch.dot(u, torch.mv(wm, v))
     return w / sigma
 
 
@@ -323,9 +332,30 @@ def _bn_eval(state, prefix, x, eps=1e-5):
     return (x - mean) * torch.rsqrt(var + eps) * g + b
 
 
-def _spade(state, prefix, x, style_map):
+def _bn_train(state, prefix, x, buffers_out=None, eps=1e-5, momentum=0.1):
+    """nn.SyncBatchNorm / BatchNorm2d in training mode (single process): batch mean and BIASED variance normalise,
+    running statistics move by `momentum` toward the batch mean / UNBIASED variance, num_batches_tracked += 1."""
     dt = x.dtype
-    n = _bn_eval(state, prefix + ".first_norm", x)
+    n = x.numel() // x.shape[1]
+    mean = x.mean(dim=(0, 2, 3))
+    var = ((x - mean.view(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+    if buffers_out is not None:
+        with torch.no_grad():
+            rm, rv = state[prefix + ".running_mean"].to(dt), state[prefix + ".running_var"].to(dt)
+            buffers_out[prefix + ".running_mean"] = rm + momentum * (mean - rm)
+            buffers_out[prefix + ".running_var"] = rv + momentum * (var * n / max(n - 1, 1) - rv)
+            buffers_out[prefix + ".num_batches_tracked"] = state[prefix + ".num_batches_tracked"] + 1
+    g = state[prefix + ".weight"].to(dt).view(1, -1, 1, 1)
+    b = state[prefix + ".bias"].to(dt).view(1, -1, 1, 1)
+    return (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + eps) * g + b
+
+
+def _spade(state, prefix, x, style_map, training=False, buffers_out=None):
+    dt = x.dtype
+    if training:
+        n = _bn_train(state, prefix + ".first_norm", x, buffers_out)
+    else:
+        n = _bn_eval(state, prefix + ".first_norm", x)
     a = torch.relu(F.conv2d(style_map, state[prefix + ".mlp_shared.0.weight"].to(dt),
                             state[prefix + ".mlp_shared.0.bias"].to(dt)))
     gamma = 1 + F.conv2d(a, state[prefix + ".mlp_gamma.weight"].to(dt), state[prefix + ".mlp_gamma.bias"].to(dt))
@@ -333,19 +363,22 @@ def _spade(state, prefix, x, style_map):
     return n * gamma + beta
 
 
-def spade_block(state, prefix, x, style_map, skip):
+def spade_block(state, prefix, x, style_map, skip, training=False, buffers_out=None):
     dt = x.dtype
-    h = F.leaky_relu(_spade(state, prefix + ".spade_0", x, style_map), 0.2)
-    h = F.conv2d(h, spectral_weight(state, prefix + ".conv_0").to(dt), state[prefix + ".conv_0.bias"].to(dt))
-    h = F.leaky_relu(_spade(state, prefix + ".spade_1", h, style_map), 0.2)
-    h = F.conv2d(h, spectral_weight(state, prefix + ".conv_1").to(dt), state[prefix + ".conv_1.bias"].to(dt))
+    tb = (training, buffers_out)
+    h = F.leaky_relu(_spade(state, prefix + ".spade_0", x, style_map, *tb), 0.2)
+    h = F.conv2d(h, spectral_weight(state, prefix + ".conv_0", *tb).to(dt), state[prefix + ".conv_0.bias"].to(dt))
+    h = F.leaky_relu(_spade(state, prefix + ".spade_1", h, style_map, *tb), 0.2)
+    h = F.conv2d(h, spectral_weight(state, prefix + ".conv_1", *tb).to(dt), state[prefix + ".conv_1.bias"].to(dt))
     # reference compares the *last spatial dim* (width) of x and x_orig, which is always equal
     return h + x if skip else h
 
 
 def synthesis_network(state, x, feature_maps, fixed_style, map3d_mode="mixed", mod_blocks=(0, 1, 2),
-                      num_blocks=9, prefix="synthesis_network", return_internal=False):
-    """x [B,C,H,W] (A8 output), feature_maps [B,F,H,W] (A7 output), fixed_style [B,1,F]."""
+                      num_blocks=9, prefix="synthesis_network", return_internal=False, training=False, buffers_out=None):
+    """x [B,C,H,W] (A8 output), feature_maps [B,F,H,W] (A7 output), fixed_style [B,1,F].
+    training=True: train-mode semantics of the reference module (batch-statistics BatchNorm, one spectral-norm power
+    iteration per conv and call); the buffers a train-mode forward would overwrite are returned through buffers_out."""
     B, _, H, W = x.shape
     fixed_map = fixed_style.reshape(B, -1, 1, 1).to(x.dtype).expand(B, fixed_style.shape[-1], H, W)
     rgb = None
@@ -360,7 +393,8 @@ def synthesis_network(state, x, feature_maps, fixed_style, map3d_mode="mixed", m
         else:
             raise ValueError("invalid map3d_mode")
         name = f"m3d_{idx}"
-        x = spade_block(state, f"{prefix}.network.{name}", x, style_map, skip=idx >= num_blocks // 2)
+        x = spade_block(state, f"{prefix}.network.{name}", x, style_map, skip=idx >= num_blocks // 2, training=training,
+                        buffers_out=buffers_out)
         if idx >= num_blocks // 2 - 1:
             dt = x.dtype
             o = F.conv2d(x, state[f"{prefix}.to_rgbs.{name}.linear.weight"].to(dt),
@@ -475,9 +509,12 @@ def render_hierarchical(state, cfg, freq, phase, cond, jitter, noise_coarse, u, 
                                                           coarse_weights=w, field=all_out)
 
 
-def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, return_internal=False, hier=None):
+def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, return_internal=False, hier=None,
+                      training=False, buffers_out=None, latent_indices=None):
     """truncation: None or (psi, avg_z, avg_freq, avg_phase, avg_styles) as produced by
     generate_avg_latent (map3d_generator.py:182-194, 295-301)."""
+    if latent_indices is not None:                       # map3d_generator.py:218-219: latents come from the pool
+        z = state["latent_pool.latents"][latent_indices]
     B = z.shape[0]
     zin = z if cfg.get("neural_field_latent_input", True) else torch.zeros_like(z)
     freq, phase = film_mapping(state, zin)
@@ -496,7 +533,8 @@ def generator_forward(state, cfg, z, cond, jitter, noise=None, truncation=None, 
     fmap_up = F.interpolate(fmap, (H, W), mode="bilinear")
     x0 = synthesis_input(state, B, H, W, dtype=z.dtype if z.dtype == torch.float64 else torch.float32)
     syn = synthesis_network(state, x0, fmap_up, styles, cfg.get("map3d_mode", "isolated"),
-                            tuple(cfg["mod_blocks"]), cfg["synthesis_blocks"], return_internal=return_internal)
+                            tuple(cfg["mod_blocks"]), cfg["synthesis_blocks"], return_internal=return_internal,
+                            training=training, buffers_out=buffers_out)
     focals = cond["intrinsics"][:, 0, 0]
     zc = focals / cond["scales"].to(focals.dtype)
     dm = ((depth - zc.view(B, 1, 1)) / (cfg["depth_length"] / 2.0)).clamp(-1, 1)

@@ -65,3 +65,24 @@ def rel_err_channels(a, b, dim=1):
 def rel_err_rms(a, b):
     a, b = a.double(), b.double()
     return float((a - b).square().mean().sqrt() / b.square().mean().sqrt().clamp_min(1e-30))
+
+
+def grad_errors(got, ref, zero_below=1e-4, skip=()):
+    """Per-parameter max-norm relative error of gradient dicts.  Gradients that are mathematically zero (a conv bias in front
+    of a batch-statistics BatchNorm) hold rounding noise (<= 2e-5 in the reference's own autograd): for those only the
+    magnitude is checked.  -> (worst relative error, name of the worst)"""
+    worst, worst_name = 0.0, None
+    for k, r in ref.items():
+        if k in skip:
+            continue
+        g = got[k]
+        assert g is not None, f"no gradient for {k}"
+        g, r = g.detach().cpu(), r.detach().cpu()
+        assert g.shape == r.shape, k
+        if float(r.abs().max()) < zero_below:
+            assert float(g.abs().max()) < zero_below, (k, float(g.abs().max()))
+            continue
+        e = rel_err(g, r)
+        if e > worst:
+            worst, worst_name = e, k
+    return worst, worst_name

@@ -7,6 +7,9 @@ BUILD CONTAINER ONLY (imports /root/reference through _ref_import.py).  Stores d
   ref_ckpt_tiny_*.pth   the files BaseTrainer.save_model writes (pickled generator module, pickled EMA object, optimizer
                         state dict) for a tiny generator -- to pin the checkpoint loader
   param_order.json      named_parameters() order of the three shipped generator configs (EMA shadow lists are positional)
+  gen_train_*.npz       TRAIN-mode generator forward + backward: weights, conditions, every random tensor, the
+                        outputs, the gradient of a fixed random projection of the outputs w.r.t. every parameter and z, and
+                        the buffers the train-mode forward overwrote (BatchNorm running statistics, spectral-norm u / v)
 Run:  python tests/golden/make_golden_train.py
 """
 import json
@@ -39,7 +42,7 @@ from lib import implicit_funcitions as ref_impl  # noqa: E402
 from lib.components.ema import ExponentialMovingAverage  # noqa: E402
 from lib.discriminators.unet_discriminators import UNetDiscriminator  # noqa: E402
 
-from make_golden import save, tiny_cfg  # noqa: E402
+from make_golden import condition_weights, save, synthetic, tiny_cfg  # noqa: E402
 
 
 def disc_fixture():
@@ -170,7 +173,61 @@ def param_order_fixture():
     print("param_order.json", {k: len(v) for k, v in out.items()})
 
 
+def generator_train_fixture(name, seed, batch=3, nerf_noise=0.3, use_pool=False, **over):
+    cfg = tiny_cfg(**over)
+    torch.manual_seed(seed)
+    G = ref_gen.Map3DGenerator(**cfg)
+    G.set_device("cpu")
+    condition_weights(G, seed)
+    g = torch.Generator().manual_seed(seed + 3)
+    with torch.no_grad():                                  # u, v off the singular vectors: the power iteration must move them
+        for k, v in G.state_dict().items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                v.copy_(torch.nn.functional.normalize(v + 0.3 * torch.randn(v.shape, generator=g), dim=0))
+        G.latent_pool.latents.copy_(torch.randn(G.latent_pool.latents.shape, generator=g))
+    G.train()
+    state0 = {k: v.clone() for k, v in G.state_dict().items()}
+    cond = synthetic.make_conditions(batch, n_vertices=128, seed=seed, pose_scale=0.6)
+    z = torch.randn(batch, cfg["latent_dim"], generator=g).requires_grad_(True)
+    idx = torch.tensor([2, 0, 3][:batch]) if use_pool else None
+    run = dict(cfg)
+    run["nerf_noise"] = nerf_noise
+    R, S = cfg["render_height"] * cfg["render_width"], cfg["num_steps"]
+    rs = seed + 7
+    torch.manual_seed(rs)                                  # the reference's consumption order (make_golden.generator_fixture)
+    jitter = torch.rand(batch, R, S, 1)
+    torch.randn(batch, 1), torch.randn(batch, 1)
+    noise = torch.randn(batch, R, S, 1) * nerf_noise
+    torch.manual_seed(rs)
+    out = G.forward(z, cond, latent_indices=idx, **run)
+    p_rgb = torch.randn(out["rgbs"].shape, generator=g)
+    p_render = torch.randn(out["rgbs_render"].shape, generator=g)
+    loss = (out["rgbs"] * p_rgb).sum() + (out["rgbs_render"] * p_render).sum()
+    loss.backward()
+    grads = {n: p.grad for n, p in G.named_parameters() if p.grad is not None}
+    if z.grad is not None:
+        grads["__z__"] = z.grad
+    state1 = G.state_dict()
+    changed = {k: v for k, v in state1.items() if not torch.equal(v, state0[k])}
+    meta = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool))}
+    meta["mod_blocks"] = list(cfg["mod_blocks"])
+    meta["nerf_noise"] = nerf_noise
+    extra = dict(latent_indices=idx) if use_pool else {}
+    save(name, state=state0, cond=cond, z=z, jitter=jitter, noise=noise, p_rgb=p_rgb, p_render=p_render,
+         meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+         out=dict(rgbs=out["rgbs"], rgbs_render=out["rgbs_render"], loss=loss), grad=grads, buffers_after=changed, **extra)
+    print("   parameters with gradient:", len(grads), "of", len(list(G.named_parameters())), "| buffers changed:", len(changed))
+
+
 if __name__ == "__main__":
+    if "--only-gen-train" in sys.argv:
+        generator_train_fixture("gen_train_mixed", 31)
+        generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
+                                white_back=True, last_back=True, clamp_mode="softplus")
+        sys.exit(0)
+    generator_train_fixture("gen_train_mixed", 31)
+    generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
+                            white_back=True, last_back=True, clamp_mode="softplus")
     frontend_fixture()
     disc_fixture()
     ema_and_checkpoint_fixture()

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import h3d_oracle as O
-from conftest import load_golden, rel_err
+from conftest import grad_errors, load_golden, rel_err
 
 synthetic = importlib.import_module("3dhumangan_amd.synthetic")
 
@@ -179,3 +179,45 @@ def test_subset_oracle_matches_reference_vectors(name):
         s2 = O.generator_forward_subset(g["state"], cfg, g["z"], g["cond"], g["jitter"], part, g["noise"])
         assert rel_err(s2["rgbs"], full["rgbs"].flatten(2)[:, :, part]) < 2e-6
         assert rel_err(s2["raw_depth"], full["raw_depth"][:, s2["ray_subset"]]) < 1e-6
+
+
+TRAIN_FIXTURES = ["gen_train_mixed", "gen_train_isolated_legacy_pool"]
+
+
+def oracle_train_step(g, dtype=torch.float32):
+    """Train-mode forward + backward of the oracle on a gen_train_* fixture -> (out, grads by name, buffers_after)."""
+    cfg = _cfg(g)
+    state = {k: (v.to(dtype) if v.is_floating_point() else v).clone() for k, v in g["state"].items()}
+    leaves = [k for k in state if k in g["grad"]]
+    for k in leaves:
+        state[k].requires_grad_(True)
+    z = g["z"].to(dtype).clone().requires_grad_(True)
+    cond = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in g["cond"].items()}
+    buffers = {}
+    out = O.generator_forward(state, cfg, z, cond, g["jitter"].to(dtype), g["noise"].to(dtype), training=True,
+                              buffers_out=buffers, latent_indices=g.get("latent_indices"))
+    loss = (out["rgbs"] * g["p_rgb"].to(dtype)).sum() + (out["rgbs_render"] * g["p_render"].to(dtype)).sum()
+    grads = torch.autograd.grad(loss, [state[k] for k in leaves] + [z], allow_unused=True)
+    named = dict(zip(leaves + ["__z__"], grads))
+    return out, loss, named, buffers
+
+
+@pytest.mark.parametrize("name", TRAIN_FIXTURES)
+def test_train_mode_forward_backward(name):
+    """the oracle's train-mode semantics (batch-statistics BatchNorm, spectral-norm power iteration) and its
+    gradients against the reference module's own autograd."""
+    g = load_golden(name)
+    out, loss, grads, buffers = oracle_train_step(g)
+    assert rel_err(out["rgbs_render"], g["out"]["rgbs_render"]) < 5e-5
+    assert rel_err(out["rgbs"], g["out"]["rgbs"]) < 5e-5
+    assert abs(float(loss) - float(g["out"]["loss"])) < 1e-4 * abs(float(g["out"]["loss"])) + 1e-3
+    skip = ("__z__",) if "latent_indices" in g else ()       # z is replaced by pool latents: no gradient reaches it
+    worst, where = grad_errors(grads, g["grad"], skip=skip)
+    assert worst < 2e-5, (where, worst)
+    for k, ref in g["buffers_after"].items():
+        assert k in buffers, k
+        if ref.is_floating_point():
+            assert rel_err(buffers[k], ref) < 1e-5, k
+        else:
+            assert torch.equal(buffers[k], ref), k
+    assert set(buffers) == set(g["buffers_after"])
