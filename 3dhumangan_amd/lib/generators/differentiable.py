@@ -1,0 +1,240 @@
+"""The differentiable (training) evaluation of the generator path -- SURVEY 8f.4, "backward passes of A4-A9".
+
+The inference engines (csrc/field_x3*.hip, synthesis_x3*.hip) keep every activation in registers / LDS and therefore have
+nothing to differentiate through; training needs the activations in HBM anyway.  This path is organised for that:
+
+  * every dense contraction is a library GEMM over ALL samples / pixels of the batch at once (``[B*N, C] x [C, C']``,
+    hipBLASLt through torch: 0.5 M x 256 x 256 problems -- the shape rocBLAS is built for), in a channels-LAST layout end
+    to end, so no transposes sit between the render and the synthesis network;
+  * what sits between two GEMMs is ONE hand-written HIP pass each way with a hand-written adjoint that recomputes instead of
+    storing: ``film_sin`` (sine activation with per-sample frequency / phase), ``h3d_ray_integrate`` /
+    ``h3d_ray_integrate_bwd`` (volume integration), ``bias_act`` (style mapping network); the SPADE normalise-modulate-
+    activate chain is one autograd node with a hand-derived backward (3 saved tensors instead of 8);
+  * ray set-up and the SMPL geometry features have no learnable inputs and run as the same HIP kernels as in inference.
+
+Train-mode semantics of the reference are reproduced: batch-statistics BatchNorm (synchronised over the process group when
+one is initialised -- the reference uses nn.SyncBatchNorm, lib/components/map3d_layers.py:162) with running-statistics
+updates, and one spectral-norm power iteration per conv and call (torch.nn.utils.spectral_norm as used at
+lib/components/map3d_layers.py:205-206).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from ..components.ops.film import film_sin
+
+
+# ------------------------------------------------------------------------------------------------ A5: the implicit function
+
+def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feature_scaler=1.0):
+    """COORDCONCATSIREN.forward (lib/implicit_funcitions/modulated.py:41-75), differentiable w.r.t. the module's parameters,
+    freq and phase.  points [B,N,3], geo [B,N,31], dirs [B,N,3] or None (= the locked direction (0,0,-1)),
+    freq / phase [B,4H] -> [B,N,F+4] = [rgb, features, sigma]."""
+    H = nf.hidden_dim
+    B = points.shape[0]
+    fr = freq * 15 + 30
+    a = film_sin(F.linear(points * input_scaler, nf.first_layer_coord.layer.weight, nf.first_layer_coord.layer.bias), w0=30.0)
+    g = film_sin(F.linear(geo if geo_feature_scaler == 1.0 else geo * geo_feature_scaler, nf.first_layer_mod.layer.weight,
+                          nf.first_layer_mod.layer.bias), w0=30.0)
+    x = torch.cat([a, g], dim=-1)
+    for k, dense in enumerate(nf.network):
+        sl = slice(k * H, (k + 1) * H)
+        x = film_sin(F.linear(x, dense.layer.weight, dense.layer.bias), fr[:, sl], phase[:, sl])
+    sigma = F.linear(x, nf.sigma_layer.weight, nf.sigma_layer.bias)
+    wc, bc = nf.color_layer_sine.layer.weight, nf.color_layer_sine.layer.bias
+    if dirs is None:                       # lock_view_dependence: the direction is the constant (0,0,-1) -> part of the bias
+        c = F.linear(x, wc[:, 3:], bc - wc[:, 2])
+    else:
+        c = F.linear(x, wc[:, 3:], bc) + F.linear(dirs, wc[:, :3])
+    c = film_sin(c, fr[:, -H:], phase[:, -H:])
+    rgb = torch.sigmoid(F.linear(c, nf.color_layer_linear.weight, nf.color_layer_linear.bias))
+    feat = F.linear(c, nf.feature_layer_linear.weight, nf.feature_layer_linear.bias)
+    return torch.cat([rgb, feat, sigma], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ batch statistics
+
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over the process group whose adjoint is the same sum (every rank's loss depends on every rank's statistics)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        ctx.group = group
+        t = t.contiguous().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def _dist_on(group):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def batch_moments(x2d, group=None):
+    """Per-channel mean and BIASED variance of x2d [M, C] over the (global) batch, plus the global row count."""
+    m = x2d.shape[0]
+    if not _dist_on(group):
+        var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
+        return mean, var, m
+    sums = torch.stack([x2d.sum(0), (x2d * x2d).sum(0)])                 # [2, C]
+    count = torch.tensor([float(m)], device=x2d.device)
+    dist.all_reduce(count, group=group)
+    sums = _AllReduceSum.apply(sums, group)
+    n = float(count.item())
+    mean = sums[0] / n
+    var = (sums[1] / n - mean * mean).clamp_min(0)
+    return mean, var, int(n)
+
+
+class _SpadeNormAct(torch.autograd.Function):
+    """y = lrelu_0.2( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )   -- SPADE2d.forward + the block's activation
+    (lib/components/map3d_layers.py:176-190, 228-233) as one node.
+
+    x [B,P,C]; mean, rstd [C] (they carry their own graph when they are batch statistics: their gradients are returned, and
+    autograd completes the batch-norm backward through var_mean / the all-reduce); g, b [C]; gamma, beta [B,P,C] (per-pixel
+    SPADE) or [B,1,C] (constant style).  Saves x, gamma, beta only."""
+
+    @staticmethod
+    def forward(ctx, x, mean, rstd, g, b, gamma, beta):
+        h = (x - mean) * (rstd * g) + b
+        u = torch.addcmul(beta, h, 1 + gamma)
+        ctx.save_for_backward(x, mean, rstd, g, b, gamma, beta)
+        return F.leaky_relu(u, 0.2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd, g, b, gamma, beta = ctx.saved_tensors
+        n = (x - mean) * rstd
+        h = n * g + b
+        u = torch.addcmul(beta, h, 1 + gamma)
+        du = torch.where(u > 0, dy, dy * 0.2)
+        del u
+        red = (0, 1) if gamma.shape[1] == x.shape[1] else None
+        d_gamma = du * h
+        d_beta = du
+        if gamma.shape[1] != x.shape[1]:                                  # constant style: reduce over the pixels
+            d_gamma = d_gamma.sum(1, keepdim=True)
+            d_beta = du.sum(1, keepdim=True)
+        dh = du * (1 + gamma)
+        d_g = (dh * n).sum((0, 1))
+        d_b = dh.sum((0, 1))
+        dn = dh * g
+        d_rstd = (dn * (x - mean)).sum((0, 1))
+        d_mean = -(dn.sum((0, 1))) * rstd
+        dx = dn * rstd
+        return dx, d_mean, d_rstd, d_g, d_b, d_gamma, d_beta
+
+
+def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1):
+    """norm: the first_norm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked)."""
+    C = x.shape[-1]
+    if training:
+        mean, var, n = batch_moments(x.reshape(-1, C), group)
+        with torch.no_grad():
+            norm.running_mean.lerp_(mean.detach().to(norm.running_mean.dtype), momentum)
+            norm.running_var.lerp_((var.detach() * (n / max(n - 1, 1))).to(norm.running_var.dtype), momentum)
+            norm.num_batches_tracked += 1
+    else:
+        mean, var = norm.running_mean, norm.running_var
+    rstd = torch.rsqrt(var + eps)
+    return _SpadeNormAct.apply(x, mean, rstd, norm.weight, norm.bias, gamma, beta)
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+
+def spectral_weight(conv, training, eps=1e-12):
+    """weight_orig / sigma of a spectral-normalised 1x1 conv holder (bias, weight_orig, weight_u, weight_v) as a [Cout, Cin]
+    matrix.  training: one power iteration first, the new u / v overwrite the buffers (torch.nn.utils.spectral_norm)."""
+    w = conv.weight_orig.flatten(1)
+    u, v = conv.weight_u, conv.weight_v
+    if training:
+        with torch.no_grad():
+            v_new = F.normalize(torch.mv(w.t(), u), dim=0, eps=eps)
+            u_new = F.normalize(torch.mv(w, v_new), dim=0, eps=eps)
+            conv.weight_v.copy_(v_new)
+            conv.weight_u.copy_(u_new)
+        u, v = u_new, v_new
+    sigma = torch.dot(u, torch.mv(w, v))
+    return w / sigma
+
+
+# ------------------------------------------------------------------------------------------------ A7-A9: synthesis
+
+def _coords(H, W, device, dtype):
+    ii = torch.linspace(-1, 1, H, device=device, dtype=dtype)[:, None].expand(H, W)
+    jj = torch.linspace(-1, 1, W, device=device, dtype=dtype)[None, :].expand(H, W)
+    return torch.stack([ii, jj], dim=-1).reshape(H * W, 2)
+
+
+def _resize_channels_last(t, render_hw, gen_hw):
+    """Bilinear (align_corners=False) resize of a channels-last map [B, Hr*Wr, C] -> [B, H*W, C] without leaving the
+    channels-last layout (F.interpolate on the NCHW *view* of the same memory)."""
+    B, _, C = t.shape
+    nchw = t.reshape(B, render_hw[0], render_hw[1], C).permute(0, 3, 1, 2)
+    up = F.interpolate(nchw, gen_hw, mode="bilinear", align_corners=False)
+    return up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)
+
+
+def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=None):
+    """SynthesisInput + bilinear resize + SynthesisNetwork (lib/generators/map3d_generator.py:58-97, 244-275;
+    lib/components/map3d_layers.py:176-275, 346-352).  fmap_low [B,R,F] channels-last rendered features, styles [B,1,F]
+    -> rgb [B,3,H,W]."""
+    sn = G.synthesis_network
+    B, R, Fd = fmap_low.shape
+    H, W = gen_hw
+    P = H * W
+    dev, dt = fmap_low.device, fmap_low.dtype
+    fixed = styles.reshape(B, 1, Fd)
+    mode, mod_blocks, nb = sn.map3d_mode, set(sn.mod_blocks), sn.num_blocks
+    if mode not in ("all", "mixed", "isolated"):
+        raise ValueError("invalid map3d_mode")
+    conv_in = G.synthesis_input.network[0]
+    x0 = torch.sin(F.linear(_coords(H, W, dev, dt), conv_in.weight.flatten(1), conv_in.bias))      # [P, F]
+    x = x0.unsqueeze(0).expand(B, P, x0.shape[-1])
+
+    def per_pixel(idx):
+        return mode == "all" or idx in mod_blocks
+
+    # the 128-wide shared convs of every per-pixel SPADE in ONE low-resolution GEMM + ONE resize (conv1x1 and the bilinear
+    # resize commute; the constant style enters as a per-sample bias after the resize)
+    names = [f"m3d_{i}" for i in range(nb)]
+    pix = [(n, s) for i, n in enumerate(names) if per_pixel(i) for s in ("spade_0", "spade_1")]
+    shared_up = {}
+    if pix:
+        w_all = torch.cat([getattr(sn.network[n], s).mlp_shared[0].weight.flatten(1) for n, s in pix], dim=0)
+        up = _resize_channels_last(F.linear(fmap_low, w_all), render_hw, gen_hw)                  # [B, P, 128 * len(pix)]
+        for k, key in enumerate(pix):
+            shared_up[key] = up[..., 128 * k:128 * (k + 1)]
+
+    def modulation(blk_name, spade_name, idx):
+        sp = getattr(sn.network[blk_name], spade_name)
+        ws, bs = sp.mlp_shared[0].weight.flatten(1), sp.mlp_shared[0].bias
+        if per_pixel(idx):
+            off = bs if mode == "isolated" else F.linear(fixed, ws, bs)          # isolated: the style is the feature map alone
+            a = torch.relu(shared_up[(blk_name, spade_name)] + off)
+        else:
+            a = torch.relu(F.linear(fixed, ws, bs))                              # [B,1,128]
+        gamma = F.linear(a, sp.mlp_gamma.weight.flatten(1), sp.mlp_gamma.bias)
+        beta = F.linear(a, sp.mlp_beta.weight.flatten(1), sp.mlp_beta.bias)
+        return sp.first_norm, gamma, beta
+
+    rgb = None
+    for idx, name in enumerate(names):
+        blk = sn.network[name]
+        x_in = x
+        h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group)
+        h = F.linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
+        h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group)
+        h = F.linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias)
+        x = h + x_in if idx >= nb // 2 else h
+        if idx >= nb // 2 - 1:
+            lin = sn.to_rgbs[name].linear
+            o = F.linear(x, lin.weight.flatten(1), lin.bias)
+            rgb = o if rgb is None else o + rgb
+    return rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)

@@ -22,6 +22,7 @@ from ..._stages import stage
 from ..components import smpl
 from ..components.ops.bias_act import bias_act
 from . import volume_rendering as vr
+from .differentiable import field_forward, synthesis_forward
 from .synthesis_pack import SynthesisPlan
 
 
@@ -113,7 +114,12 @@ class FullyConnectedLayer(nn.Module):
         return self._folded[1], self._folded[2]
 
     def forward(self, x):
-        wt, b = self.folded()
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            # training form: the gains stay in the graph (equalised learning rate), bias_act is differentiable
+            wt = (self.weight.float() * self.weight_gain).t()
+            b = None if self.bias is None else self.bias.float() * self.bias_gain
+        else:
+            wt, b = self.folded()
         y = x.float() @ wt
         if self.activation == "linear":
             return y if b is None else y + b
@@ -357,15 +363,25 @@ class Map3DGenerator(nn.Module):
         _, styles = self.synthesis_mapping_network(latent)
         return fr, ph, styles
 
-    @torch.no_grad()
-    def render(self, freq, phase, conditions, render_width, render_height, ray_start, ray_end, coarse_steps, fine_steps=None,
-               h_stddev=0, v_stddev=0, h_mean=0, v_mean=0, hierarchical_sample=False, sample_dist=None,
-               lock_view_dependence=False, staged=False, max_points=50000, jitter=None, noise=None, fused=True, **kwargs):
+    def render(self, *args, differentiable=False, **kwargs):
         """reference :381-523.  -> rgb_render [B,3,Hr,Wr], feature_maps [B,R,F] (channels LAST: it feeds the
         synthesis kernel directly; use .transpose for NCHW), depths [B,R,1], weights [B,R,S,1], None.
 
         ``staged``/``max_points`` chunking is a memory work-around of the reference and is not needed: the field
-        tensor never materialises in the fused path."""
+        tensor never materialises in the fused path.  ``differentiable=True`` evaluates the field as library GEMMs + HIP
+        activation / integration kernels with hand-written adjoints (lib/generators/differentiable.py) instead of the fused
+        inference kernel."""
+        if differentiable:
+            return self._render(*args, differentiable=True, **kwargs)
+        with torch.no_grad():
+            return self._render(*args, **kwargs)
+
+    def _render(self, freq, phase, conditions, render_width, render_height, ray_start, ray_end, coarse_steps, fine_steps=None,
+                h_stddev=0, v_stddev=0, h_mean=0, v_mean=0, hierarchical_sample=False, sample_dist=None,
+                lock_view_dependence=False, staged=False, max_points=50000, jitter=None, noise=None, fused=True,
+                differentiable=False, **kwargs):
+        if hierarchical_sample and differentiable:
+            raise NotImplementedError("hierarchical_sample=True has no differentiable path (no shipped config trains with it)")
         if hierarchical_sample:
             return self._render_hierarchical(freq, phase, conditions, render_width, render_height, ray_start, ray_end,
                                              int(coarse_steps), int(coarse_steps if fine_steps is None else fine_steps),
@@ -394,8 +410,15 @@ class Map3DGenerator(nn.Module):
         scaler = 2.0 / self.side_length
         clamp_mode = kwargs["clamp_mode"]
         last_back, white_back = kwargs.get("last_back", False), kwargs.get("white_back", False)
-        can_fuse = fused and self.neural_field.fused_supported(S)
-        if can_fuse:
+        can_fuse = fused and not differentiable and self.neural_field.fused_supported(S)
+        if differentiable:
+            with stage(self, "neural_field"):
+                field = field_forward(self.neural_field, pts, freq, phase, geo, dirs, input_scaler=scaler)
+            with stage(self, "ray_integrate"):
+                feats, depths, weights = vr.ray_integration(field.reshape(B, R, S, -1), z_vals, noise_std=0, noise=noise,
+                                                            clamp_mode=clamp_mode, last_back=last_back,
+                                                            white_back=white_back, consume_rng=False)
+        elif can_fuse:
             with stage(self, "render_fused"):
                 feats, depths, weights = self.neural_field.render(pts, freq, phase, geo, dirs, z_vals, S,
                                                                   input_scaler=scaler, noise=noise, clamp_mode=clamp_mode,
@@ -406,7 +429,7 @@ class Map3DGenerator(nn.Module):
             with stage(self, "ray_integrate"):
                 feats, depths, weights = vr.ray_integration(field.reshape(B, R, S, -1), z_vals, noise_std=0, noise=noise,
                                                             clamp_mode=clamp_mode, last_back=last_back,
-                                                            white_back=white_back)
+                                                            white_back=white_back, consume_rng=False)
         rgb_render = (feats[..., :3] * 2 - 1).reshape(B, render_height, render_width, 3).permute(0, 3, 1, 2)
         return rgb_render, feats[..., 3:], depths, weights, None
 
@@ -444,7 +467,8 @@ class Map3DGenerator(nn.Module):
             drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24, first call
             noise_coarse = drawn * nerf_noise if nerf_noise != 0 else None
         with stage(self, "ray_integrate"):
-            _, _, w = vr.ray_integration(coarse, z_vals, noise_std=0, noise=noise_coarse, clamp_mode=clamp_mode)
+            _, _, w = vr.ray_integration(coarse, z_vals, noise_std=0, noise=noise_coarse, clamp_mode=clamp_mode,
+                                         consume_rng=False)
         with stage(self, "resample"):
             w = w.reshape(B * R, S) + 1e-5
             zv = z_vals.reshape(B * R, S)
@@ -463,24 +487,41 @@ class Map3DGenerator(nn.Module):
         with stage(self, "ray_integrate"):
             feats, depths, weights = vr.ray_integration(all_out, all_z, noise_std=0, noise=noise, clamp_mode=clamp_mode,
                                                         last_back=kwargs.get("last_back", False),
-                                                        white_back=kwargs.get("white_back", False))
+                                                        white_back=kwargs.get("white_back", False), consume_rng=False)
         rgb_render = (feats[..., :3] * 2 - 1).reshape(B, render_height, render_width, 3).permute(0, 3, 1, 2)
         return rgb_render, feats[..., 3:], depths, weights, None
 
-    def _synthesize(self, feature_maps, styles, render_hw):
+    def _synthesize(self, feature_maps, styles, render_hw, differentiable=False):
+        if differentiable:
+            with stage(self, "synthesis"):
+                return synthesis_forward(self, feature_maps, styles, render_hw, (self.gen_height, self.gen_width),
+                                         training=self.training, group=getattr(self, "process_group", None))
         plan = self.synthesis_plan(feature_maps.device)
         return plan.run(feature_maps, styles.reshape(styles.shape[0], -1), render_hw, (self.gen_height, self.gen_width),
                         owner=self)
 
-    @torch.no_grad()
+    def wants_autograd(self, kwargs):
+        """Which evaluation a forward call gets.  ``.train()`` mode -> the differentiable path with the reference's train-mode
+        semantics (batch-statistics BatchNorm, spectral-norm power iteration), whether or not autograd is recording;
+        ``.eval()`` mode -> the fused inference engines, never recorded.  ``differentiable=True / False`` overrides the
+        choice (True in eval mode: gradients through the running-statistics network, e.g. latent optimisation)."""
+        d = kwargs.get("differentiable")
+        return self.training if d is None else bool(d)
+
     def forward(self, latent, conditions, render_height, render_width, latent_indices=None, **kwargs):
         """reference :208-280 -> {"rgbs", "rgbs_render"}"""
         if not latent.is_cuda:
             _lib.need_cuda(latent)
+        diff = self.wants_autograd(kwargs)
+        kwargs.pop("differentiable", None)
         with torch.cuda.device(latent.device):          # kernels launch on the current device's stream
-            return self._forward(latent, conditions, render_height, render_width, latent_indices, **kwargs)
+            if diff:
+                return self._forward(latent, conditions, render_height, render_width, latent_indices, differentiable=True,
+                                     **kwargs)
+            with torch.no_grad():
+                return self._forward(latent, conditions, render_height, render_width, latent_indices, **kwargs)
 
-    def _forward(self, latent, conditions, render_height, render_width, latent_indices=None, **kwargs):
+    def _forward(self, latent, conditions, render_height, render_width, latent_indices=None, differentiable=False, **kwargs):
         if kwargs.get("disable_render", False):
             raise NotImplementedError("disable_render=True is not set by any config and has no HIP path")
         num_steps = kwargs.get("num_steps", 24)
@@ -489,10 +530,11 @@ class Map3DGenerator(nn.Module):
         fr, ph, styles = self._mapping(latent, kwargs)
         rk = {k: v for k, v in kwargs.items() if k not in ("coarse_steps", "fine_steps", "render_width", "render_height")}
         rgb_render, fmap, _, _, _ = self.render(fr, ph, conditions, render_width, render_height,
-                                                coarse_steps=num_steps, fine_steps=num_steps, **rk)
+                                                coarse_steps=num_steps, fine_steps=num_steps, differentiable=differentiable,
+                                                **rk)
         if kwargs.get("disable_synthesis", False):
             return {"rgbs": rgb_render, "rgbs_render": rgb_render}
-        rgb = self._synthesize(fmap, styles, (render_height, render_width))
+        rgb = self._synthesize(fmap, styles, (render_height, render_width), differentiable)
         return {"rgbs": rgb, "rgbs_render": rgb_render}
 
     @torch.no_grad()

@@ -57,12 +57,53 @@ def ray_directions_world(focals, cam2world_matrix, resolution, num_steps):
     return d.unsqueeze(2).expand(B, W * H, num_steps, 3).reshape(B, W * H * num_steps, 3).contiguous()
 
 
+def _integrate(field, z, nz, clamp, last_back, white_back):
+    B, R, S, C1 = field.shape
+    feats = torch.empty((B, R, C1 - 1), device=field.device, dtype=torch.float32)
+    depth = torch.empty((B, R, 1), device=field.device, dtype=torch.float32)
+    weights = torch.empty((B, R, S, 1), device=field.device, dtype=torch.float32)
+    rc = _lib.load().h3d_ray_integrate(_lib.ptr(field), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(feats), _lib.ptr(depth),
+                                       _lib.ptr(weights), B * R, S, C1 - 1, clamp, last_back, white_back,
+                                       _lib.stream_handle())
+    _lib.check(rc, "h3d_ray_integrate")
+    return feats, depth, weights
+
+
+class _RayIntegration(torch.autograd.Function):
+    """h3d_ray_integrate with its hand-written adjoint h3d_ray_integrate_bwd (gradient w.r.t. the field tensor; the sample
+    depths and the noise are not learnable on this path and get none)."""
+
+    @staticmethod
+    def forward(ctx, field, z, nz, clamp, last_back, white_back):
+        ctx.save_for_backward(field, z, nz)
+        ctx.flags = (clamp, last_back, white_back)
+        return _integrate(field, z, nz, clamp, last_back, white_back)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_feats, g_depth, g_weights):
+        field, z, nz = ctx.saved_tensors
+        clamp, last_back, white_back = ctx.flags
+        B, R, S, C1 = field.shape
+        gf = (torch.zeros((B, R, C1 - 1), device=field.device) if g_feats is None else g_feats.contiguous().float())
+        gd = None if g_depth is None else g_depth.contiguous().float()
+        gw = None if g_weights is None else g_weights.contiguous().float()
+        d_field = torch.empty_like(field)
+        rc = _lib.load().h3d_ray_integrate_bwd(_lib.ptr(field), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(gf), _lib.ptr(gd),
+                                               _lib.ptr(gw), _lib.ptr(d_field), B * R, S, C1 - 1, clamp, last_back,
+                                               white_back, _lib.stream_handle())
+        _lib.check(rc, "h3d_ray_integrate_bwd")
+        return d_field, None, None, None, None, None
+
+
 def ray_integration(input, z_vals, device=None, noise_std=0.5, last_back=False, white_back=False,
-                    clamp_mode=None, fill_mode=None, noise=None):
+                    clamp_mode=None, fill_mode=None, noise=None, consume_rng=True):
     """NeRF volume integration.  reference: volume_rendering.py:12-56.
 
     input [B,R,S,C+1] (density last), z_vals [B,R,S,1] -> (features [B,R,C], depth [B,R,1], weights [B,R,S,1]).
-    ``noise`` (already scaled, [B,R,S,1]) overrides the internal ``randn * noise_std`` draw."""
+    ``noise`` (already scaled, [B,R,S,1]) overrides the internal ``randn * noise_std`` draw; ``consume_rng=False``: the caller
+    has already drawn (and possibly discarded) the noise tensor, nothing is drawn here.  Differentiable w.r.t. ``input``
+    (h3d_ray_integrate_bwd)."""
     if clamp_mode not in _CLAMP:
         raise Exception("Need to choose clamp mode")
     if fill_mode is not None:
@@ -71,21 +112,16 @@ def ray_integration(input, z_vals, device=None, noise_std=0.5, last_back=False, 
     B, R, S, C1 = input.shape
     field = input.contiguous().float()
     z = z_vals.reshape(B, R, S).contiguous().float()
-    if noise is None:
+    if noise is None and consume_rng:
         # the reference always consumes RNG here (volume_rendering.py:24), even for noise_std == 0
         noise = torch.randn((B, R, S, 1), device=field.device) * noise_std
         if noise_std == 0:
             noise = None
     nz = None if noise is None else noise.reshape(B, R, S).contiguous().float()
-    feats = torch.empty((B, R, C1 - 1), device=field.device, dtype=torch.float32)
-    depth = torch.empty((B, R, 1), device=field.device, dtype=torch.float32)
-    weights = torch.empty((B, R, S, 1), device=field.device, dtype=torch.float32)
-    lib = _lib.load()
-    rc = lib.h3d_ray_integrate(_lib.ptr(field), _lib.ptr(z), _lib.ptr(nz), _lib.ptr(feats), _lib.ptr(depth),
-                               _lib.ptr(weights), B * R, S, C1 - 1, _CLAMP[clamp_mode], int(bool(last_back)),
-                               int(bool(white_back)), _lib.stream_handle())
-    _lib.check(rc, "h3d_ray_integrate")
-    return feats, depth, weights
+    flags = (_CLAMP[clamp_mode], int(bool(last_back)), int(bool(white_back)))
+    if torch.is_grad_enabled() and field.requires_grad:
+        return _RayIntegration.apply(field, z.detach(), None if nz is None else nz.detach(), *flags)
+    return _integrate(field, z, nz, *flags)
 
 
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):

@@ -320,6 +320,30 @@ int h3d_modconv2d(const float* x, const float* smod, const float* dmod, const fl
                   float* out, int B, int Cin, int Cout, int H, int W, int k, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Training side: streaming kernels the differentiable generator path is assembled from; the GEMMs between
+ * them are library GEMMs (hipBLASLt through torch).  Caller owns every buffer.
+ *
+ * h3d_film_sin       y = sin(freq[b,c] * x[b,n,c] + phase[b,c])   == the activation of SineLayer / FiLMLayer
+ *                    (lib/components/pigan_layers.py:63-71, 74-87) applied to the Linear output x.
+ *                    x, y [B,N,C] dtype 0 = f32 / 1 = f16 (fp32 arithmetic); freq, phase [B,C] fp32, or both NULL:
+ *                    y = sin(w0 * x).
+ * h3d_film_sin_bwd   dx = dy * cos(.) * freq;  partial [B, nblk, 2, C] fp32 with nblk = ceil(N / h3d_film_sin_rows()):
+ *                    per-workgroup sums of dy*cos(.)*x (-> d freq) and dy*cos(.) (-> d phase); the caller sums over nblk
+ *                    (deterministic).  partial may be NULL when freq / phase need no gradient.
+ * h3d_ray_integrate_bwd   gradient of h3d_ray_integrate w.r.t. `field` given the gradients of its three outputs
+ *                    (g_feats [n_rays,C]; g_depth [n_rays] or NULL; g_weights [n_rays,S] or NULL) -> d_field [n_rays,S,C+1].
+ *                    Same flags as the forward call.  S <= 2048.
+ */
+int h3d_film_sin_rows(void);
+int h3d_film_sin(const void* x, const float* freq, const float* phase, void* y, int B, int64_t N, int C, int dtype,
+                 float w0, h3d_stream_t stream);
+int h3d_film_sin_bwd(const void* x, const float* freq, const float* phase, const void* dy, void* dx, float* partial,
+                     int B, int64_t N, int C, int dtype, float w0, h3d_stream_t stream);
+int h3d_ray_integrate_bwd(const float* field, const float* z_vals, const float* noise, const float* g_feats,
+                          const float* g_depth, const float* g_weights, float* d_field, int64_t n_rays, int S, int C,
+                          int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
  *     lib/components/ops/bias_act.cpp:32 with grad=0; kernel spec lib/components/ops/bias_act.cu:23-147
  * x, y: n dense elements; dtype: 0 = f32, 1 = f16, 2 = f64; b: size_b elements or NULL;
@@ -329,6 +353,17 @@ int h3d_modconv2d(const float* x, const float* smod, const float* dmod, const fl
 int h3d_bias_act(const void* x, const void* b, void* y, int64_t n, int dtype,
                  int64_t size_b, int64_t step_b, int act, float alpha, float gain, float clamp,
                  h3d_stream_t stream);
+
+/* P1  bias_act gradients == the same plugin entry with grad = 1 / 2 (bias_act.cpp:32, bias_act.cu:23-147; call sites
+ *     lib/components/ops/bias_act.py:179, 198).
+ * order 1:  out = g * gain * act'(.)            g = dL/dy              (the plugin's x argument with grad=1)
+ * order 2:  out = g * dy2 * gain * act''(.)     g = d(dL)/d(dx), dy2 = the dy of the first-order call
+ * The derivative is evaluated from what the forward kept: yref (= y) for every activation but swish, xref (= x, the
+ * bias b is added here) for swish; linear needs neither.  Elements whose forward output was clamped get 0.
+ */
+int h3d_bias_act_grad(const void* g, const void* b, const void* xref, const void* yref, const void* dy2, void* out,
+                      int64_t n, int dtype, int64_t size_b, int64_t step_b, int order, int act, float alpha,
+                      float gain, float clamp, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P2  upfirdn2d forward == _plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)

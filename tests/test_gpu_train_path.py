@@ -1,0 +1,262 @@
+"""GPU parity tests of the training side: the hand-written adjoints (bias_act gradients, film_sin, volume
+integration) against autograd through the fp64 oracle, and the differentiable generator path -- train-mode forward, parameter
+gradients, buffer updates -- against vectors produced by the reference module's own autograd."""
+import importlib
+
+import pytest
+import torch
+
+import h3d_oracle as O
+from conftest import grad_errors, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+gens = importlib.import_module("3dhumangan_amd.lib.generators")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+bias_act_mod = importlib.import_module("3dhumangan_amd.lib.components.ops.bias_act")
+film = importlib.import_module("3dhumangan_amd.lib.components.ops.film")
+synthetic = importlib.import_module("3dhumangan_amd.synthetic")
+
+DEV = "cuda"
+ACTS = ("linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish")
+
+
+# ------------------------------------------------------------------ P1 gradients
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("clamp", [None, 0.8])
+def test_bias_act_first_and_second_order(act, clamp):
+    """dL/dx, dL/db and the double backward (gradient of a function of dL/dx, as R1 needs) vs autograd through the oracle."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 6, 5, 4, generator=g) * 1.5
+    x = torch.where(x.abs() < 0.05, x + 0.2, x)                 # keep clear of the kinks of relu / lrelu / elu / clamp
+    b = torch.randn(6, generator=g) * 0.3
+    p = torch.randn(3, 6, 5, 4, generator=g)
+    r = torch.randn(3, 6, 5, 4, generator=g)
+
+    def run(xx, bb, fn, pp, rr):
+        xx, bb = xx.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+        y = fn(xx, bb)
+        gx, gb = torch.autograd.grad((y * pp).sum(), [xx, bb], create_graph=True)
+        second = torch.autograd.grad((gx * rr).sum(), [xx, bb], allow_unused=True) if gx.requires_grad else (None, None)
+        return y, gx, gb, second
+
+    ref = run(x.double(), b.double(), lambda xx, bb: O.bias_act(xx, bb, 1, act, alpha=0.3, gain=1.7, clamp=clamp),
+              p.double(), r.double())
+    got = run(x.to(DEV), b.to(DEV), lambda xx, bb: bias_act_mod.bias_act(xx, bb, 1, act, alpha=0.3, gain=1.7, clamp=clamp),
+              p.to(DEV), r.to(DEV))
+    assert rel_err(got[0].cpu(), ref[0]) < 2e-6
+    assert rel_err(got[1].cpu(), ref[1]) < 5e-6, "dx"
+    assert rel_err(got[2].cpu(), ref[2]) < 5e-6, "db"
+    for k, name in ((0, "d2x"), (1, "d2b")):
+        a, e = got[3][k], ref[3][k]
+        if e is None or float(e.abs().max()) == 0:
+            assert a is None or float(a.abs().max()) < 1e-6, name
+        else:
+            assert rel_err(a.cpu(), e) < 2e-5, name
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float16, 4e-3)])
+def test_bias_act_grad_dtypes(dtype, tol):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(64, 48, generator=g) + 0.01).to(dtype)
+    b = torch.randn(48, generator=g).to(dtype)
+    for act in ("lrelu", "swish", "softplus"):
+        xr, br = x.double().requires_grad_(True), b.double().requires_grad_(True)
+        O.bias_act(xr, br, 1, act).square().sum().backward()
+        xd, bd = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        bias_act_mod.bias_act(xd, bd, 1, act).square().sum().backward()
+        assert xd.grad.dtype == dtype
+        assert rel_err(xd.grad.cpu(), xr.grad) < tol and rel_err(bd.grad.cpu(), br.grad) < tol, act
+
+
+# ------------------------------------------------------------------ film_sin
+
+@pytest.mark.parametrize("B,N,C", [(2, 1500, 32), (3, 700, 40), (1, 513, 30), (2, 2100, 256), (2, 1029, 420), (1, 64, 1028)])
+def test_film_sin_forward_backward(B, N, C):
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, N, C, generator=g) * 2
+    fr = torch.randn(B, C, generator=g) * 7 + 30
+    ph = torch.randn(B, C, generator=g) * 3
+    p = torch.randn(B, N, C, generator=g)
+    xr, fr_r, ph_r = (t.double().requires_grad_(True) for t in (x, fr, ph))
+    yr = torch.sin(fr_r[:, None] * xr + ph_r[:, None])
+    (yr * p.double()).sum().backward()
+    xd, fd, pd = (t.to(DEV).requires_grad_(True) for t in (x, fr, ph))
+    yd = film.film_sin(xd, fd, pd)
+    (yd * p.to(DEV)).sum().backward()
+    assert rel_err(yd.cpu(), yr) < 5e-6          # arguments reach |150|: fp32 argument rounding, not the kernel, sets this
+    assert rel_err(xd.grad.cpu(), xr.grad) < 1e-5
+    assert rel_err(fd.grad.cpu(), fr_r.grad) < 2e-5
+    assert rel_err(pd.grad.cpu(), ph_r.grad) < 2e-5
+    # the frequency-free form of the first layers: sin(30 x)
+    x2 = x.to(DEV).requires_grad_(True)
+    film.film_sin(x2, w0=30.0).mul(p.to(DEV)).sum().backward()
+    x2r = x.double().requires_grad_(True)
+    torch.sin(30.0 * x2r).mul(p.double()).sum().backward()
+    assert rel_err(x2.grad.cpu(), x2r.grad) < 1e-5
+
+
+def test_film_sin_half_precision_io():
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(2, 900, 64, generator=g)).half()
+    fr, ph = torch.randn(2, 64, generator=g) * 5 + 30, torch.randn(2, 64, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    fd = fr.to(DEV).requires_grad_(True)
+    y = film.film_sin(xd, fd, ph.to(DEV))
+    assert y.dtype == torch.float16
+    y.float().sum().backward()
+    xr = x.double().requires_grad_(True)
+    fr_r = fr.double().requires_grad_(True)
+    yr = torch.sin(fr_r[:, None] * xr + ph.double()[:, None])
+    yr.sum().backward()
+    assert rel_err(y.float().cpu(), yr) < 2e-3
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < 3e-3 and xd.grad.dtype == torch.float16
+    assert rel_err(fd.grad.cpu(), fr_r.grad) < 3e-3
+
+
+# ------------------------------------------------------------------ A6 backward
+
+@pytest.mark.parametrize("S,C", [(8, 35), (64, 259), (100, 67), (200, 131), (1, 3), (33, 6)])
+@pytest.mark.parametrize("clamp_mode", ["relu", "softplus"])
+def test_ray_integration_backward_vs_oracle(S, C, clamp_mode):
+    g = torch.Generator().manual_seed(S * 1000 + C)
+    B, R = 2, 29
+    field = torch.randn(B, R, S, C + 1, generator=g)
+    field[..., -1] = field[..., -1] * 3 + 0.5
+    z = torch.sort(torch.rand(B, R, S, 1, generator=g) + 11.0, dim=2).values
+    noise = torch.randn(B, R, S, 1, generator=g) * 0.3
+    pf, pd, pw = (torch.randn(s, generator=g) for s in ((B, R, C), (B, R, 1), (B, R, S, 1)))
+    for last_back in (False, True):
+        for white_back in (False, True):
+            fr = field.double().requires_grad_(True)
+            of, od, ow = O.ray_integration(fr, z.double(), noise.double(), clamp_mode, last_back, white_back)
+            ((of * pf).sum() + (od * pd).sum() + (ow * pw).sum()).backward()
+            fd = field.to(DEV).requires_grad_(True)
+            gf, gd, gw = vr.ray_integration(fd, z.to(DEV), noise=noise.to(DEV), clamp_mode=clamp_mode, last_back=last_back,
+                                            white_back=white_back)
+            ((gf * pf.to(DEV)).sum() + (gd * pd.to(DEV)).sum() + (gw * pw.to(DEV)).sum()).backward()
+            tag = (last_back, white_back)
+            assert rel_err(fd.grad[..., :-1].cpu(), fr.grad[..., :-1]) < 1e-5, tag
+            assert rel_err(fd.grad[..., -1].cpu(), fr.grad[..., -1]) < 5e-5, tag
+    # only one of the three outputs used downstream (the others arrive as None / zeros)
+    fd = field.to(DEV).requires_grad_(True)
+    vr.ray_integration(fd, z.to(DEV), noise_std=0, clamp_mode=clamp_mode)[0].sum().backward()
+    fr = field.double().requires_grad_(True)
+    O.ray_integration(fr, z.double(), None, clamp_mode)[0].sum().backward()
+    assert rel_err(fd.grad.cpu(), fr.grad) < 5e-5
+
+
+# ------------------------------------------------------------------ the differentiable generator
+
+def _build(meta, state, train=True):
+    cfg = dict(meta)
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    G = gens.Map3DGenerator(**cfg)
+    G.load_state_dict(state, strict=True)
+    G = G.to(DEV)
+    G.set_device(DEV)
+    return (G.train() if train else G.eval()), cfg
+
+
+@pytest.mark.parametrize("name", ["gen_train_mixed", "gen_train_isolated_legacy_pool"])
+def test_train_step_against_reference_autograd(name):
+    """Train-mode forward, the gradient of a fixed projection of both outputs w.r.t. EVERY parameter, and the buffers the
+    forward overwrites (BatchNorm running statistics, spectral-norm u / v) against the reference module (tolerance 1e-3)."""
+    g = load_golden(name)
+    G, cfg = _build(g["meta"], g["state"])
+    cond = {k: v.to(DEV) for k, v in g["cond"].items()}
+    z = g["z"].to(DEV).requires_grad_(True)
+    idx = g["latent_indices"].to(DEV) if "latent_indices" in g else None
+    out = G(z, cond, latent_indices=idx, jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV), **cfg)
+    assert out["rgbs"].requires_grad and out["rgbs_render"].requires_grad
+    assert rel_err(out["rgbs_render"].detach().cpu(), g["out"]["rgbs_render"]) < 1e-4
+    assert rel_err(out["rgbs"].detach().cpu(), g["out"]["rgbs"]) < 2e-4
+    loss = (out["rgbs"] * g["p_rgb"].to(DEV)).sum() + (out["rgbs_render"] * g["p_render"].to(DEV)).sum()
+    loss.backward()
+    got = {n: p.grad for n, p in G.named_parameters()}
+    got["__z__"] = z.grad
+    skip = ("__z__",) if idx is not None else ()
+    for k in g["grad"]:
+        assert got.get(k) is not None or k in skip, f"no gradient for {k}"
+    worst, where = grad_errors(got, g["grad"], skip=skip)
+    assert worst < 1e-3, (where, worst)
+    unused = [n for n, v in got.items() if v is not None and n not in g["grad"] and float(v.abs().max()) > 0]
+    assert not unused, unused                                   # nothing receives a gradient the reference does not give
+    sd = G.state_dict()
+    for k, ref in g["buffers_after"].items():
+        if ref.is_floating_point():
+            assert rel_err(sd[k].cpu(), ref) < 1e-4, k
+        else:
+            assert torch.equal(sd[k].cpu(), ref), k
+    changed = {k for k, v in sd.items() if k in g["state"] and not torch.equal(v.cpu(), g["state"][k])}
+    assert changed == set(g["buffers_after"]), changed ^ set(g["buffers_after"])
+
+
+def test_differentiable_path_in_eval_mode_matches_the_inference_engines():
+    """differentiable=True in eval mode is the same function as the fused engines (running statistics, stored u / v) and it
+    leaves every buffer alone; gradients reach the latent."""
+    g = load_golden("gen_tiny_mixed")
+    G, cfg = _build(g["meta"], g["state"], train=False)
+    cond = {k: v.to(DEV) for k, v in g["cond"].items()}
+    kw = dict(jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV))
+    fast = G(g["z"].to(DEV), cond, **kw, **cfg)
+    before = {k: v.clone() for k, v in G.state_dict().items()}
+    z = g["z"].to(DEV).requires_grad_(True)
+    slow = G(z, cond, differentiable=True, **kw, **cfg)
+    for k in ("rgbs", "rgbs_render"):
+        assert not fast[k].requires_grad and slow[k].requires_grad
+        assert rel_err(slow[k].detach().cpu(), g["out"][k]) < 1e-4, k
+        assert rel_err(slow[k].detach(), fast[k]) < 2e-4, k
+    slow["rgbs"].square().mean().backward()
+    assert z.grad is not None and float(z.grad.abs().max()) > 0
+    assert all(torch.equal(v, before[k]) for k, v in G.state_dict().items())
+    # train mode under no_grad: train semantics (buffers move), nothing recorded
+    G.train()
+    with torch.no_grad():
+        out = G(g["z"].to(DEV), cond, **kw, **cfg)
+    assert not out["rgbs"].requires_grad
+    assert not torch.equal(G.state_dict()["synthesis_network.network.m3d_0.spade_0.first_norm.running_mean"],
+                           before["synthesis_network.network.m3d_0.spade_0.first_norm.running_mean"])
+
+
+def test_train_step_at_real_width_vs_oracle():
+    """MAP3DBN512's widths (hidden 256, 9 blocks, mixed mode) at a reduced image size: forward + gradients of the product's
+    train path against autograd through the oracle."""
+    configs = importlib.import_module("3dhumangan_amd.configs")
+    from test_oracle_golden import oracle_train_step
+    cfg = dict(configs.MAP3DBN512)
+    cfg.update(gen_height=64, gen_width=32, render_height=12, render_width=6, num_steps=12, dataset_length=4, nerf_noise=0.0)
+    cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+    torch.manual_seed(7)
+    G = gens.Map3DGenerator(**cfg)
+    with torch.no_grad():
+        G.neural_field.sigma_layer.weight.mul_(60.0)
+        G.neural_field.sigma_layer.bias.fill_(0.5)
+    G = G.to(DEV).train()
+    G.set_device(DEV)
+    state = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    B, R, S = 2, 72, 12
+    cond = synthetic.make_conditions(B, n_vertices=512, seed=3, pose_scale=0.5)
+    gen = torch.Generator().manual_seed(11)
+    z = torch.randn(B, cfg["latent_dim"], generator=gen)
+    jitter = torch.rand(B, R, S, 1, generator=gen)
+    noise = torch.zeros(B, R, S, 1)
+    p_rgb = torch.randn(B, 3, 64, 32, generator=gen)
+    p_render = torch.randn(B, 3, 12, 6, generator=gen)
+    zd = z.to(DEV).requires_grad_(True)
+    out = G(zd, {k: v.to(DEV) for k, v in cond.items()}, jitter=jitter.to(DEV), noise=noise.to(DEV), **cfg)
+    ((out["rgbs"] * p_rgb.to(DEV)).sum() + (out["rgbs_render"] * p_render.to(DEV)).sum()).backward()
+    got = {n: p.grad for n, p in G.named_parameters() if p.grad is not None}
+    got["__z__"] = zd.grad
+    meta = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, list, tuple))}
+    fake = dict(meta=meta, state=state, grad={k: None for k in got}, z=z, cond=cond, jitter=jitter, noise=noise, p_rgb=p_rgb,
+                p_render=p_render)
+    ref_out, _, ref_grads, _ = oracle_train_step(fake)
+    assert rel_err(out["rgbs"].detach().cpu(), ref_out["rgbs"].detach()) < 2e-4
+    assert rel_err(out["rgbs_render"].detach().cpu(), ref_out["rgbs_render"].detach()) < 1e-4
+    ref_grads = {k: v.detach() for k, v in ref_grads.items() if v is not None}
+    gmax = max(float(v.abs().max()) for v in ref_grads.values())
+    worst, where = grad_errors(got, ref_grads, zero_below=1e-6 * gmax)
+    assert worst < 1e-3, (where, worst)
