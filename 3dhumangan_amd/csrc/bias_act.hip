@@ -182,7 +182,7 @@ extern "C" int h3d_bias_act_grad(const void* g, const void* b, const void* xref,
     H3D_REQUIRE(order == 1 || order == 2, "h3d_bias_act_grad: order must be 1 or 2 (got %d)", order);
     H3D_REQUIRE(act >= 1 && act <= 9, "h3d_bias_act_grad: no kernel for activation index %d", act);
     H3D_REQUIRE(dtype >= 0 && dtype <= 2, "h3d_bias_act_grad: dtype %d (0=f32,1=f16,2=f64)", dtype);
-    H3D_REQUIRE(act == 9 ? xref != nullptr : (act == 1 || yref != nullptr),
+    H3D_REQUIRE(act == 9 ? xref != nullptr : ((act == 1 && clamp < 0.f) || yref != nullptr),
                 "h3d_bias_act_grad: activation %d needs %s", act, act == 9 ? "xref" : "yref");
     H3D_REQUIRE(!b || (size_b >= 1 && step_b >= 1), "h3d_bias_act_grad: bias given but size_b/step_b invalid");
     H3D_REQUIRE(order == 1 || dy2, "h3d_bias_act_grad: order 2 needs dy");

@@ -55,8 +55,13 @@ class _BiasAct(torch.autograd.Function):
     def forward(ctx, x, b, dim, spec, alpha, gain, clamp):
         _, _, idx, ref, second = spec
         y = _forward(x, b, dim, idx, alpha, gain, clamp)
-        keep_x = ref == "x"            # (the reference also keeps x for every twice-differentiable activation; only swish reads it)
-        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if ref == "y" else None)
+        # x is read by the kernels for swish only; for the other twice-differentiable activations it is kept as the graph
+        # anchor the second-order gradient is returned on (d(dx)/dx, evaluated from y), as the reference does
+        keep_x = ref == "x" or second
+        # y feeds the derivative of the "y" activations and the clamp mask (the reference drops the mask for 'linear', whose
+        # gradient then ignores the clamp; here the clamped elements get zero gradient for every activation)
+        keep_y = ref == "y" or (clamp >= 0 and ref != "x")
+        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if keep_y else None)
         ctx.cfg = (dim, spec, alpha, gain, clamp)
         return y
 

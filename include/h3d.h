@@ -359,7 +359,8 @@ int h3d_bias_act(const void* x, const void* b, void* y, int64_t n, int dtype,
  * order 1:  out = g * gain * act'(.)            g = dL/dy              (the plugin's x argument with grad=1)
  * order 2:  out = g * dy2 * gain * act''(.)     g = d(dL)/d(dx), dy2 = the dy of the first-order call
  * The derivative is evaluated from what the forward kept: yref (= y) for every activation but swish, xref (= x, the
- * bias b is added here) for swish; linear needs neither.  Elements whose forward output was clamped get 0.
+ * bias b is added here) for swish; linear needs neither unless clamp >= 0 (then yref).  Elements whose forward output was
+ * clamped get 0.
  */
 int h3d_bias_act_grad(const void* g, const void* b, const void* xref, const void* yref, const void* dy2, void* out,
                       int64_t n, int dtype, int64_t size_b, int64_t step_b, int order, int act, float alpha,
