@@ -72,11 +72,13 @@ class _AllReduceSum(torch.autograd.Function):
 
 
 def _dist_on(group):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    """group: a process group, None (= the default group when torch.distributed is initialised) or False (never synchronise)."""
+    return group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 def batch_moments(x2d, group=None):
-    """Per-channel mean and BIASED variance of x2d [M, C] over the (global) batch, plus the global row count."""
+    """Per-channel mean and BIASED variance of x2d [M, C] over the (global) batch, plus the global row count (an int, or a
+    one-element device tensor when it had to be all-reduced)."""
     m = x2d.shape[0]
     if not _dist_on(group):
         var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
@@ -85,10 +87,9 @@ def batch_moments(x2d, group=None):
     count = torch.tensor([float(m)], device=x2d.device)
     dist.all_reduce(count, group=group)
     sums = _AllReduceSum.apply(sums, group)
-    n = float(count.item())
-    mean = sums[0] / n
-    var = (sums[1] / n - mean * mean).clamp_min(0)
-    return mean, var, int(n)
+    mean = sums[0] / count                                   # the count stays on the device: no host synchronisation
+    var = (sums[1] / count - mean * mean).clamp_min(0)
+    return mean, var, count
 
 
 class _SpadeNormAct(torch.autograd.Function):
@@ -115,7 +116,6 @@ class _SpadeNormAct(torch.autograd.Function):
         u = torch.addcmul(beta, h, 1 + gamma)
         du = torch.where(u > 0, dy, dy * 0.2)
         del u
-        red = (0, 1) if gamma.shape[1] == x.shape[1] else None
         d_gamma = du * h
         d_beta = du
         if gamma.shape[1] != x.shape[1]:                                  # constant style: reduce over the pixels
@@ -138,7 +138,8 @@ def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentu
         mean, var, n = batch_moments(x.reshape(-1, C), group)
         with torch.no_grad():
             norm.running_mean.lerp_(mean.detach().to(norm.running_mean.dtype), momentum)
-            norm.running_var.lerp_((var.detach() * (n / max(n - 1, 1))).to(norm.running_var.dtype), momentum)
+            unbias = n / (n - 1).clamp_min(1) if torch.is_tensor(n) else n / max(n - 1, 1)
+            norm.running_var.lerp_((var.detach() * unbias).to(norm.running_var.dtype), momentum)
             norm.num_batches_tracked += 1
     else:
         mean, var = norm.running_mean, norm.running_var

@@ -135,6 +135,66 @@ def discriminator_step_bench(a, rank, world, dist_on, dev):
             "loss": {k: float(v) for k, v in last.items()}}))
 
 
+def train_step_bench(a, rank, world, dist_on, dev):
+    """BASELINE config 4: one whole adversarial iteration per step = discriminator step (generator forward in train mode under
+    no_grad, D forward on real + fake, R1 double backward, all-gather of the R1 statistics, gradient all-reduce, Adam) +
+    generator step (differentiable generator forward, D forward, backward through both, gradient all-reduce, Adam, EMA).
+    Per rank `--batch` images of the reference-native 512x256 geometry (96x48 rays x 32 samples, hidden 256)."""
+    trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+    disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+    ema_mod = importlib.import_module("3dhumangan_amd.lib.components.ema")
+    G, cfg = build_generator(a.config, (512, 256), (96, 48), 32, dev)
+    G.train()
+    z, cond, jitter = make_inputs(cfg, a.batch, dev, seed=1234 + rank)
+    torch.manual_seed(99)
+    D = disc.UNetDiscriminator(**{k: v for k, v in cfg.items() if k != "neural_field_cls"}).to(dev)
+    meta = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+    meta.update(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, gen_lr=5e-5, betas=(0.0, 0.9))
+    opt_d = torch.optim.Adam(D.parameters(), lr=cfg.get("disc_lr", 2e-4), betas=(0.0, 0.9))
+    opt_g = trainers.make_generator_optimizer(G, meta)
+    ema = ema_mod.ExponentialMovingAverage(G.parameters(), decay=0.999)
+    g = torch.Generator().manual_seed(7 + rank)
+    real = torch.randn(a.batch, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
+    gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (a.batch, 512, 256), generator=g).to(dev)
+    last, ev = {}, {"d": [], "g": []}
+    fwd = {k: v for k, v in cfg.items() if isinstance(k, str)}
+
+    def step():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        with torch.no_grad():
+            fake = G(z, cond, jitter=jitter, **fwd)["rgbs"]
+        d = trainers.discriminator_step(D, opt_d, real, fake, gt, meta, do_r1=True, distributed=dist_on,
+                                        grad_clip=cfg.get("grad_clip", 10.0))
+        e[1].record()
+        gs = trainers.generator_step(G, D, opt_g, z, cond, meta, gt_segments=gt, ema=ema, distributed=dist_on,
+                                     generator_kwargs=dict(jitter=jitter))
+        e[2].record()
+        ev["d"].append((e[0], e[1]))
+        ev["g"].append((e[1], e[2]))
+        last.update({"d_" + k: v for k, v in d.items()})
+        last.update({"g_" + k: v for k, v in gs.items()})
+
+    dt = timed_loop(step, a.steps, a.warmup, dist_on)
+    torch.cuda.synchronize()
+    ms = {k: sum(s.elapsed_time(t) for s, t in v[-a.steps:]) / a.steps for k, v in ev.items()}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "adversarial training iterations: images/sec at 512x256 (D step + G step)", "value": a.batch * world * a.steps / dt,
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32 (library GEMMs + HIP activation / integration kernels; discriminator: torch / MIOpen convolutions)",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; UNetDiscriminator "
+                                   "6 blocks; R1 every step; GAN + segmentation losses; Adam on both networks; EMA",
+                       "global_batch": a.batch * world,
+                       "parallelism": f"batch-sharded x{world}: SyncBN moment all-reduces, RCCL all-gather of the R1 statistics, "
+                                      "bucketed gradient all-reduce"},
+            "stage_ms": {"discriminator_step": ms["d"], "generator_step": ms["g"]},
+            "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
+            "loss": {k: float(v) for k, v in last.items()}}))
+
+
 def kernel_rooflines(G, cfg, batch, stage_ms):
     """Algorithmic work of each HIP stage / measured HIP-event time.
 
@@ -375,8 +435,9 @@ def main():
     ap.add_argument("--res", default="512x512", help="output HxW; rays are 3/16 of it per axis (96 for 512)")
     ap.add_argument("--render", default="", help="rays HxW (default: 3/16 of --res per axis, the MAP3DBN512 ratio)")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--mode", default="generator", choices=["generator", "dstep"],
-                    help="generator: the headline forward benchmark; dstep: BASELINE config 4's discriminator step")
+    ap.add_argument("--mode", default="generator", choices=["generator", "dstep", "trainstep"],
+                    help="generator: the headline forward benchmark; dstep: BASELINE config 4's discriminator step; "
+                         "trainstep: config 4's whole iteration (D step + G step)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
@@ -387,8 +448,8 @@ def main():
     if dist_on:
         init_distributed(local)                                       # RCCL over xGMI
     dev = torch.device("cuda", local)
-    if a.mode == "dstep":
-        discriminator_step_bench(a, rank, world, dist_on, dev)
+    if a.mode in ("dstep", "trainstep"):
+        (discriminator_step_bench if a.mode == "dstep" else train_step_bench)(a, rank, world, dist_on, dev)
         if dist_on:
             torch.distributed.destroy_process_group()
         return

@@ -124,6 +124,81 @@ def test_r1_allgather_and_sharded_discriminator_step_world2():
     assert all(r[1] == "ok" for r in res), res
 
 
+# ---------------------------------------------------------------- generator step: synchronised BatchNorm, world size 2 (gloo)
+
+def _syncbn_worker(rank, world, port, q):
+    """The synthesis half of the differentiable generator (pure torch + collectives, so it runs on CPU) on a batch shard:
+    with the BatchNorm moments all-reduced, outputs, averaged gradients and the updated running statistics equal the
+    single-process whole-batch step -- which is itself pinned to the reference's autograd by the golden train fixtures."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+        from conftest import load_golden
+        gens = importlib.import_module("3dhumangan_amd.lib.generators")
+        impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+        diff = importlib.import_module("3dhumangan_amd.lib.generators.differentiable")
+        g = load_golden("gen_train_mixed")
+        cfg = dict(g["meta"])
+        cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+
+        def make():
+            G = gens.Map3DGenerator(**cfg)
+            G.load_state_dict(g["state"], strict=True)
+            return G.train()
+
+        B, Fd = 4, cfg["feature_dim"]
+        rhw, ghw = (cfg["render_height"], cfg["render_width"]), (cfg["gen_height"], cfg["gen_width"])
+        gen = torch.Generator().manual_seed(5)
+        fmap = torch.randn(B, rhw[0] * rhw[1], Fd, generator=gen)
+        styles = torch.randn(B, 1, Fd, generator=gen)
+        proj = torch.randn(B, 3, *ghw, generator=gen)
+        whole = make()
+        f_all = fmap.clone().requires_grad_(True)
+        # single-process reference: the whole batch with the collective path disabled (group=False)
+        out_all = diff.synthesis_forward(whole, f_all, styles, rhw, ghw, training=True, group=False)
+        (out_all * proj).sum().backward()
+        lo, hi = par.shard_bounds(B, rank, world)
+        mine = make()
+        f_loc = fmap[lo:hi].clone().requires_grad_(True)
+        out = diff.synthesis_forward(mine, f_loc, styles[lo:hi], rhw, ghw, training=True, group=dist.group.WORLD)
+        (out * proj[lo:hi]).sum().backward()
+        par.allreduce_gradients(list(mine.parameters()), average=False)
+        assert float((out - out_all[lo:hi]).abs().max() / out_all.abs().max()) < 1e-5
+        assert float((f_loc.grad - f_all.grad[lo:hi]).abs().max() / f_all.grad.abs().max()) < 1e-4
+        worst, checked = 0.0, 0
+        for (n, a), (_, b) in zip(mine.named_parameters(), whole.named_parameters()):
+            if b.grad is None or float(b.grad.abs().max()) < 1e-4:
+                continue
+            worst = max(worst, float((a.grad - b.grad).abs().max() / b.grad.abs().max()))
+            checked += 1
+        assert checked > 100 and worst < 2e-4, (checked, worst)
+        sa, sb = mine.state_dict(), whole.state_dict()
+        for k in sb:
+            if "running_" in k or k.endswith(("weight_u", "weight_v")):
+                assert float((sa[k] - sb[k]).abs().max()) < 1e-5 * (1 + float(sb[k].abs().max())), k
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_generator_synthesis_step_with_synchronised_batchnorm_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 # ---------------------------------------------------------------- bench.py's distributed plumbing, world size 2 (gloo)
 
 def _bench_worker(rank, world, port, q):
