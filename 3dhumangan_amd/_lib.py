@@ -69,6 +69,11 @@ _SIGNATURES = {
     "h3d_film_sin": (C.c_int, [_p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_film_sin_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_ray_integrate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "h3d_spade_rows": (C.c_int, []),
+    "h3d_channel_moments": (C.c_int, [_p, _p, _i, _l, _i, _p]),
+    "h3d_spade_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
+    "h3d_spade_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
+    "h3d_spade_bwd_apply": (C.c_int, [_p] * 14 + [_i, _l, _i, _i, _f, _p]),
     "h3d_bias_act": (C.c_int, [_p, _p, _p, _l, _i, _l, _l, _i, _f, _f, _f, _p]),
     "h3d_bias_act_grad": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _l, _l, _i, _i, _f, _f, _f, _p]),
     "h3d_upfirdn2d": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), _i, _i, _i, _i, C.POINTER(_l),

@@ -1,0 +1,312 @@
+// Training-side SPADE kernels for gfx950 (backward of A9): BatchNorm + SPADE modulation + LeakyReLU
+//     y = lrelu( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )
+// (lib/components/map3d_layers.py:176-190 followed by the block's activation, :228-233) as ONE pass forward and TWO passes
+// backward over channels-last activations x [B, P, C], instead of the ~12 elementwise / reduction passes torch's autograd
+// spends on the same chain.  gamma / beta are per pixel [B, P, C] or per sample [B, C] (constant-style SPADE).  All HBM-bound.
+//
+//   h3d_channel_moments      per-workgroup sums of x and x^2 per channel            (batch statistics; caller reduces)
+//   h3d_spade_fwd            the forward pass
+//   h3d_spade_bwd_reduce     per-workgroup sums of dh and dh * n per channel, dh = dL/d(normalised-affine output)
+//   h3d_spade_bwd_apply      dx (with the batch-statistics terms), dgamma, dbeta (tensors, or per-workgroup sums per sample)
+//
+// Thread layout (all four): a workgroup owns `rows` consecutive pixels of one batch item; thread t owns V consecutive channels
+// (q = t % QP) of the rows g, g + G, ... (g = t / QP), so per-channel constants stay in registers and consecutive lanes touch
+// consecutive 16 bytes.  Partial sums leave through LDS in a fixed order: the two-stage reductions are deterministic.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRows = 512;
+
+template <int V> __device__ __forceinline__ void ld(const float* p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = p[0];
+    }
+}
+template <int V> __device__ __forceinline__ void st(float* p, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else p[0] = v[0];
+}
+
+struct Tile {
+    int Q, QP, G, g, b;
+    int64_t r0, r1;
+    template <int V> __device__ __forceinline__ void init(int64_t P, int C) {
+        Q = C / V;
+        QP = Q < kThreads ? Q : kThreads;
+        G = kThreads / QP;
+        g = threadIdx.x / QP;
+        b = blockIdx.y;
+        r0 = (int64_t)blockIdx.x * kRows;
+        r1 = r0 + kRows < P ? r0 + kRows : P;
+    }
+};
+
+// two per-channel sums of this workgroup -> out[0][c], out[1][c]   (every thread must call it)
+template <int V>
+__device__ __forceinline__ void block_sums(float (*red)[kThreads][V], const Tile& T, int q, const float (&a)[V],
+                                           const float (&c)[V], float* out, int C) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < V; ++k) { red[0][t][k] = a[k]; red[1][t][k] = c[k]; }
+    __syncthreads();
+    if (T.g == 0 && q < T.Q) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int gg = 0; gg < T.G; ++gg) { s0 += red[0][gg * T.QP + t][k]; s1 += red[1][gg * T.QP + t][k]; }
+            out[q * V + k] = s0;
+            out[C + q * V + k] = s1;
+        }
+    }
+    __syncthreads();
+}
+
+template <int V>
+__global__ __launch_bounds__(kThreads) void channel_moments(const float* __restrict__ x, float* __restrict__ partial,
+                                                            int64_t P, int C) {
+    __shared__ float red[2][kThreads][V];
+    Tile T;
+    T.init<V>(P, C);
+    float* out = partial + ((int64_t)T.b * gridDim.x + blockIdx.x) * 2 * C;
+    for (int q0 = 0; q0 < T.Q; q0 += T.QP) {
+        const int q = q0 + threadIdx.x - T.g * T.QP;
+        float s[V], ss[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = ss[k] = 0.f;
+        if (T.g < T.G && q < T.Q)
+            for (int64_t r = T.r0 + T.g; r < T.r1; r += T.G) {
+                float v[V];
+                ld<V>(x + ((int64_t)T.b * P + r) * C + q * V, v);
+#pragma unroll
+                for (int k = 0; k < V; ++k) { s[k] += v[k]; ss[k] = fmaf(v[k], v[k], ss[k]); }
+            }
+        block_sums<V>(red, T, q, s, ss, out, C);
+    }
+}
+
+// scale = rstd * g, shift = b - mean * scale
+template <int V, bool PIX>
+__global__ __launch_bounds__(kThreads) void spade_fwd(const float* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y, int64_t P, int C,
+                                                      float slope) {
+    Tile T;
+    T.init<V>(P, C);
+    if (T.g >= T.G) return;
+    for (int q = threadIdx.x - T.g * T.QP; q < T.Q; q += T.QP) {
+        float sc[V], sh[V], ga[V], be[V];
+        ld<V>(scale + q * V, sc);
+        ld<V>(shift + q * V, sh);
+        if (!PIX) {
+            ld<V>(gamma + (int64_t)T.b * C + q * V, ga);
+            ld<V>(beta + (int64_t)T.b * C + q * V, be);
+        }
+        for (int64_t r = T.r0 + T.g; r < T.r1; r += T.G) {
+            const int64_t off = ((int64_t)T.b * P + r) * C + q * V;
+            float v[V];
+            ld<V>(x + off, v);
+            if (PIX) { ld<V>(gamma + off, ga); ld<V>(beta + off, be); }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float u = fmaf(fmaf(v[k], sc[k], sh[k]), 1.f + ga[k], be[k]);
+                v[k] = u > 0.f ? u : u * slope;
+            }
+            st<V>(y + off, v);
+        }
+    }
+}
+
+// partial[b][blk][0][c] = sum dh, [1][c] = sum dh * n   with n = (x - mean) * rstd, h = n * g + b, u = h (1 + gamma) + beta,
+// du = dy * lrelu'(u), dh = du * (1 + gamma)
+template <int V, bool PIX>
+__global__ __launch_bounds__(kThreads) void spade_bwd_reduce(const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gw,
+                                                             const float* __restrict__ gb, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ dy,
+                                                             float* __restrict__ partial, int64_t P, int C, float slope) {
+    __shared__ float red[2][kThreads][V];
+    Tile T;
+    T.init<V>(P, C);
+    float* out = partial + ((int64_t)T.b * gridDim.x + blockIdx.x) * 2 * C;
+    for (int q0 = 0; q0 < T.Q; q0 += T.QP) {
+        const int q = q0 + threadIdx.x - T.g * T.QP;
+        float s1[V], s2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+        if (T.g < T.G && q < T.Q) {
+            float mu[V], rs[V], w[V], bb[V], ga[V], be[V];
+            ld<V>(mean + q * V, mu);
+            ld<V>(rstd + q * V, rs);
+            ld<V>(gw + q * V, w);
+            ld<V>(gb + q * V, bb);
+            if (!PIX) {
+                ld<V>(gamma + (int64_t)T.b * C + q * V, ga);
+                ld<V>(beta + (int64_t)T.b * C + q * V, be);
+            }
+            for (int64_t r = T.r0 + T.g; r < T.r1; r += T.G) {
+                const int64_t off = ((int64_t)T.b * P + r) * C + q * V;
+                float v[V], d[V];
+                ld<V>(x + off, v);
+                ld<V>(dy + off, d);
+                if (PIX) { ld<V>(gamma + off, ga); ld<V>(beta + off, be); }
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float n = (v[k] - mu[k]) * rs[k];
+                    const float u = fmaf(fmaf(n, w[k], bb[k]), 1.f + ga[k], be[k]);
+                    const float dh = (u > 0.f ? d[k] : d[k] * slope) * (1.f + ga[k]);
+                    s1[k] += dh;
+                    s2[k] = fmaf(dh, n, s2[k]);
+                }
+            }
+        }
+        block_sums<V>(red, T, q, s1, s2, out, C);
+    }
+}
+
+// dx = rstd * g * (dh - c1 - n * c2)   (c1 = sum dh / M, c2 = sum dh n / M for batch statistics; zeros for running statistics)
+// PIX: dgamma = du * h, dbeta = du as tensors.  !PIX: their per-workgroup sums -> partial[b][blk][0|1][c].
+template <int V, bool PIX>
+__global__ __launch_bounds__(kThreads) void spade_bwd_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gw,
+                                                            const float* __restrict__ gb, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ dy,
+                                                            const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ partial, int64_t P,
+                                                            int C, float slope) {
+    __shared__ float red[2][kThreads][V];
+    Tile T;
+    T.init<V>(P, C);
+    float* out = PIX ? nullptr : partial + ((int64_t)T.b * gridDim.x + blockIdx.x) * 2 * C;
+    for (int q0 = 0; q0 < T.Q; q0 += T.QP) {
+        const int q = q0 + threadIdx.x - T.g * T.QP;
+        float sg[V], sb[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) sg[k] = sb[k] = 0.f;
+        if (T.g < T.G && q < T.Q) {
+            float mu[V], rs[V], w[V], bb[V], ga[V], be[V], k1[V], k2[V];
+            ld<V>(mean + q * V, mu);
+            ld<V>(rstd + q * V, rs);
+            ld<V>(gw + q * V, w);
+            ld<V>(gb + q * V, bb);
+            ld<V>(c1 + q * V, k1);
+            ld<V>(c2 + q * V, k2);
+            if (!PIX) {
+                ld<V>(gamma + (int64_t)T.b * C + q * V, ga);
+                ld<V>(beta + (int64_t)T.b * C + q * V, be);
+            }
+            for (int64_t r = T.r0 + T.g; r < T.r1; r += T.G) {
+                const int64_t off = ((int64_t)T.b * P + r) * C + q * V;
+                float v[V], d[V], o_g[V], o_b[V];
+                ld<V>(x + off, v);
+                ld<V>(dy + off, d);
+                if (PIX) { ld<V>(gamma + off, ga); ld<V>(beta + off, be); }
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float n = (v[k] - mu[k]) * rs[k];
+                    const float h = fmaf(n, w[k], bb[k]);
+                    const float u = fmaf(h, 1.f + ga[k], be[k]);
+                    const float du = u > 0.f ? d[k] : d[k] * slope;
+                    const float dh = du * (1.f + ga[k]);
+                    v[k] = rs[k] * w[k] * (dh - k1[k] - n * k2[k]);
+                    o_g[k] = du * h;
+                    o_b[k] = du;
+                    sg[k] += o_g[k];
+                    sb[k] += du;
+                }
+                st<V>(dx + off, v);
+                if (PIX) { st<V>(dgamma + off, o_g); st<V>(dbeta + off, o_b); }
+            }
+        }
+        if (!PIX) block_sums<V>(red, T, q, sg, sb, out, C);
+    }
+}
+
+bool vec_ok(int C, std::initializer_list<const void*> ptrs) {
+    if (C % 4) return false;
+    for (const void* p : ptrs)
+        if (p && !h3d::aligned16(p)) return false;
+    return true;
+}
+
+int check_shape(const char* what, int B, int64_t P, int C) {
+    if (B < 0 || P < 0 || C < 1 || B > 65535) {
+        h3d::set_error("%s: bad shape B=%d P=%lld C=%d", what, B, (long long)P, C);
+        return H3D_EINVAL;
+    }
+    return H3D_OK;
+}
+
+}  // namespace
+
+extern "C" int h3d_spade_rows(void) { return kRows; }
+
+extern "C" int h3d_channel_moments(const float* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream) {
+    if (int rc = check_shape("h3d_channel_moments", B, P, C)) return rc;
+    if (B == 0 || P == 0) return H3D_OK;
+    H3D_REQUIRE(x && partial, "h3d_channel_moments: null pointer");
+    const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    h3d::pre_launch();
+    if (vec_ok(C, {x})) hipLaunchKernelGGL(channel_moments<4>, grid, dim3(kThreads), 0, s, x, partial, P, C);
+    else hipLaunchKernelGGL(channel_moments<1>, grid, dim3(kThreads), 0, s, x, partial, P, C);
+    return h3d::launch_status("h3d_channel_moments");
+}
+
+extern "C" int h3d_spade_fwd(const float* x, const float* scale, const float* shift, const float* gamma, const float* beta,
+                             float* y, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
+    if (int rc = check_shape("h3d_spade_fwd", B, P, C)) return rc;
+    if (B == 0 || P == 0) return H3D_OK;
+    H3D_REQUIRE(x && scale && shift && gamma && beta && y, "h3d_spade_fwd: null pointer");
+    const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = vec_ok(C, {x, scale, shift, gamma, beta, y});
+    h3d::pre_launch();
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_fwd<V, PIX>), grid, dim3(kThreads), 0, s, x, scale, shift, gamma, beta, y, P, C, slope)
+    if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
+    else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
+#undef H3D_GO
+    return h3d::launch_status("h3d_spade_fwd");
+}
+
+extern "C" int h3d_spade_bwd_reduce(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                    const float* gamma, const float* beta, const float* dy, float* partial, int B, int64_t P,
+                                    int C, int per_pixel, float slope, h3d_stream_t stream) {
+    if (int rc = check_shape("h3d_spade_bwd_reduce", B, P, C)) return rc;
+    if (B == 0 || P == 0) return H3D_OK;
+    H3D_REQUIRE(x && mean && rstd && g && b && gamma && beta && dy && partial, "h3d_spade_bwd_reduce: null pointer");
+    const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy});
+    h3d::pre_launch();
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_reduce<V, PIX>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, gamma, beta, dy, partial, P, C, slope)
+    if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
+    else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
+#undef H3D_GO
+    return h3d::launch_status("h3d_spade_bwd_reduce");
+}
+
+extern "C" int h3d_spade_bwd_apply(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                   const float* gamma, const float* beta, const float* dy, const float* c1, const float* c2,
+                                   float* dx, float* dgamma, float* dbeta, float* partial, int B, int64_t P, int C,
+                                   int per_pixel, float slope, h3d_stream_t stream) {
+    if (int rc = check_shape("h3d_spade_bwd_apply", B, P, C)) return rc;
+    if (B == 0 || P == 0) return H3D_OK;
+    H3D_REQUIRE(x && mean && rstd && g && b && gamma && beta && dy && c1 && c2 && dx, "h3d_spade_bwd_apply: null pointer");
+    H3D_REQUIRE(per_pixel ? (dgamma && dbeta) : (partial != nullptr),
+                "h3d_spade_bwd_apply: %s", per_pixel ? "per-pixel mode needs dgamma and dbeta" : "per-sample mode needs partial");
+    const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta});
+    h3d::pre_launch();
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_apply<V, PIX>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta, partial, P, C, slope)
+    if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
+    else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
+#undef H3D_GO
+    return h3d::launch_status("h3d_spade_bwd_apply");
+}

@@ -8,8 +8,8 @@ nothing to differentiate through; training needs the activations in HBM anyway. 
     to end, so no transposes sit between the render and the synthesis network;
   * what sits between two GEMMs is ONE hand-written HIP pass each way with a hand-written adjoint that recomputes instead of
     storing: ``film_sin`` (sine activation with per-sample frequency / phase), ``h3d_ray_integrate`` /
-    ``h3d_ray_integrate_bwd`` (volume integration), ``bias_act`` (style mapping network); the SPADE normalise-modulate-
-    activate chain is one autograd node with a hand-derived backward (3 saved tensors instead of 8);
+    ``h3d_ray_integrate_bwd`` (volume integration), ``bias_act`` (style mapping network), and the SPADE normalise-modulate-
+    activate chain (``spade_norm_act``: one pass forward, two backward, csrc/spade_train.hip);
   * ray set-up and the SMPL geometry features have no learnable inputs and run as the same HIP kernels as in inference.
 
 Train-mode semantics of the reference are reproduced: batch-statistics BatchNorm (synchronised over the process group when
@@ -18,10 +18,10 @@ updates, and one spectral-norm power iteration per conv and call (torch.nn.utils
 lib/components/map3d_layers.py:205-206).
 """
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 from ..components.ops.film import film_sin
+from ..components.ops.spade import spade_norm_act
 
 
 # ------------------------------------------------------------------------------------------------ A5: the implicit function
@@ -50,101 +50,6 @@ def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feat
     rgb = torch.sigmoid(F.linear(c, nf.color_layer_linear.weight, nf.color_layer_linear.bias))
     feat = F.linear(c, nf.feature_layer_linear.weight, nf.feature_layer_linear.bias)
     return torch.cat([rgb, feat, sigma], dim=-1)
-
-
-# ------------------------------------------------------------------------------------------------ batch statistics
-
-class _AllReduceSum(torch.autograd.Function):
-    """Sum over the process group whose adjoint is the same sum (every rank's loss depends on every rank's statistics)."""
-
-    @staticmethod
-    def forward(ctx, t, group):
-        ctx.group = group
-        t = t.contiguous().clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g, None
-
-
-def _dist_on(group):
-    """group: a process group, None (= the default group when torch.distributed is initialised) or False (never synchronise)."""
-    return group is not False and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-
-
-def batch_moments(x2d, group=None):
-    """Per-channel mean and BIASED variance of x2d [M, C] over the (global) batch, plus the global row count (an int, or a
-    one-element device tensor when it had to be all-reduced)."""
-    m = x2d.shape[0]
-    if not _dist_on(group):
-        var, mean = torch.var_mean(x2d, dim=0, unbiased=False)
-        return mean, var, m
-    sums = torch.stack([x2d.sum(0), (x2d * x2d).sum(0)])                 # [2, C]
-    count = torch.tensor([float(m)], device=x2d.device)
-    dist.all_reduce(count, group=group)
-    sums = _AllReduceSum.apply(sums, group)
-    mean = sums[0] / count                                   # the count stays on the device: no host synchronisation
-    var = (sums[1] / count - mean * mean).clamp_min(0)
-    return mean, var, count
-
-
-class _SpadeNormAct(torch.autograd.Function):
-    """y = lrelu_0.2( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )   -- SPADE2d.forward + the block's activation
-    (lib/components/map3d_layers.py:176-190, 228-233) as one node.
-
-    x [B,P,C]; mean, rstd [C] (they carry their own graph when they are batch statistics: their gradients are returned, and
-    autograd completes the batch-norm backward through var_mean / the all-reduce); g, b [C]; gamma, beta [B,P,C] (per-pixel
-    SPADE) or [B,1,C] (constant style).  Saves x, gamma, beta only."""
-
-    @staticmethod
-    def forward(ctx, x, mean, rstd, g, b, gamma, beta):
-        h = (x - mean) * (rstd * g) + b
-        u = torch.addcmul(beta, h, 1 + gamma)
-        ctx.save_for_backward(x, mean, rstd, g, b, gamma, beta)
-        return F.leaky_relu(u, 0.2)
-
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
-        x, mean, rstd, g, b, gamma, beta = ctx.saved_tensors
-        n = (x - mean) * rstd
-        h = n * g + b
-        u = torch.addcmul(beta, h, 1 + gamma)
-        du = torch.where(u > 0, dy, dy * 0.2)
-        del u
-        d_gamma = du * h
-        d_beta = du
-        if gamma.shape[1] != x.shape[1]:                                  # constant style: reduce over the pixels
-            d_gamma = d_gamma.sum(1, keepdim=True)
-            d_beta = du.sum(1, keepdim=True)
-        dh = du * (1 + gamma)
-        d_g = (dh * n).sum((0, 1))
-        d_b = dh.sum((0, 1))
-        dn = dh * g
-        d_rstd = (dn * (x - mean)).sum((0, 1))
-        d_mean = -(dn.sum((0, 1))) * rstd
-        dx = dn * rstd
-        return dx, d_mean, d_rstd, d_g, d_b, d_gamma, d_beta
-
-
-def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1):
-    """norm: the first_norm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked)."""
-    C = x.shape[-1]
-    if training:
-        mean, var, n = batch_moments(x.reshape(-1, C), group)
-        with torch.no_grad():
-            norm.running_mean.lerp_(mean.detach().to(norm.running_mean.dtype), momentum)
-            unbias = n / (n - 1).clamp_min(1) if torch.is_tensor(n) else n / max(n - 1, 1)
-            norm.running_var.lerp_((var.detach() * unbias).to(norm.running_var.dtype), momentum)
-            norm.num_batches_tracked += 1
-    else:
-        mean, var = norm.running_mean, norm.running_var
-    rstd = torch.rsqrt(var + eps)
-    return _SpadeNormAct.apply(x, mean, rstd, norm.weight, norm.bias, gamma, beta)
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm
@@ -182,7 +87,7 @@ def _resize_channels_last(t, render_hw, gen_hw):
     return up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)
 
 
-def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=None):
+def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=None, spade_kernels=None):
     """SynthesisInput + bilinear resize + SynthesisNetwork (lib/generators/map3d_generator.py:58-97, 244-275;
     lib/components/map3d_layers.py:176-275, 346-352).  fmap_low [B,R,F] channels-last rendered features, styles [B,1,F]
     -> rgb [B,3,H,W]."""
@@ -229,9 +134,9 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
     for idx, name in enumerate(names):
         blk = sn.network[name]
         x_in = x
-        h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group)
+        h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels)
         h = F.linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
-        h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group)
+        h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels)
         h = F.linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias)
         x = h + x_in if idx >= nb // 2 else h
         if idx >= nb // 2 - 1:

@@ -449,6 +449,9 @@ def main():
         init_distributed(local)                                       # RCCL over xGMI
     dev = torch.device("cuda", local)
     if a.mode in ("dstep", "trainstep"):
+        # MIOpen's default find mode benchmarks every convolution configuration at first use (minutes for the discriminator's
+        # fwd / bwd / double-bwd shapes); the immediate-mode heuristics cost a few percent of conv time and no warm-up
+        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
         (discriminator_step_bench if a.mode == "dstep" else train_step_bench)(a, rank, world, dist_on, dev)
         if dist_on:
             torch.distributed.destroy_process_group()

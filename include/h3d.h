@@ -343,6 +343,31 @@ int h3d_ray_integrate_bwd(const float* field, const float* z_vals, const float* 
                           const float* g_depth, const float* g_weights, float* d_field, int64_t n_rays, int S, int C,
                           int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
+/* Training-side SPADE (backward of A9): BatchNorm + SPADE modulation + LeakyReLU of one SPADEBlock half
+ *     y = lrelu_slope( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )
+ * == SPADE2d.forward + the block's activation (lib/components/map3d_layers.py:176-190, 228-233) over channels-last fp32
+ * activations x [B,P,C].  gamma / beta: [B,P,C] when per_pixel, else [B,C].  Per-channel vectors [C] fp32.
+ * "partial" buffers are [B, nblk, 2, C] fp32 with nblk = ceil(P / h3d_spade_rows()): per-workgroup sums the caller adds up
+ * (deterministic two-stage reductions; with a process group the caller all-reduces the [2,C] totals -- SyncBatchNorm).
+ *   h3d_channel_moments    partial[..][0] = sum x, [1] = sum x^2                      (batch statistics)
+ *   h3d_spade_fwd          scale = rstd * g, shift = b - mean * scale
+ *   h3d_spade_bwd_reduce   partial[..][0] = sum dh, [1] = sum dh * n;  n = (x - mean) rstd, dh = dL/d(n g + b)   (= d b, d g)
+ *   h3d_spade_bwd_apply    dx = rstd g (dh - c1 - n c2)  (c1, c2 = the reduced sums / row count for batch statistics, zeros for
+ *                          running statistics); per_pixel: dgamma, dbeta [B,P,C]; else partial[..][0] = sum_p dgamma,
+ *                          [1] = sum_p dbeta per sample
+ */
+int h3d_spade_rows(void);
+int h3d_channel_moments(const float* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream);
+int h3d_spade_fwd(const float* x, const float* scale, const float* shift, const float* gamma, const float* beta, float* y,
+                  int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream);
+int h3d_spade_bwd_reduce(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                         const float* gamma, const float* beta, const float* dy, float* partial, int B, int64_t P, int C,
+                         int per_pixel, float slope, h3d_stream_t stream);
+int h3d_spade_bwd_apply(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                        const float* gamma, const float* beta, const float* dy, const float* c1, const float* c2, float* dx,
+                        float* dgamma, float* dbeta, float* partial, int B, int64_t P, int C, int per_pixel, float slope,
+                        h3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
  *     lib/components/ops/bias_act.cpp:32 with grad=0; kernel spec lib/components/ops/bias_act.cu:23-147

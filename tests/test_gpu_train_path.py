@@ -149,6 +149,37 @@ def test_ray_integration_backward_vs_oracle(S, C, clamp_mode):
     assert rel_err(fd.grad.cpu(), fr.grad) < 5e-5
 
 
+# ------------------------------------------------------------------ SPADE kernels
+
+@pytest.mark.parametrize("B,P,C", [(2, 1300, 32), (3, 513, 40), (2, 700, 30), (2, 2100, 256), (1, 600, 420), (2, 64, 1028)])
+@pytest.mark.parametrize("per_pixel", [True, False])
+def test_spade_kernels_vs_torch_stand_in(B, P, C, per_pixel):
+    """The four HIP kernels of csrc/spade_train.hip against the plain-torch kernel set (fp64) on the same inputs."""
+    from _torch_spade_kernels import TorchKernels
+    spade = importlib.import_module("3dhumangan_amd.lib.components.ops.spade")
+    hip, ref = spade.HipKernels(), TorchKernels()
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, P, C, generator=gen) * 1.3 + 0.2
+    shp = (B, P, C) if per_pixel else (B, C)
+    gamma, beta = torch.randn(shp, generator=gen) * 0.5, torch.randn(shp, generator=gen) * 0.5
+    dy = torch.randn(B, P, C, generator=gen)
+    mean, rstd = torch.randn(C, generator=gen) * 0.2, torch.rand(C, generator=gen) + 0.5
+    g, b = torch.randn(C, generator=gen) * 0.3 + 1, torch.randn(C, generator=gen) * 0.2
+    c1, c2 = torch.randn(C, generator=gen) * 0.1, torch.randn(C, generator=gen) * 0.1
+    d = lambda *ts: [t.to(DEV) for t in ts]
+    f64 = lambda *ts: [t.double() for t in ts]
+    assert rel_err(hip.moments(*d(x)).cpu(), ref.moments(x.double())) < 1e-6
+    scale, shift = rstd * g, b - mean * rstd * g
+    assert rel_err(hip.forward(*d(x, scale, shift, gamma, beta)).cpu(), ref.forward(*f64(x, scale, shift, gamma, beta))) < 2e-6
+    args = (x, mean, rstd, g, b, gamma, beta, dy)
+    assert rel_err(hip.backward_sums(*d(*args)).cpu(), ref.backward_sums(*f64(*args))) < 2e-5
+    got = hip.backward_apply(*d(*args, c1, c2))
+    want = ref.backward_apply(*f64(*args, c1, c2))
+    for a, e, name in zip(got, want, ("dx", "dgamma", "dbeta")):
+        assert a.shape == e.shape, name
+        assert rel_err(a.cpu(), e) < 2e-5, name
+
+
 # ------------------------------------------------------------------ the differentiable generator
 
 def _build(meta, state, train=True):

@@ -1,0 +1,58 @@
+"""Steady-state kernel breakdown of the config-4 training iteration (bench.py --mode trainstep) with torch.profiler: MIOpen's
+find-mode kernels of the warm-up steps stay out of the table.  usage: python tools/train_profile.py [batch] [g|d|both]"""
+import importlib
+import os
+import sys
+
+import torch
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+dev = "cuda"
+trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+G, cfg = bench.build_generator("MAP3DBN512", (512, 256), (96, 48), 32, dev)
+G.train()
+z, cond, jitter = bench.make_inputs(cfg, batch, dev)
+torch.manual_seed(99)
+D = disc.UNetDiscriminator(**{k: v for k, v in cfg.items() if k != "neural_field_cls"}).to(dev)
+meta = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+meta.update(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, gen_lr=5e-5, betas=(0.0, 0.9))
+opt_d = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.0, 0.9))
+opt_g = trainers.make_generator_optimizer(G, meta)
+g = torch.Generator().manual_seed(7)
+real = torch.randn(batch, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
+gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (batch, 512, 256), generator=g).to(dev)
+fwd = {k: v for k, v in cfg.items() if isinstance(k, str)}
+
+
+def step():
+    if which in ("d", "both"):
+        with torch.no_grad():
+            fake = G(z, cond, jitter=jitter, **fwd)["rgbs"]
+        trainers.discriminator_step(D, opt_d, real, fake, gt, meta, do_r1=True, grad_clip=cfg.get("grad_clip", 10.0))
+    if which in ("g", "both"):
+        trainers.generator_step(G, D, opt_g, z, cond, meta, gt_segments=gt, generator_kwargs=dict(jitter=jitter))
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+N = 2
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(N):
+        step()
+    torch.cuda.synchronize()
+rows = [(e.key, e.device_time_total / N / 1e3, e.count // N) for e in prof.key_averages() if e.device_time_total > 0]
+rows.sort(key=lambda r: -r[1])
+total = sum(r[1] for r in rows if not r[0].startswith(("aten::", "autograd::", "_", "Optimizer")))
+print(f"# steady-state device time per iteration (batch {batch}, part {which}); kernels only sum to {total:.1f} ms")
+for k, ms, n in rows[:70]:
+    print(f"{ms:9.2f} ms  x{n:<5d} {k[:150]}")
