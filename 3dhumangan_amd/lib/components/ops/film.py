@@ -50,6 +50,8 @@ class _FilmSin(torch.autograd.Function):
 def film_sin(x, freq=None, phase=None, w0=1.0):
     """x [B,N,C] (fp32 or fp16), freq / phase [B,C] -> sin(freq * x + phase); without freq / phase: sin(w0 * x)."""
     _lib.need_cuda(x, freq, phase)
+    if x.dtype == torch.bfloat16:                     # bf16 autocast: the kernels take f32 / f16 activations
+        x = x.float()
     if x.dtype not in _DT:
         raise TypeError(f"film_sin: unsupported dtype {x.dtype}")
     assert x.ndim == 3 and (freq is None) == (phase is None)

@@ -57,7 +57,12 @@ def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feat
 def spectral_weight(conv, training, eps=1e-12):
     """weight_orig / sigma of a spectral-normalised 1x1 conv holder (bias, weight_orig, weight_u, weight_v) as a [Cout, Cin]
     matrix.  training: one power iteration first, the new u / v overwrite the buffers (torch.nn.utils.spectral_norm)."""
-    w = conv.weight_orig.flatten(1)
+    with torch.autocast("cuda", enabled=False):          # under AMP the power iteration and sigma stay in fp32
+        return _spectral_weight_fp32(conv, training, eps)
+
+
+def _spectral_weight_fp32(conv, training, eps):
+    w = conv.weight_orig.flatten(1).float()
     u, v = conv.weight_u, conv.weight_v
     if training:
         with torch.no_grad():

@@ -15,20 +15,27 @@ from . import losses
 
 
 def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta, do_r1=True, r1_mode="per_sample",
-                       distributed=False, grad_clip=None):
+                       distributed=False, grad_clip=None, amp_dtype=None, scaler=None):
     """-> dict of detached scalars.  meta: gan_lambda, segmentation_lambda, r1_lambda, label_dim (config keys).
     r1_mode "reference" reproduces the reference's penalty on this rank's shard exactly (see losses.py); "per_sample" gathers
-    the per-sample squared gradient norms of ALL ranks and penalises their global mean."""
+    the per-sample squared gradient norms of ALL ranks and penalises their global mean.  ``amp_dtype`` / ``scaler``: the
+    reference's AMP mode (autocast around the discriminator forwards; the R1 gradient is taken of the SCALED prediction sum and
+    unscaled afterwards, phase_trainer.py:270-283)."""
+    amp = dict(device_type="cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None)
     gan_lambda, seg_lambda = meta["gan_lambda"], meta["segmentation_lambda"]
     optimizer.zero_grad(set_to_none=True)
     real = real_images.detach().requires_grad_(True)
-    out_real = D(real, None, 1.0)
-    out_fake = D(fake_images.detach(), None, 1.0)
+    with torch.autocast(**amp):
+        out_real = D(real, None, 1.0)
+        out_fake = D(fake_images.detach(), None, 1.0)
+    out_real = {k: v.float() for k, v in out_real.items()}
+    out_fake = {k: v.float() for k, v in out_fake.items()}
     gan = losses.logistic_d_loss(out_real["prediction"], out_fake["prediction"], gan_lambda) if gan_lambda > 0 else \
         (out_real["prediction"].sum() + out_fake["prediction"].sum()) * 0
     penalty, r1_scale = real.new_zeros(()), 1.0
     if do_r1:
-        grad = losses.r1_gradient(real, out_real, gan_lambda)
+        scale = scaler.get_scale() if scaler is not None else 1.0
+        grad = losses.r1_gradient(real, out_real, gan_lambda, scale=scale)
         stat = losses.r1_statistic(grad, r1_mode)
         if distributed and r1_mode == "per_sample":
             stat = parallel.r1_allgather(stat)           # [world * b]; only this rank's slice carries a graph
@@ -45,10 +52,17 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
                                                meta.get("segmentation_weights"))
         seg = (s_real + s_gen) * seg_lambda
     loss = gan + 4 * penalty + seg                       # lazy regularisation factor of the reference (:392)
-    (gan + 4 * r1_scale * penalty + seg).backward()
+    total = gan + 4 * r1_scale * penalty + seg
+    (scaler.scale(total) if scaler is not None else total).backward()
     if distributed:
         parallel.allreduce_gradients(D.parameters(), average=True)
+    if scaler is not None:
+        scaler.unscale_(optimizer)
     if grad_clip is not None:
         torch.nn.utils.clip_grad_norm_(D.parameters(), grad_clip)
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
     return dict(loss=loss.detach(), gan=gan.detach(), r1=penalty.detach(), segmentation=seg.detach())

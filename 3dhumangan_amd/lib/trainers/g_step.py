@@ -52,37 +52,48 @@ def topk_count(meta, d_step_count, batch):
 
 
 def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=None, distributed=False, d_step_count=0,
-                   gen_modal="rgbs", latent_indices=None, generator_kwargs=None):
+                   gen_modal="rgbs", latent_indices=None, generator_kwargs=None, amp_dtype=None, scaler=None):
     """-> dict of detached scalars.  meta: the config dict (gan_lambda, segmentation_lambda, label_dim, grad_clip and every
     forward key of the generator).  ``gt_segments`` [B,H,W] int64 (the rasterised body-part labels of the conditions) feeds
     the segmentation term; the unconditional phase of the reference (latent_lambda = perceptual = photometric = 0 in every
-    shipped config)."""
+    shipped config).
+
+    ``amp_dtype`` (torch.float16 / torch.bfloat16) runs both networks under autocast -- the reference's AMP mode
+    (base_trainer.py:50-51, torch.cuda.amp.autocast + GradScaler): the library GEMMs and convolutions run in that type, the
+    HIP kernels between them compute in fp32; pass a torch.amp.GradScaler as ``scaler`` for float16."""
     gan_lambda, seg_lambda = meta.get("gan_lambda", 0), meta.get("segmentation_lambda", 0)
     optimizer.zero_grad(set_to_none=True)
     fwd = {k: v for k, v in meta.items() if isinstance(k, str)}
     fwd.update(generator_kwargs or {})
     fwd.update(latent_indices=latent_indices, disable_synthesis=(gen_modal != "rgbs"))
-    out = G(z, conditions, **fwd)
-    d_out = D(out[gen_modal], conditions, 1.0)
-    pred = d_out["prediction"]
-    k = topk_count(meta, d_step_count, pred.shape[0])
-    pred = torch.topk(pred, k, dim=0).values
-    gan = gan_lambda * F.softplus(-pred).mean() if gan_lambda > 0 else pred.sum() * 0
-    seg = pred.new_zeros(())
-    if "segments" in d_out and d_out["segments"].shape[1] > 0:
-        if seg_lambda > 0 and gt_segments is not None:
-            seg = losses.segmentation_loss(d_out["segments"], gt_segments, meta["label_dim"],
-                                           meta.get("segmentation_weights"))[0] * seg_lambda
-        else:
-            seg = d_out["segments"].sum() * 0
-    latent = d_out["latents"].sum() * 0 if "latents" in d_out else 0.0
-    loss = gan + seg + latent
-    loss.backward()
+    with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
+        out = G(z, conditions, **fwd)
+        d_out = D(out[gen_modal], conditions, 1.0)
+        pred = d_out["prediction"].float()
+        k = topk_count(meta, d_step_count, pred.shape[0])
+        pred = torch.topk(pred, k, dim=0).values
+        gan = gan_lambda * F.softplus(-pred).mean() if gan_lambda > 0 else pred.sum() * 0
+        seg = pred.new_zeros(())
+        if "segments" in d_out and d_out["segments"].shape[1] > 0:
+            if seg_lambda > 0 and gt_segments is not None:
+                seg = losses.segmentation_loss(d_out["segments"].float(), gt_segments, meta["label_dim"],
+                                               meta.get("segmentation_weights"))[0] * seg_lambda
+            else:
+                seg = d_out["segments"].sum() * 0
+        latent = d_out["latents"].sum() * 0 if "latents" in d_out else 0.0
+        loss = gan + seg + latent
+    (scaler.scale(loss) if scaler is not None else loss).backward()
     if distributed:
         parallel.allreduce_gradients([p for p in G.parameters() if p.grad is not None], average=True)
+    if scaler is not None:
+        scaler.unscale_(optimizer)
     if meta.get("grad_clip") is not None:
         torch.nn.utils.clip_grad_norm_(G.parameters(), meta["grad_clip"])
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
     if ema is not None:
         ema.update(G.parameters())
     return dict(loss=loss.detach(), gan=gan.detach(), segmentation=seg.detach(), topk=k)

@@ -16,13 +16,16 @@ def logistic_d_loss(pred_real, pred_gen, gan_lambda=1.0):
     return gan_lambda * (F.softplus(pred_gen).mean() + F.softplus(-pred_real).mean())
 
 
-def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0):
-    """d sum(D(x).prediction) / dx with the graph kept (double backward); softmax(segments) when the GAN head is off."""
+def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0, scale=1.0):
+    """d sum(D(x).prediction) / dx with the graph kept (double backward); softmax(segments) when the GAN head is off.
+    ``scale``: the GradScaler's loss scale under fp16 AMP -- the target is scaled before the backward pass (so that half-
+    precision gradients inside the discriminator do not underflow) and the result unscaled, as phase_trainer.py:270-283."""
     if gan_lambda > 0:
         target = d_output_real["prediction"].sum()
     else:
         target = torch.softmax(d_output_real["segments"], dim=1).sum()
-    return torch.autograd.grad(outputs=target, inputs=d_input_real, create_graph=True)[0]
+    grad = torch.autograd.grad(outputs=target * scale, inputs=d_input_real, create_graph=True)[0]
+    return grad if scale == 1.0 else grad * (1.0 / scale)
 
 
 def r1_statistic(grad, mode="per_sample"):

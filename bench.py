@@ -153,6 +153,8 @@ def train_step_bench(a, rank, world, dist_on, dev):
     opt_d = torch.optim.Adam(D.parameters(), lr=cfg.get("disc_lr", 2e-4), betas=(0.0, 0.9))
     opt_g = trainers.make_generator_optimizer(G, meta)
     ema = ema_mod.ExponentialMovingAverage(G.parameters(), decay=0.999)
+    amp_dtype = {"none": None, "fp16": torch.float16, "bf16": torch.bfloat16}[a.amp]
+    scalers = (torch.amp.GradScaler("cuda"), torch.amp.GradScaler("cuda")) if a.amp == "fp16" else (None, None)
     g = torch.Generator().manual_seed(7 + rank)
     real = torch.randn(a.batch, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
     gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (a.batch, 512, 256), generator=g).to(dev)
@@ -162,13 +164,13 @@ def train_step_bench(a, rank, world, dist_on, dev):
     def step():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
-        with torch.no_grad():
-            fake = G(z, cond, jitter=jitter, **fwd)["rgbs"]
+        with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
+            fake = G(z, cond, jitter=jitter, **fwd)["rgbs"].float()
         d = trainers.discriminator_step(D, opt_d, real, fake, gt, meta, do_r1=True, distributed=dist_on,
-                                        grad_clip=cfg.get("grad_clip", 10.0))
+                                        grad_clip=cfg.get("grad_clip", 10.0), amp_dtype=amp_dtype, scaler=scalers[0])
         e[1].record()
         gs = trainers.generator_step(G, D, opt_g, z, cond, meta, gt_segments=gt, ema=ema, distributed=dist_on,
-                                     generator_kwargs=dict(jitter=jitter))
+                                     generator_kwargs=dict(jitter=jitter), amp_dtype=amp_dtype, scaler=scalers[1])
         e[2].record()
         ev["d"].append((e[0], e[1]))
         ev["g"].append((e[1], e[2]))
@@ -183,7 +185,8 @@ def train_step_bench(a, rank, world, dist_on, dev):
             "metric": "adversarial training iterations: images/sec at 512x256 (D step + G step)", "value": a.batch * world * a.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32 (library GEMMs + HIP activation / integration kernels; discriminator: torch / MIOpen convolutions)",
+            "dtype": ("fp32" if a.amp == "none" else f"AMP {a.amp} autocast (GEMMs / convolutions in {a.amp}, HIP kernels fp32)") +
+                     " (library GEMMs + HIP activation / integration / SPADE kernels; discriminator: torch / MIOpen convolutions)",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; UNetDiscriminator "
                                    "6 blocks; R1 every step; GAN + segmentation losses; Adam on both networks; EMA",
@@ -438,6 +441,8 @@ def main():
     ap.add_argument("--mode", default="generator", choices=["generator", "dstep", "trainstep"],
                     help="generator: the headline forward benchmark; dstep: BASELINE config 4's discriminator step; "
                          "trainstep: config 4's whole iteration (D step + G step)")
+    ap.add_argument("--amp", default="none", choices=["none", "fp16", "bf16"],
+                    help="trainstep: autocast type of the library GEMMs / convolutions (the reference's AMP mode is fp16)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
@@ -449,9 +454,12 @@ def main():
         init_distributed(local)                                       # RCCL over xGMI
     dev = torch.device("cuda", local)
     if a.mode in ("dstep", "trainstep"):
-        # MIOpen's default find mode benchmarks every convolution configuration at first use (minutes for the discriminator's
-        # fwd / bwd / double-bwd shapes); the immediate-mode heuristics cost a few percent of conv time and no warm-up
-        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+        # MIOpen benchmarks every convolution configuration at first use (minutes for the discriminator's fwd / bwd /
+        # double-bwd shapes; its immediate-mode fallback, MIOPEN_FIND_MODE=FAST, lands on naive kernels: 24 s per D step).
+        # The search results of a previous run are reused when they were kept (tools/miopen_db, written by MIOpen itself).
+        db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "miopen_db")
+        if os.path.isdir(db):
+            os.environ.setdefault("MIOPEN_USER_DB_PATH", db)
         (discriminator_step_bench if a.mode == "dstep" else train_step_bench)(a, rank, world, dist_on, dev)
         if dist_on:
             torch.distributed.destroy_process_group()

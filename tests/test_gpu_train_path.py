@@ -314,3 +314,28 @@ def test_train_step_at_real_width_vs_oracle():
     flat_r = torch.cat([g64[k].detach().flatten() for _, _, k in report])
     cos = float(torch.dot(flat_p, flat_r) / (flat_p.norm() * flat_r.norm()))
     assert cos > 1 - 1e-4, cos
+
+
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16])
+def test_train_step_under_autocast(amp):
+    """The reference's AMP mode (base_trainer.py:50-51): under autocast the library GEMMs run in half precision and the HIP
+    kernels in fp32.  Tolerance of this tier: outputs within 3e-2 of the fp32 path, gradient direction cos > 0.99."""
+    g = load_golden("gen_train_mixed")
+    cond = {k: v.to(DEV) for k, v in g["cond"].items()}
+    runs = {}
+    for mode in ("fp32", "amp"):
+        G, cfg = _build(g["meta"], g["state"])
+        z = g["z"].to(DEV)
+        with torch.autocast("cuda", dtype=amp, enabled=mode == "amp"):
+            out = G(z, cond, jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV), **cfg)
+            loss = (out["rgbs"].float() * g["p_rgb"].to(DEV)).sum() + (out["rgbs_render"].float() * g["p_render"].to(DEV)).sum()
+        loss.backward()
+        runs[mode] = (out, {n: p.grad.float() for n, p in G.named_parameters() if p.grad is not None})
+    for k in ("rgbs", "rgbs_render"):
+        assert rel_err(runs["amp"][0][k].float().detach(), runs["fp32"][0][k].detach()) < 3e-2, k
+    names = [n for n in runs["fp32"][1] if float(runs["fp32"][1][n].abs().max()) > 1e-3]
+    a = torch.cat([runs["amp"][1][n].flatten() for n in names]).double()
+    b = torch.cat([runs["fp32"][1][n].flatten() for n in names]).double()
+    assert torch.isfinite(a).all()
+    cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    assert cos > 0.99, cos

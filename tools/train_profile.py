@@ -6,7 +6,6 @@ import sys
 
 import torch
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
