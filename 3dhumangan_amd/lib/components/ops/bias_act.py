@@ -107,6 +107,8 @@ def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None, 
     assert isinstance(x, torch.Tensor)
     if act not in activation_funcs:
         raise KeyError(f"unknown activation {act!r}")
+    if x.dtype == torch.bfloat16:                     # bf16 autocast: the kernels take f32 / f16 / f64
+        x = x.float()
     if x.dtype not in _DTYPES:
         raise TypeError(f"bias_act: unsupported dtype {x.dtype}")
     _lib.need_cuda(x, b)

