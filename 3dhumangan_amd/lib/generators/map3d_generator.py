@@ -1,7 +1,8 @@
 """Map3DGenerator -- drop-in for the reference class of the same name
 (lib/generators/map3d_generator.py:101-523): same constructor kwargs (the whole config dict is splatted in), same
 state_dict key schema, same ``forward`` / ``staged_forward`` / ``set_device`` / ``generate_avg_latent`` surface and
-output dict keys.  Inference only; every hot stage is a HIP kernel behind libh3d.so:
+output dict keys.  In `.eval()` mode every hot stage is a fused HIP kernel behind libh3d.so (in `.train()` mode the
+differentiable path of lib/generators/differentiable.py runs instead, see Map3DGenerator.wants_autograd):
 
     mapping networks (B x L GEMVs)      torch GEMMs on the device + h3d_bias_act        (A1, A2)
     ray set-up                          h3d_ray_setup                                     (A3)
@@ -425,7 +426,7 @@ class Map3DGenerator(nn.Module):
                                                                   last_back=last_back, white_back=white_back)
         else:
             with stage(self, "neural_field"):
-                field = self.neural_field(pts, freq, phase, geo, dirs, input_scaler=scaler)
+                field = self.neural_field(pts, freq, phase, geo, dirs, input_scaler=scaler, differentiable=False)
             with stage(self, "ray_integrate"):
                 feats, depths, weights = vr.ray_integration(field.reshape(B, R, S, -1), z_vals, noise_std=0, noise=noise,
                                                             clamp_mode=clamp_mode, last_back=last_back,
@@ -462,7 +463,8 @@ class Map3DGenerator(nn.Module):
         with stage(self, "geo_features"):
             geo = self.get_geo_features(pts, *mesh)
         with stage(self, "neural_field"):
-            coarse = self.neural_field(pts, freq, phase, geo, dirs_for(S), input_scaler=scaler).reshape(B, R, S, -1)
+            coarse = self.neural_field(pts, freq, phase, geo, dirs_for(S), input_scaler=scaler,
+                                       differentiable=False).reshape(B, R, S, -1)
         if noise_coarse is None:
             drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24, first call
             noise_coarse = drawn * nerf_noise if nerf_noise != 0 else None
@@ -478,7 +480,8 @@ class Map3DGenerator(nn.Module):
         with stage(self, "geo_features"):
             geo = self.get_geo_features(fine_pts, *mesh)
         with stage(self, "neural_field"):
-            fine = self.neural_field(fine_pts, freq, phase, geo, dirs_for(Sf), input_scaler=scaler).reshape(B, R, Sf, -1)
+            fine = self.neural_field(fine_pts, freq, phase, geo, dirs_for(Sf), input_scaler=scaler,
+                                     differentiable=False).reshape(B, R, Sf, -1)
         with stage(self, "resample"):
             all_out, all_z = vr.merge_samples(fine, coarse, fine_z, z_vals)
         if noise is None:

@@ -3,7 +3,9 @@ lib/implicit_funcitions/modulated.py:6-75), evaluated by the fp32-MFMA HIP kerne
 h3d_neural_field / h3d_render_fused.
 
 Same constructor arguments, same parameter names (so reference state_dicts load unchanged), same forward
-signature and output channel order [rgb(3), feat(F), sigma(1)].  Inference only (no autograd through the kernel).
+signature and output channel order [rgb(3), feat(F), sigma(1)].  `.eval()`: the fused inference kernels (no autograd
+through them).  `.train()` (or ``differentiable=True``): the differentiable evaluation of lib/generators/differentiable.py --
+library GEMMs + the HIP film_sin kernels with hand-written adjoints.
 """
 import ctypes
 import math
@@ -126,11 +128,26 @@ class COORDCONCATSIREN(nn.Module):
         self._packed[x3] = (key, dev_blob)
         return dev_blob
 
-    @torch.no_grad()
     def forward(self, input, frequencies, phase_shifts, geo_feature, ray_directions, input_scaler=1.,
-                geo_feature_scaler=1., **kwargs):
+                geo_feature_scaler=1., differentiable=None, **kwargs):
         """input [B,N,3], frequencies/phase_shifts [B,4H], geo_feature [B,N,31], ray_directions [B,N,3] or None
         (None == the lock_view_dependence direction (0,0,-1))  ->  [B,N,F+4]."""
+        if self.training if differentiable is None else differentiable:
+            from ..generators.differentiable import field_forward
+            _lib.need_cuda(input, frequencies, phase_shifts, geo_feature, ray_directions)
+            if input.dim() < 3:
+                out = field_forward(self, input.unsqueeze(1), frequencies, phase_shifts, geo_feature.unsqueeze(1),
+                                    None if ray_directions is None else ray_directions.unsqueeze(1), input_scaler,
+                                    geo_feature_scaler)
+                return out.squeeze(1)
+            return field_forward(self, input, frequencies, phase_shifts, geo_feature, ray_directions, input_scaler,
+                                 geo_feature_scaler)
+        with torch.no_grad():
+            return self._forward_fused(input, frequencies, phase_shifts, geo_feature, ray_directions, input_scaler,
+                                       geo_feature_scaler)
+
+    def _forward_fused(self, input, frequencies, phase_shifts, geo_feature, ray_directions, input_scaler=1.,
+                       geo_feature_scaler=1.):
         unsq = input.dim() < 3
         if unsq:
             input, geo_feature = input.unsqueeze(1), geo_feature.unsqueeze(1)

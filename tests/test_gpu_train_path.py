@@ -226,6 +226,36 @@ def test_train_step_against_reference_autograd(name):
     assert changed == set(g["buffers_after"]), changed ^ set(g["buffers_after"])
 
 
+def test_field_operator_is_differentiable_in_train_mode():
+    """COORDCONCATSIREN.forward as a stand-alone operator: train mode gives gradients w.r.t. its weights, frequencies and phases
+    that agree with autograd through the oracle; eval mode is the fused kernel and records nothing."""
+    g = load_golden("field_h40")
+    H = int(g["out"].shape[-1]) - 4
+    net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=H, hidden_dim=H, geo_feature_dim=31, output_dim=H + 4, feature_dim=H,
+                                num_blocks=4)
+    net.load_state_dict({k[len("neural_field."):] if k.startswith("neural_field.") else k: v for k, v in g["state"].items()})
+    net = net.to(DEV)
+    ins = [g[k] for k in ("points", "freq", "phase", "geo", "dirs")]
+    p = torch.randn(g["out"].shape, generator=torch.Generator().manual_seed(1))
+    net.eval()
+    assert not net(*[t.to(DEV) for t in ins], input_scaler=0.7).requires_grad
+    net.train()
+    fr, ph = ins[1].to(DEV).requires_grad_(True), ins[2].to(DEV).requires_grad_(True)
+    out = net(ins[0].to(DEV), fr, ph, ins[3].to(DEV), ins[4].to(DEV), input_scaler=0.7)
+    (out * p.to(DEV)).sum().backward()
+    st = {"neural_field." + k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    fr64, ph64 = ins[1].double().requires_grad_(True), ins[2].double().requires_grad_(True)
+    ref = O.neural_field(st, ins[0].double(), fr64, ph64, ins[3].double(), ins[4].double(), 0.7)
+    (ref * p.double()).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    got = {"neural_field." + n: q.grad for n, q in net.named_parameters()}
+    got.update(freq=fr.grad, phase=ph.grad)
+    want = {k: v.grad for k, v in st.items()}
+    want.update(freq=fr64.grad, phase=ph64.grad)
+    worst, where = grad_errors(got, want, zero_below=1e-9)
+    assert worst < 1e-3, (where, worst)
+
+
 def test_differentiable_path_in_eval_mode_matches_the_inference_engines():
     """differentiable=True in eval mode is the same function as the fused engines (running statistics, stored u / v) and it
     leaves every buffer alone; gradients reach the latent."""
