@@ -23,7 +23,7 @@ def make_field(state, hidden, feature, prefix="neural_field.", precision=None):
     net.load_state_dict(sd)
     if precision:
         net.precision = precision
-    return net.to(DEV)
+    return net.to(DEV).eval()          # eval: the fused inference kernels (train mode would take the differentiable path)
 
 
 def random_state(hidden, feature, seed, precision=None):
@@ -36,7 +36,7 @@ def random_state(hidden, feature, seed, precision=None):
                 p.add_(0.05 * torch.randn_like(p))
     if precision:
         net.precision = precision
-    return {"neural_field." + k: v.detach().clone() for k, v in net.state_dict().items()}, net.to(DEV)
+    return {"neural_field." + k: v.detach().clone() for k, v in net.state_dict().items()}, net.to(DEV).eval()
 
 
 @pytest.mark.parametrize("engine", ENGINES)

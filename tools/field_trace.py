@@ -16,7 +16,7 @@ dev = "cuda"
 B, R, S = 8, 9216, 64
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 256        # width: 256 -> field_x3, > 256 -> field_x3t (or H3D_FIELD_PRECISION)
 net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=H, hidden_dim=H, geo_feature_dim=31, output_dim=H + 4, feature_dim=H,
-                            num_blocks=4).to(dev)
+                            num_blocks=4).to(dev).eval()
 N = R * S
 pts = torch.rand(B, N, 3, device=dev) * 2 - 1
 geo = torch.rand(B, N, 31, device=dev) * 2 - 1

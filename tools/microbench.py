@@ -57,7 +57,7 @@ def main():
         impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
         H = a.F
         net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=H, hidden_dim=H, geo_feature_dim=31, output_dim=H + 4,
-                                    feature_dim=H, num_blocks=4).to(dev)
+                                    feature_dim=H, num_blocks=4).to(dev).eval()
         if a.engine:
             net.precision = a.engine
         N = a.R * a.S
