@@ -37,10 +37,11 @@ def _forward(x, b, dim, idx, alpha, gain, clamp):
 
 def _grad(order, g, b, xref, yref, dy2, dim, idx, alpha, gain, clamp):
     g = g.contiguous()
+    dy2 = None if dy2 is None else dy2.contiguous()          # bound to a local: it must outlive the launch
     bc, size_b, step_b = _bias_layout(g, b, dim)
     out = torch.empty_like(g)
     rc = _lib.load().h3d_bias_act_grad(_lib.ptr(g), _lib.ptr(bc), _lib.ptr(xref), _lib.ptr(yref),
-                                       _lib.ptr(None if dy2 is None else dy2.contiguous()), _lib.ptr(out), g.numel(),
+                                       _lib.ptr(dy2), _lib.ptr(out), g.numel(),
                                        _DTYPES[g.dtype], size_b, step_b, order, idx, alpha, gain, clamp, _lib.stream_handle())
     _lib.check(rc, "h3d_bias_act_grad")
     return out
