@@ -7,6 +7,9 @@ BUILD CONTAINER ONLY (imports /root/reference through _ref_import.py).  Stores d
   ref_ckpt_tiny_*.pth   the files BaseTrainer.save_model writes (pickled generator module, pickled EMA object, optimizer
                         state dict) for a tiny generator -- to pin the checkpoint loader
   param_order.json      named_parameters() order of the three shipped generator configs (EMA shadow lists are positional)
+  gstep_tiny.npz/.json  PhaseTrainer.init_optimizer's five Adam groups for a tiny Map3DGenerator (names per group, learning
+                        rates) and PhaseTrainer._train_generator run on stand-in generator / discriminator modules: the z it
+                        drew, loss, top-k count and the gradients it left on the generator -- pins the G step's loss algebra
   gen_train_*.npz       TRAIN-mode generator forward + backward: weights, conditions, every random tensor, the
                         outputs, the gradient of a fixed random projection of the outputs w.r.t. every parameter and z, and
                         the buffers the train-mode forward overwrote (BatchNorm running statistics, spectral-norm u / v)
@@ -219,7 +222,75 @@ def generator_train_fixture(name, seed, batch=3, nerf_noise=0.3, use_pool=False,
     print("   parameters with gradient:", len(grads), "of", len(list(G.named_parameters())), "| buffers changed:", len(changed))
 
 
+def gstep_fixture():
+    import lib.trainers.phase_trainer as pt
+    # ---- optimiser groups of a real (tiny) generator
+    cfg = tiny_cfg()
+    torch.manual_seed(41)
+    G = ref_gen.Map3DGenerator(**cfg)
+    kw = dict(latent_dim=16, gen_height=32, gen_width=16, semantic_dim=0, label_dim=3, discriminator_blocks=2)
+    D = UNetDiscriminator(**kw).eval()
+    sd = D.state_dict()
+    with torch.no_grad():                                      # as in disc_fixture: fp16-exact weights, exact spectral-norm vectors
+        for k, v in sd.items():
+            if v.is_floating_point():
+                v.copy_(v.half().float())
+        for k, v in sd.items():
+            if k.endswith("weight_orig"):
+                U, S, Vh = torch.linalg.svd(v.flatten(1), full_matrices=False)
+                sd[k.replace("weight_orig", "weight_u")].copy_(U[:, 0])
+                sd[k.replace("weight_orig", "weight_v")].copy_(Vh[0])
+    D.load_state_dict(sd)
+    meta = dict(gen_lr=5e-5, disc_lr=2e-4, betas=(0.0, 0.9), weight_decay=0, appearance_codes_lr_mul=1.0,
+                mapping_net_lr_mul=0.05, neural_field_lr_mul=0.05)
+    me = types.SimpleNamespace(generator_ddp=G, discriminator_ddp=D, output_dir="/nonexistent", device="cpu")
+    pt.PhaseTrainer.init_optimizer(me, meta)
+    names = {id(p): n for n, p in G.named_parameters()}
+    groups = [dict(name=g["name"], lr=g["lr"], params=[names[id(p)] for p in g["params"]]) for g in me.optimizer_G.param_groups]
+
+    # ---- _train_generator on stand-in networks
+    class StubG(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(16, 3 * 32 * 16)
+            self.latent_pool = torch.nn.Embedding(4, 16)
+
+        def forward(self, z, conditions, disable_synthesis=False, latent_indices=None, **kw):
+            img = torch.tanh(self.lin(z)).view(z.shape[0], 3, 32, 16)
+            return {"rgbs": img, "rgbs_render": img[:, :, ::4, ::4]}
+
+    torch.manual_seed(42)
+    sg = StubG()
+    B = 5
+    g = torch.Generator().manual_seed(43)
+    data = dict(images=torch.randn(B, 3, 32, 16, generator=g), latents=torch.randn(B, 16, generator=g),
+                rasterized_segments=torch.randint(0, 3, (B, 32, 16), generator=g), indices=torch.arange(B) % 4)
+    tmeta = dict(gan_lambda=1.0, segmentation_lambda=1.0, latent_dim=16, z_dist="gaussian", latent_lambda=0,
+                 perceptual_lambda=[0, 0, 0, 0], photometric_lambda=0, label_dim=3, topk_interval=2000, topk_v=0.5)
+    phase = dict(uncond=True, gen_modal="rgbs", rotate=True, name="p")
+    me2 = types.SimpleNamespace(device="cpu", amp=False, batch_split=1, scaler=torch.cuda.amp.GradScaler(enabled=False),
+                                generator_ddp=sg, discriminator_ddp=D, discriminator=types.SimpleNamespace(step=40000))
+    me2._get_disc_input_gen = types.MethodType(pt.PhaseTrainer._get_disc_input_gen, me2)
+    me2._calculate_segmentation_loss = types.MethodType(pt.PhaseTrainer._calculate_segmentation_loss, me2)
+    torch.manual_seed(44)
+    z = torch.randn((B, 16))                                  # what z_sampler will draw
+    torch.manual_seed(44)
+    loss, topk = pt.PhaseTrainer._train_generator(me2, data, 1.0, tmeta, phase)
+    disc16 = {k: (v.half() if v.is_floating_point() and not k.endswith(("weight_u", "weight_v")) else v)
+              for k, v in D.state_dict().items()}
+    save("gstep_tiny", stub={k: v for k, v in sg.state_dict().items()}, disc=disc16, data=data, z=z,
+         loss=torch.tensor(loss), topk=torch.tensor(topk), grad={n: p.grad for n, p in sg.named_parameters() if p.grad is not None})
+    json.dump(dict(groups=groups, disc_kwargs=kw, meta=tmeta, d_step=40000, generator_meta={k: v for k, v in cfg.items()
+                                                                                         if isinstance(v, (int, float, str, bool))}
+                   | {"mod_blocks": list(cfg["mod_blocks"])}),
+              open(os.path.join(HERE, "gstep_tiny.json"), "w"), indent=0)
+    print("   groups:", [(g["name"], len(g["params"]), g["lr"]) for g in groups], "| loss", loss, "topk", topk)
+
+
 if __name__ == "__main__":
+    if "--only-gstep" in sys.argv:
+        gstep_fixture()
+        sys.exit(0)
     if "--only-gen-train" in sys.argv:
         generator_train_fixture("gen_train_mixed", 31)
         generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
@@ -228,6 +299,7 @@ if __name__ == "__main__":
     generator_train_fixture("gen_train_mixed", 31)
     generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
                             white_back=True, last_back=True, clamp_mode="softplus")
+    gstep_fixture()
     frontend_fixture()
     disc_fixture()
     ema_and_checkpoint_fixture()
