@@ -25,5 +25,12 @@ for c in FETCH_SIZE WRITE_SIZE sq1 sq2 wide; do
   python tools/pmc_dump.py $(find $OUT/pmc_$c -name '*.db' | head -1) "$KERN" > $OUT/pmc_$c.txt
 done
 python tools/traffic_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt MAP3DBN512_512x512_b16_s64 $OUT/hbm_traffic.json
+# BASELINE config 4: one adversarial iteration per step (MIOpen's search results come from tools/miopen_db)
+python bench.py --mode trainstep --batch 4 --steps 5 --warmup 2 > $OUT/trainstep_1gpu.json 2> $OUT/trainstep.err
+python tools/train_profile.py 4 g > $OUT/trainstep_gstep_kernels.txt 2>> $OUT/trainstep.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_train -o k -- python $REPO/bench.py --mode trainstep --batch 4 --steps 3 --warmup 2 > $OUT/trainstep_bench_under_rocprof.json 2>> $OUT/trainstep.err
+cd $REPO
+python tools/rocprof_summary.py $(find $OUT/stats_train -name '*.db' | head -1) $OUT/trainstep_kernel_stats.csv
 find $OUT -name '*.db' -delete
 tail -c 400 $OUT/bench.json
