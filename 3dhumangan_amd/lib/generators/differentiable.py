@@ -31,7 +31,6 @@ def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feat
     freq and phase.  points [B,N,3], geo [B,N,31], dirs [B,N,3] or None (= the locked direction (0,0,-1)),
     freq / phase [B,4H] -> [B,N,F+4] = [rgb, features, sigma]."""
     H = nf.hidden_dim
-    B = points.shape[0]
     fr = freq * 15 + 30
     a = film_sin(F.linear(points * input_scaler, nf.first_layer_coord.layer.weight, nf.first_layer_coord.layer.bias), w0=30.0)
     g = film_sin(F.linear(geo if geo_feature_scaler == 1.0 else geo * geo_feature_scaler, nf.first_layer_mod.layer.weight,
@@ -97,7 +96,7 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
     lib/components/map3d_layers.py:176-275, 346-352).  fmap_low [B,R,F] channels-last rendered features, styles [B,1,F]
     -> rgb [B,3,H,W]."""
     sn = G.synthesis_network
-    B, R, Fd = fmap_low.shape
+    B, _, Fd = fmap_low.shape
     H, W = gen_hw
     P = H * W
     dev, dt = fmap_low.device, fmap_low.dtype

@@ -2,7 +2,6 @@
 import importlib
 import math
 import sys
-import os
 
 import numpy as np
 import torch

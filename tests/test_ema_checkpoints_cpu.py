@@ -9,7 +9,7 @@ import sys
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, rel_err
+from conftest import GOLDEN, load_golden
 
 ck = importlib.import_module("3dhumangan_amd.checkpoints")
 ema_mod = importlib.import_module("3dhumangan_amd.lib.components.ema")

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import h3d_oracle as O
-from conftest import load_golden, rel_err, rel_err_channels
+from conftest import load_golden, rel_err_channels
 
 pytestmark = pytest.mark.gpu
 gens = importlib.import_module("3dhumangan_amd.lib.generators")

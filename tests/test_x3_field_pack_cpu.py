@@ -4,7 +4,6 @@ power-of-two scales, hi + lo halves, biases, head rows -- and a float64 restatem
 data must reproduce the oracle's COORDCONCATSIREN.  No GPU, no kernel launch."""
 import ctypes
 import importlib
-import math
 
 import pytest
 import torch

@@ -1,7 +1,6 @@
 """Development aid: cycle trace of one workgroup of the fused x3 field kernel (library built with
 -DH3D_EXPERIMENT_TRACE via tools/build_variant.sh, H3D_LIB pointing at it).  The trace buffer travels in the unused
 `out` pointer of the fused entry point."""
-import ctypes
 import importlib
 import os
 import sys

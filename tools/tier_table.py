@@ -3,7 +3,6 @@ same batch; error = per-channel max-norm relative deviation of the image / rende
 (oracle/h3d_oracle.py: generator_forward_subset).  Writes profiles/<tag>_precision_tiers.json.
 
     python tools/tier_table.py r2"""
-import importlib
 import json
 import os
 import sys
