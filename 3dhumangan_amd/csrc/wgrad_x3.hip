@@ -1,0 +1,183 @@
+// Weight-gradient GEMM of the training path for gfx950:  dW[Co, Ci] = sum_r dY[r, Co]^T X[r, Ci]  with r over the M rows
+// (samples / pixels) of the batch -- M ~ 0.5 M, Co, Ci <= a few hundred.  The library GEMM handles this "tall-skinny TN" shape
+// at ~50 TFLOP/s in fp32; here it is a split-K kernel on the bf16 matrix cores with split operands (x = hi + lo,
+// hi*hi + hi*lo + lo*hi, fp32 accumulate: 16 mantissa bits per operand, fp32 exponent range, so gradients need no scaling).
+//
+//   workgroup (4 waves, 2 x 2)   owns one K-slice (rows_per_wg rows) of one [64 NA x 64 NB] block of dW; wave (wy, wx) owns
+//                                NA x NB 32x32 accumulator tiles (NA = NB = 4: the whole 256 x 256 gradient in 256 registers)
+//   k-step = 16 rows             the [16 x 64 NA] slab of dY and the [16 x 64 NB] slab of X are loaded once per workgroup with
+//                                16-byte coalesced loads (one k-step ahead, in registers) and parked in LDS as fp32, double
+//                                buffered, one barrier per k-step; a lane builds its MFMA fragments (8 consecutive rows of one
+//                                column -- the contraction runs over the SLOW index of both operands) from eight ds_read_b32
+//                                and splits them into bf16 hi / lo words in registers
+//   output                       partial[slice][Co][Ci] fp32; the caller sums the slices (deterministic)
+// HBM traffic: M (Co + Ci) 4 bytes read once per column block -- the kernel is HBM-bound at 256 x 256 (arithmetic intensity
+// 3 x 2 x 256 x 256 / (512 x 4) = 192 bf16 FLOP per byte against 2.5 PFLOP/s / 5 TB/s = 500).
+#include "x3_common.hpp"
+
+namespace {
+
+using h3d::BF16;
+using h3d::f32x16;
+
+constexpr int kThreads = 256;
+constexpr int kKS = 16;                       // rows per k-step
+
+struct Args {
+    const float* dY;
+    const float* X;
+    float* partial;
+    int64_t M;
+    int Co, Ci, ldy, ldx, rows_per_wg;
+};
+
+template <int NT>
+__device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restrict__ src, int ld, int64_t row0, int64_t M,
+                                          int col0, int ncols, int t) {
+    constexpr int W4 = 16 * NT;               // float4 per slab row (slab width 64 NT floats)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int idx = j * kThreads + t;
+        const int row = idx / W4, c = (idx - row * W4) * 4;
+        const int64_t rr = row0 + row;
+        r[j] = (rr < M && col0 + c < ncols) ? *reinterpret_cast<const float4*>(src + rr * ld + col0 + c)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void park_slab(const float4 (&r)[NT], float* lds, int t) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(lds + (j * kThreads + t) * 4) = r[j];
+}
+
+// bf16 hi / lo fragments of column `col` of an LDS slab of width W: element e <-> row 8 * (lane >> 5) + e
+template <int W>
+__device__ __forceinline__ void read_frag(const float* lds, int col, int lane, BF16::vec8& hi, BF16::vec8& lo) {
+    const float* p = lds + (8 * (lane >> 5)) * W + col;
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = h3d::split2_bf16(p[(2 * e) * W], p[(2 * e + 1) * W], l[e]);
+    hi = __builtin_bit_cast(BF16::vec8, h3d::u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(BF16::vec8, h3d::u32x4{l[0], l[1], l[2], l[3]});
+}
+
+template <int NA, int NB>
+__global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
+    constexpr int WA = 64 * NA, WB = 64 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kBuf = kKS * (WA + WB);        // floats per buffer: the dY slab, then the X slab
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int co0 = blockIdx.y * WA, ci0 = blockIdx.z * WB;
+    const int64_t r_begin = (int64_t)blockIdx.x * A.rows_per_wg;
+    const int64_t r_end = r_begin + A.rows_per_wg < A.M ? r_begin + A.rows_per_wg : A.M;
+    const int n_steps = r_end > r_begin ? (int)((r_end - r_begin + kKS - 1) / kKS) : 0;
+
+    f32x16 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    float4 ra[NA], rb[NB];
+    // rows past r_end must not leak into this slice: the loaders clip at min(M, r_end) through the `M` argument
+    load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_slab<NB>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t);
+    park_slab<NA>(ra, smem, t);
+    park_slab<NB>(rb, smem + kKS * WA, t);
+    __syncthreads();
+
+    for (int s = 0; s < n_steps; ++s) {
+        const float* curA = smem + (s & 1) * kBuf;
+        const float* curB = curA + kKS * WA;
+        float* nxtA = smem + ((s + 1) & 1) * kBuf;
+        if (s + 1 < n_steps) {
+            const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
+            load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
+            load_slab<NB>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t);
+        }
+        BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) read_frag<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane, ah[a], al[a]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) read_frag<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane, bh[b], bl[b]);
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[a][b] = BF16::mfma(al[a], bh[b], acc[a][b]);
+                acc[a][b] = BF16::mfma(ah[a], bl[b], acc[a][b]);
+                acc[a][b] = BF16::mfma(ah[a], bh[b], acc[a][b]);
+            }
+        if (s + 1 < n_steps) {
+            park_slab<NA>(ra, nxtA, t);
+            park_slab<NB>(rb, nxtA + kKS * WA, t);
+        }
+        __syncthreads();
+    }
+
+    // accumulator tile (a, b): lane holds column ci = lane & 31, rows co = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)
+    float* out = A.partial + (int64_t)blockIdx.x * A.Co * A.Ci;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ci = ci0 + (wx * NB + b) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + (wy * NA + a) * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+                if (co < A.Co && ci < A.Ci) out[(int64_t)co * A.Ci + ci] = acc[a][b][i];
+            }
+        }
+}
+
+int tiles_for(int c) { return c > 128 ? 4 : c > 64 ? 2 : 1; }
+
+template <int NA, int NB>
+int launch(const Args& a, int slices, hipStream_t st) {
+    constexpr size_t lds = 2 * kKS * (64 * NA + 64 * NB) * sizeof(float);
+    const dim3 grid((unsigned)slices, (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
+    h3d::pre_launch();
+    hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB>), grid, dim3(kThreads), lds, st, a);
+    return h3d::launch_status("h3d_wgrad_x3");
+}
+
+}  // namespace
+
+// Number of K-slices (= leading dimension of `partial`) and rows per slice for a problem: about one workgroup per compute unit (the 4 x 4 kernel holds 392 registers per lane: one workgroup per CU),
+// at least 256 rows each.
+extern "C" int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci) {
+    if (M <= 0 || Co <= 0 || Ci <= 0) return 0;
+    const int na = tiles_for(Co), nb = tiles_for(Ci);
+    const int64_t blocks = (int64_t)((Co + 64 * na - 1) / (64 * na)) * ((Ci + 64 * nb - 1) / (64 * nb));
+    int64_t want = ((int64_t)h3d::compute_units() + blocks - 1) / blocks;
+    const int64_t most = (M + 255) / 256;
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx,
+                            int slices, h3d_stream_t stream) {
+    H3D_REQUIRE(dY && X && partial, "h3d_wgrad_x3: null pointer");
+    H3D_REQUIRE(M >= 1 && Co >= 1 && Ci >= 1, "h3d_wgrad_x3: bad shape M=%lld Co=%d Ci=%d", (long long)M, Co, Ci);
+    H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
+                "h3d_wgrad_x3: Co, Ci and the leading dimensions must be multiples of 4 (Co=%d Ci=%d ldy=%d ldx=%d)", Co, Ci, ldy, ldx);
+    H3D_REQUIRE(h3d::aligned16(dY) && h3d::aligned16(X), "h3d_wgrad_x3: operands must be 16-byte aligned");
+    H3D_REQUIRE(slices >= 1 && slices <= 65535 * 16, "h3d_wgrad_x3: slices=%d out of range", slices);
+    Args a;
+    a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx;
+    const int64_t per = (M + slices - 1) / slices;
+    a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int na = tiles_for(Co), nb = tiles_for(Ci);
+#define H3D_CASE(NA, NB) if (na == NA && nb == NB) return launch<NA, NB>(a, slices, st)
+    H3D_CASE(4, 4); H3D_CASE(4, 2); H3D_CASE(4, 1); H3D_CASE(2, 4); H3D_CASE(2, 2); H3D_CASE(2, 1);
+    H3D_CASE(1, 4); H3D_CASE(1, 2); H3D_CASE(1, 1);
+#undef H3D_CASE
+    h3d::set_error("h3d_wgrad_x3: no kernel for tile counts %d x %d", na, nb);
+    return H3D_EUNSUPPORTED;
+}

@@ -1,0 +1,70 @@
+"""y = x W^T + b with the weight gradient on the hand-written split-K matrix-core kernel (csrc/wgrad_x3.hip).
+
+Forward and the data gradient are library GEMMs ([M, C] x [C, C'] with M ~ 0.5 M rows: the shape hipBLASLt is good at, 83 % of the
+fp32 matrix peak measured); the WEIGHT gradient dW = dY^T X contracts over the M rows and produces a tiny output -- the library
+runs it at ~50 TFLOP/s, h3d_wgrad_x3 streams both operands once (HBM-bound).  Used by lib/generators/differentiable.py for every
+layer with enough rows; anything else (few rows, half-precision autocast inputs, odd widths, CPU tensors) is F.linear."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .... import _lib
+
+MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this the library GEMM is as good
+ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
+
+
+def wgrad_x3(dy, x):
+    """dy [M, Co], x [M, Ci] fp32 row-major (row stride >= width, multiple of 4) -> dy^T x [Co, Ci] fp32."""
+    _lib.need_cuda(dy, x)
+    M, Co = dy.shape
+    Ci = x.shape[1]
+    lib = _lib.load()
+    slices = lib.h3d_wgrad_x3_slices(M, Co, Ci)
+    partial = torch.empty((slices, Co, Ci), device=dy.device, dtype=torch.float32)
+    rc = lib.h3d_wgrad_x3(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), M, Co, Ci, dy.stride(0), x.stride(0), slices,
+                          _lib.stream_handle())
+    _lib.check(rc, "h3d_wgrad_x3")
+    return partial.sum(dim=0) if slices > 1 else partial[0]
+
+
+def _rows(t):
+    """[..., C] -> a [M, C] view with unit column stride and a row stride that is a multiple of 4, or a contiguous copy."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or t2.stride(0) % 4 or t2.stride(0) < t2.shape[1] or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+class _LinearX3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w
+        dy2 = _rows(dy)
+        if ctx.needs_input_grad[1]:
+            dw = wgrad_x3(dy2, _rows(x))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(dim=0)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """F.linear(x, w, b); the weight gradient goes to the HIP kernel when the problem is one it is built for."""
+    Co, Ci = w.shape
+    rows = x.numel() // max(Ci, 1)
+    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and torch.is_grad_enabled()
+            and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS and Co % 4 == 0 and Ci % 4 == 0
+            and Co >= 32 and Ci >= 32):
+        return _LinearX3.apply(x, w, b)
+    return F.linear(x, w, b)

@@ -3,9 +3,11 @@
 The inference engines (csrc/field_x3*.hip, synthesis_x3*.hip) keep every activation in registers / LDS and therefore have
 nothing to differentiate through; training needs the activations in HBM anyway.  This path is organised for that:
 
-  * every dense contraction is a library GEMM over ALL samples / pixels of the batch at once (``[B*N, C] x [C, C']``,
-    hipBLASLt through torch: 0.5 M x 256 x 256 problems -- the shape rocBLAS is built for), in a channels-LAST layout end
-    to end, so no transposes sit between the render and the synthesis network;
+  * forward and data-gradient contractions are library GEMMs over ALL samples / pixels of the batch at once
+    (``[B*N, C] x [C, C']``, hipBLASLt through torch: 0.5 M x 256 x 256 problems -- the shape rocBLAS is built for), in a
+    channels-LAST layout end to end, so no transposes sit between the render and the synthesis network; the WEIGHT gradients
+    (contraction over the 0.5 M rows, tiny output) run on the hand-written split-K matrix-core kernel of csrc/wgrad_x3.hip
+    (``ops.linear``);
   * what sits between two GEMMs is ONE hand-written HIP pass each way with a hand-written adjoint that recomputes instead of
     storing: ``film_sin`` (sine activation with per-sample frequency / phase), ``h3d_ray_integrate`` /
     ``h3d_ray_integrate_bwd`` (volume integration), ``bias_act`` (style mapping network), and the SPADE normalise-modulate-
@@ -21,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from ..components.ops.film import film_sin
+from ..components.ops.linear import linear
 from ..components.ops.spade import spade_norm_act
 
 
@@ -32,22 +35,22 @@ def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feat
     freq / phase [B,4H] -> [B,N,F+4] = [rgb, features, sigma]."""
     H = nf.hidden_dim
     fr = freq * 15 + 30
-    a = film_sin(F.linear(points * input_scaler, nf.first_layer_coord.layer.weight, nf.first_layer_coord.layer.bias), w0=30.0)
-    g = film_sin(F.linear(geo if geo_feature_scaler == 1.0 else geo * geo_feature_scaler, nf.first_layer_mod.layer.weight,
+    a = film_sin(linear(points * input_scaler, nf.first_layer_coord.layer.weight, nf.first_layer_coord.layer.bias), w0=30.0)
+    g = film_sin(linear(geo if geo_feature_scaler == 1.0 else geo * geo_feature_scaler, nf.first_layer_mod.layer.weight,
                           nf.first_layer_mod.layer.bias), w0=30.0)
     x = torch.cat([a, g], dim=-1)
     for k, dense in enumerate(nf.network):
         sl = slice(k * H, (k + 1) * H)
-        x = film_sin(F.linear(x, dense.layer.weight, dense.layer.bias), fr[:, sl], phase[:, sl])
-    sigma = F.linear(x, nf.sigma_layer.weight, nf.sigma_layer.bias)
+        x = film_sin(linear(x, dense.layer.weight, dense.layer.bias), fr[:, sl], phase[:, sl])
+    sigma = linear(x, nf.sigma_layer.weight, nf.sigma_layer.bias)
     wc, bc = nf.color_layer_sine.layer.weight, nf.color_layer_sine.layer.bias
     if dirs is None:                       # lock_view_dependence: the direction is the constant (0,0,-1) -> part of the bias
-        c = F.linear(x, wc[:, 3:], bc - wc[:, 2])
+        c = linear(x, wc[:, 3:], bc - wc[:, 2])
     else:
-        c = F.linear(x, wc[:, 3:], bc) + F.linear(dirs, wc[:, :3])
+        c = linear(x, wc[:, 3:], bc) + linear(dirs, wc[:, :3])
     c = film_sin(c, fr[:, -H:], phase[:, -H:])
-    rgb = torch.sigmoid(F.linear(c, nf.color_layer_linear.weight, nf.color_layer_linear.bias))
-    feat = F.linear(c, nf.feature_layer_linear.weight, nf.feature_layer_linear.bias)
+    rgb = torch.sigmoid(linear(c, nf.color_layer_linear.weight, nf.color_layer_linear.bias))
+    feat = linear(c, nf.feature_layer_linear.weight, nf.feature_layer_linear.bias)
     return torch.cat([rgb, feat, sigma], dim=-1)
 
 
@@ -105,7 +108,7 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
     if mode not in ("all", "mixed", "isolated"):
         raise ValueError("invalid map3d_mode")
     conv_in = G.synthesis_input.network[0]
-    x0 = torch.sin(F.linear(_coords(H, W, dev, dt), conv_in.weight.flatten(1), conv_in.bias))      # [P, F]
+    x0 = torch.sin(linear(_coords(H, W, dev, dt), conv_in.weight.flatten(1), conv_in.bias))      # [P, F]
     x = x0.unsqueeze(0).expand(B, P, x0.shape[-1])
 
     def per_pixel(idx):
@@ -118,7 +121,7 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
     shared_up = {}
     if pix:
         w_all = torch.cat([getattr(sn.network[n], s).mlp_shared[0].weight.flatten(1) for n, s in pix], dim=0)
-        up = _resize_channels_last(F.linear(fmap_low, w_all), render_hw, gen_hw)                  # [B, P, 128 * len(pix)]
+        up = _resize_channels_last(linear(fmap_low, w_all), render_hw, gen_hw)                  # [B, P, 128 * len(pix)]
         for k, key in enumerate(pix):
             shared_up[key] = up[..., 128 * k:128 * (k + 1)]
 
@@ -126,12 +129,12 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         sp = getattr(sn.network[blk_name], spade_name)
         ws, bs = sp.mlp_shared[0].weight.flatten(1), sp.mlp_shared[0].bias
         if per_pixel(idx):
-            off = bs if mode == "isolated" else F.linear(fixed, ws, bs)          # isolated: the style is the feature map alone
+            off = bs if mode == "isolated" else linear(fixed, ws, bs)          # isolated: the style is the feature map alone
             a = torch.relu(shared_up[(blk_name, spade_name)] + off)
         else:
-            a = torch.relu(F.linear(fixed, ws, bs))                              # [B,1,128]
-        gamma = F.linear(a, sp.mlp_gamma.weight.flatten(1), sp.mlp_gamma.bias)
-        beta = F.linear(a, sp.mlp_beta.weight.flatten(1), sp.mlp_beta.bias)
+            a = torch.relu(linear(fixed, ws, bs))                              # [B,1,128]
+        gamma = linear(a, sp.mlp_gamma.weight.flatten(1), sp.mlp_gamma.bias)
+        beta = linear(a, sp.mlp_beta.weight.flatten(1), sp.mlp_beta.bias)
         return sp.first_norm, gamma, beta
 
     rgb = None
@@ -139,12 +142,12 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         blk = sn.network[name]
         x_in = x
         h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels)
-        h = F.linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
+        h = linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
         h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels)
-        h = F.linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias)
+        h = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias)
         x = h + x_in if idx >= nb // 2 else h
         if idx >= nb // 2 - 1:
             lin = sn.to_rgbs[name].linear
-            o = F.linear(x, lin.weight.flatten(1), lin.bias)
+            o = linear(x, lin.weight.flatten(1), lin.bias)
             rgb = o if rgb is None else o + rgb
     return rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)

@@ -343,6 +343,16 @@ int h3d_ray_integrate_bwd(const float* field, const float* z_vals, const float* 
                           const float* g_depth, const float* g_weights, float* d_field, int64_t n_rays, int S, int C,
                           int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
+/* Weight gradient of a dense layer of the training path:  dW[Co,Ci] = dY[M,Co]^T X[M,Ci]  (the `grad_weight` torch's
+ * AddmmBackward computes for F.linear; lib/generators/differentiable.py routes every layer with enough rows here).
+ * Split-K over the M rows on the bf16 matrix cores with split operands (fp32-class: 16 mantissa bits per operand, fp32
+ * accumulation).  dY, X fp32 row-major with leading dimensions ldy, ldx (multiples of 4, 16-byte aligned bases);
+ * partial [slices, Co, Ci] fp32 with slices = h3d_wgrad_x3_slices(M, Co, Ci) (or any value >= 1): the caller sums over slices.
+ */
+int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci);
+int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx, int slices,
+                 h3d_stream_t stream);
+
 /* Training-side SPADE (backward of A9): BatchNorm + SPADE modulation + LeakyReLU of one SPADEBlock half
  *     y = lrelu_slope( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )
  * == SPADE2d.forward + the block's activation (lib/components/map3d_layers.py:176-190, 228-233) over channels-last fp32

@@ -149,6 +149,44 @@ def test_ray_integration_backward_vs_oracle(S, C, clamp_mode):
     assert rel_err(fd.grad.cpu(), fr.grad) < 5e-5
 
 
+# ------------------------------------------------------------------ weight-gradient kernel
+
+@pytest.mark.parametrize("M,Co,Ci", [(5000, 256, 256), (70001, 256, 128), (33000, 128, 256), (20000, 64, 64), (17, 32, 36),
+                                     (30000, 420, 420), (40000, 768, 256), (9000, 40, 256)])
+def test_wgrad_x3_vs_fp64(M, Co, Ci):
+    """dW = dY^T X on the split-K bf16 x3 kernel against a float64 product: ragged row counts (not a multiple of the 16-row
+    k-step or of the slice), every tile configuration, widths that are not a multiple of 32, gradients of very different
+    magnitude per column (no scaling is applied: bf16 halves have fp32's exponent range), strided operands."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(M + Co)
+    col_scale = torch.logspace(-9, 1, Co)[torch.randperm(Co, generator=g)]
+    dy = torch.randn(M, Co, generator=g) * col_scale
+    wide = torch.randn(M, Ci + 8, generator=g)
+    x = wide[:, 4:4 + Ci]                                        # row stride Ci + 8, 16-byte aligned start
+    ref = dy.double().t() @ x.double()
+    got = lin.wgrad_x3(dy.to(DEV), wide.to(DEV)[:, 4:4 + Ci])
+    assert got.shape == (Co, Ci)
+    err = ((got.cpu().double() - ref).abs().amax(1) / ref.abs().amax(1)).max()      # per output row: each has its own scale
+    assert float(err) < 2e-4, float(err)
+
+
+def test_linear_with_hip_weight_gradient_matches_autograd():
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 7000, 64, generator=g)
+    w, b = torch.randn(96, 64, generator=g) * 0.1, torch.randn(96, generator=g)
+    p = torch.randn(3, 7000, 96, generator=g)
+    outs = []
+    for fn, dt, dev in ((torch.nn.functional.linear, torch.float64, "cpu"), (lin.linear, torch.float32, DEV)):
+        xx, ww, bb = (t.to(dev, dt).requires_grad_(True) for t in (x, w, b))
+        y = fn(xx, ww, bb)
+        (y * p.to(dev, dt)).sum().backward()
+        outs.append((y.detach().cpu(), xx.grad.cpu(), ww.grad.cpu(), bb.grad.cpu()))
+    assert lin.ENABLED and 3 * 7000 >= lin.MIN_ROWS
+    for a, e, name, tol in zip(outs[1], outs[0], ("y", "dx", "dw", "db"), (1e-5, 1e-5, 1e-4, 1e-5)):
+        assert rel_err(a, e) < tol, name
+
+
 # ------------------------------------------------------------------ SPADE kernels
 
 @pytest.mark.parametrize("B,P,C", [(2, 1300, 32), (3, 513, 40), (2, 700, 30), (2, 2100, 256), (1, 600, 420), (2, 64, 1028)])
@@ -192,8 +230,18 @@ def _build(meta, state, train=True):
     return (G.train() if train else G.eval()), cfg
 
 
+@pytest.fixture(params=["library_wgrad", "hip_wgrad"])
+def wgrad_route(request, monkeypatch):
+    """The tiny fixtures have too few rows for ops.linear to pick the HIP weight-gradient kernel on its own: run the train-step
+    parity once as it would run (library GEMM) and once with every eligible layer forced onto h3d_wgrad_x3."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    if request.param == "hip_wgrad":
+        monkeypatch.setattr(lin, "MIN_ROWS", 0)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["gen_train_mixed", "gen_train_isolated_legacy_pool"])
-def test_train_step_against_reference_autograd(name):
+def test_train_step_against_reference_autograd(name, wgrad_route):
     """Train-mode forward, the gradient of a fixed projection of both outputs w.r.t. EVERY parameter, and the buffers the
     forward overwrites (BatchNorm running statistics, spectral-norm u / v) against the reference module (tolerance 1e-3)."""
     g = load_golden(name)
