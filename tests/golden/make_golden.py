@@ -209,8 +209,9 @@ def hierarchical_fixture(name="gen_tiny_hierarchical", seed=5, n_vertices=128, b
          pdf=dict(bins=bins, weights=w, u=u2, samples=samples))
 
 
-def field_fixture(name, seed, hidden, n_points=96):
-    """COORDCONCATSIREN alone at a width that is / is not a multiple of the MFMA tile."""
+def field_fixture(name, seed, hidden, n_points=96, half_exact=False):
+    """COORDCONCATSIREN alone at a width that is / is not a multiple of the MFMA tile.  half_exact: the weights are rounded to
+    fp16-representable values first and stored as fp16 (the real-width fixtures: 1 - 2.5 MB instead of 2 - 5)."""
     torch.manual_seed(seed)
     net = ref_impl.COORDCONCATSIREN(input_dim=3, latent_dim=hidden, hidden_dim=hidden, geo_feature_dim=31,
                                     output_dim=hidden + 4, feature_dim=hidden, num_blocks=4).eval()
@@ -218,6 +219,8 @@ def field_fixture(name, seed, hidden, n_points=96):
         for p in net.parameters():
             if p.ndim == 1:
                 p.add_(0.05 * torch.randn_like(p))
+            if half_exact:
+                p.copy_(p.half().float())
     B = 2
     pts = torch.rand(B, n_points, 3) * 2 - 1
     geo = torch.rand(B, n_points, 31) * 2 - 1
@@ -226,8 +229,8 @@ def field_fixture(name, seed, hidden, n_points=96):
     phase = torch.randn(B, 4 * hidden)
     with torch.no_grad():
         out = net(pts, freq, phase, geo, dirs, input_scaler=2. / 2.85)
-    save(name, state={"neural_field." + k: v for k, v in net.state_dict().items()},
-         points=pts, geo=geo, dirs=dirs, freq=freq, phase=phase, out=out)
+    state = {"neural_field." + k: (v.half() if half_exact else v) for k, v in net.state_dict().items()}
+    save(name, state=state, points=pts, geo=geo, dirs=dirs, freq=freq, phase=phase, out=out)
 
 
 def integration_fixture():
@@ -368,6 +371,10 @@ def harness_fixture():
 
 
 if __name__ == "__main__":
+    if "--only-real-width" in sys.argv:
+        for hidden in (256, 384, 420):
+            field_fixture(f"field_h{hidden}", seed=100 + hidden, hidden=hidden, n_points=32, half_exact=True)
+        sys.exit(0)
     config_fixture()
     harness_fixture()
     hierarchical_fixture()
@@ -377,6 +384,8 @@ if __name__ == "__main__":
                       render_height=6, render_width=5, gen_height=20, gen_width=12, num_steps=16, nerf_noise=0.0)
     field_fixture("field_h64", seed=3, hidden=64)
     field_fixture("field_h40", seed=4, hidden=40)
+    for hidden in (256, 384, 420):               # the three shipped widths (MAP3DBN512, MAP3DBN, MAP3DBN512L), 64 points each
+        field_fixture(f"field_h{hidden}", seed=100 + hidden, hidden=hidden, n_points=32, half_exact=True)
     integration_fixture()
     geo_fixture()
     ops_fixture()

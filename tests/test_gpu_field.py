@@ -53,6 +53,18 @@ def test_field_golden(name, hidden, engine):
         assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL
 
 
+@pytest.mark.parametrize("hidden,engine", [(256, "f16x3"), (256, "f16x3t"), (256, "f32"), (384, "f16x3t"), (384, "f32"),
+                                           (420, "f16x3t"), (420, "f32")])
+def test_field_reference_vectors_at_shipped_widths(hidden, engine):
+    """The reference module's own output at the widths of MAP3DBN512 / MAP3DBN / MAP3DBN512L (not the oracle's)."""
+    g = load_golden(f"field_h{hidden}")
+    net = make_field({k: v.float() for k, v in g["state"].items()}, hidden, hidden, precision=engine)
+    out = net(g["points"].to(DEV), g["freq"].to(DEV), g["phase"].to(DEV), g["geo"].to(DEV), g["dirs"].to(DEV),
+              input_scaler=2.0 / 2.85)
+    for sl in (slice(0, 3), slice(3, 3 + hidden), slice(3 + hidden, 4 + hidden)):
+        assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL, sl
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", ["gen_tiny_mixed", "gen_tiny_isolated_legacy"])
 def test_field_in_generator_fixture(name, engine):
