@@ -29,6 +29,20 @@ def wgrad_x3(dy, x):
     return partial.sum(dim=0) if slices > 1 else partial[0]
 
 
+def wgrad_narrow(wide, narrow):
+    """wide [M, C], narrow [M, n] (n <= 4) fp32 -> narrow^T wide [n, C] (streams `wide` once; csrc/wgrad_narrow.hip)."""
+    _lib.need_cuda(wide, narrow)
+    M, C = wide.shape
+    n = narrow.shape[1]
+    narrow = narrow.contiguous()
+    lib = _lib.load()
+    nblk = (M + lib.h3d_wgrad_narrow_rows() - 1) // lib.h3d_wgrad_narrow_rows()
+    partial = torch.empty((nblk, n, C), device=wide.device, dtype=torch.float32)
+    rc = lib.h3d_wgrad_narrow(_lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(partial), M, C, wide.stride(0), n, _lib.stream_handle())
+    _lib.check(rc, "h3d_wgrad_narrow")
+    return partial.sum(dim=0)
+
+
 def _rows(t):
     """[..., C] -> a [M, C] view with unit column stride and a row stride that is a multiple of 4, or a contiguous copy."""
     t2 = t.reshape(-1, t.shape[-1])
@@ -53,7 +67,13 @@ class _LinearX3(torch.autograd.Function):
             dx = dy @ w
         dy2 = _rows(dy)
         if ctx.needs_input_grad[1]:
-            dw = wgrad_x3(dy2, _rows(x))
+            Co, Ci = w.shape
+            if Co <= 4:
+                dw = wgrad_narrow(_rows(x), dy2)                     # [Co, Ci]
+            elif Ci <= 4:
+                dw = wgrad_narrow(dy2, _rows(x)).t()                 # [Ci, Co] -> [Co, Ci]
+            else:
+                dw = wgrad_x3(dy2, _rows(x))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0)
         return dx, dw, db
@@ -64,7 +84,8 @@ def linear(x, w, b=None):
     Co, Ci = w.shape
     rows = x.numel() // max(Ci, 1)
     if (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and torch.is_grad_enabled()
-            and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS and Co % 4 == 0 and Ci % 4 == 0
-            and Co >= 32 and Ci >= 32):
+            and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS
+            and ((Co % 4 == 0 and Ci % 4 == 0 and Co >= 32 and Ci >= 32)           # h3d_wgrad_x3
+                 or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):             # h3d_wgrad_narrow (heads, ToRGB, coordinates)
         return _LinearX3.apply(x, w, b)
     return F.linear(x, w, b)

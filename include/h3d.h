@@ -353,6 +353,14 @@ int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci);
 int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx, int slices,
                  h3d_stream_t stream);
 
+/* Weight gradient with one narrow side: out[j][c] = sum_r narrow[r][j] * wide[r][c], j < nn <= 4 (ToRGB 3 x C, density /
+ * colour heads, the coordinate layer transposed).  wide [M, C] fp32 with leading dimension ldw, narrow [M, nn] fp32 contiguous;
+ * partial [ceil(M / h3d_wgrad_narrow_rows()), nn, C] fp32, the caller sums over the first dimension.
+ */
+int h3d_wgrad_narrow_rows(void);
+int h3d_wgrad_narrow(const float* wide, const float* narrow, float* partial, int64_t M, int C, int ldw, int nn,
+                     h3d_stream_t stream);
+
 /* Training-side SPADE (backward of A9): BatchNorm + SPADE modulation + LeakyReLU of one SPADEBlock half
  *     y = lrelu_slope( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )
  * == SPADE2d.forward + the block's activation (lib/components/map3d_layers.py:176-190, 228-233) over channels-last fp32

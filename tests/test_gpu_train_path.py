@@ -170,6 +170,31 @@ def test_wgrad_x3_vs_fp64(M, Co, Ci):
     assert float(err) < 2e-4, float(err)
 
 
+@pytest.mark.parametrize("M,C,n", [(5000, 256, 3), (70001, 420, 1), (3000, 30, 4), (2000, 1028, 2)])
+def test_wgrad_narrow_vs_fp64(M, C, n):
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(M + C)
+    wide, narrow = torch.randn(M, C, generator=g), torch.randn(M, n, generator=g)
+    got = lin.wgrad_narrow(wide.to(DEV), narrow.to(DEV))
+    ref = narrow.double().t() @ wide.double()
+    assert got.shape == (n, C) and rel_err(got.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("Co,Ci", [(3, 64), (1, 96), (64, 3)])
+def test_linear_with_narrow_weight_gradient(Co, Ci):
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(Co * 100 + Ci)
+    x, w, b = torch.randn(2, 9000, Ci, generator=g), torch.randn(Co, Ci, generator=g) * 0.2, torch.randn(Co, generator=g)
+    p = torch.randn(2, 9000, Co, generator=g)
+    res = []
+    for fn, dt, dev in ((torch.nn.functional.linear, torch.float64, "cpu"), (lin.linear, torch.float32, DEV)):
+        xx, ww, bb = (t.to(dev, dt).requires_grad_(True) for t in (x, w, b))
+        (fn(xx, ww, bb) * p.to(dev, dt)).sum().backward()
+        res.append((xx.grad.cpu(), ww.grad.cpu(), bb.grad.cpu()))
+    for a, e, name in zip(res[1], res[0], ("dx", "dw", "db")):
+        assert a.shape == e.shape and rel_err(a, e) < 2e-5, name
+
+
 def test_linear_with_hip_weight_gradient_matches_autograd():
     lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
     g = torch.Generator().manual_seed(2)
