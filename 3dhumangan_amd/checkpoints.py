@@ -9,7 +9,10 @@ The pickled objects name classes under the reference's import paths (`lib.genera
 `lib.components.ema.ExponentialMovingAverage`, ...), which do not exist here.  They are restored WITHOUT the reference on
 the path: an unpickler maps every class under `lib.` / `configs` to a stand-in built on the fly (an nn.Module subclass when
 the pickled state has module dictionaries), which is all `state_dict()` needs; torch's own classes (spectral-norm hooks,
-parameters, tensors) resolve normally.  Only data is taken from the file.
+parameters, tensors) resolve normally.  Only data is taken from the file: every other global a pickle may name is checked
+against an allow-list (torch's tensor / storage / parameter rebuild helpers, torch.nn classes, `collections.OrderedDict`,
+numpy's array reconstruction) and anything else -- `os.system`, `builtins.eval`, ... -- raises `UnpicklingError`, so a
+downloaded `*_generator.pth` cannot run code.  Plain state-dict files go through `weights_only=True` first.
 """
 import io
 import pickle
@@ -19,7 +22,32 @@ import torch.nn as nn
 
 from .lib.components.ema import ExponentialMovingAverage
 
-_REF_PREFIXES = ("lib.", "configs", "lib")
+# globals a trainer checkpoint legitimately names, besides the reference's own classes (which become stand-ins)
+_ALLOWED_EXACT = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "slice"), ("builtins", "complex"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "object"), ("builtins", "getattr"),      # getattr: nn.utils.parametrize / bound-method pickles of torch hooks
+    ("copyreg", "_reconstructor"), ("functools", "partial"), ("_codecs", "encode"),   # _codecs.encode: bytes in protocol 2
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+    ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+}
+_ALLOWED_PREFIXES = ("torch.nn.", "torch.optim.", "torch.distributions.")
+_ALLOWED_TORCH_MODULES = {"torch", "torch._utils", "torch._tensor", "torch.storage", "torch.serialization", "torch.nn",
+                          "torch.nn.parameter", "torch.cuda.amp.grad_scaler", "torch.amp.grad_scaler", "torch.optim"}
+_DENIED_NAMES = {"eval", "exec", "compile", "__import__", "open", "system", "popen", "load", "loads"}
+
+
+def _allowed(module, name):
+    if module == "__builtin__":                      # protocol-2 spelling, which pickle itself maps to builtins
+        module = "builtins"
+    if name in _DENIED_NAMES and (module, name) not in _ALLOWED_EXACT:
+        return False
+    if (module, name) in _ALLOWED_EXACT:
+        return True
+    if module in _ALLOWED_TORCH_MODULES:
+        return True
+    return module.startswith(_ALLOWED_PREFIXES)
 
 
 class _Bag:
@@ -52,8 +80,11 @@ def _stub_for(module, name):
 
 class _RefUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module == "lib" or module.startswith("lib.") or module.startswith("configs"):
+        if module == "lib" or module.startswith("lib.") or module == "configs" or module.startswith("configs."):
             return _stub_for(module, name)
+        if not _allowed(module, name):
+            raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}, which is not on the allow-list of "
+                                         "3dhumangan_amd.checkpoints (only tensors, torch.nn classes and plain containers load)")
         return super().find_class(module, name)
 
 
@@ -68,7 +99,12 @@ class _RefPickleModule:
 
 
 def load_reference_pickle(path, map_location="cpu"):
-    """torch.load of a file written by the reference's trainer, reference classes replaced by stand-ins."""
+    """torch.load of a file written by the reference's trainer, reference classes replaced by stand-ins.  Plain state-dict
+    files load through torch's own restricted loader; only files that hold pickled objects reach the allow-listing unpickler."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError):
+        pass
     return torch.load(path, map_location=map_location, pickle_module=_RefPickleModule, weights_only=False)
 
 

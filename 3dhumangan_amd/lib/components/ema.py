@@ -27,9 +27,11 @@ class ExponentialMovingAverage:
         if self.num_updates is not None:
             self.num_updates += 1
         rate = 1.0 - self.current_decay()
-        live = [p for p in parameters if p.requires_grad]
-        for s, p in zip(self.shadow_params, live):
-            s.sub_(rate * (s - p))                        # same association as the reference: s -= (1-d) * (s - p)
+        live = [p.detach() for p in parameters if p.requires_grad]
+        # same association as the reference, s -= (1-d) * (s - p), as three multi-tensor kernels instead of ~3 per parameter
+        diff = torch._foreach_sub(self.shadow_params, live)
+        torch._foreach_mul_(diff, rate)
+        torch._foreach_sub_(self.shadow_params, diff)
 
     @torch.no_grad()
     def copy_to(self, parameters):

@@ -3,8 +3,8 @@ _train_discriminator, lib/trainers/phase_trainer.py:297-318, 344-430), batch-sha
 
 The fake images come from the HIP generator under no_grad (the reference also generates them under no_grad, :357-379); the
 discriminator runs through torch autograd.  Multi-GPU: every rank holds a batch shard; the ONLY data-path collectives are
-  * the all-gather of the per-sample R1 statistics (parallel.r1_allgather, RCCL over xGMI) so that every rank applies the
-    same global-batch penalty, and
+  * the all-gather of the R1 statistics (parallel.r1_allgather, RCCL over xGMI) so that every rank applies the same
+    global penalty, and
   * the all-reduce of the discriminator gradients (parallel.allreduce_gradients), the exchange DDP does implicitly in the
     reference.
 """
@@ -14,17 +14,26 @@ from ... import parallel
 from . import losses
 
 
-def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta, do_r1=True, r1_mode="per_sample",
-                       distributed=False, grad_clip=None, amp_dtype=None, scaler=None):
+def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta, do_r1=True, r1_mode="reference",
+                       distributed=False, grad_clip=None, amp_dtype=None, scaler=None, update_scaler=False):
     """-> dict of detached scalars.  meta: gan_lambda, segmentation_lambda, r1_lambda, label_dim (config keys).
-    r1_mode "reference" reproduces the reference's penalty on this rank's shard exactly (see losses.py); "per_sample" gathers
-    the per-sample squared gradient norms of ALL ranks and penalises their global mean.  ``amp_dtype`` / ``scaler``: the
-    reference's AMP mode (autocast around the discriminator forwards; the R1 gradient is taken of the SCALED prediction sum and
-    unscaled afterwards, phase_trainer.py:270-283)."""
+
+    ``r1_mode``: "reference" (default, drop-in) is the reference's penalty -- the channel norms of sample 0 of the shard
+    (losses.py); "per_sample" is the textbook statistic, opt-in: with the shipped ``r1_lambda`` it is about C times stronger.
+    Either statistic is all-gathered over the ranks (parallel.r1_allgather) and the penalty is the mean over ALL gathered
+    values: for "reference" that equals the mean over ranks of the per-rank penalties, which is what the reference gets from
+    DDP's gradient averaging; for "per_sample" it is the global-batch mean.
+
+    ``amp_dtype`` / ``scaler``: the reference's AMP mode (autocast around the discriminator forwards; the R1 gradient is taken
+    of the SCALED prediction sum and unscaled afterwards, phase_trainer.py:270-283).  The reference shares ONE GradScaler
+    between both steps and updates it once per iteration, in train_generator (phase_trainer.py:335-338); its D step only
+    calls scaler.step -- so ``update_scaler`` is off by default here."""
     amp = dict(device_type="cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None)
     gan_lambda, seg_lambda = meta["gan_lambda"], meta["segmentation_lambda"]
     optimizer.zero_grad(set_to_none=True)
-    real = real_images.detach().requires_grad_(True)
+    real = real_images.detach()
+    if do_r1:
+        real = real.requires_grad_(True)                 # the input gradient is only needed by the penalty
     with torch.autocast(**amp):
         out_real = D(real, None, 1.0)
         out_fake = D(fake_images.detach(), None, 1.0)
@@ -34,17 +43,17 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
         (out_real["prediction"].sum() + out_fake["prediction"].sum()) * 0
     penalty, r1_scale = real.new_zeros(()), 1.0
     if do_r1:
-        scale = scaler.get_scale() if scaler is not None else 1.0
+        # the loss scale as a device tensor (scaler.scale(1)): no host synchronisation, unlike scaler.get_scale()
+        scale = scaler.scale(real.new_ones(())) if scaler is not None else None
         grad = losses.r1_gradient(real, out_real, gan_lambda, scale=scale)
         stat = losses.r1_statistic(grad, r1_mode)
-        if distributed and r1_mode == "per_sample":
-            stat = parallel.r1_allgather(stat)           # [world * b]; only this rank's slice carries a graph
-            # the global mean already divides this rank's share by world * b; the gradient all-reduce below AVERAGES over
-            # the ranks (right for the per-shard means gan / seg), so the R1 term is pre-multiplied by world
+        if distributed:
+            stat = parallel.r1_allgather(stat)           # all ranks' statistics; only this rank's slice carries a graph
+            # the mean over the gathered values already divides this rank's share by the world size; the gradient all-reduce
+            # below AVERAGES over the ranks (right for the per-shard means gan / seg), so the R1 term is pre-multiplied by it
             r1_scale = float(torch.distributed.get_world_size())
         penalty = 0.5 * meta["r1_lambda"] * stat.mean()
-        if torch.isnan(penalty):
-            penalty = real.new_zeros(())
+        penalty = torch.where(torch.isnan(penalty), torch.zeros_like(penalty), penalty)   # the reference's NaN guard (:291)
     seg = real.new_zeros(())
     if seg_lambda > 0 and out_real["segments"].shape[1] > 0:
         s_real, acc, _ = losses.segmentation_loss(out_real["segments"], gt_segments, meta["label_dim"], meta.get("segmentation_weights"))
@@ -62,7 +71,8 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
         torch.nn.utils.clip_grad_norm_(D.parameters(), grad_clip)
     if scaler is not None:
         scaler.step(optimizer)
-        scaler.update()
+        if update_scaler:
+            scaler.update()
     else:
         optimizer.step()
     return dict(loss=loss.detach(), gan=gan.detach(), r1=penalty.detach(), segmentation=seg.detach())

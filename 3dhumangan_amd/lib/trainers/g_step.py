@@ -52,7 +52,8 @@ def topk_count(meta, d_step_count, batch):
 
 
 def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=None, distributed=False, d_step_count=0,
-                   gen_modal="rgbs", latent_indices=None, generator_kwargs=None, amp_dtype=None, scaler=None):
+                   gen_modal="rgbs", latent_indices=None, generator_kwargs=None, amp_dtype=None, scaler=None,
+                   update_scaler=True):
     """-> dict of detached scalars.  meta: the config dict (gan_lambda, segmentation_lambda, label_dim, grad_clip and every
     forward key of the generator).  ``gt_segments`` [B,H,W] int64 (the rasterised body-part labels of the conditions) feeds
     the segmentation term; the unconditional phase of the reference (latent_lambda = perceptual = photometric = 0 in every
@@ -84,14 +85,15 @@ def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=N
         loss = gan + seg + latent
     (scaler.scale(loss) if scaler is not None else loss).backward()
     if distributed:
-        parallel.allreduce_gradients([p for p in G.parameters() if p.grad is not None], average=True)
+        parallel.allreduce_gradients(G.parameters(), average=True)      # rank-invariant set (see parallel.py)
     if scaler is not None:
         scaler.unscale_(optimizer)
     if meta.get("grad_clip") is not None:
         torch.nn.utils.clip_grad_norm_(G.parameters(), meta["grad_clip"])
     if scaler is not None:
         scaler.step(optimizer)
-        scaler.update()
+        if update_scaler:
+            scaler.update()                # once per iteration, here: the one scaler is shared with the D step (:335-338)
     else:
         optimizer.step()
     if ema is not None:

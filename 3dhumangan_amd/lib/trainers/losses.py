@@ -4,8 +4,9 @@ R1: the reference's `_calculate_r1_regularization` (:259-294) does NOT compute t
 `grad_real = [p * inv_scale for p in grad_real][0]` iterates over the BATCH dimension of the gradient and keeps sample 0, and
 the following `view(size(0), -1).pow(2).sum(1).mean()` then averages the squared norms of that one sample's CHANNELS:
     penalty_ref = 0.5 * r1_lambda * mean_c sum_{h,w} grad[0, c, h, w]^2
-`r1_statistic(..., mode="reference")` reproduces that bit for bit (drop-in parity); mode="per_sample" is the textbook
-||grad_x D||^2 per sample, the statistic that is all-gathered across ranks (parallel.r1_allgather) in the multi-GPU step.
+`r1_statistic(..., mode="reference")` reproduces that bit for bit (drop-in parity, the default of discriminator_step);
+mode="per_sample" is the textbook ||grad_x D||^2 per sample (opt-in: about C times stronger at the same r1_lambda).  In
+the multi-GPU step either statistic is all-gathered across the ranks (parallel.r1_allgather).
 """
 import torch
 import torch.nn.functional as F
@@ -16,7 +17,7 @@ def logistic_d_loss(pred_real, pred_gen, gan_lambda=1.0):
     return gan_lambda * (F.softplus(pred_gen).mean() + F.softplus(-pred_real).mean())
 
 
-def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0, scale=1.0):
+def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0, scale=None):
     """d sum(D(x).prediction) / dx with the graph kept (double backward); softmax(segments) when the GAN head is off.
     ``scale``: the GradScaler's loss scale under fp16 AMP -- the target is scaled before the backward pass (so that half-
     precision gradients inside the discriminator do not underflow) and the result unscaled, as phase_trainer.py:270-283."""
@@ -24,8 +25,10 @@ def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0, scale=1.0):
         target = d_output_real["prediction"].sum()
     else:
         target = torch.softmax(d_output_real["segments"], dim=1).sum()
+    if scale is None or (not torch.is_tensor(scale) and scale == 1.0):
+        return torch.autograd.grad(outputs=target, inputs=d_input_real, create_graph=True)[0]
     grad = torch.autograd.grad(outputs=target * scale, inputs=d_input_real, create_graph=True)[0]
-    return grad if scale == 1.0 else grad * (1.0 / scale)
+    return grad * (1.0 / scale)                     # `scale` may be a device scalar: no host round trip
 
 
 def r1_statistic(grad, mode="per_sample"):

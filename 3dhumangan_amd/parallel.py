@@ -42,31 +42,59 @@ def gather_images(local, total, group=None):
 
 
 def r1_allgather(local_stat, group=None):
-    """The one data-path collective of the training step (BASELINE north_star: "RCCL all-gather over xGMI for the
-    discriminator R1 step only"): all-gather of the per-sample R1 statistics ||grad_x D(x_i)||^2 [b] of every rank's batch
-    shard -> [world * b], identical on every rank, so that every rank applies the SAME global-batch penalty
-    0.5 * r1_lambda * mean(...) (the reference gets a mean over ranks implicitly, through DDP's gradient averaging of
-    per-rank penalties: lib/trainers/phase_trainer.py:259-294, 392).  b floats per rank: latency-bound, one small RCCL
-    all-gather per step.
+    """The one data-path collective of the training step that the north_star names ("RCCL all-gather over xGMI for the
+    discriminator R1 step only"): all-gather of the R1 statistics of every rank's batch shard -- the per-sample
+    ||grad_x D(x_i)||^2 [b_r], or the reference's per-channel norms of the shard's first sample [C] -> one vector with every
+    rank's values, identical on every rank, so that every rank applies the SAME penalty 0.5 * r1_lambda * mean(...) (the
+    reference gets a mean over ranks implicitly, through DDP's gradient averaging of per-rank penalties:
+    lib/trainers/phase_trainer.py:259-294, 392).  A few floats per rank: latency-bound.
+
+    Shards may be uneven (shard_bounds gives earlier ranks the remainder): the lengths are exchanged first and the values
+    travel padded to the longest shard, as gather_images does.
 
     Autograd: this rank's slice of the result keeps its graph (the double-backward through D), the other ranks' slices are
-    constants -- backward of mean(result) therefore yields exactly this rank's share of the global-batch gradient."""
+    constants -- backward of mean(result) therefore yields exactly this rank's share of the global gradient."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_stat
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    parts = [torch.empty_like(local_stat) for _ in range(world)]
-    dist.all_gather(parts, local_stat.detach().contiguous(), group=group)
+    if local_stat.dim() != 1:
+        raise ValueError(f"r1_allgather takes a vector of statistics, got shape {tuple(local_stat.shape)}")
+    n = torch.tensor([local_stat.shape[0]], dtype=torch.int64, device=local_stat.device)
+    lens = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(t.item()) for t in lens]
+    longest = max(lens)
+    pad = local_stat.new_zeros(longest)
+    pad[: lens[rank]] = local_stat.detach()
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    parts = [t[:k] for t, k in zip(parts, lens)]
     parts[rank] = local_stat
     return torch.cat(parts, dim=0)
 
 
 def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=64 << 20):
     """Sum (or average) the .grad of `parameters` over the ranks with a few large flat all-reduces (RCCL ring all-reduce is
-    per-link bound on xGMI: fewer, larger messages -- 64 MB buckets -- instead of one collective per tensor)."""
+    per-link bound on xGMI: fewer, larger messages -- 64 MB buckets -- instead of one collective per tensor).
+
+    The set of tensors that travel is the same on every rank by construction: every ``requires_grad`` parameter that has a
+    gradient on ANY rank (one small MAX all-reduce of the has-gradient flags first); a rank that lacks one of them
+    contributes zeros.  Parameters without a gradient anywhere (a head the loss does not touch, an unused latent pool) stay
+    ``None`` everywhere, as under DDP.  The reduction writes straight into views of the flat bucket: one pack, one collective,
+    one unpack per bucket."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
-    grads = [p.grad for p in parameters if p.grad is not None]
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return
+    dev = params[0].device
+    flags = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    live = [p for p, f in zip(params, flags.tolist()) if f]
+    for p in live:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
     bucket, size = [], 0
 
     def flush():
@@ -76,13 +104,14 @@ def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=64 <<
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat.div_(world)
-        off = 0
-        for g in bucket:
-            g.copy_(flat[off: off + g.numel()].view_as(g))
-            off += g.numel()
+        torch._foreach_copy_(bucket, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in bucket]), bucket)])
         bucket.clear()
 
-    for g in grads:
+    for p in live:
+        g = p.grad
+        if bucket and (g.dtype != bucket[0].dtype):
+            flush()
+            size = 0
         bucket.append(g)
         size += g.numel() * g.element_size()
         if size >= bucket_bytes:

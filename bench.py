@@ -71,29 +71,60 @@ def init_distributed(local, backend="nccl"):
         dist.init_process_group(backend)
 
 
-def timed_loop(step, steps, warmup, dist_on, device="cuda"):
+def timed_loop(step, steps, warmup, dist_on, device="cuda", telemetry=None, step_ms=None):
     """W untimed warm-up steps, then EXACTLY `steps` timed ones bracketed by a barrier + device synchronise on both sides;
-    returns the MAX over ranks of the elapsed seconds (the job is as slow as its slowest rank)."""
+    returns the MAX over ranks of the elapsed seconds (the job is as slow as its slowest rank).  `telemetry` (a
+    _telemetry.Telemetry) samples clocks / power across warm-up and timed region; `step_ms` (a list) receives the HIP-event
+    duration of every timed step (an event per step boundary on the current stream: no synchronisation added)."""
     import torch.distributed as dist
     sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
+    if telemetry is not None:
+        telemetry.start()
     for _ in range(warmup):
         step()
     if dist_on:
         dist.barrier()
     sync()
+    marks = []
+    if telemetry is not None:
+        telemetry.mark("timed_begin")
     t0 = time.perf_counter()
+    if step_ms is not None:
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[0].record()
     for _ in range(steps):
         step()
+        if step_ms is not None:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
     sync()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if telemetry is not None:
+        telemetry.mark("timed_end")
+        telemetry.stop()
+    if step_ms is not None:
+        step_ms.extend(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     par = importlib.import_module("3dhumangan_amd.parallel")
     return par.max_over_ranks(dt, device=device if device == "cuda" else None)
 
 
-def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on):
-    return timed_loop(lambda: G.forward(z, cond, jitter=jitter, **cfg), steps, warmup, dist_on)
+def step_time_summary(step_ms):
+    """min / median / first-5 / last-5 means of the per-step HIP-event times: a clock ramp (DVFS settling to the power
+    budget) shows as first-5 < last-5."""
+    if not step_ms:
+        return None
+    v = sorted(step_ms)
+    k = min(5, len(step_ms))
+    return dict(n=len(step_ms), min=v[0], median=v[len(v) // 2], max=v[-1], mean=sum(v) / len(v),
+                first5_mean=sum(step_ms[:k]) / k, last5_mean=sum(step_ms[-k:]) / k,
+                every=[round(x, 3) for x in (step_ms if len(step_ms) <= 40 else step_ms[::max(1, len(step_ms) // 40)])])
+
+
+def timed_steps(G, cfg, z, cond, jitter, steps, warmup, dist_on, telemetry=None, step_ms=None):
+    return timed_loop(lambda: G.forward(z, cond, jitter=jitter, **cfg), steps, warmup, dist_on, telemetry=telemetry,
+                      step_ms=step_ms)
 
 
 def discriminator_step_bench(a, rank, world, dist_on, dev):
@@ -154,7 +185,7 @@ def train_step_bench(a, rank, world, dist_on, dev):
     opt_g = trainers.make_generator_optimizer(G, meta)
     ema = ema_mod.ExponentialMovingAverage(G.parameters(), decay=0.999)
     amp_dtype = {"none": None, "fp16": torch.float16, "bf16": torch.bfloat16}[a.amp]
-    scalers = (torch.amp.GradScaler("cuda"), torch.amp.GradScaler("cuda")) if a.amp == "fp16" else (None, None)
+    scaler = torch.amp.GradScaler("cuda") if a.amp == "fp16" else None      # ONE scaler for both steps, as base_trainer
     g = torch.Generator().manual_seed(7 + rank)
     real = torch.randn(a.batch, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
     gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (a.batch, 512, 256), generator=g).to(dev)
@@ -167,10 +198,10 @@ def train_step_bench(a, rank, world, dist_on, dev):
         with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
             fake = G(z, cond, jitter=jitter, **fwd)["rgbs"].float()
         d = trainers.discriminator_step(D, opt_d, real, fake, gt, meta, do_r1=True, distributed=dist_on,
-                                        grad_clip=cfg.get("grad_clip", 10.0), amp_dtype=amp_dtype, scaler=scalers[0])
+                                        grad_clip=cfg.get("grad_clip", 10.0), amp_dtype=amp_dtype, scaler=scaler)
         e[1].record()
         gs = trainers.generator_step(G, D, opt_g, z, cond, meta, gt_segments=gt, ema=ema, distributed=dist_on,
-                                     generator_kwargs=dict(jitter=jitter), amp_dtype=amp_dtype, scaler=scalers[1])
+                                     generator_kwargs=dict(jitter=jitter), amp_dtype=amp_dtype, scaler=scaler)
         e[2].record()
         ev["d"].append((e[0], e[1]))
         ev["g"].append((e[1], e[2]))
@@ -445,6 +476,7 @@ def main():
                     help="trainstep: autocast type of the library GEMMs / convolutions (the reference's AMP mode is fp16; bf16 "
                          "is there for measurement only: too coarse for the sine layers, and MIOpen's bf16 convolutions are slow)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample clocks / power around the timed region")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
     a = ap.parse_args()
@@ -472,7 +504,11 @@ def main():
     G, cfg = build_generator(a.config, (H, W), render, a.samples, dev)
     z, cond, jitter = make_inputs(cfg, a.batch, dev, seed=1234 + rank)
     G.stage_timer = StageTimer()
-    dt = timed_steps(G, cfg, z, cond, jitter, a.steps, a.warmup, dist_on)
+    tel = None
+    if rank == 0 and not a.no_telemetry:
+        tel = importlib.import_module("3dhumangan_amd._telemetry").Telemetry(local)
+    step_ms = []
+    dt = timed_steps(G, cfg, z, cond, jitter, a.steps, a.warmup, dist_on, telemetry=tel, step_ms=step_ms)
     torch.cuda.synchronize()
     # drop warm-up samples: keep the last `steps` events of each stage
     stage_ms = {}
@@ -545,6 +581,8 @@ def main():
                                     ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
         "kernels": kernels,
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
+        "step_ms": step_time_summary(step_ms),
+        "telemetry": tel.report() if tel is not None else None,
         "extra": extra,
     }
     out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, sorted({0, a.batch - 1}))

@@ -91,3 +91,23 @@ def test_ema_update_rule():
     assert torch.equal(p.detach(), torch.tensor([4.0, 5.0]))
     with pytest.raises(ValueError):
         ema_mod.ExponentialMovingAverage([p], decay=1.5)
+
+
+def test_unpickler_refuses_globals_outside_the_allow_list(tmp_path):
+    """A downloaded checkpoint must not be able to run code: a pickle that names os.system (or any global that is neither a
+    reference class, a torch tensor / module helper nor a plain container) is refused, not resolved."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+
+    path = tmp_path / "evil_generator.pth"
+    torch.save({"w": torch.zeros(2), "payload": Evil()}, str(path))
+    with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+        ck.load_reference_pickle(str(path))
+    # a plain state-dict file still loads (through torch's weights_only loader)
+    ok = tmp_path / "ok_state_dict.pth"
+    torch.save({"w": torch.arange(3.0)}, str(ok))
+    assert torch.equal(ck.load_reference_pickle(str(ok))["w"], torch.arange(3.0))

@@ -75,23 +75,33 @@ def _r1_worker(rank, world, port, q):
         torch.manual_seed(3)                                   # same weights and same global batch on every rank
         D = disc.UNetDiscriminator(latent_dim=8, gen_height=16, gen_width=8, label_dim=2, discriminator_blocks=2).eval()
         g = torch.Generator().manual_seed(4)
-        total = 4
+        total = 5                                              # uneven shards: 3 + 2
         real, fake = torch.randn(total, 3, 16, 8, generator=g), torch.randn(total, 3, 16, 8, generator=g)
         gt = torch.zeros(total, 16, 8, dtype=torch.long)
         meta = dict(gan_lambda=1.0, segmentation_lambda=0.0, r1_lambda=10.0, label_dim=2)
         # single-process truth on the whole batch
         ref = disc.UNetDiscriminator(latent_dim=8, gen_height=16, gen_width=8, label_dim=2, discriminator_blocks=2).eval()
         ref.load_state_dict(D.state_dict())
-        r_ref = trainers.discriminator_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), real, fake, gt, meta)
+        r_ref = trainers.discriminator_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), real, fake, gt, meta,
+                                            r1_mode="per_sample")
         # sharded step: gathered statistics identical on both ranks, gradients equal to the whole-batch ones
         lo, hi = par.shard_bounds(total, rank, world)
         stat = torch.arange(lo, hi, dtype=torch.float32, requires_grad=True) * 1.0
         gathered = par.r1_allgather(stat)
         assert torch.equal(gathered.detach(), torch.arange(total, dtype=torch.float32))
         gathered.mean().backward()                              # only the local slice carries a graph
-        r_loc = trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real[lo:hi], fake[lo:hi], gt[lo:hi], meta,
-                                            distributed=True)
+        # R1 only (gan / segmentation are per-shard means: with uneven shards their rank average is not the whole-batch mean)
+        meta_r1 = dict(meta, gan_lambda=1.0)
+        r_loc = trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real[lo:hi], fake[lo:hi], gt[lo:hi], meta_r1,
+                                            distributed=True, r1_mode="per_sample")
         assert abs(float(r_loc["r1"]) - float(r_ref["r1"])) <= 1e-5 * abs(float(r_ref["r1"])), (r_loc["r1"], r_ref["r1"])
+        # even shards (the first 4 samples): every discriminator gradient equals the single-process whole-batch gradient
+        ref.zero_grad(set_to_none=True)
+        trainers.discriminator_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), real[:4], fake[:4], gt[:4], meta,
+                                    r1_mode="per_sample")
+        lo, hi = par.shard_bounds(4, rank, world)
+        trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real[lo:hi], fake[lo:hi], gt[lo:hi], meta,
+                                    distributed=True, r1_mode="per_sample")
         worst = 0.0
         checked = 0
         for (n, a), (_, b) in zip(D.named_parameters(), ref.named_parameters()):
@@ -100,6 +110,32 @@ def _r1_worker(rank, world, port, q):
                 worst = max(worst, float((a.grad - b.grad).abs().max() / b.grad.abs().max().clamp_min(1e-12)))
                 checked += 1
         assert checked > 20 and worst < 1e-4, (checked, worst)
+        # the default ("reference") statistic, sharded: the penalty is the rank mean of the per-rank reference penalties and
+        # the gradients the rank mean of the per-rank gradients -- what DDP's averaging gives the reference
+        per_rank = []
+        for r in range(world):
+            a0, a1 = par.shard_bounds(4, r, world)
+            ref.zero_grad(set_to_none=True)
+            rr = trainers.discriminator_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), real[a0:a1], fake[a0:a1], gt[a0:a1], meta)
+            per_rank.append((float(rr["r1"]), {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}))
+        r_def = trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real[lo:hi], fake[lo:hi], gt[lo:hi], meta,
+                                            distributed=True)
+        want = sum(v for v, _ in per_rank) / world
+        assert abs(float(r_def["r1"]) - want) <= 1e-5 * abs(want), (r_def["r1"], want)
+        worst = 0.0
+        for n, p in D.named_parameters():
+            if p.grad is not None:
+                w = sum(gr[n] for _, gr in per_rank) / world
+                worst = max(worst, float((p.grad - w).abs().max() / w.abs().max().clamp_min(1e-12)))
+        assert worst < 1e-4, worst
+        # rank-variant gradient sets: a parameter with a gradient on rank 0 only still travels (zeros from the others), one
+        # without a gradient anywhere stays None
+        a, b, c = (torch.nn.Parameter(torch.ones(3)) for _ in range(3))
+        a.grad = torch.full((3,), float(rank + 1))
+        if rank == 0:
+            b.grad = torch.full((3,), 4.0)
+        par.allreduce_gradients([a, b, c], average=True)
+        assert torch.equal(a.grad, torch.full((3,), 1.5)) and torch.equal(b.grad, torch.full((3,), 2.0)) and c.grad is None
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
