@@ -26,6 +26,12 @@
 //   fused A6    the feature head is evaluated with the operands swapped (rows = samples), so the weighted sum over
 //               the samples of a ray is a sum over accumulator registers; compositing weights come from a
 //               segmented 32-lane product scan (S = 8..32: 32/S rays per wave step; S = 64, 128: carry).
+//
+// X2 variant (template parameter, h3d_neural_field_x2 / h3d_render_fused_x2): the hidden-layer contractions (FiLM 0-3, the
+// hidden part of the colour layer, the feature head) run in the "x2" arithmetic of x3_common.hpp -- one f16 product + one
+// block-scaled fp6 product for the two cross terms -- which halves the matrix-pipe time and the energy per contraction; the
+// input layers (K = 3 / 31 / view direction) and the 1-row heads stay on three f16 products.  Error model and budget:
+// tests/x2_emulation.py, tests/test_x2_error_model_cpu.py (2e-5 at the operator boundary at width 256).
 #include "x3_common.hpp"
 #include <string.h>
 #include <math.h>
@@ -58,12 +64,12 @@ enum { ST_COORD = 0, ST_GEO, ST_FILM0, ST_FILM1, ST_FILM2, ST_FILM3, ST_COLOR, S
 enum { W_COORD = 0, W_F0A, W_GEO, W_F0B, W_F1, W_F2, W_F3, W_COLOR, W_FEAT, W_COUNT };
 
 struct LayoutX3 {        // offsets in BYTES into the blob (all multiples of 16)
-    int HdP, FP, NT, KS, stages;
+    int HdP, FP, NT, KS, stages, head_planes;
     int64_t w[W_COUNT];
     int64_t inv_scale;   // float[W_COUNT]: 1 / (weight scale * input scale) per matrix
     int64_t bias;        // float[ST_COUNT][HdP]
     int64_t b_feat;      // float[FP]
-    int64_t head_w;      // f16 [4 heads: sigma, r, g, b][2 hi/lo][KS][2 halves][8]  (A-fragment rows of the head tile)
+    int64_t head_w;      // f16 [4 heads: sigma, r, g, b][planes: hi, lo (, hi * 2^-12: x2)][KS][2 halves][8]  (A-fragment rows of the head tile)
     int64_t head_inv;    // float[4] 1/(weight scale * kSA)
     int64_t head_b;      // float[4]
     int64_t total;
@@ -73,8 +79,9 @@ int tiles_for(int Hd) { int nt = 4; while (nt * 32 < Hd) nt *= 2; return nt; }  
 
 int stages_of(int wi, int KS) { return wi == W_COORD ? 1 : wi == W_GEO ? 2 : wi == W_COLOR ? KS + 1 : KS; }
 
-LayoutX3 make_layout(int Hd, int F) {
+LayoutX3 make_layout(int Hd, int F, bool x2 = false) {
     LayoutX3 L;
+    L.head_planes = x2 ? 3 : 2;
     const int w = Hd > F ? Hd : F;
     L.NT = tiles_for(w);
     L.HdP = L.FP = L.NT * 32;
@@ -87,7 +94,7 @@ LayoutX3 make_layout(int Hd, int F) {
     L.inv_scale = take(4 * W_COUNT);
     L.bias = take(4 * (int64_t)ST_COUNT * L.HdP);
     L.b_feat = take(4 * (int64_t)L.FP);
-    L.head_w = take(2 * (int64_t)4 * 2 * L.KS * 16);
+    L.head_w = take(2 * (int64_t)4 * L.head_planes * L.KS * 16);
     L.head_inv = take(16);
     L.head_b = take(16);
     L.total = o;
@@ -132,6 +139,19 @@ __device__ __forceinline__ unsigned split2_act(float a, float b, unsigned& lo) {
     return __builtin_bit_cast(unsigned, h2);
 }
 
+// x2: the lo halves travel multiplied by rho = 2^12 (they only feed the fp6 conversion and the heads' scaled plane)
+__device__ __forceinline__ unsigned split2_act_x2(float a, float b, unsigned& lo) {
+    const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
+    const float fa = (float)h2.x, fb = (float)h2.y;
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(la) : "v"(la), "v"(kX2Rho));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(lb) : "v"(lb), "v"(kX2Rho));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{la, lb}, half2v));
+    return __builtin_bit_cast(unsigned, h2);
+}
+
 // two fp32 (already scaled) -> packed f16 hi halves (returned) and packed f16 lo halves
 __device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {
     const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
@@ -163,11 +183,12 @@ __device__ __forceinline__ void set_word(half8& f, int w, unsigned v) {
 // (FiLM affine, bias, de-scaling and 1/2pi folded into the two LDS tables), split to f16 hi/lo.  The work of one
 // 32-feature tile is cut into eight chunks of two activations so that the consuming GEMM can hide one chunk behind
 // each of the eight tile-pair sections that precede the tile's first use; table values are fetched one chunk ahead.
-template <int NT>
+template <int NT, bool X2 = false>
 struct FilmProducer {
     f32x16 (&src)[NT];
     half8 (&xh)[2 * NT + 1];
     half8 (&xl)[2 * NT + 1];
+    i32x8 (&b6)[NT];          // x2: the fp6 activation record of each K-tile
     const float* tab;         // LDS [HdP/2][4]: A1[n], A1[n+1], A0[n], A0[n+1]
     int h;
     f32x4 tv;
@@ -192,10 +213,17 @@ struct FilmProducer {
         if constexpr (C < 7) tv = ld4(tab + 2 * chan<TILE, C + 1>());
         else if constexpr (TILE + 1 < NT) tv = ld4(tab + 2 * chan<TILE + 1, 0>());
         unsigned lo;
-        const unsigned hi = split2_act(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo);
+        const unsigned hi = X2 ? split2_act_x2(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo)
+                               : split2_act(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo);
         // registers 4*rg + 2*(C%2) + {0, 1} of the tile = k-step 2*TILE + (rg >> 1), word 2*(rg & 1) + C%2
         set_word(xh[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), hi);
         set_word(xl[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), lo);
+    }
+    // x2: fp6 record of K-tile TILE from its four finished f16 fragments (runs in the first section of k-step 2 * TILE of the
+    // consuming GEMM; the record is first used one k-step later)
+    template <int TILE>
+    __device__ __forceinline__ void convert() {
+        if constexpr (X2) b6[TILE] = x2_record(xl[2 * TILE], xl[2 * TILE + 1], xh[2 * TILE], xh[2 * TILE + 1]);
     }
 };
 
@@ -221,22 +249,25 @@ __device__ __forceinline__ void next_tile0(NEXT& next) {
 // (next_tile0), tile t+1 runs inside the sections of k-steps 2t, 2t+1, and tile 0 of `next` inside the last k-step.
 // HEAD: the four head rows (sigma, r, g, b) ride along as a ninth tile accumulated in hacc (feature-major: row = head,
 // column = sample), A fragments from LDS, one k-step of look-ahead.
-template <int NT, int KSG, bool ZERO, bool SWAP, bool HEAD, typename RING, typename PROD, typename NEXT>
-__device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1], half8 (&xl)[2 * NT + 1], RING& ring, PROD& prod,
-                                      NEXT& next, f32x16& hacc, const unsigned char* head_lds, int lane) {
-    constexpr int KS = 2 * NT, P = NT / 2, W = NT, PER = 8 / W;
-    u32x4 hwh, hwl;
-    // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo: [head][plane][KS][half][16 B]
-    const unsigned char* hbase = head_lds + ((((lane & 3) * 2) * KS) * 2 + (lane >> 5)) * 16;
+template <int NT, int KSG, bool ZERO, bool SWAP, bool HEAD, bool X2, typename RING, typename PROD, typename NEXT>
+__device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1], half8 (&xl)[2 * NT + 1], i32x8 (&b6)[NT], RING& ring,
+                                      PROD& prod, NEXT& next, f32x16& hacc, const unsigned char* head_lds, int lane) {
+    constexpr int KS = 2 * NT, P = NT / 2, W = NT, PER = 8 / W, PL = X2 ? 3 : 2;
+    u32x4 hwh, hwl, hws;
+    // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo (/ hi * 2^-12: the x2 lo
+    // fragments are pre-multiplied by 2^12): [head][plane][KS][half][16 B]
+    const unsigned char* hbase = head_lds + ((((lane & 3) * PL) * KS) * 2 + (lane >> 5)) * 16;
     auto load_head = [&](int s) __attribute__((always_inline)) {
         hwh = *reinterpret_cast<const u32x4*>(hbase + s * 32);
         hwl = *reinterpret_cast<const u32x4*>(hbase + (KS + s) * 32);
+        if constexpr (X2) hws = *reinterpret_cast<const u32x4*>(hbase + (2 * KS + s) * 32);
     };
     if constexpr (HEAD) load_head(0);
     __builtin_amdgcn_sched_barrier(0);
-    gemm_x3_roll<F16, NT, KSG, 2 * NT + 1, SWAP, kLookF, kValuF, ZERO>(dst, xh, xl, ring, [&](auto gc) __attribute__((always_inline)) {
+    auto hook = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int t = g / W + 1, j = g % W;
+        if constexpr (X2 && j == 0 && t - 1 < NT) prod.template convert<t - 1>();      // first section of k-step 2 * (t - 1)
         if constexpr (t < NT) {
             static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
         }
@@ -251,12 +282,19 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
                 } else {
                     hacc = F16::mfma(ah, xh[s], hacc);
                 }
-                hacc = F16::mfma(ah, xl[s], hacc);
+                hacc = F16::mfma(X2 ? __builtin_bit_cast(half8, hws) : ah, xl[s], hacc);
                 hacc = F16::mfma(al, xh[s], hacc);
             }
             if constexpr (p == 1 % P && s + 1 < KS) load_head(s + 1);
         }
-    });
+    };
+    if constexpr (X2) {
+        constexpr int KS3 = KSG - KS;
+        const half8 tail[1] = {xl[KS]};                 // view direction k-step: assembled from memory, lo unscaled
+        gemm_x2_roll<NT, KS, KS3, 2 * NT + 1, NT, SWAP, kLookF, kValuF, ZERO>(dst, xh, b6, tail, ring, hook);
+    } else {
+        gemm_x3_roll<F16, NT, KSG, 2 * NT + 1, SWAP, kLookF, kValuF, ZERO>(dst, xh, xl, ring, hook);
+    }
 }
 
 // Input GEMM (1 or 2 k-steps, fragments prebuilt) with the tile-0 work of the layer that consumes its result.
@@ -271,9 +309,12 @@ __device__ __forceinline__ void input_layer(f32x16 (&dst)[NT], const half8 (&ih)
 struct NoProducer {
     __device__ __forceinline__ void prime() {}
     template <int TILE, int C> __device__ __forceinline__ void chunk() {}
+    template <int TILE> __device__ __forceinline__ void convert() {}
 };
 
-template <int NT, bool FUSED>
+constexpr int kRingX2 = 8;       // x2: one more buffer, the refill lags one stage (WeightRing LAG = 1)
+
+template <int NT, bool FUSED, bool X2>
 __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     float* tfeat0 = tab0 + ST_COUNT * 2 * HdP;          // [HdP] feature-head bias
     float* scratch = tfeat0 + HdP;                      // [4 waves][64]: compositing weights, background terms
     unsigned char* head0 = reinterpret_cast<unsigned char*>(scratch + 4 * 64);          // head A-fragment rows
-    unsigned char* ring_lds = head0 + 4 * 2 * KS * 32;                                   // [ring depth][NT*2 KB]
+    unsigned char* ring_lds = head0 + 4 * (X2 ? 3 : 2) * KS * 32;                        // [ring depth][NT*2 KB]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -323,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         for (int idx = t; idx < HdP; idx += 256) tfeat0[idx] = idx < F ? bf[idx] : 0.f;
         const u32x4* hsrc = reinterpret_cast<const u32x4*>(blob + L.head_w);
         u32x4* hdst = reinterpret_cast<u32x4*>(head0);
-        for (int idx = t; idx < 4 * 2 * KS * 2; idx += 256) hdst[idx] = hsrc[idx];
+        for (int idx = t; idx < 4 * (X2 ? 3 : 2) * KS * 2; idx += 256) hdst[idx] = hsrc[idx];
     }
     __syncthreads();
 
@@ -347,7 +388,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     __syncthreads();
     H3D_TRACE(0);
 #endif
-    WeightRing<NT> ring;
+    typedef typename std::conditional<X2, WeightRing<NT, kRingX2, 1>, WeightRing<NT>>::type Ring;
+    Ring ring;
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
 
     float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
@@ -373,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 
         H3D_TRACE(6);
         half8 xh[KS + 1], xl[KS + 1];
+        i32x8 b6[NT];
         f32x16 hacc;
         NoProducer none;
 
@@ -397,32 +440,32 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         }
         // ---- the layer chain.  Producers (FiLM epilogue of a layer's source accumulators) are created up front because the
         //      tile-0 chunks of producer l+1 run inside the last k-step of GEMM l.
-        FilmProducer<NT> p_coord{Y, xh, xl, tab + ST_COORD * 2 * HdP, h};
-        FilmProducer<NT> p_geo{Y, xh, xl, tab + ST_GEO * 2 * HdP, h};
-        FilmProducer<NT> p_f0{X, xh, xl, tab + ST_FILM0 * 2 * HdP, h};
-        FilmProducer<NT> p_f1{Y, xh, xl, tab + ST_FILM1 * 2 * HdP, h};
-        FilmProducer<NT> p_f2{X, xh, xl, tab + ST_FILM2 * 2 * HdP, h};
-        FilmProducer<NT> p_f3{Y, xh, xl, tab + ST_FILM3 * 2 * HdP, h};
-        FilmProducer<NT> p_col{X, xh, xl, tab + ST_COLOR * 2 * HdP, h};
+        FilmProducer<NT, X2> p_coord{Y, xh, xl, b6, tab + ST_COORD * 2 * HdP, h};
+        FilmProducer<NT, X2> p_geo{Y, xh, xl, b6, tab + ST_GEO * 2 * HdP, h};
+        FilmProducer<NT, X2> p_f0{X, xh, xl, b6, tab + ST_FILM0 * 2 * HdP, h};
+        FilmProducer<NT, X2> p_f1{Y, xh, xl, b6, tab + ST_FILM1 * 2 * HdP, h};
+        FilmProducer<NT, X2> p_f2{X, xh, xl, b6, tab + ST_FILM2 * 2 * HdP, h};
+        FilmProducer<NT, X2> p_f3{Y, xh, xl, b6, tab + ST_FILM3 * 2 * HdP, h};
+        FilmProducer<NT, X2> p_col{X, xh, xl, b6, tab + ST_COLOR * 2 * HdP, h};
         // coordinate first layer -> Y ; FiLM 0, coordinate half: X = W0a * sin(30 * (Wc p + bc))
         {
             const half8 ih[2] = {ch, ch}, il[2] = {cl, cl};
             input_layer<NT, 1>(Y, ih, il, ring, p_coord);
         }
         pin_agpr<NT>(Y);
-        layer<NT, KS, true, false, false>(X, xh, xl, ring, p_coord, none, hacc, head_lds, lane);
+        layer<NT, KS, true, false, false, X2>(X, xh, xl, b6, ring, p_coord, none, hacc, head_lds, lane);
         pin_agpr<NT>(X);
         // geometry first layer -> Y ; FiLM 0, geometry half: X += W0b * sin(30 * (Wg g + bg))
         input_layer<NT, 2>(Y, gh, gl, ring, p_geo);
         pin_agpr<NT>(X); pin_agpr<NT>(Y);
-        layer<NT, KS, false, false, false>(X, xh, xl, ring, p_geo, p_f0, hacc, head_lds, lane);
+        layer<NT, KS, false, false, false, X2>(X, xh, xl, b6, ring, p_geo, p_f0, hacc, head_lds, lane);
         pin_agpr<NT>(X);
         // FiLM 1..3
-        layer<NT, KS, true, false, false>(Y, xh, xl, ring, p_f0, p_f1, hacc, head_lds, lane);
+        layer<NT, KS, true, false, false, X2>(Y, xh, xl, b6, ring, p_f0, p_f1, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
-        layer<NT, KS, true, false, false>(X, xh, xl, ring, p_f1, p_f2, hacc, head_lds, lane);
+        layer<NT, KS, true, false, false, X2>(X, xh, xl, b6, ring, p_f1, p_f2, hacc, head_lds, lane);
         pin_agpr<NT>(X);
-        layer<NT, KS, true, false, false>(Y, xh, xl, ring, p_f2, p_f3, hacc, head_lds, lane);
+        layer<NT, KS, true, false, false, X2>(Y, xh, xl, b6, ring, p_f2, p_f3, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
         // colour FiLM: X = Wc[:, 3:] * film3(Y) + Wc[:, :3] * dir  (+ density head on film3(Y))
         {
@@ -438,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             }
             split8(v, kSA, xh[KS], xl[KS]);
         }
-        layer<NT, KS + 1, true, false, true>(X, xh, xl, ring, p_f3, p_col, hacc, head_lds, lane);
+        layer<NT, KS + 1, true, false, true, X2>(X, xh, xl, b6, ring, p_f3, p_col, hacc, head_lds, lane);
         pin_agpr<NT>(X);
         H3D_TRACE(7);
         // density of this lane's sample: head row 0 = accumulator register 0 of the lower lane half
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         }
 
         // ---- feature head, sample-major accumulator: Y = film_color(X)^T * Wf^T  (+ colour heads on film_color(X))
-        layer<NT, KS, true, true, true>(Y, xh, xl, ring, p_col, none, hacc, head_lds, lane);
+        layer<NT, KS, true, true, true, X2>(Y, xh, xl, b6, ring, p_col, none, hacc, head_lds, lane);
         pin_agpr<NT>(Y);
         float rgb[3];
         {
@@ -592,23 +635,30 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 }
 
 size_t lds_bytes(const LayoutX3& L) {
-    return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64) + (size_t)4 * 2 * L.KS * 32 +
-           H3D_RING_DEPTH * (size_t)L.NT * 2048;
+    return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64) + (size_t)4 * L.head_planes * L.KS * 32 +
+           (L.head_planes == 3 ? kRingX2 : H3D_RING_DEPTH) * (size_t)L.NT * 2048;
 }
 
-template <int NT, bool FUSED>
+template <int NT, bool FUSED, bool X2>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED>));
+    H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED, X2>));
     h3d::pre_launch();
-    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
-    return h3d::launch_status(FUSED ? "h3d_render_fused_x3" : "h3d_neural_field_x3");
+    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    return h3d::launch_status(FUSED ? (X2 ? "h3d_render_fused_x2" : "h3d_render_fused_x3") : (X2 ? "h3d_neural_field_x2" : "h3d_neural_field_x3"));
 }
 
 template <bool FUSED>
 int launch(const Args& A, int B, int64_t groups, hipStream_t st) {
+    if (A.L.head_planes == 3) {
+        switch (A.L.NT) {
+            case 4: return launch_one<4, FUSED, true>(A, B, groups, st);
+            case 8: return launch_one<8, FUSED, true>(A, B, groups, st);
+            default: break;
+        }
+    }
     switch (A.L.NT) {
-        case 4: return launch_one<4, FUSED>(A, B, groups, st);
-        case 8: return launch_one<8, FUSED>(A, B, groups, st);
+        case 4: return launch_one<4, FUSED, false>(A, B, groups, st);
+        case 8: return launch_one<8, FUSED, false>(A, B, groups, st);
         default:
             h3d::set_error("x3 field kernel: width %d exceeds the 256 this engine keeps in registers "
                            "(use the fp32 engine, h3d_neural_field / h3d_render_fused)", A.L.HdP);
@@ -686,6 +736,65 @@ void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int 
                 }
 }
 
+// ---- x2 packing: fp6 (e2m3) codes and block scales
+float e2m3_value(unsigned c) {
+    const int e = (c >> 3) & 3, m = c & 7;
+    const float r = e ? ldexpf(1.f + m / 8.f, e - 1) : m / 8.f;
+    return (c & 32) ? -r : r;
+}
+unsigned e2m3_code(float v) {            // round-to-nearest-even on the code grid, saturating at 7.5
+    const unsigned sign = v < 0.f ? 32u : 0u;
+    const float a = fminf(fabsf(v), 7.5f);
+    const float step = a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f;
+    const float q = nearbyintf(a / step) * step;         // default rounding mode: ties to even; spacing doubles exactly at 2 and 4
+    unsigned c;
+    if (q < 2.f) c = (unsigned)(q * 8.f);                // 0 .. 15: subnormals 0..7 and [1, 2)
+    else if (q < 4.f) c = 16u + (unsigned)((q - 2.f) * 4.f);
+    else c = 24u + (unsigned)((q - 4.f) * 2.f);
+    return sign | c;
+}
+
+// W [n_out, ld] row-major; K range [in_begin, in_begin + in_count) in accumulator order over KSm (even) k-steps ->
+// stages [KSm][NT][hi fragment 1 KiB | fp6 half-record 1 KiB], weights scaled by `scale` (the f16 scale of the matrix)
+void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, unsigned char* dst) {
+    for (int T = 0; T < KSm / 2; ++T)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int nn = 32 * nt + (lane & 31), hh = lane >> 5;
+                float hi[16], lo[16], mx = 0.f;
+                for (int j = 0; j < 2; ++j)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = acc_k(2 * T + j, hh, e);
+                        float v = 0.f;
+                        if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+                        const uint16_t h16 = f32_to_f16_rn(v);
+                        hi[8 * j + e] = f16_to_f32(h16);
+                        lo[8 * j + e] = v - hi[8 * j + e];
+                        mx = fmaxf(mx, fabsf(hi[8 * j + e]));
+                        uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2) * 1024);
+                        hd[lane * 8 + e] = h16;
+                    }
+                // block scale alpha = 2^ea with |hi| * alpha <= 3.75; the instruction multiplies the codes by 2^(byte - 127) = 1 / alpha
+                int ea = mx > 0.f ? (int)floorf(log2f(3.75f / mx)) : 0;
+                if (ea > 100) ea = 100;
+                if (ea < -100) ea = -100;
+                const float alpha = ldexpf(1.f, ea);
+                unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int sl = 0; sl < 32; ++sl) {
+                    const float v = sl < 16 ? hi[sl] * alpha : lo[sl - 16] * alpha * kX2Rho;
+                    const uint64_t code = e2m3_code(v);
+                    const int bit = 6 * sl;
+                    rec[bit / 32] |= (unsigned)(code << (bit & 31));
+                    if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
+                }
+                rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+                for (int j = 0; j < 2; ++j) {
+                    unsigned* cd = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2 + 1) * 1024);
+                    for (int d = 0; d < 4; ++d) cd[lane * 4 + d] = rec[4 * j + d];
+                }
+            }
+}
+
 }  // namespace
 
 extern "C" int h3d_field_x3_layout(int Hd, int F, int64_t* out, int n_out) {
@@ -705,10 +814,10 @@ extern "C" int64_t h3d_field_pack_x3_size(int Hd, int F) {
     return make_layout(Hd, F).total;
 }
 
-extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob_) {
-    H3D_REQUIRE(p && blob_, "h3d_field_pack_x3: null pointer");
-    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_pack_x3: widths up to 256 (got %d, %d)", Hd, F);
-    const LayoutX3 L = make_layout(Hd, F);
+static int field_pack(const h3d_field_params* p, int Hd, int F, void* blob_, bool x2) {
+    H3D_REQUIRE(p && blob_, "h3d_field_pack_x3 / _x2: null pointer");
+    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_pack_x3 / _x2: widths up to 256 (got %d, %d)", Hd, F);
+    const LayoutX3 L = make_layout(Hd, F, x2);
     unsigned char* blob = static_cast<unsigned char*>(blob_);
     memset(blob, 0, L.total);
     float* invs = reinterpret_cast<float*>(blob + L.inv_scale);
@@ -719,7 +828,8 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
         for (int nn = 0; nn < n_out; ++nn)
             for (int k = 0; k < in_count; ++k) mx = fmaxf(mx, fabsf(w[(int64_t)nn * ld + in_begin + k]));
         const float sc = mx > 0.f ? exp2f(floorf(log2f(target / mx))) : 1.f;
-        pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]), acc_order);
+        if (x2 && acc_order) pack_x2(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, blob + L.w[wi]);
+        else pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]), acc_order);
         invs[wi] = 1.f / (sc * in_scale);
         return sc;
     };
@@ -728,8 +838,13 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
     // FiLM 0: both halves must share one scale because they accumulate into the same registers
     {
         const float sc = pow2_scale(p->w_film[0], (int64_t)Hd * 2 * Hd, target);
-        pack_x3(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0A]), true);
-        pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]), true);
+        if (x2) {
+            pack_x2(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, blob + L.w[W_F0A]);
+            pack_x2(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, blob + L.w[W_F0B]);
+        } else {
+            pack_x3(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0A]), true);
+            pack_x3(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[W_F0B]), true);
+        }
         invs[W_F0A] = invs[W_F0B] = 1.f / (sc * kSA);
     }
     for (int l = 1; l < 4; ++l) mat(W_F1 + l - 1, p->w_film[l], Hd, 0, Hd, Hd, L.KS, kSA, true);
@@ -738,7 +853,8 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
     {
         const float sc = pow2_scale(p->w_color, (int64_t)Hd * (Hd + 3), target);
         uint16_t* dst = reinterpret_cast<uint16_t*>(blob + L.w[W_COLOR]);
-        pack_x3(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, dst, true);
+        if (x2) pack_x2(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, blob + L.w[W_COLOR]);
+        else pack_x3(p->w_color, Hd + 3, 3, Hd, Hd, L.KS, L.NT, sc, dst, true);
         pack_x3(p->w_color, Hd + 3, 0, 3, Hd, 1, L.NT, sc, dst + (int64_t)L.KS * L.NT * 2 * 64 * 8, false);
         invs[W_COLOR] = 1.f / (sc * kSA);
     }
@@ -752,7 +868,8 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
     }
     float* bf = reinterpret_cast<float*>(blob + L.b_feat);
     for (int nn = 0; nn < F; ++nn) bf[nn] = p->b_feat[nn];
-    // heads: [head][hi/lo][ks][half][8]
+    // heads: [head][hi / lo (/ hi * 2^-12)][ks][half][8]
+    const int PL = L.head_planes;
     uint16_t* hw = reinterpret_cast<uint16_t*>(blob + L.head_w);
     float* hinv = reinterpret_cast<float*>(blob + L.head_inv);
     float* hb = reinterpret_cast<float*>(blob + L.head_b);
@@ -765,12 +882,31 @@ extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void*
                     const int k = acc_k(ks, hh, e);
                     const float v = k < Hd ? w[k] * sc : 0.f;
                     const uint16_t hi = f32_to_f16_rn(v), lo = f32_to_f16_rn(v - f16_to_f32(hi));
-                    hw[((((int64_t)hd * 2 + 0) * L.KS + ks) * 2 + hh) * 8 + e] = hi;
-                    hw[((((int64_t)hd * 2 + 1) * L.KS + ks) * 2 + hh) * 8 + e] = lo;
+                    hw[((((int64_t)hd * PL + 0) * L.KS + ks) * 2 + hh) * 8 + e] = hi;
+                    hw[((((int64_t)hd * PL + 1) * L.KS + ks) * 2 + hh) * 8 + e] = lo;
+                    if (x2) hw[((((int64_t)hd * PL + 2) * L.KS + ks) * 2 + hh) * 8 + e] = f32_to_f16_rn(f16_to_f32(hi) / kX2Rho);
                 }
         hinv[hd] = 1.f / (sc * kSA);
         hb[hd] = hd == 0 ? p->b_sigma[0] : p->b_rgb[hd - 1];
     }
+    return H3D_OK;
+}
+
+extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob) { return field_pack(p, Hd, F, blob, false); }
+extern "C" int h3d_field_pack_x2(const h3d_field_params* p, int Hd, int F, void* blob) { return field_pack(p, Hd, F, blob, true); }
+extern "C" int64_t h3d_field_pack_x2_size(int Hd, int F) {
+    if (Hd < 1 || F < 1 || Hd > 256 || F > 256) return -1;
+    return make_layout(Hd, F, true).total;
+}
+extern "C" int h3d_field_x2_layout(int Hd, int F, int64_t* out, int n_out) {
+    H3D_REQUIRE(out && n_out >= 20, "h3d_field_x2_layout: need room for 20 values");
+    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_x2_layout: widths up to 256 (got %d, %d)", Hd, F);
+    const LayoutX3 L = make_layout(Hd, F, true);
+    int i = 0;
+    out[i++] = L.NT; out[i++] = L.KS; out[i++] = L.HdP; out[i++] = L.stages;
+    for (int w = 0; w < W_COUNT; ++w) out[i++] = L.w[w];
+    out[i++] = L.inv_scale; out[i++] = L.bias; out[i++] = L.b_feat; out[i++] = L.head_w; out[i++] = L.head_inv;
+    out[i++] = L.head_b; out[i++] = L.total;
     return H3D_OK;
 }
 
@@ -788,9 +924,9 @@ static int check_x3(const void* packed, const float* points, const float* geo, c
     return H3D_OK;
 }
 
-extern "C" int h3d_neural_field_x3(const void* packed, const float* points, const float* geo, const float* dirs,
-                                   const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
-                                   int geo_stride, float input_scaler, h3d_stream_t stream) {
+static int neural_field_x(bool x2, const void* packed, const float* points, const float* geo, const float* dirs,
+                          const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                          int geo_stride, float input_scaler, h3d_stream_t stream) {
     int rc = check_x3(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
     H3D_REQUIRE(out, "h3d_neural_field_x3: null output");
@@ -799,17 +935,28 @@ extern "C" int h3d_neural_field_x3(const void* packed, const float* points, cons
     A.blob = static_cast<const unsigned char*>(packed);
     A.points = points; A.geo = geo; A.dirs = dirs; A.freq = freq; A.phase = phase; A.out = out;
     A.N = N; A.Hd = Hd; A.F = F; A.geo_stride = geo_stride; A.S = 32; A.input_scaler = input_scaler;
-    A.L = make_layout(Hd, F);
+    A.L = make_layout(Hd, F, x2);
     const int64_t groups = (N + 127) / 128;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_neural_field_x3: N too large");
     return launch<false>(A, B, groups, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int h3d_render_fused_x3(const void* packed, const float* points, const float* geo, const float* dirs,
-                                   const float* freq, const float* phase, const float* z_vals, const float* noise,
-                                   float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
-                                   int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
-                                   h3d_stream_t stream) {
+extern "C" int h3d_neural_field_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                                   int geo_stride, float input_scaler, h3d_stream_t stream) {
+    return neural_field_x(false, packed, points, geo, dirs, freq, phase, out, B, N, Hd, F, geo_stride, input_scaler, stream);
+}
+extern "C" int h3d_neural_field_x2(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
+                                   int geo_stride, float input_scaler, h3d_stream_t stream) {
+    return neural_field_x(true, packed, points, geo, dirs, freq, phase, out, B, N, Hd, F, geo_stride, input_scaler, stream);
+}
+
+static int render_fused_x(bool x2, const void* packed, const float* points, const float* geo, const float* dirs,
+                          const float* freq, const float* phase, const float* z_vals, const float* noise,
+                          float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                          int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                          h3d_stream_t stream) {
     const int64_t N = (int64_t)R * S;
     int rc = check_x3(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
@@ -831,7 +978,7 @@ extern "C" int h3d_render_fused_x3(const void* packed, const float* points, cons
     A.R = R;
     A.log2S = -1;
     if (S <= 32) { A.log2S = 0; while ((1 << A.log2S) < S) ++A.log2S; }
-    A.L = make_layout(Hd, F);
+    A.L = make_layout(Hd, F, x2);
     const int unit = S > 32 ? S : 32;
     const int64_t units = (N + unit - 1) / unit;
     const int64_t groups = (units + 3) / 4;
@@ -861,4 +1008,21 @@ extern "C" int h3d_render_fused_x3(const void* packed, const float* points, cons
     }
 #endif
     return launch<true>(A, B, groups, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int h3d_render_fused_x3(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, const float* z_vals, const float* noise,
+                                   float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                                   int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                                   h3d_stream_t stream) {
+    return render_fused_x(false, packed, points, geo, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F,
+                          geo_stride, input_scaler, clamp_mode, last_back, white_back, stream);
+}
+extern "C" int h3d_render_fused_x2(const void* packed, const float* points, const float* geo, const float* dirs,
+                                   const float* freq, const float* phase, const float* z_vals, const float* noise,
+                                   float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
+                                   int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
+                                   h3d_stream_t stream) {
+    return render_fused_x(true, packed, points, geo, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F,
+                          geo_stride, input_scaler, clamp_mode, last_back, white_back, stream);
 }

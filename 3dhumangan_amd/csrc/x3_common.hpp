@@ -92,10 +92,12 @@ __device__ __forceinline__ void relayout_tile(const unsigned (&P)[4][2], typenam
 
 // Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
 // ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
-template <int NT, int DEPTH = H3D_RING_DEPTH>
+// LAG = 1 keeps the buffer of stage t - 1 readable during stage t (the refill issued after acquire(t) is stage
+// t + kBuf - 2 and lands in the buffer of stage t - 2): the x2 engines read an fp6 record that spans two consecutive stages.
+template <int NT, int DEPTH = H3D_RING_DEPTH, int LAG = 0>
 struct WeightRing {
     static constexpr int kBuf = DEPTH;
-    static_assert(DEPTH >= 3 && (DEPTH - 2) * (NT * 2 / 4) < 64, "ring depth out of range for the 6-bit vmcnt field");
+    static_assert(DEPTH - LAG >= 3 && (DEPTH - 2 - LAG) * (NT * 2 / 4) < 64, "ring depth out of range for the 6-bit vmcnt field");
     static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
     static constexpr int kStage = NT * 2048;
     const unsigned char* gsrc;    // global stream + this lane's slot
@@ -110,7 +112,7 @@ struct WeightRing {
         total = total_stages;
         issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
 #pragma unroll
-        for (int i = 0; i < kBuf - 1; ++i) issue();
+        for (int i = 0; i < kBuf - 1 - LAG; ++i) issue();
     }
     // One 1 KB piece of the stage being filled.  Issued through inline asm on purpose: hipcc models
     // global_load_lds as a FLAT access that touches both LDS and memory and, while one is pending, degrades EVERY
@@ -121,7 +123,7 @@ struct WeightRing {
     template <int C>
     __device__ __forceinline__ void issue_chunk() {           // C = 0 .. kChunks-1, in order
 #ifdef H3D_EXPERIMENT_NO_REFILL
-        if (issue_pos >= kBuf - 1) { if (C == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 : issue_pos + 1; } return; }
+        if (issue_pos >= kBuf - 1 - LAG) { if (C == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 - LAG : issue_pos + 1; } return; }
 #endif
         if (C == 0) {
             cur_g = gsrc + (int64_t)issue_pos * kStage;
@@ -148,7 +150,7 @@ struct WeightRing {
 #ifdef H3D_EXPERIMENT_NO_REFILL
         constexpr int kKeep = 0;
 #else
-        constexpr int kKeep = (kBuf - 2) * kChunks;
+        constexpr int kKeep = (kBuf - 2 - LAG) * kChunks;
 #endif
 #ifndef H3D_EXPERIMENT_NO_BARRIER
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
@@ -251,10 +253,14 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
             acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
             acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
         }
+#if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 2      // timing experiments only (wrong results)
         acc[n0] = mm<T, SWAP>(b.h[0], xl[s], acc[n0]);
         acc[n1] = mm<T, SWAP>(b.h[1], xl[s], acc[n1]);
+#endif
+#if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 3
         acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);
         acc[n1] = mm<T, SWAP>(b.l[1], xh[s], acc[n1]);
+#endif
         // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
         // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()
         constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
@@ -269,6 +275,127 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
         __builtin_amdgcn_sched_barrier(0);
     });
     H3D_TRACE(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- x2
+// "x2" arithmetic: W.x = hi.hi on v_mfma_f32_32x32x16_f16 + the two cross terms (hi.lo + lo.hi) in ONE block-scaled fp6
+// instruction, v_mfma_scale_f32_32x32x64_f8f6f4 (e2m3 operands): the cross terms are 2^-11 of the main term and need only a
+// few significant bits.  Per K-tile (32 input features = 2 k-steps) and output tile: 2 f16 MFMAs (64 cycles) + 1 fp6 MFMA
+// (32 cycles) instead of 6 f16 MFMAs (192 cycles), and 83 nJ instead of 150 nJ (tools/probes/mfma_scale_probe.hip) -- the
+// engines are power-limited, so the energy is what sets the clock.
+//   operand slots of the fp6 instruction (verified by tools/probes/{mfma_scale,fp6_cvt}_probe.hip): lane half h of A
+//   contracts slot s (bits [6s, 6s+6) of the lane's 6 dwords) with slot s of lane half h of B; per-lane e8m0 scales.
+//   A record (weights, 32 B per lane and K-tile): slots 0-15 = q6(hi(W)) of the lane's 16 features (acc order: slot 8j+e =
+//   element e of k-step 2T+j), slots 16-31 = q6(lo(W)); dword 6 = the lane's block scale (all four bytes), dword 7 = 0.
+//   B record (activations): v_cvt_scalef32_pk32_fp6_f16 of [lo'(k-step 2T), lo'(2T+1), hi(2T), hi(2T+1)] (lo' = lo * 2^12).
+//   Stream: a stage is still one k-step, [tile][1 KiB f16 hi fragment][1 KiB]; the second KiB of an x2 k-step holds dwords
+//   0-3 (even k-step) / 4-7 (odd k-step) of the K-tile's A records, of an x3 k-step (inputs assembled from memory) the f16
+//   lo fragment as before.  The record is read in the odd k-step from two ring buffers (WeightRing LAG = 1).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+
+constexpr int kX2ScaleB = 127 - 14;        // e8m0 of the activation codes: hi * 4, lo * 2^12 * 4  ->  2^-14 with rho = 2^12
+constexpr float kX2Rho = 4096.f;           // lo planes travel multiplied by rho
+constexpr float kX2CvtScale = 0.25f;       // v_cvt_scalef32 divides by its scale: codes = q6(x * 4)
+
+// the K-tile's activation record from its four f16 fragments
+__device__ __forceinline__ i32x8 x2_record(const F16::vec8& l0, const F16::vec8& l1, const F16::vec8& h0, const F16::vec8& h1) {
+    typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+    const f16x16 lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f16x16 hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f16x32 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
+                                             23, 24, 25, 26, 27, 28, 29, 30, 31);
+    const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, kX2CvtScale);
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(i32x8, (u32x8)__builtin_shufflevector(r, r, 0, 1, 2, 3, 4, 5, -1, -1));   // dwords 6, 7: unused by fp6 operands
+}
+
+template <bool SWAP>
+__device__ __forceinline__ f32x16 mm6(const i32x8& w, const i32x8& x, const f32x16& c) {
+    const int sw = w[6];                     // the lane's weight block scale
+#ifdef H3D_EXPERIMENT_NO_MFMA
+    f32x16 r = c; r[0] += (float)(w[0] + x[0] + sw); return r;
+#endif
+    return SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(x, w, c, 2, 2, 0, kX2ScaleB * 0x01010101, 0, sw)
+                : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 2, 2, 0, sw, 0, kX2ScaleB * 0x01010101);
+}
+
+// acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3
+// k-steps (B operands xh[s], xl3[s - KS2]: fragments assembled from memory, lo unscaled).  Same ring protocol, look-ahead
+// and hook convention as gemm_x3_roll; a section carries 2 (even x2 k-step), 4 (odd) or 6 (x3) MFMAs.
+template <int NT, int KS2, int KS3, int KSA, int KT, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
+__device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 (&xh)[KSA], const i32x8 (&b6)[KT],
+                                             const F16::vec8 (&xl3)[KS3 > 0 ? KS3 : 1], RING& ring, HOOK hook = HOOK()) {
+    typedef F16 T;
+    constexpr int KS = KS2 + KS3, P = NT / 2, G = KS * P, NB = L + 1;
+    static_assert(NT % 2 == 0 && KS2 % 2 == 0 && KS <= KSA && KS2 / 2 <= KT && L >= 1 && L <= P, "look-ahead is at most one k-step");
+    static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
+    struct Pair { typename T::vec8 h[2], l[2]; u32x4 c[2][2]; } buf[NB];
+    const unsigned char* st[2];
+    auto load_pair = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, s = q / P;
+        const unsigned char* b0 = st[s & 1] + (q % P) * 4096;
+        Pair& b = buf[q % NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            b.h[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 0) * 1024));
+            if constexpr (s >= KS2) {
+                b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 1) * 1024));
+            } else if constexpr (s % 2 == 1) {
+                const unsigned char* bp = st[(s - 1) & 1] + (q % P) * 4096;
+                b.c[i][0] = *reinterpret_cast<const u32x4*>(bp + (i * 2 + 1) * 1024);
+                b.c[i][1] = *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 1) * 1024);
+            }
+        }
+    };
+    st[0] = ring.acquire();
+    ring.issue();
+    static_for<0, L>(load_pair);
+    static_for<0, G>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int s = g / P, p = g % P;
+        if constexpr (p == P - L && s + 1 < KS) {
+            st[(s + 1) & 1] = ring.acquire();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (g + L < G) load_pair(IC<g + L>{});
+        hook(gc);
+        const Pair& b = buf[g % NB];
+        constexpr int n0 = 2 * p, n1 = 2 * p + 1;
+        if constexpr (ZERO && s == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], zero);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], zero);
+        } else {
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
+        }
+        constexpr int n_mfma = s >= KS2 ? 6 : s % 2 == 1 ? 4 : 2;
+        if constexpr (s >= KS2) {
+            acc[n0] = mm<T, SWAP>(b.h[0], xl3[s - KS2], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.h[1], xl3[s - KS2], acc[n1]);
+            acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.l[1], xh[s], acc[n1]);
+        } else if constexpr (s % 2 == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const i32x8 w6 = {(int)b.c[i][0][0], (int)b.c[i][0][1], (int)b.c[i][0][2], (int)b.c[i][0][3],
+                                  (int)b.c[i][1][0], (int)b.c[i][1][1], (int)b.c[i][1][2], (int)b.c[i][1][3]};
+                acc[n0 + i] = mm6<SWAP>(w6, b6[s / 2], acc[n0 + i]);
+            }
+        }
+        constexpr int since = g - (P - L);
+        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_chunk<since % P>();
+        if constexpr (VALU_PER_MFMA > 0) {
+#pragma unroll
+            for (int i = 0; i < n_mfma; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER_MFMA, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 // Force an accumulator set into the AGPR half of the register file at this point (MFMA reads / writes C there

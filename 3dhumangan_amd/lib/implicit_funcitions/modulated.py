@@ -58,6 +58,7 @@ class COORDCONCATSIREN(nn.Module):
             _uniform_(lin, 1.0 / lin.weight.shape[1])
         self._packed = {}
         # Arithmetic engine (all meet the 1e-3 parity budget):
+        #   "f16x2"   as f16x3 with the two cross products of a contraction in one block-scaled fp6 instruction (widths <= 256)
         #   "f16x3"   split-operand f16 matrix cores, activations register-resident (widths <= 256)
         #   "f16x3t"  split-operand f16 matrix cores, activations LDS-resident, any width <= 448 (MAP3DBN 384, MAP3DBN512L 420)
         #   "f32"     fp32 matrix cores (any width <= 512)
@@ -76,6 +77,7 @@ class COORDCONCATSIREN(nn.Module):
     # the extra trailing arguments (before the stream) of the field / render entry points
     _ENGINES = {
         "f16x3": ("h3d_field_pack_x3_size", "h3d_field_pack_x3", "h3d_neural_field_x3", "h3d_render_fused_x3", 32, ()),
+        "f16x2": ("h3d_field_pack_x2_size", "h3d_field_pack_x2", "h3d_neural_field_x2", "h3d_render_fused_x2", 32, ()),
         "f16x3t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t", "h3d_render_fused_x3t", 64, ()),
         "f16x1t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t_tier", "h3d_render_fused_x3t_tier",
                    64, (1,)),

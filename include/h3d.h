@@ -163,6 +163,31 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
                         int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A5 / A5+A6 in the "x2" arithmetic (csrc/x3_common.hpp): the hidden-layer contractions evaluate W.x as one f16 product
+ * hi*hi plus ONE block-scaled fp6 (e2m3) matrix instruction for the two cross terms hi*lo + lo*hi, which are 2^-11 of the
+ * main term -- half the matrix-pipe time and 55 % of the energy of three f16 products; inputs (K = 3 / 31 / view direction)
+ * and the four 1-row heads keep three f16 products.  2e-5 at the operator boundary at width 256 (error model:
+ * tests/test_x2_error_model_cpu.py).  Same arguments, results and limits as the _x3 entry points; own blob format:
+ * h3d_field_x2_layout reports the same 20 values as h3d_field_x3_layout; the stages of the seven accumulator-fed
+ * matrices are [tile][1 KiB f16 hi fragment][1 KiB half of the K-tile's fp6 records] (record = 32 B per lane: 32 6-bit
+ * codes, slots 0-15 q6(hi * alpha), slots 16-31 q6(lo * 2^12 * alpha) of the lane's 16 features in accumulator order, then
+ * the e8m0 byte of 1 / alpha four times, then 0; dwords 0-3 travel with the even k-step, 4-7 with the odd one) and
+ * head_w has a third plane (hi * 2^-12).
+ */
+int64_t h3d_field_pack_x2_size(int Hd, int F);
+int h3d_field_pack_x2(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+int h3d_field_x2_layout(int Hd, int F, int64_t* out, int n_out);
+int h3d_neural_field_x2(const void* packed, const float* points, const float* geo, const float* dirs,
+                        const float* freq, const float* phase, float* out,
+                        int B, int64_t N, int Hd, int F, int geo_stride, float input_scaler,
+                        h3d_stream_t stream);
+int h3d_render_fused_x2(const void* packed, const float* points, const float* geo, const float* dirs,
+                        const float* freq, const float* phase, const float* z_vals, const float* noise,
+                        float* feats, float* depth, float* weights,
+                        int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
+                        int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A5 / A5+A6, split-operand arithmetic as the _x3 entry points, for hidden widths up to 448 ("x3t": the activations of
  * a 64-sample tile live in LDS as ready-made MFMA fragments and the output features are split over the four waves, so
  * the width is bounded by LDS instead of registers; csrc/x3t_common.hpp).  Covers MAP3DBN (384) and MAP3DBN512L (420).

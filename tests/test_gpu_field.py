@@ -13,7 +13,7 @@ DEV = "cuda"
 FIELD_TOL = 1e-3      # north_star: within 1e-3 relative fp32; measured errors are ~1e-5
 
 
-ENGINES = ["f16x3", "f16x3t", "f32"]
+ENGINES = ["f16x2", "f16x3", "f16x3t", "f32"]
 
 
 def make_field(state, hidden, feature, prefix="neural_field.", precision=None):
@@ -53,7 +53,7 @@ def test_field_golden(name, hidden, engine):
         assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL
 
 
-@pytest.mark.parametrize("hidden,engine", [(256, "f16x3"), (256, "f16x3t"), (256, "f32"), (384, "f16x3t"), (384, "f32"),
+@pytest.mark.parametrize("hidden,engine", [(256, "f16x2"), (256, "f16x3"), (256, "f16x3t"), (256, "f32"), (384, "f16x3t"), (384, "f32"),
                                            (420, "f16x3t"), (420, "f32")])
 def test_field_reference_vectors_at_shipped_widths(hidden, engine):
     """The reference module's own output at the widths of MAP3DBN512 / MAP3DBN / MAP3DBN512L (not the oracle's)."""
@@ -83,7 +83,8 @@ def test_field_in_generator_fixture(name, engine):
     assert rel_err(b.cpu(), ref) < FIELD_TOL
 
 
-@pytest.mark.parametrize("hidden,feature,N,engine", [(256, 256, 200, "f32"), (256, 256, 200, "f16x3"), (384, 384, 130, "f32"),
+@pytest.mark.parametrize("hidden,feature,N,engine", [(256, 256, 200, "f32"), (256, 256, 200, "f16x3"), (256, 256, 200, "f16x2"), (128, 96, 77, "f16x2"),
+                                                     (200, 256, 333, "f16x2"), (32, 32, 1, "f16x2"), (384, 384, 130, "f32"),
                                                      (420, 420, 64, "f32"), (32, 32, 1, "f32"), (32, 32, 1, "f16x3"),
                                                      (128, 96, 77, "f32"), (128, 96, 77, "f16x3"), (200, 256, 333, "f16x3"),
                                                      (384, 384, 130, "f16x3t"), (420, 420, 200, "f16x3t"), (256, 256, 65, "f16x3t"),
@@ -107,6 +108,8 @@ def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
 
 @pytest.mark.parametrize("S,R,hidden,engine", [(8, 20, 32, "f32"), (16, 30, 48, "f32"), (32, 9, 64, "f32"), (64, 5, 256, "f32"),
                                                 (128, 3, 64, "f32"), (32, 7, 384, "f32"), (8, 20, 32, "f16x3"),
+                                                (8, 20, 32, "f16x2"), (16, 30, 48, "f16x2"), (32, 9, 64, "f16x2"), (64, 5, 256, "f16x2"),
+                                                (128, 3, 64, "f16x2"), (32, 7, 256, "f16x2"), (96, 3, 128, "f16x2"),
                                                 (16, 30, 48, "f16x3"), (32, 9, 64, "f16x3"), (64, 5, 256, "f16x3"),
                                                 (128, 3, 64, "f16x3"), (32, 7, 256, "f16x3"), (96, 3, 128, "f16x3"),
                                                 (8, 20, 32, "f16x3t"), (16, 30, 48, "f16x3t"), (32, 9, 64, "f16x3t"),

@@ -1,0 +1,112 @@
+"""Host-side packing of the x2 field engine (h3d_field_pack_x2, a HOST function of libh3d.so) checked on the CPU: the f16 hi
+fragments and the fp6 records (32 six-bit e2m3 codes + block scale per lane and K-tile, split over the even / odd k-step's
+stage) are decoded through h3d_field_x2_layout, and the arithmetic of csrc/x3_common.hpp (gemm_x2_roll) restated in float64
+on the decoded data must equal tests/x2_emulation.py -- the model whose error against the reference's vectors is bounded in
+tests/test_x2_error_model_cpu.py.  No GPU, no kernel launch."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from x2_emulation import acc_k, f16, q_e2m3, x2_matmul
+
+L = importlib.import_module("3dhumangan_amd._lib")
+impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+W_NAMES = ["coord", "f0a", "geo", "f0b", "f1", "f2", "f3", "color", "feat"]
+CODES = torch.tensor([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875,
+                      2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5], dtype=torch.float64)
+
+
+def pack(net, Hd, F):
+    lib = L.load()
+    lins = net._params_for_pack()
+    host = [(l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous()) for l in lins]
+    P = L.FieldParams()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    P.w_coord, P.b_coord = vp(host[0][0]), vp(host[0][1])
+    P.w_geo, P.b_geo = vp(host[1][0]), vp(host[1][1])
+    for k in range(4):
+        P.w_film[k], P.b_film[k] = host[2 + k][0].data_ptr(), host[2 + k][1].data_ptr()
+    P.w_sigma, P.b_sigma = vp(host[6][0]), vp(host[6][1])
+    P.w_color, P.b_color = vp(host[7][0]), vp(host[7][1])
+    P.w_rgb, P.b_rgb = vp(host[8][0]), vp(host[8][1])
+    P.w_feat, P.b_feat = vp(host[9][0]), vp(host[9][1])
+    nbytes = lib.h3d_field_pack_x2_size(Hd, F)
+    blob = torch.zeros(nbytes, dtype=torch.uint8)
+    L.check(lib.h3d_field_pack_x2(ctypes.byref(P), Hd, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack_x2")
+    lay = (ctypes.c_int64 * 20)()
+    L.check(lib.h3d_field_x2_layout(Hd, F, lay, 20), "h3d_field_x2_layout")
+    return blob, list(lay), host
+
+
+def decode_x2(blob, off, KS, NT):
+    """-> (Whi [32 NT, 16 KS] f16 values in feature order,
+           per K-tile T, output row n, lane half h: codes_hi [16], codes_lo [16] (values), scale 2^(byte - 127))"""
+    st = blob[off: off + KS * NT * 2048].view(KS, NT, 2, 1024)
+    Whi = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+    hi = st[:, :, 0].contiguous().view(torch.float16).double().view(KS, NT, 64, 8)
+    for ks in range(KS):
+        for h in range(2):
+            for e in range(8):
+                Whi[:, acc_k(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
+    recs = {}
+    half = st[:, :, 1].contiguous().view(torch.int32).view(KS, NT, 64, 4)
+    for T in range(KS // 2):
+        rec = torch.cat([half[2 * T], half[2 * T + 1]], dim=-1).numpy().astype(np.uint32)      # [NT, 64, 8]
+        bits = np.zeros((NT, 64, 32), dtype=np.int64)
+        for s in range(32):
+            b = 6 * s
+            v = rec[..., b // 32].astype(np.uint64) >> np.uint64(b & 31)
+            if (b & 31) > 26:
+                v |= rec[..., b // 32 + 1].astype(np.uint64) << np.uint64(32 - (b & 31))
+            bits[..., s] = (v & np.uint64(63)).astype(np.int64)
+        vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
+        sb = rec[..., 6]
+        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == 0)
+        scale = torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127))
+        recs[T] = (vals, scale)                        # vals [NT, 64, 32]; lanes = 32 * h + (row % 32)
+    return Whi, recs
+
+
+@pytest.mark.parametrize("Hd", [64, 256])
+def test_field_x2_pack_is_the_emulated_arithmetic(Hd):
+    F = Hd
+    torch.manual_seed(Hd + 1)
+    net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=Hd, hidden_dim=Hd, geo_feature_dim=31, output_dim=F + 4, feature_dim=F,
+                                num_blocks=4)
+    blob, lay, host = pack(net, Hd, F)
+    NT, KS, HdP, n_stages = lay[0:4]
+    woff = dict(zip(W_NAMES, lay[4:13]))
+    inv = dict(zip(W_NAMES, blob[lay[13]: lay[13] + 36].view(torch.float32).double()))
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(23, Hd, generator=g, dtype=torch.float64) * 2 - 1).float().double()          # sine outputs: |x| <= 1
+    for name, Wsrc in (("f1", host[3][0]), ("f3", host[5][0]), ("feat", host[9][0]), ("color", host[7][0][:, 3:])):
+        Whi, recs = decode_x2(blob, woff[name], KS, NT)
+        sc = 1.0 / float(inv[name])                                                            # activation scale kSA = 1
+        # hi plane = f16(W * sc) in accumulator order, zero padding outside the matrix
+        want = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+        want[:Wsrc.shape[0], :Hd] = f16(Wsrc.double() * sc)
+        assert torch.equal(Whi, want), name
+        # the kernel's arithmetic on the decoded operands
+        xp = torch.nn.functional.pad(x, (0, 16 * KS - Hd))
+        xh = f16(xp)
+        xl = xp - xh
+        Bh, Bl = q_e2m3(xh * 4.0), q_e2m3(f16(xl * 4096.0) * 4.0)
+        y = xh @ Whi.t()
+        for T, (vals, scale) in recs.items():
+            for h in range(2):
+                feats = torch.tensor([acc_k(2 * T + j, h, e) for j in range(2) for e in range(8)])
+                a = vals[:, 32 * h: 32 * h + 32].reshape(32 * NT, 32)                           # rows n = 32 * nt + (lane & 31)
+                s = scale[:, 32 * h: 32 * h + 32].reshape(32 * NT)
+                cross = Bl[:, feats] @ a[:, :16].t() + Bh[:, feats] @ a[:, 16:].t()
+                y = y + cross * s * 2.0 ** -14
+        y = (y / sc)[:, :Wsrc.shape[0]]
+        emu = x2_matmul(x, Wsrc)
+        assert float((y - emu).abs().max() / emu.abs().max()) < 1e-12, name
+        exact = x @ Wsrc.double().t()
+        assert float((y - exact).abs().max() / exact.abs().max()) < 2e-5, name
+    # heads: third plane = hi * 2^-12
+    hw = blob[lay[16]: lay[16] + 2 * 4 * 3 * KS * 16].view(torch.float16).double().view(4, 3, KS, 2, 8)
+    assert torch.equal(hw[:, 2], f16(hw[:, 0] / 4096.0))
