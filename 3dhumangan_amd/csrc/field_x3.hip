@@ -774,10 +774,13 @@ void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int 
                         uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2) * 1024);
                         hd[lane * 8 + e] = h16;
                     }
-                // block scale alpha = 2^ea with |hi| * alpha <= 3.75; the instruction multiplies the codes by 2^(byte - 127) = 1 / alpha
-                int ea = mx > 0.f ? (int)floorf(log2f(3.75f / mx)) : 0;
+                // block scale alpha = 2^ea: the largest with |hi| * alpha <= 7.5 unless a lo code would saturate (then half of
+                // it); the instruction multiplies the codes by 2^(byte - 127) = 1 / alpha
+                int ea = mx > 0.f ? (int)floorf(log2f(7.5f / mx)) : 0;
                 if (ea > 100) ea = 100;
                 if (ea < -100) ea = -100;
+                for (int i = 0; i < 16; ++i)
+                    if (fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f) { --ea; break; }
                 const float alpha = ldexpf(1.f, ea);
                 unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int sl = 0; sl < 32; ++sl) {

@@ -12,7 +12,15 @@
 //     the LDS ring by LDS-DMA.
 // Supported: C <= 256, per-pixel-style blocks only before the first skip block (true for map3d_mode mixed /
 // isolated with the shipped mod_blocks); anything else stays on the fp32 engine (h3d_synthesis).
+//
+// X2 variant (template parameter, h3d_synthesis_x2): every conv / gamma / beta contraction in the "x2" arithmetic of
+// x3_common.hpp -- f16 hi halves (11 bits; the reference trains these very convolutions under fp16 autocast,
+// lib/trainers/base_trainer.py:50-51, so their inputs are f16-representable by construction) and ONE block-scaled fp6
+// instruction for both cross terms.  Activations are not bounded here, so the fp6 record of a K-tile carries a per-lane
+// (= per-pixel) power-of-two scale taken from the largest of the lane's 16 values.  The bilinear resize product keeps three
+// bf16 products (12 small MFMAs per SPADE).
 #include "x3_common.hpp"
+#include <type_traits>
 
 using namespace h3d;
 
@@ -49,36 +57,70 @@ __device__ __forceinline__ float linspace_pm1(int n, int i) {
 // tile t IS element e of the lane's B fragment of k-step 2t + j, so fragments are assembled without any cross-lane move;
 // the host packs the K dimension of those weight matrices accordingly (pack_stream_bf16(acc_order=True)):
 //     feature of k-slot (h, e) of k-step ks:  32*(ks/2) + (e & 3) + 8*(2*(ks & 1) + (e >> 2)) + 4*h
-__device__ __forceinline__ void set_word(bf8& f, int w, unsigned v) {
+template <typename V8>
+__device__ __forceinline__ void set_word(V8& f, int w, unsigned v) {
     u32x4 t = __builtin_bit_cast(u32x4, f);
     t[w] = v;
-    f = __builtin_bit_cast(bf8, t);
+    f = __builtin_bit_cast(V8, t);
 }
 
 // fp32 values of one accumulator tile set -> bf16 hi/lo B fragments (all tiles at once; the progressive variant is
 // SpadeProducer).  val(nt, rg) returns the 4 values of register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
-template <int NT, typename F>
-__device__ __forceinline__ void make_frags(bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], f32x16 (&src)[NT], F val) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// x2: two fp32 -> packed f16 hi halves (returned) and packed f16 halves of lo * 2^12
+__device__ __forceinline__ unsigned split2_x2(float a, float b, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 hv = __builtin_convertvector(f32x2{a, b}, h2);
+    const float fa = (float)hv.x, fb = (float)hv.y;
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(la) : "v"(la), "v"(kX2Rho));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(lb) : "v"(lb), "v"(kX2Rho));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{la, lb}, h2));
+    return __builtin_bit_cast(unsigned, hv);
+}
+
+// x2: the fp6 record of a K-tile whose largest |activation| of this lane is amax = m * 2^e (1 <= m < 2): codes = q6(y / cs)
+// with cs = 2^(e-2) when m < 1.875 (largest hi code < 7.5: no saturation) and 2^(e-1) otherwise.  lo' = lo * 2^12 <= 2^(e+1)
+// can reach code 8 in the first case and is then clipped to 7.5 (an error of 2^-4 of a term that is 2^-12 of the product).
+__device__ __forceinline__ i32x8 x2_record_dyn(const F16::vec8& l0, const F16::vec8& l1, const F16::vec8& h0, const F16::vec8& h1, float amax) {
+    unsigned eb = (__builtin_bit_cast(unsigned, amax) + 0x100000u) >> 23;   // biased exponent, + 1 when m >= 1.875 (amax >= 0)
+    eb = eb < 16u ? 16u : eb;                                               // all-zero / tiny tiles: any in-range scale
+    return x2_record(l0, l1, h0, h1, __builtin_bit_cast(float, (eb - 2u) << 23), (int)eb - 2);
+}
+
+// fp32 values of one accumulator tile set -> hi/lo B fragments (all tiles at once; the progressive variant is
+// SpadeProducer).  val(nt, rg) returns the 4 values of register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
+// X2: f16 hi fragments, lo' fragments and the fp6 record of every K-tile.
+template <int NT, bool X2, typename V8, typename F>
+__device__ __forceinline__ void make_frags(V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], f32x16 (&src)[NT], F val) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         pin1(src[nt]);                       // the source tile sits in AGPRs until this iteration reads it
+        float amax = 0.f;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const float4 y = val(nt, rg);
-            unsigned l0, l1;
-            const unsigned h0 = split2_bf16(y.x, y.y, l0), h1 = split2_bf16(y.z, y.w, l1);
+            unsigned l0, l1, h0, h1;
+            if constexpr (X2) {
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
+                h0 = split2_x2(y.x, y.y, l0); h1 = split2_x2(y.z, y.w, l1);
+            } else {
+                h0 = split2_bf16(y.x, y.y, l0); h1 = split2_bf16(y.z, y.w, l1);
+            }
             set_word(xh[2 * nt + (rg >> 1)], 2 * (rg & 1) + 0, h0);
             set_word(xh[2 * nt + (rg >> 1)], 2 * (rg & 1) + 1, h1);
             set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 0, l0);
             set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 1, l1);
         }
+        if constexpr (X2) b6[nt] = x2_record_dyn(xl[2 * nt], xl[2 * nt + 1], xh[2 * nt], xh[2 * nt + 1], amax);
         // bound the scheduler's load hoisting to one tile: the table reads of all tiles at once would cost
         // hundreds of registers on top of the resident activations
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // two fp32 -> packed bf16 hi halves (returned) and packed bf16 lo halves; plain VALU only (VOP3P instructions beside
 // MFMAs cost several issue slots on this chip, and hipcc's SLP vectoriser would pack the two subtractions).
@@ -105,11 +147,12 @@ __device__ __forceinline__ float lrelu_plain(float v) {
 //           conv bias of v folded into sh);  otherwise y = lrelu(v) (per-pixel style: v is already modulated)
 //   RGB     also accumulates the ToRGB of v (the previous block's output) into rgb[3]: wr = LDS [3][HdP]
 // Source values are read from the AGPRs eight at a time: a v_accvgpr_read between MFMAs waits for the matrix pipe.
-template <int NT, bool AFFINE, bool RGB>
+template <int NT, bool AFFINE, bool RGB, bool X2, typename V8>
 struct SpadeProducer {
     f32x16 (&src)[NT];
-    bf8 (&xh)[2 * NT];
-    bf8 (&xl)[2 * NT];
+    V8 (&xh)[2 * NT];
+    V8 (&xl)[2 * NT];
+    i32x8 (&b6)[NT];
     const float* ab;
     const float* wr;
     float (&rgb)[3];
@@ -117,6 +160,7 @@ struct SpadeProducer {
     f32x4 tv;
     f32x2 w0, w1, w2;
     float sv[8];
+    float amax;               // x2: largest |activation| of the tile in production (this lane)
 
     template <int TILE, int C>
     __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
@@ -149,34 +193,54 @@ struct SpadeProducer {
         }
         if constexpr (C < 7) fetch<TILE, C + 1>();
         else if constexpr (TILE + 1 < NT) fetch<TILE + 1, 0>();
-        unsigned lo;
-        const unsigned hi = split2_plain(lrelu_plain(y0), lrelu_plain(y1), lo);
+        unsigned lo, hi;
+        const float z0 = lrelu_plain(y0), z1 = lrelu_plain(y1);
+        if constexpr (X2) {
+            amax = C == 0 ? fmaxf(fabsf(z0), fabsf(z1)) : fmaxf(amax, fmaxf(fabsf(z0), fabsf(z1)));
+            hi = split2_x2(z0, z1, lo);
+        } else {
+            hi = split2_plain(z0, z1, lo);
+        }
         // registers 4*rg + 2*(C%2) + {0, 1} of the tile = k-step 2*TILE + (rg >> 1), word 2*(rg & 1) + C%2
         set_word(xh[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), hi);
         set_word(xl[2 * TILE + (rg >> 1)], 2 * (rg & 1) + (C % 2), lo);
+    }
+    // x2: fp6 record of the finished tile (called before chunk<TILE + 1, 0> restarts the running maximum)
+    template <int TILE>
+    __device__ __forceinline__ void convert() {
+        if constexpr (X2) b6[TILE] = x2_record_dyn(xl[2 * TILE], xl[2 * TILE + 1], xh[2 * TILE], xh[2 * TILE + 1], amax);
     }
 };
 
 // conv GEMM dst (+)= W * frags(producer(src)) with the fragment epilogue of tile t+1 hidden behind the MFMAs of k-steps
 // 2t, 2t+1 (which only need tile t); only tile 0's epilogue is exposed.  src and dst are different register sets.
-template <int NT, bool ZERO, typename RING, typename PROD>
-__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], bf8 (&xh)[2 * NT], bf8 (&xl)[2 * NT], RING& ring, PROD& prod) {
+template <int NT, bool ZERO, bool X2, typename V8, typename RING, typename PROD>
+__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], RING& ring, PROD& prod) {
     prod.prime();
     static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
     __builtin_amdgcn_sched_barrier(0);
     constexpr int W = NT, PER = 8 / W;          // sections per 2-k-step window, chunks per section
-    gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, [&](auto gc) __attribute__((always_inline)) {
+    auto hook = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int t = g / W + 1, j = g % W;
+        if constexpr (X2 && j == 0 && t - 1 < NT) prod.template convert<t - 1>();       // first section of k-step 2 (t - 1)
         if constexpr (t < NT) {
             static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
         }
-    });
+    };
+    if constexpr (X2) {
+        const F16::vec8 none[1] = {};
+        gemm_x2_roll<NT, 2 * NT, 0, 2 * NT, NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, b6, none, ring, hook);
+    } else {
+        gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, hook);
+    }
 }
 
-template <int NT, int DEPTH, bool SEG>
+template <int NT, int DEPTH, bool SEG, bool X2>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
+    typedef typename std::conditional<X2, F16, BF16>::type T;
+    typedef typename T::vec8 frag8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HdP = A.HdP, C = A.C;
     float* tab0 = smem;                                      // [table_floats] static tables (descriptor offsets)
@@ -203,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     __syncthreads();
     H3D_TRACE(0);
 #endif
-    WeightRing<NT, DEPTH> ring;
+    WeightRing<NT, DEPTH + (X2 ? 1 : 0), X2 ? 1 : 0> ring;        // x2: the fp6 records span two stages (LAG = 1)
     ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
 
     // ---- this lane's pixel: synthesis-input coordinates and bilinear taps into the low-res maps
@@ -243,7 +307,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     // texel row of this half-wave (k = 8h + e) and the per-column offsets (wave-uniform)
     const float* trow = Gb + ((int64_t)min(ya + h, A.Hr - 1) * A.Wr) * A.g_channels + m;
     f32x16 x[NT];
-    bf8 xh[KS], xl[KS];
+    frag8 xh[KS], xl[KS];
+    i32x8 b6[NT];
     float rgb_acc[3] = {0.f, 0.f, 0.f};
 
     const int64_t wtile = (int64_t)b * gridDim.x * 4 + (int64_t)blockIdx.x * 4 + wave;
@@ -283,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 
     // constant-style SPADE: y = lrelu(v * a + b) -> fragments
     auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {       // ab: [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]
-        make_frags<NT>(xh, xl, v, [&](int nt, int rg) {
+        make_frags<NT, X2>(xh, xl, b6, v, [&](int nt, int rg) {
             const int n = nt * 32 + rg * 8 + 4 * h;
             const f32x4 ta = ld4(ab + 2 * n), tb = ld4(ab + 2 * n + 4);
             float4 y;
@@ -351,7 +416,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             const h3d_spade_desc& Sp = Bk.spade[s];
             f32x16 acc[NT];
             // ---- shared-MLP activations a = relu(resize(G) + cst) of this lane's pixel as B fragments
-            bf8 ah[8], al[8];
+            frag8 ah[8], al[8];
+            i32x8 a6[4];
             const float* cs = cstt + Sp.cst_index * kShared;
             {
                 float tq[4][8];
@@ -373,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     d[tt] = BF16::mfma(th, wil, d[tt]);
                     d[tt] = BF16::mfma(tl, wih, d[tt]);
                 }
-                make_frags<4>(ah, al, d, [&](int nt, int rg) {
+                make_frags<4, X2>(ah, al, a6, d, [&](int nt, int rg) {
                     const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
                     float4 y;
                     y.x = fmaxf(d[nt][rg * 4 + 0] + k4.x, 0.f);
@@ -387,7 +453,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
             set_bias(acc, vec);
             pin_agpr<NT>(x); pin_agpr<NT>(acc);
-            gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+            const F16::vec8 none[1] = {};
+            (void)none;
+            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, kLook>(acc, ah, a6, none, ring);
+            else gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
             pin_agpr<NT>(x); pin_agpr<NT>(acc);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -408,11 +477,12 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             }
             // beta:   y = lrelu(acc + beta)
             pin_agpr<NT>(acc);
-            gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
+            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, kLook>(acc, ah, a6, none, ring);
+            else gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
             pin_agpr<NT>(acc);
             {
-                SpadeProducer<NT, false, false> prod{acc, xh, xl, nullptr, nullptr, rgb_acc, h, HdP};
-                conv_progressive<NT, true>(x, xh, xl, ring, prod);
+                SpadeProducer<NT, false, false, X2, frag8> prod{acc, xh, xl, b6, nullptr, nullptr, rgb_acc, h, HdP};
+                conv_progressive<NT, true, X2>(x, xh, xl, b6, ring, prod);
             }
             pin_agpr<NT>(x);
         }
@@ -433,7 +503,12 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             // constant style before the first skip block: x is both source and destination, so the fragments
             // are completed before the conv starts
             const_frags(x, abt + Sp.ab_index * 2 * HdP);
-            gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+            if constexpr (X2) {
+                const F16::vec8 none[1] = {};
+                gemm_x2_roll<NT, KS, 0, KS, NT, false, kLook, 0, true>(x, xh, b6, none, ring);
+            } else {
+                gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+            }
             pin_agpr<NT>(x);
         }
         if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
@@ -453,13 +528,13 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         pin_agpr<NT>(x);
         {   // conv 0, with the ToRGB of the previous skip block's output (this block's input x) riding along
             const float* wr_prev = (blk > A.first_skip && D.block[blk - 1].to_rgb) ? tab + D.block[blk - 1].w_rgb : zero0 + opaque;
-            SpadeProducer<NT, true, true> prod{x, xh, xl, abt + Bk.spade[0].ab_index * 2 * HdP, wr_prev, rgb_acc, h, HdP};
-            conv_progressive<NT, true>(acc, xh, xl, ring, prod);
+            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, abt + Bk.spade[0].ab_index * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+            conv_progressive<NT, true, X2>(acc, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x); pin_agpr<NT>(acc);
         {
-            SpadeProducer<NT, true, false> prod{acc, xh, xl, abt + Bk.spade[1].ab_index * 2 * HdP, nullptr, rgb_acc, h, HdP};
-            conv_progressive<NT, false>(x, xh, xl, ring, prod);
+            SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, abt + Bk.spade[1].ab_index * 2 * HdP, nullptr, rgb_acc, h, HdP};
+            conv_progressive<NT, false, X2>(x, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x);
         if (Bk.to_rgb && h == 0) {          // bias of this block's ToRGB; its weights ride in the next block's conv 0
@@ -493,20 +568,20 @@ size_t lds_bytes(const Args& A, int NT, int depth) {
            (size_t)depth * NT * 2048;
 }
 
-template <int NT, int DEPTH, bool SEG>
+template <int NT, int DEPTH, bool SEG, bool X2>
 int launch_seg(const Args& A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG>));
+    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2>));
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG>), dim3((unsigned)groups, (unsigned)B), dim3(256),
-                       lds_bytes(A, NT, DEPTH), st, A);
-    return h3d::launch_status("h3d_synthesis_x3");
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2>), dim3((unsigned)groups, (unsigned)B), dim3(256),
+                       lds_bytes(A, NT, DEPTH + (X2 ? 1 : 0)), st, A);
+    return h3d::launch_status(X2 ? "h3d_synthesis_x2" : "h3d_synthesis_x3");
 }
 
-template <int NT, int DEPTH>
+template <int NT, int DEPTH, bool X2>
 int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
     // the state load/store paths are compiled only into the segmented variant (they cost registers)
-    return (A.load_state || A.store_state) ? launch_seg<NT, DEPTH, true>(A, B, groups, st)
-                                           : launch_seg<NT, DEPTH, false>(A, B, groups, st);
+    return (A.load_state || A.store_state) ? launch_seg<NT, DEPTH, true, X2>(A, B, groups, st)
+                                           : launch_seg<NT, DEPTH, false, X2>(A, B, groups, st);
 }
 
 }  // namespace
@@ -516,10 +591,10 @@ extern "C" int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr) {
     return H >= 1 && Hr >= 1 && Wr >= 1 && W >= 32 && W % 32 == 0 && (int64_t)31 * Wr < (int64_t)6 * W;
 }
 
-extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
-                                const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
-                                const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
-                                float* state, int load_state, int store_state, h3d_stream_t stream_) {
+static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                       const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                       const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                       float* state, int load_state, int store_state, h3d_stream_t stream_) {
     H3D_REQUIRE(stream && tables && desc && rgb, "h3d_synthesis_x3: null pointer");
     H3D_REQUIRE(h3d::aligned16(stream) && h3d::aligned16(tables), "h3d_synthesis_x3: stream/tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3: n_blocks=%d", desc->n_blocks);
@@ -590,14 +665,36 @@ extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const 
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
     if (!any_pixel) A.g_channels = 0;
     A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip; A.n_pixel_blocks = n_pixel_blocks;
-    const bool deep = lds_bytes(A, NT, 6) <= 160 * 1024;      // deepest weight ring the tables leave room for
-    if (lds_bytes(A, NT, kRingDepth) > 160 * 1024) {
-        h3d::set_error("h3d_synthesis_x3: tables (%d floats) + ring do not fit the 160 KB LDS; use h3d_synthesis", table_floats);
+    const int extra = x2 ? 1 : 0;                                      // x2 keeps one more ring buffer (WeightRing LAG = 1)
+    const bool deep = lds_bytes(A, NT, 6 + extra) <= 160 * 1024;      // deepest weight ring the tables leave room for
+    if (lds_bytes(A, NT, kRingDepth + extra) > 160 * 1024) {
+        h3d::set_error("h3d_synthesis_x3 / _x2: tables (%d floats) + ring do not fit the 160 KB LDS; use h3d_synthesis", table_floats);
         return H3D_EUNSUPPORTED;
     }
     const int64_t groups = ((int64_t)H * W + 127) / 128;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_synthesis_x3: image too large");
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    if (NT == 8) return deep ? launch_one<8, 6>(A, B, groups, st) : launch_one<8, kRingDepth>(A, B, groups, st);
-    return deep ? launch_one<4, 6>(A, B, groups, st) : launch_one<4, kRingDepth>(A, B, groups, st);
+    if (x2) {
+        if (NT == 8) return deep ? launch_one<8, 6, true>(A, B, groups, st) : launch_one<8, kRingDepth, true>(A, B, groups, st);
+        return deep ? launch_one<4, 6, true>(A, B, groups, st) : launch_one<4, kRingDepth, true>(A, B, groups, st);
+    }
+    if (NT == 8) return deep ? launch_one<8, 6, false>(A, B, groups, st) : launch_one<8, kRingDepth, false>(A, B, groups, st);
+    return deep ? launch_one<4, 6, false>(A, B, groups, st) : launch_one<4, kRingDepth, false>(A, B, groups, st);
 }
+
+extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                float* state, int load_state, int store_state, h3d_stream_t stream_) {
+    return synthesis_x(false, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
+                       state, load_state, store_state, stream_);
+}
+extern "C" int h3d_synthesis_x2(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                float* state, int load_state, int store_state, h3d_stream_t stream_) {
+    return synthesis_x(true, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
+                       state, load_state, store_state, stream_);
+}
+/* LDS the x2 variant needs beyond the x3 one, for host-side planning (one more ring buffer) */
+extern "C" int h3d_synthesis_x2_extra_lds(int C) { return (C > 128 ? 8 : 4) * 2048; }

@@ -295,30 +295,34 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
-constexpr int kX2ScaleB = 127 - 14;        // e8m0 of the activation codes: hi * 4, lo * 2^12 * 4  ->  2^-14 with rho = 2^12
+constexpr int kX2ScaleB = 127 - 14;        // static e8m0 of the cross terms for |x| <= 1: hi * 4, lo * 2^12 * 4  ->  2^-14 with rho = 2^12
 constexpr float kX2Rho = 4096.f;           // lo planes travel multiplied by rho
 constexpr float kX2CvtScale = 0.25f;       // v_cvt_scalef32 divides by its scale: codes = q6(x * 4)
 
-// the K-tile's activation record from its four f16 fragments
-__device__ __forceinline__ i32x8 x2_record(const F16::vec8& l0, const F16::vec8& l1, const F16::vec8& h0, const F16::vec8& h1) {
+// the K-tile's activation record from its four f16 fragments: codes = q6(value / cvt_scale), true value = code * 2^(scale_byte
+// - 127) (hi) resp. * 2^-12 of that (lo'); dword 6 = the lane's e8m0 scale byte (op_sel 0 reads byte 0), dword 7 unused
+__device__ __forceinline__ i32x8 x2_record(const F16::vec8& l0, const F16::vec8& l1, const F16::vec8& h0, const F16::vec8& h1,
+                                           float cvt_scale = kX2CvtScale, int scale_byte = kX2ScaleB + 12) {
     typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
     const f16x16 lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     const f16x16 hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     const f16x32 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
                                              23, 24, 25, 26, 27, 28, 29, 30, 31);
-    const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, kX2CvtScale);
+    const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, cvt_scale);
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
-    return __builtin_bit_cast(i32x8, (u32x8)__builtin_shufflevector(r, r, 0, 1, 2, 3, 4, 5, -1, -1));   // dwords 6, 7: unused by fp6 operands
+    i32x8 o = __builtin_bit_cast(i32x8, (u32x8)__builtin_shufflevector(r, r, 0, 1, 2, 3, 4, 5, -1, -1));   // dword 7 stays undefined
+    o[6] = scale_byte - 12;                  // both cross terms carry the 2^-12 of the lo planes
+    return o;
 }
 
 template <bool SWAP>
 __device__ __forceinline__ f32x16 mm6(const i32x8& w, const i32x8& x, const f32x16& c) {
-    const int sw = w[6];                     // the lane's weight block scale
+    const int sw = w[6], sx = x[6];          // the lanes' block scales (weights: 1 / alpha; activations: see x2_record)
 #ifdef H3D_EXPERIMENT_NO_MFMA
-    f32x16 r = c; r[0] += (float)(w[0] + x[0] + sw); return r;
+    f32x16 r = c; r[0] += (float)(w[0] + x[0] + sw + sx); return r;
 #endif
-    return SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(x, w, c, 2, 2, 0, kX2ScaleB * 0x01010101, 0, sw)
-                : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 2, 2, 0, sw, 0, kX2ScaleB * 0x01010101);
+    return SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(x, w, c, 2, 2, 0, sx, 0, sw)
+                : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 2, 2, 0, sw, 0, sx);
 }
 
 // acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3

@@ -149,13 +149,15 @@ class SynthesisPlan:
         self.g_channels = SHARED * len(self.pixel_ids)
         self.device = device
         self._x3 = None
+        self._x2 = None
         self._x3t = None
-        # Arithmetic engine: "bf16x3" split-bf16 matrix cores, register-resident activations (C <= 256);
+        # Arithmetic engine: "f16x2" one f16 product + one block-scaled fp6 product (both cross terms) per contraction,
+        # register-resident activations (C <= 256); "bf16x3" split-bf16 matrix cores, register-resident activations (C <= 256);
         # "bf16x3t" split-bf16 matrix cores, LDS-resident activations (C <= 448: MAP3DBN 384, MAP3DBN512L 420);
         # "f32" fp32 matrix cores (anything else).  Opt-in reduced-precision tiers on the bf16x3t kernel (NOT within the
         # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16x2t" weights f16 hi + lo, activations one f16 value (two
         # products); "f16x1t" plain f16 products.
-        default = "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
+        default = "f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
@@ -179,6 +181,14 @@ class SynthesisPlan:
         x3 = self.build_x3()
         per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED
         return all(4 * (seg["tables"].numel() + per_sample) + 4 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
+
+    def x2_supported(self):
+        """x3_supported with room for the x2 kernel's fifth ring buffer."""
+        if not self.x3_supported():
+            return False
+        x3 = self.build_x3()
+        per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED
+        return all(4 * (seg["tables"].numel() + per_sample) + 5 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
 
     @staticmethod
     def pack_stream_bf16(w_out_in, KS, NT, acc_order=True, dtype=torch.bfloat16):
@@ -205,6 +215,61 @@ class SynthesisPlan:
             return t.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8)
 
         return torch.stack([frag(hi), frag(lo)], dim=2).contiguous().view(torch.int16).flatten()
+
+    @staticmethod
+    def e2m3_codes(v):
+        """fp32 tensor -> 6-bit e2m3 codes (int64): round-to-nearest-even on the code grid, saturating at 7.5 (the same
+        arithmetic as csrc/field_x3.hip: e2m3_code and as v_cvt_scalef32_pk32_fp6_f16)."""
+        a = v.abs().clamp(max=7.5)
+        step = torch.where(a < 2, torch.full_like(a, 0.125), torch.where(a < 4, torch.full_like(a, 0.25), torch.full_like(a, 0.5)))
+        q = torch.round(a / step) * step
+        code = torch.where(q < 2, q * 8, torch.where(q < 4, 16 + (q - 2) * 4, 24 + (q - 4) * 2)).to(torch.int64)
+        return code | ((v < 0).to(torch.int64) << 5)
+
+    @classmethod
+    def pack_stream_x2(cls, w_out_in, KS, NT):
+        """[n_out, n_in] -> weight-stream stages of the x2 engines, [KS][NT][1 KiB f16 hi fragment | 1 KiB half of the fp6
+        records] as int16 bit patterns (csrc/x3_common.hpp).  K in accumulator-register order.  The fp6 record of a lane
+        (output row n = 32 nt + lane % 32, half h = lane // 32) and K-tile T holds, for the lane's 16 input features (k-steps
+        2T, 2T+1), slots 0-15 = q6(hi * alpha), slots 16-31 = q6(lo * 2^12 * alpha) (alpha the largest power of two with
+        max|hi| * alpha <= 7.5 and no saturated lo code), six bits per slot, then the e8m0 byte of 1 / alpha four times, then zero: 8 dwords, the first four
+        in the even k-step's stage, the last four in the odd one's."""
+        assert KS % 2 == 0
+        n_out, n_in = w_out_in.shape
+        dev = w_out_in.device
+        wp = torch.zeros(32 * NT, 16 * KS, dtype=torch.float32, device=dev)
+        wp[:n_out, :n_in] = w_out_in.float()
+        ks = torch.arange(KS, device=dev).view(KS, 1, 1)
+        hh = torch.arange(2, device=dev).view(1, 2, 1)
+        e = torch.arange(8, device=dev).view(1, 1, 8)
+        k = 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh          # [KS, 2, 8]
+        wp = wp[:, k.reshape(-1)]                                                      # columns now [ks][h][e]
+        hi16 = wp.to(torch.float16)
+        hi = hi16.float()
+        lo = wp - hi
+        N, T = 32 * NT, KS // 2
+        hi_frag = hi16.view(NT, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, NT, 64, 8).contiguous().view(torch.int16)
+        # slot groups: [N, T, j, h, e] -> [N, T, h, (j, e)]
+        grp = lambda t: t.view(N, T, 2, 2, 8).permute(0, 1, 3, 2, 4).reshape(N, T, 2, 16)
+        gh, gl = grp(hi), grp(lo)
+        mx = gh.abs().amax(dim=-1)
+        ea = torch.where(mx > 0, torch.floor(torch.log2(7.5 / mx.clamp_min(1e-38))), torch.zeros_like(mx)).clamp(-100, 100)
+        ea = ea - ((gl.abs() * 4096.0 * torch.exp2(ea).unsqueeze(-1)).amax(dim=-1) > 7.5).to(ea.dtype)   # no saturated lo code
+        alpha = torch.exp2(ea).unsqueeze(-1)
+        codes = cls.e2m3_codes(torch.cat([gh * alpha, gl * alpha * 4096.0], dim=-1))    # [N, T, 2, 32]
+        c = codes.view(N, T, 2, 8, 4)
+        b0 = c[..., 0] | ((c[..., 1] & 3) << 6)
+        b1 = (c[..., 1] >> 2) | ((c[..., 2] & 15) << 4)
+        b2 = (c[..., 2] >> 4) | (c[..., 3] << 2)
+        rec = torch.zeros(N, T, 2, 32, dtype=torch.uint8, device=dev)
+        rec[..., :24] = torch.stack([b0, b1, b2], dim=-1).reshape(N, T, 2, 24).to(torch.uint8)
+        rec[..., 24:28] = (127 - ea).to(torch.uint8).unsqueeze(-1)
+        # [N = (nt, j32), T, h, (half, 16 B)] -> stage [ks = 2T + half][nt][lane = 32 h + j32][16 B]
+        rec = rec.view(NT, 32, T, 2, 2, 16).permute(2, 4, 0, 3, 1, 5).reshape(KS, NT, 64 * 16)
+        out = torch.empty(KS, NT, 2, 1024, dtype=torch.uint8, device=dev)
+        out[:, :, 0] = hi_frag.reshape(KS, NT, 64 * 8).view(torch.uint8).reshape(KS, NT, 1024)
+        out[:, :, 1] = rec
+        return out.view(torch.int16).flatten()
 
     # ------------------------------------------------------------------ split-bf16 engine with LDS-resident activations
     def x3t_supported(self):
@@ -286,11 +351,13 @@ class SynthesisPlan:
     # kernel is not bound by them -- so segmentation is off by default.
     X3_SEGMENT_BYTES = int(os.environ.get("H3D_SYNTH_SEGMENT_BYTES", 1 << 40))
 
-    def build_x3(self):
+    def build_x3(self, x2=False):
         """Segments of consecutive blocks whose weight streams each stay well inside the 4 MB L2 of an XCD; each
-        segment carries its own descriptor, fp32 tables and bf16 hi/lo stream."""
-        if self._x3 is not None:
-            return self._x3
+        segment carries its own descriptor, fp32 tables and bf16 hi/lo stream (x2: f16 hi fragments + fp6 records)."""
+        cache = "_x2" if x2 else "_x3"
+        if getattr(self, cache, None) is not None:
+            return getattr(self, cache)
+        pack = self.pack_stream_x2 if x2 else self.pack_stream_bf16
         C = self.C
         NT = 8 if C > 128 else 4
         HdP = NT * 32
@@ -345,14 +412,14 @@ class SynthesisPlan:
                     d, so = dst.spade[s], src.spade[s]
                     d.pixel_style, d.g_offset, d.cst_index, d.ab_index = so.pixel_style, so.g_offset, so.cst_index, so.ab_index
                     if raw["pixel"]:
-                        stream.append(self.pack_stream_bf16(raw["wgam"], SHARED // 16, NT))
-                        stream.append(self.pack_stream_bf16(raw["wbet"], SHARED // 16, NT))
+                        stream.append(pack(raw["wgam"], SHARED // 16, NT))
+                        stream.append(pack(raw["wbet"], SHARED // 16, NT))
                         stages += 2 * (SHARED // 16)
                         sc, sh = _pad(raw["sc"], HdP), _pad(raw["sh"], HdP)
                         d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), sc, sh + sc * carry]))
                     else:
                         ab_carry[so.ab_index] = carry
-                    stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
+                    stream.append(pack(raw["conv_w"], 2 * NT, NT))
                     stages += 2 * NT
                     d.b_conv = -1                                   # folded: the kernel has no bias add
                     carry = _pad(raw["conv_b"], HdP)
@@ -364,8 +431,8 @@ class SynthesisPlan:
                     dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
             segments.append(dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
                                  stages=stages, blocks=blocks))
-        self._x3 = dict(segments=segments, HdP=HdP, NT=NT, state=None, ab_carry=ab_carry)
-        return self._x3
+        setattr(self, cache, dict(segments=segments, HdP=HdP, NT=NT, state=None, ab_carry=ab_carry))
+        return getattr(self, cache)
 
     def per_forward_tables(self, feature_maps, fixed_style, HdP=None):
         """feature_maps [B,R,F] (rendered, channels last), fixed_style [B,F] -> (G, cst, ab)."""
@@ -389,11 +456,11 @@ class SynthesisPlan:
             ab[:, :, 1, : self.C] = self.sh_c * gamma1 + beta
         return G, cst, ab
 
-    def x3_forward_tables(self, feature_maps, fixed_style):
+    def x3_forward_tables(self, feature_maps, fixed_style, x2=False):
         """per_forward_tables for the x3 engine: the conv biases folded into the constant-style shifts (build_x3) and
         `ab` in the kernel's layout [B, n_ab, HdP/2, 4] = sc[n], sc[n+1], sh[n], sh[n+1] (one 16-byte LDS read per two
         channels)."""
-        x3 = self.build_x3()
+        x3 = self.build_x3(x2)
         G, cst, ab = self.per_forward_tables(feature_maps, fixed_style, x3["HdP"])
         if ab is not None:
             ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]
@@ -406,9 +473,10 @@ class SynthesisPlan:
         B = fixed_style.shape[0]
         Hr, Wr = render_hw
         H, W = out_hw
-        if self.engine not in ("bf16x3", "f32") and self.engine not in self.X3T_TIERS:
+        if self.engine not in ("bf16x3", "f16x2", "f32") and self.engine not in self.X3T_TIERS:
             raise ValueError(f"unknown synthesis engine {self.engine!r}")
-        x3 = self.build_x3() if self.engine == "bf16x3" else None
+        x2 = self.engine == "f16x2"
+        x3 = self.build_x3(x2) if self.engine in ("bf16x3", "f16x2") else None
         tier = self.X3T_TIERS.get(self.engine, self.X3T_TIERS["bf16x3t"])
         x3t = self.build_x3t(tier[0]) if self.engine in self.X3T_TIERS else None
         if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
@@ -416,11 +484,11 @@ class SynthesisPlan:
             x3, x3t = None, (self.build_x3t() if self.x3t_supported() else None)
         with stage(owner, "synthesis_tables"):
             if x3:
-                G, cst, ab = self.x3_forward_tables(feature_maps.float(), fixed_style.float())
+                G, cst, ab = self.x3_forward_tables(feature_maps.float(), fixed_style.float(), x2)
             else:
                 G, cst, ab = self.per_forward_tables(feature_maps.float(), fixed_style.float(), x3t["HdP"] if x3t else None)
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
-        what = "h3d_synthesis_x3" if x3 else "h3d_synthesis_x3t" if x3t else "h3d_synthesis"
+        what = ("h3d_synthesis_x2" if x2 else "h3d_synthesis_x3") if x3 else "h3d_synthesis_x3t" if x3t else "h3d_synthesis"
         with stage(owner, "synthesis"):
             if x3t:
                 rc = _lib.load().h3d_synthesis_x3t_tier(_lib.ptr(x3t["wblob"]), _lib.ptr(x3t["tables"]),
@@ -439,8 +507,9 @@ class SynthesisPlan:
                     x3["trace"] = torch.zeros(4096, dtype=torch.int64, device=fixed_style.device)
                     state = x3["trace"]
                 lib, rc = _lib.load(), 0
+                entry = lib.h3d_synthesis_x2 if x2 else lib.h3d_synthesis_x3
                 for i, seg in enumerate(segs):
-                    rc = lib.h3d_synthesis_x3(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]),
+                    rc = entry(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]),
                                               seg["tables"].numel(), ctypes.byref(seg["desc"]), _lib.ptr(G),
                                               self.g_channels, Hr, Wr, _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab),
                                               len(self.const_ids), _lib.ptr(rgb), B, H, W, _lib.ptr(state), int(i > 0),

@@ -166,7 +166,7 @@ def discriminator_step_bench(a, rank, world, dist_on, dev):
             "loss": {k: float(v) for k, v in last.items()}}))
 
 
-def train_step_bench(a, rank, world, dist_on, dev):
+def train_step_bench(a, rank, world, dist_on, dev, emit=True):
     """BASELINE config 4: one whole adversarial iteration per step = discriminator step (generator forward in train mode under
     no_grad, D forward on real + fake, R1 double backward, all-gather of the R1 statistics, gradient all-reduce, Adam) +
     generator step (differentiable generator forward, D forward, backward through both, gradient all-reduce, Adam, EMA).
@@ -211,8 +211,9 @@ def train_step_bench(a, rank, world, dist_on, dev):
     dt = timed_loop(step, a.steps, a.warmup, dist_on)
     torch.cuda.synchronize()
     ms = {k: sum(s.elapsed_time(t) for s, t in v[-a.steps:]) / a.steps for k, v in ev.items()}
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = ({
             "metric": "adversarial training iterations: images/sec at 512x256 (D step + G step)", "value": a.batch * world * a.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -226,7 +227,10 @@ def train_step_bench(a, rank, world, dist_on, dev):
                                       "bucketed gradient all-reduce"},
             "stage_ms": {"discriminator_step": ms["d"], "generator_step": ms["g"]},
             "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
-            "loss": {k: float(v) for k, v in last.items()}}))
+            "loss": {k: float(v) for k, v in last.items()}})
+        if emit:
+            print(json.dumps(line))
+    return line
 
 
 def kernel_rooflines(G, cfg, batch, stage_ms):
@@ -242,25 +246,33 @@ def kernel_rooflines(G, cfg, batch, stage_ms):
     pts, px = batch * R * S, batch * H * W
     out = {}
 
-    def mfma_entry(flop, ms, x3, extra=None):
-        peak = MFMA_F16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
+    def mfma_entry(flop, ms, engine, extra=None):
+        """engine: the arithmetic of the kernel's contractions.  Matrix-pipe time issued per algorithmic f16-rate product:
+        x3 = three f16/bf16 products; x2 = one f16 product + one block-scaled fp6 instruction per two k-steps that takes the
+        time of one f16 instruction (both cross terms) = 1.5; f32 = the fp32 matrix instruction (its own peak)."""
+        kind = "x2" if engine.endswith("x2") else "x3" if engine.endswith("x3") or engine.endswith("x3t") else "f32"
+        peak = MFMA_F32_PEAK_TF if kind == "f32" else MFMA_F16_PEAK_TF
+        factor = {"x3": 3.0, "x2": 1.5, "f32": 1.0}[kind]
+        label = {"x3": "split f16/bf16 x3: hi*hi + hi*lo + lo*hi, three 16-bit MFMA products (fp32-class)",
+                 "x2": "x2: f16 hi*hi + one block-scaled fp6 (e2m3) MFMA for both cross terms (1e-3-class, measured 2e-4)",
+                 "f32": "fp32 MFMA"}[kind]
         ach = flop / ms / 1e9
-        e = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, ms=ms, flop=flop,
-                 engine="split f16/bf16 x3 (fp32-class)" if x3 else "fp32 MFMA",
-                 mfma_pipe_util=(3 * ach / peak) if x3 else ach / peak, frac_of_fp32_mfma_peak=ach / MFMA_F32_PEAK_TF)
+        e = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, ms=ms, flop=flop, engine=f"{engine}: {label}",
+                 mfma_issue_factor=factor, mfma_pipe_util=factor * ach / peak, frac_of_fp32_mfma_peak=ach / MFMA_F32_PEAK_TF)
         if extra:
             e.update(extra)
         return e
 
     if "render_fused" in stage_ms:
         fl = 2.0 * (7 * Hd * Hd + 41 * Hd) * pts
-        out["h3d_render_fused"] = mfma_entry(fl, stage_ms["render_fused"][0], G.neural_field.precision == "f16x3")
+        out["h3d_render_fused"] = mfma_entry(fl, stage_ms["render_fused"][0], G.neural_field.precision)
     if "synthesis" in stage_ms:
         executed = 2.0 * (18 * Hd * Hd + 2 * n_mod * 128 * 2 * Hd + 6 * 3 * Hd) * px      # after the exact folding
         reference_form = 2.0 * (18 * Hd * Hd + 6932 * Hd) * px                              # SURVEY 8(d) figure
         ms = stage_ms["synthesis"][0]
-        out["h3d_synthesis"] = mfma_entry(executed, ms, G.synthesis_plan(next(G.parameters()).device).engine == "bf16x3",
-                                          dict(reference_formulation_TFLOPs=reference_form / ms / 1e9))
+        out["h3d_synthesis"] = mfma_entry(executed, ms, G.synthesis_plan(next(G.parameters()).device).engine,
+                                          dict(reference_formulation_TFLOPs=reference_form / ms / 1e9,
+                                               reference_formulation_frac=reference_form / ms / 1e9 / MFMA_F16_PEAK_TF))
     if "geo_features" in stage_ms:
         ms = stage_ms["geo_features"][0]
         by = pts * (3 + 31) * 4.0 + batch * 6890 * (3 + 3 + 16) * 4.0            # points in, features out, mesh once
@@ -482,17 +494,17 @@ def main():
     a = ap.parse_args()
 
     rank, world, local, dist_on = dist_env()
+    # MIOpen benchmarks every convolution configuration at first use (minutes for the discriminator's fwd / bwd / double-bwd
+    # shapes; its immediate-mode fallback lands on naive kernels: 24 s per D step).  The search results of a previous run
+    # are reused (tools/miopen_db, written by MIOpen itself); must be set before the first convolution.
+    db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "miopen_db")
+    if os.path.isdir(db):
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", db)
     torch.cuda.set_device(local)
     if dist_on:
         init_distributed(local)                                       # RCCL over xGMI
     dev = torch.device("cuda", local)
     if a.mode in ("dstep", "trainstep"):
-        # MIOpen benchmarks every convolution configuration at first use (minutes for the discriminator's fwd / bwd /
-        # double-bwd shapes; its immediate-mode fallback, MIOPEN_FIND_MODE=FAST, lands on naive kernels: 24 s per D step).
-        # The search results of a previous run are reused when they were kept (tools/miopen_db, written by MIOpen itself).
-        db = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "miopen_db")
-        if os.path.isdir(db):
-            os.environ.setdefault("MIOPEN_USER_DB_PATH", db)
         (discriminator_step_bench if a.mode == "dstep" else train_step_bench)(a, rank, world, dist_on, dev)
         if dist_on:
             torch.distributed.destroy_process_group()
@@ -528,8 +540,8 @@ def main():
     kernels["h3d_ray_integrate"] = ray_integrate_roofline(cfg, a.batch)
     dominant = max((k for k in kernels if "frac" in kernels[k] and k != "h3d_ray_integrate"),
                    key=lambda k: kernels[k]["ms"])
-    roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "engine", "mfma_pipe_util",
-                                              "frac_of_fp32_mfma_peak")}
+    roof = {k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "engine", "mfma_issue_factor",
+                                              "mfma_pipe_util", "frac_of_fp32_mfma_peak")}
     roof["kernel"] = dominant
     # HBM traffic per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate passes,
     # corrected as MI355X_MICROARCH.md prescribes); only valid for the workload it was measured on.
@@ -563,14 +575,29 @@ def main():
         extra["cfg5_MAP3DBN512_1024x1024_192x192rays_s128"] = side_run("MAP3DBN512", (1024, 1024), (192, 192), 128, 4, 3)
         extra["headline_workload_on_strict_fp32_mfma_engines"] = side_run(a.config, (H, W), render, a.samples, a.batch, 2,
                                                                         engines=("f32", "f32"))
+        extra["headline_workload_on_x3_engines"] = side_run(a.config, (H, W), render, a.samples, a.batch, n2,
+                                                          engines=("f16x3", "bf16x3"))
         extra["op_rooflines"] = op_rooflines()
+        # BASELINE config 4's per-GPU share (one adversarial iteration: D step with R1 + G step, batch 4, 512x256, 96x48 rays x
+        # 32), fp32, MIOpen's search results from tools/miopen_db: the same code path as `--mode trainstep`
+        try:
+            torch.cuda.reset_peak_memory_stats()
+            t4 = train_step_bench(argparse.Namespace(config=a.config, batch=4, steps=3, warmup=2, amp="none"), 0, 1, False, dev, emit=False)
+            extra["cfg4_trainstep_b4"] = dict(images_per_s=t4["value"], ms_per_iteration=t4["ms_per_step"],
+                                              discriminator_step_ms=t4["stage_ms"]["discriminator_step"],
+                                              generator_step_ms=t4["stage_ms"]["generator_step"], peak_memory_GB=t4["peak_memory_GB"],
+                                              batch=4, steps=3, warmup=2, dtype=t4["dtype"], workload=t4["config"]["workload"])
+            torch.cuda.empty_cache()
+        except Exception as e:                                  # noqa: BLE001 -- a side workload must not lose the headline
+            extra["cfg4_trainstep_b4"] = dict(error=repr(e)[:300])
 
     out = {
         "metric": "generator images/sec at 512^2", "value": value, "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 in/out; GEMMs as split f16/bf16 hi+lo (3 MFMA products, fp32 accumulate): fp32-class results, "
-                 "parity 1e-3 vs the fp32 reference met with 1e-5",
+        "dtype": f"f32 in/out, fp32 accumulate; contractions: field {G.neural_field.precision}, synthesis "
+                 f"{G.synthesis_plan(dev).engine} (x2 = f16 hi*hi + one block-scaled fp6 MFMA for the two cross terms; x3 = three "
+                 "f16/bf16 products); parity 1e-3 vs the fp32 reference checked in this run (`checked`)",
         "data": "synthetic",
         "config": {"workload": f"{a.config} generator-only forward, {H}x{W} output, {render[0]}x{render[1]} rays, "
                                f"{a.samples} samples/ray, hidden {cfg['hidden_dim']}, batch {a.batch}/GPU, "

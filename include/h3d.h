@@ -302,6 +302,20 @@ int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tabl
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                      float* state, int load_state, int store_state, h3d_stream_t stream_handle);
 
+/* h3d_synthesis_x3 in the "x2" arithmetic (csrc/x3_common.hpp, see the _x2 field entry points): every conv / gamma /
+ * beta contraction is one f16 product hi*hi plus one block-scaled fp6 (e2m3) matrix instruction for the two cross terms;
+ * activations are not bounded here, so every pixel's K-tile record carries its own power-of-two scale (largest of its 16
+ * values).  f16 hi halves: inputs of these convolutions must be f16-representable (|x| < 65504) -- the reference trains
+ * them under fp16 autocast (lib/trainers/base_trainer.py:50-51).  Same arguments, limits and return codes as
+ * h3d_synthesis_x3; the stream holds, per stage, [tile][1 KiB f16 hi fragment][1 KiB half of the K-tile's fp6 records]
+ * (record layout as for h3d_field_pack_x2; SynthesisPlan.pack_stream_x2), and the kernel needs
+ * h3d_synthesis_x2_extra_lds(C) more bytes of LDS than h3d_synthesis_x3 (one more ring buffer). */
+int h3d_synthesis_x2(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                     const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                     const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                     float* state, int load_state, int store_state, h3d_stream_t stream_handle);
+int h3d_synthesis_x2_extra_lds(int C);
+
 /* Same network, split-bf16 arithmetic as h3d_synthesis_x3, for widths up to 448 ("x3t": the activations of a 64-pixel
  * tile live in LDS as ready-made MFMA fragments, the channels are split over the four waves; csrc/x3t_common.hpp).
  * tiles = h3d_synthesis_x3t_tiles(C) (even, >= 4; -1 when C > 448), HdP = 32*tiles.

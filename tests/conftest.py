@@ -14,6 +14,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# MIOpen (the discriminator's convolutions): reuse the shipped search results for config 4's shapes instead of benchmarking
+# every configuration at first use (minutes); must be set before the first convolution runs
+_MIOPEN_DB = os.path.join(ROOT, "tools", "miopen_db")
+if os.path.isdir(_MIOPEN_DB):
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / driver GPU tier)")
 

@@ -38,10 +38,12 @@ def _setup(B=2):
     return G, cfg, z, cond, jit
 
 
+@pytest.mark.parametrize("engines", [("f16x2", "f16x2"), ("f16x3", "bf16x3")])
 @pytest.mark.parametrize("thrash", [False, True])
-def test_x3_kernels_are_bit_reproducible_over_200_launches(thrash):
+def test_x3_kernels_are_bit_reproducible_over_200_launches(thrash, engines):
     G, cfg, z, cond, jit = _setup()
-    assert G.neural_field.precision == "f16x3" and G.synthesis_plan(DEV).engine == "bf16x3"
+    assert G.neural_field.precision == "f16x2" and G.synthesis_plan(DEV).engine == "f16x2"
+    G.neural_field.precision, G.synthesis_plan(DEV).engine = engines
     first = G.forward(z, cond, jitter=jit, **cfg)
     ref_rgb, ref_ren = first["rgbs"].clone(), first["rgbs_render"].clone()
     side = torch.cuda.Stream()
@@ -61,5 +63,5 @@ def test_x3_kernels_are_bit_reproducible_over_200_launches(thrash):
     G.neural_field.precision = "f32"
     G.synthesis_plan(DEV).engine = "f32"
     strict = G.forward(z, cond, jitter=jit, **cfg)
-    assert rel_err(ref_rgb.cpu(), strict["rgbs"].cpu()) < 2e-4
+    assert rel_err(ref_rgb.cpu(), strict["rgbs"].cpu()) < (2e-4 if engines[1] == "bf16x3" else 1e-3)
     assert rel_err(ref_ren.cpu(), strict["rgbs_render"].cpu()) < 2e-4

@@ -32,14 +32,57 @@ def decode_matrix(stream_i16, stage0, KS, NT):
     return W
 
 
-def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W):
-    """float64 restatement of synthesis_x3_kernel on the plan's own tables / stream."""
-    x3 = plan.build_x3()
+CODES = torch.tensor([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875,
+                      2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5], dtype=torch.float64)
+
+
+def decode_x2(stream_i16, stage0, KS, NT):
+    """x2 stages [KS][NT][1 KiB f16 hi fragment | 1 KiB record halves] -> (Whi [32 NT, 16 KS] in feature order, groups for
+    x2_emulation.x2_operands_matmul: (features [16], codes_hi [N, 16], codes_lo [N, 16], block scale [N]))."""
+    n = KS * NT * 1024                                                # int16 elements
+    st = stream_i16[stage0 * NT * 1024: stage0 * NT * 1024 + n].view(KS, NT, 2, 512)
+    hi = st[:, :, 0].contiguous().view(torch.float16).double().view(KS, NT, 64, 8)
+    Whi = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+    for ks in range(KS):
+        for h in range(2):
+            for e in range(8):
+                Whi[:, acc_k(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
+    half = st[:, :, 1].contiguous().view(torch.uint8).view(KS, NT, 64, 16).to(torch.int64)
+    groups = []
+    for T in range(KS // 2):
+        rec = torch.cat([half[2 * T], half[2 * T + 1]], dim=-1)                     # [NT, 64, 32 bytes]
+        b = rec[..., :24].reshape(NT, 64, 8, 3)
+        c = torch.stack([b[..., 0] & 63, (b[..., 0] >> 6) | ((b[..., 1] & 15) << 2), (b[..., 1] >> 4) | ((b[..., 2] & 3) << 4),
+                         b[..., 2] >> 2], dim=-1).reshape(NT, 64, 32)
+        vals = CODES[c & 31] * torch.where((c & 32) > 0, -1.0, 1.0)
+        assert torch.equal(rec[..., 24:28], rec[..., 24:25].expand(-1, -1, 4)) and int(rec[..., 28:].abs().max()) == 0
+        scale = torch.exp2((rec[..., 24] - 127).double())
+        for h in range(2):
+            feats = torch.tensor([acc_k(2 * T + j, h, e) for j in range(2) for e in range(8)])
+            v = vals[:, 32 * h: 32 * h + 32].reshape(32 * NT, 32)
+            groups.append((feats, v[:, :16], v[:, 16:], scale[:, 32 * h: 32 * h + 32].reshape(32 * NT)))
+    return Whi, groups
+
+
+def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
+    """float64 restatement of synthesis_x3_kernel on the plan's own tables / stream (x2: the x2 arithmetic on the decoded f16
+    fragments and fp6 records, with the per-pixel activation scales of csrc/synthesis_x3.hip)."""
+    x3 = plan.build_x3(x2)
     assert len(x3["segments"]) == 1
     seg, NT, HdP = x3["segments"][0], x3["NT"], x3["HdP"]
     desc, tab = seg["desc"], seg["tables"].double()
     stream = seg["stream"]
-    G, cst, ab = plan.x3_forward_tables(fmap_lowres.float(), fixed_style.float())
+    G, cst, ab = plan.x3_forward_tables(fmap_lowres.float(), fixed_style.float(), x2)
+
+    def decode(stream_, stage0, KS, NT_):
+        return decode_x2(stream_, stage0, KS, NT_) if x2 else decode_matrix(stream_, stage0, KS, NT_)
+
+    def mm(y, ops):                                                   # y @ W.t() in the engine's arithmetic
+        if not x2:
+            return y @ ops.t()
+        from x2_emulation import x2_operands_matmul
+        yp = torch.nn.functional.pad(y, (0, ops[0].shape[1] - y.shape[-1]))
+        return x2_operands_matmul(yp, ops[0], ops[1], dynamic=True)
     B = fixed_style.shape[0]
     vec = lambda off, n=HdP: tab[off: off + n]
     ii = torch.linspace(-1, 1, H, dtype=torch.float64).view(H, 1).expand(H, W).reshape(-1)
@@ -59,17 +102,17 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W):
             d = bk.spade[s]
             if d.pixel_style:
                 a = torch.relu(Gup[:, :, d.g_offset: d.g_offset + 128] + cst[:, d.cst_index].double()[:, None, :])
-                Wg = decode_matrix(stream, stage, 8, NT); stage += 8
-                Wb = decode_matrix(stream, stage, 8, NT); stage += 8
-                g1 = vec(d.vec) + a @ Wg.t()
-                y = lrelu((x * vec(d.vec + 2 * HdP) + vec(d.vec + 3 * HdP)) * g1 + vec(d.vec + HdP) + a @ Wb.t())
+                Wg = decode(stream, stage, 8, NT); stage += 8
+                Wb = decode(stream, stage, 8, NT); stage += 8
+                g1 = vec(d.vec) + mm(a, Wg)
+                y = lrelu((x * vec(d.vec + 2 * HdP) + vec(d.vec + 3 * HdP)) * g1 + vec(d.vec + HdP) + mm(a, Wb))
             else:
                 t4 = ab[:, d.ab_index].double()                       # [B, HdP/2, 2 (sc | sh), 2 (channel pair)]
                 sc = t4[:, :, 0, :].reshape(B, 1, HdP)
                 sh = t4[:, :, 1, :].reshape(B, 1, HdP)
                 y = lrelu(x * sc + sh)
-            Wc = decode_matrix(stream, stage, 2 * NT, NT); stage += 2 * NT
-            x = y @ Wc.t() + (x_in if (s == 1 and bk.skip) else 0.0)
+            Wc = decode(stream, stage, 2 * NT, NT); stage += 2 * NT
+            x = mm(y, Wc) + (x_in if (s == 1 and bk.skip) else 0.0)
         if bk.to_rgb:
             wr = torch.stack([vec(bk.w_rgb), vec(bk.w_rgb + HdP), vec(bk.w_rgb + 2 * HdP)])          # [3, HdP]
             rgb = rgb + x @ wr.t() + vec(bk.w_rgb + 3 * HdP, 3)
@@ -77,8 +120,9 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W):
     return rgb.view(B, H, W, 3).permute(0, 3, 1, 2)
 
 
+@pytest.mark.parametrize("x2", [False, True])
 @pytest.mark.parametrize("mode,width", [("mixed", 32), ("isolated", 40)])
-def test_x3_plan_matches_oracle(mode, width):
+def test_x3_plan_matches_oracle(mode, width, x2):
     meta = dict(load_golden("gen_tiny_mixed")["meta"])
     meta.update(map3d_mode=mode, hidden_dim=width, latent_dim=width, feature_dim=width, gen_height=12, gen_width=8,
                 render_height=5, render_width=4)
@@ -101,7 +145,7 @@ def test_x3_plan_matches_oracle(mode, width):
     B, Hr, Wr, H, W = 2, 5, 4, 12, 8
     fmap = torch.randn(B, Hr * Wr, width)
     style = torch.randn(B, width)
-    got = emulate(plan, fmap, style, Hr, Wr, H, W)
+    got = emulate(plan, fmap, style, Hr, Wr, H, W, x2)
     fm = fmap.view(B, Hr, Wr, width).permute(0, 3, 1, 2)
     fm_up = torch.nn.functional.interpolate(fm, (H, W), mode="bilinear")
     x0 = O.synthesis_input(sd, B, H, W)

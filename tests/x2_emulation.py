@@ -6,8 +6,10 @@ A product W.x is evaluated as
                                                      significant bits because they are 2^-11 of the main term
 (lo.lo, 2^-22 relative, is dropped as in the x3 engines).  hi = f16 rounding, lo = the fp32 residual; q6 = round-to-nearest-even,
 saturating e2m3 (1 sign, 2 exponent, 3 mantissa bits: 0, 0.125 .. 0.875, 1 .. 7.5) of the value times a power-of-two scale:
-weights: one scale per (output row, 16-feature slot group) chosen so that |hi| <= 3.75, lo with 2^12 times that scale;
-activations: static scales 4 (hi, |x| <= 1 after a sine) and 4 * 2^12 (lo).
+weights: one power-of-two scale alpha per (output row, 16-feature slot group): the largest with |hi| alpha <= 7.5 if no lo code
+saturates (|lo| 2^12 alpha <= 7.5), else half of it; activations: static scales 4 (hi, |x| <= 1 after a sine: field engine) and
+4 * 2^12 (lo), or, for unbounded activations (synthesis engine), a per-(sample, group) power of two from the largest |x| of
+the group: the largest with |hi| / cs < 7.5.
 """
 import numpy as np
 import torch
@@ -43,7 +45,15 @@ def slot_groups(K):
     return [g for g in groups if len(g)]
 
 
-def x2_matmul(x, W, x_scale_hi=4.0, rho=4096.0, w_target=8192.0, hi_max=3.75):
+def weight_alpha(Wh_g, Wl_g, rho=4096.0):
+    """Block scale of one slot group: Wh_g, Wl_g [N, 16] -> alpha [N] (see the module docstring)."""
+    wmax = Wh_g.abs().amax(dim=1)
+    a2 = torch.where(wmax > 0, 2.0 ** torch.floor(torch.log2(7.5 / wmax.clamp_min(1e-300))), torch.ones_like(wmax))
+    ok = (Wl_g.abs() * rho * a2[:, None]).amax(dim=1) <= 7.5
+    return torch.where(ok, a2, a2 / 2)
+
+
+def x2_matmul(x, W, x_scale_hi=4.0, rho=4096.0, w_target=8192.0):
     """x [..., K] (float), W [N, K] -> x @ W.T evaluated in the x2 arithmetic (float64 accumulation stands in for fp32)."""
     x, W = x.double(), W.double()
     K = W.shape[1]
@@ -58,8 +68,7 @@ def x2_matmul(x, W, x_scale_hi=4.0, rho=4096.0, w_target=8192.0, hi_max=3.75):
     Bh = q_e2m3(xh * x_scale_hi)
     Bl = q_e2m3(f16(xl * rho) * x_scale_hi)          # the lo plane travels as f16 (pre-scaled by rho) into the conversion
     for g in slot_groups(K):
-        wmax = Wh[:, g].abs().amax(dim=1)
-        alpha = torch.where(wmax > 0, 2.0 ** torch.floor(torch.log2(hi_max / wmax.clamp_min(1e-300))), torch.ones_like(wmax))
+        alpha = weight_alpha(Wh[:, g], Wl[:, g], rho)
         Ah = q_e2m3(Wh[:, g] * alpha[:, None])
         Al = q_e2m3(Wl[:, g] * rho * alpha[:, None])
         cross = (Bl[..., g] @ Ah.t() + Bh[..., g] @ Al.t()) / (alpha * x_scale_hi * rho)
@@ -78,3 +87,38 @@ def x3_matmul(x, W, w_target=8192.0):
     xh = f16(x)
     xl = f16(x - xh)
     return (xh @ Wh.t() + xl @ Wh.t() + xh @ Wl.t()) / sc
+
+
+def x2_operands_matmul(x, Whi, groups, dynamic=True, x_scale_hi=4.0, rho=4096.0):
+    """The kernel's arithmetic on DECODED operands: Whi [N, K] f16 values (feature order), groups = list of
+    (feature index tensor [16], codes_hi [N, 16], codes_lo [N, 16], block_scale [N] = 1 / alpha) -> x @ W.T.
+    dynamic: per-(row of x, group) power-of-two activation scale from the largest |x| of the group (synthesis engine);
+    otherwise the static scale of the field engine (|x| <= 1)."""
+    x = x.double()
+    xh = f16(x)
+    xl = f16((x - xh) * rho)                       # lo' as the f16 fragment the conversion reads
+    y = xh @ Whi.t()
+    for feats, a_hi, a_lo, s in groups:
+        gh, gl = xh[..., feats], xl[..., feats]
+        if dynamic:
+            amax = x[..., feats].abs().amax(dim=-1, keepdim=True).float().double()      # the kernel's fp32 running maximum
+            e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -113)))
+            tight = amax / 2.0 ** e < 1.875                                               # then |hi| / 2^(e-2) < 7.5
+            cs = torch.where(tight, 2.0 ** (e - 2), 2.0 ** (e - 1))
+        else:
+            cs = torch.full_like(gh[..., :1], 1.0 / x_scale_hi)
+        Bh, Bl = q_e2m3(gh / cs), q_e2m3(gl / cs)
+        y = y + (Bl @ a_hi.t() + Bh @ a_lo.t()) * s * (cs / rho)
+    return y
+
+
+def x2_weight_operands(W, rho=4096.0):
+    """What SynthesisPlan.pack_stream_x2 encodes (no matrix scale): -> (Whi, groups) for x2_operands_matmul."""
+    W = W.double()
+    Wh = f16(W)
+    Wl = W - Wh
+    groups = []
+    for g in slot_groups(W.shape[1]):
+        alpha = weight_alpha(Wh[:, g], Wl[:, g], rho)
+        groups.append((g, q_e2m3(Wh[:, g] * alpha[:, None]), q_e2m3(Wl[:, g] * rho * alpha[:, None]), 1.0 / alpha))
+    return Wh, groups
