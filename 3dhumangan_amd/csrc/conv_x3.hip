@@ -1,0 +1,177 @@
+// 3x3 / 1x1 convolution (stride 1, "same" zero padding) of channels-last fp32 activations on the bf16 matrix cores with split
+// ("x3") operands, for gfx950: the discriminator's convolutions (reference: lib/discriminators/unet_discriminators.py:8-72, the
+// nn.Conv2d(fin, fout, 3, 1, 1) / (fin, fout, 1) layers of ResBlock) -- forward AND backward-data (the same implicit GEMM on
+// the flipped, transposed weights; the host packs either).  The weight gradient is h3d_conv_wgrad_x3 (wgrad_x3.hip).
+//
+//   out[p, o] = bias[o] + sum_{tap, i} W[o, i, tap] * x[p + tap, i]         p = (b, y, x) row-major, x / out [B, H, W, C]
+//
+// Implicit GEMM with M = pixels, N = output channels, K = taps x input channels, on the machinery of the register-resident x3
+// engines (x3_common.hpp): a wavefront owns 32 pixels and up to 256 output channels (accumulators in AGPRs), the weights are the
+// MFMA A operand, pulled once per workgroup (4 waves = 128 pixels) from L2 into the LDS ring by LDS-DMA in consumption order
+// [output block][tap][channel chunk][k-step][tile][hi|lo]; the activations are the B operand: a lane reads 8 consecutive input
+// channels of its (shifted) pixel -- 32 contiguous bytes, channels-last -- one chunk (<= 128 channels) ahead of the matrix
+// pipe, and splits them into bf16 hi / lo fragments in registers (fp32 exponent range: gradients need no scaling; 16 mantissa
+// bits per operand: ~2e-5 against fp64).  Every product is hi*hi + hi*lo + lo*hi with fp32 accumulation.
+#include "x3_common.hpp"
+
+using namespace h3d;
+
+namespace {
+
+constexpr int kDepth = 7;          // ring stages (NT * 2 KiB each)
+
+struct Args {
+    const float* x;                // [P, Cin]
+    const unsigned char* stream;   // packed weights
+    const float* bias;             // [Cout] or null
+    float* out;                    // [P, Cout]
+    int64_t P;                     // B * H * W
+    int H, W, Cin, Cout, k, n_chunks, stages_per_oblk;
+};
+
+// this lane's 8 consecutive channels (16 ks + 8 h ..) of its shifted pixel for the KSC k-steps of one chunk: 2 float4 per k-step
+template <int KSC>
+__device__ __forceinline__ void load_chunk(float4 (&raw)[2 * KSC], const float* __restrict__ src, bool valid, int h) {
+#pragma unroll
+    for (int s = 0; s < KSC; ++s) {
+        const float4* q = reinterpret_cast<const float4*>(src + 16 * s + 8 * h);
+        raw[2 * s] = valid ? q[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        raw[2 * s + 1] = valid ? q[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int KSC>
+__device__ __forceinline__ void split_chunk(const float4 (&raw)[2 * KSC], BF16::vec8 (&xh)[KSC], BF16::vec8 (&xl)[KSC]) {
+#pragma unroll
+    for (int s = 0; s < KSC; ++s) {
+        unsigned hw[4], lw[4];
+        hw[0] = split2_bf16(raw[2 * s].x, raw[2 * s].y, lw[0]);
+        hw[1] = split2_bf16(raw[2 * s].z, raw[2 * s].w, lw[1]);
+        hw[2] = split2_bf16(raw[2 * s + 1].x, raw[2 * s + 1].y, lw[2]);
+        hw[3] = split2_bf16(raw[2 * s + 1].z, raw[2 * s + 1].w, lw[3]);
+        xh[s] = __builtin_bit_cast(BF16::vec8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+        xl[s] = __builtin_bit_cast(BF16::vec8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+    }
+}
+
+template <int NT, int KSC>
+__global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_lds[];
+    constexpr int L = NT >= 4 ? 2 : 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int oblk = blockIdx.y;
+    const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + m;
+    const bool okp = p < A.P;
+    const int64_t pc = okp ? p : A.P - 1;
+    const int64_t HW = (int64_t)A.H * A.W;
+    const int rem = (int)(pc % HW);
+    const int y = rem / A.W, x = rem - y * A.W;
+    const int pad = A.k / 2;
+    const int n_iter = A.k * A.k * A.n_chunks;
+
+    WeightRing<NT, kDepth> ring;
+    ring.init(A.stream + (int64_t)oblk * A.stages_per_oblk * (NT * 2048), ring_lds, A.stages_per_oblk, wave, lane);
+
+    f32x16 acc[NT];
+    float4 raw[2 * KSC];
+    BF16::vec8 xh[KSC], xl[KSC];
+    auto source = [&](int it, bool& valid) -> const float* {
+        const int tap = it / A.n_chunks, chunk = it - tap * A.n_chunks;
+        const int ty = tap / A.k - pad, tx = tap - (tap / A.k) * A.k - pad;
+        valid = okp && (unsigned)(y + ty) < (unsigned)A.H && (unsigned)(x + tx) < (unsigned)A.W;
+        const int64_t q = valid ? pc + (int64_t)ty * A.W + tx : pc;
+        return A.x + q * A.Cin + chunk * (16 * KSC);
+    };
+    {
+        bool valid;
+        const float* src = source(0, valid);
+        load_chunk<KSC>(raw, src, valid, h);
+    }
+    // first chunk: fresh accumulators
+    split_chunk<KSC>(raw, xh, xl);
+    if (n_iter > 1) {
+        bool valid;
+        const float* src = source(1, valid);
+        load_chunk<KSC>(raw, src, valid, h);
+    }
+    gemm_x3_roll<BF16, NT, KSC, KSC, false, L, 0, true>(acc, xh, xl, ring);
+#pragma unroll 1
+    for (int it = 1; it < n_iter; ++it) {
+        pin_agpr<NT>(acc);
+        split_chunk<KSC>(raw, xh, xl);
+        if (it + 1 < n_iter) {
+            bool valid;
+            const float* src = source(it + 1, valid);
+            load_chunk<KSC>(raw, src, valid, h);
+        }
+        gemm_x3_roll<BF16, NT, KSC, KSC, false, L>(acc, xh, xl, ring);
+    }
+    ring.drain();
+    // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
+    if (okp) {
+        float* __restrict__ o = A.out + p * A.Cout + oblk * (NT * 32);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = nt * 32 + rg * 8 + 4 * h;
+                float4 v = make_float4(acc[nt][4 * rg], acc[nt][4 * rg + 1], acc[nt][4 * rg + 2], acc[nt][4 * rg + 3]);
+                if (A.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(A.bias + oblk * (NT * 32) + n);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                *reinterpret_cast<float4*>(o + n) = v;
+            }
+        }
+    }
+}
+
+template <int NT, int KSC>
+int launch(const Args& A, int n_oblk, hipStream_t st) {
+    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC>));
+    const int64_t tiles = (A.P + 127) / 128;
+    h3d::pre_launch();
+    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
+    return h3d::launch_status("h3d_conv_x3");
+}
+
+}  // namespace
+
+// Tiling of a [Cout <- Cin] convolution: out[0] = tiles NT per output block (2, 4 or 8), out[1] = output blocks, out[2] = k-steps
+// per channel chunk (4 or 8), out[3] = chunks.  -1 when the channel counts are not supported (both must be multiples of 64).
+extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
+    if (!out || Cin < 64 || Cout < 64 || Cin % 64 || Cout % 64) return -1;
+    const int NT = Cout >= 256 ? 8 : Cout >= 128 ? 4 : 2;
+    if (Cout % (32 * NT)) return -1;
+    const int KSC = Cin % 128 == 0 ? 8 : 4;
+    out[0] = NT; out[1] = Cout / (32 * NT); out[2] = KSC; out[3] = Cin / (16 * KSC);
+    return 0;
+}
+
+extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
+                           int Cout, int k, h3d_stream_t stream_) {
+    H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
+    H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
+    H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
+                "h3d_conv_x3: operands must be 16-byte aligned");
+    int til[4];
+    if (h3d_conv_x3_tiling(Cin, Cout, til)) {
+        h3d::set_error("h3d_conv_x3: channel counts must be multiples of 64 (got %d -> %d)", Cin, Cout);
+        return H3D_EUNSUPPORTED;
+    }
+    if (B == 0) return H3D_OK;
+    Args A{};
+    A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out;
+    A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
+    A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * til[2];
+    H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const int NT = til[0], KSC = til[2];
+#define H3D_CASE(N, K) if (NT == N && KSC == K) return launch<N, K>(A, til[1], st)
+    H3D_CASE(8, 8); H3D_CASE(8, 4); H3D_CASE(4, 8); H3D_CASE(4, 4); H3D_CASE(2, 8); H3D_CASE(2, 4);
+#undef H3D_CASE
+    return H3D_EUNSUPPORTED;
+}

@@ -29,19 +29,33 @@ struct Args {
     float* partial;
     int64_t M;
     int Co, Ci, ldy, ldx, rows_per_wg;
+    int conv_k, H, W, slices;     // conv_k > 0: weight gradient of a k x k convolution over [B, H, W] pixels (rows of X shifted per tap)
 };
 
-template <int NT>
+// row of X that pairs with row rr of dY for filter tap (ty, tx): the shifted pixel, or -1 outside the image (zero padding)
+__device__ __forceinline__ int64_t shifted_row(int64_t rr, int ty, int tx, int H, int W) {
+    const int64_t HW = (int64_t)H * W;
+    const int rem = (int)(rr % HW);
+    const int y = rem / W, x = rem - y * W;
+    if ((unsigned)(y + ty) >= (unsigned)H || (unsigned)(x + tx) >= (unsigned)W) return -1;
+    return rr + (int64_t)ty * W + tx;
+}
+
+template <int NT, bool SHIFT = false>
 __device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restrict__ src, int ld, int64_t row0, int64_t M,
-                                          int col0, int ncols, int t) {
+                                          int col0, int ncols, int t, int ty = 0, int tx = 0, int H = 1, int W = 1) {
     constexpr int W4 = 16 * NT;               // float4 per slab row (slab width 64 NT floats)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int idx = j * kThreads + t;
         const int row = idx / W4, c = (idx - row * W4) * 4;
-        const int64_t rr = row0 + row;
-        r[j] = (rr < M && col0 + c < ncols) ? *reinterpret_cast<const float4*>(src + rr * ld + col0 + c)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t rr = row0 + row;
+        bool ok = rr < M && col0 + c < ncols;
+        if (SHIFT && ok) {
+            rr = shifted_row(rr, ty, tx, H, W);
+            ok = rr >= 0;
+        }
+        r[j] = ok ? *reinterpret_cast<const float4*>(src + rr * ld + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -62,7 +76,7 @@ __device__ __forceinline__ void read_frag(const float* lds, int col, int lane, B
     lo = __builtin_bit_cast(BF16::vec8, h3d::u32x4{l[0], l[1], l[2], l[3]});
 }
 
-template <int NA, int NB>
+template <int NA, int NB, bool CONV = false>
 __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
     constexpr int WA = 64 * NA, WB = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -70,7 +84,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int co0 = blockIdx.y * WA, ci0 = blockIdx.z * WB;
-    const int64_t r_begin = (int64_t)blockIdx.x * A.rows_per_wg;
+    const int tap = CONV ? blockIdx.x / A.slices : 0, slice = CONV ? blockIdx.x - tap * A.slices : blockIdx.x;
+    const int ty = CONV ? tap / A.conv_k - A.conv_k / 2 : 0, tx = CONV ? tap - (tap / A.conv_k) * A.conv_k - A.conv_k / 2 : 0;
+    const int64_t r_begin = (int64_t)slice * A.rows_per_wg;
     const int64_t r_end = r_begin + A.rows_per_wg < A.M ? r_begin + A.rows_per_wg : A.M;
     const int n_steps = r_end > r_begin ? (int)((r_end - r_begin + kKS - 1) / kKS) : 0;
 
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
     float4 ra[NA], rb[NB];
     // rows past r_end must not leak into this slice: the loaders clip at min(M, r_end) through the `M` argument
     load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
-    load_slab<NB>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t);
+    load_slab<NB, CONV>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
     park_slab<NA>(ra, smem, t);
     park_slab<NB>(rb, smem + kKS * WA, t);
     __syncthreads();
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
             load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
-            load_slab<NB>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t);
+            load_slab<NB, CONV>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
         }
         BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
 #pragma unroll
@@ -139,10 +155,12 @@ int tiles_for(int c) { return c > 128 ? 4 : c > 64 ? 2 : 1; }
 template <int NA, int NB>
 int launch(const Args& a, int slices, hipStream_t st) {
     constexpr size_t lds = 2 * kKS * (64 * NA + 64 * NB) * sizeof(float);
-    const dim3 grid((unsigned)slices, (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
+    const int taps = a.conv_k > 0 ? a.conv_k * a.conv_k : 1;
+    const dim3 grid((unsigned)(slices * taps), (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
     h3d::pre_launch();
-    hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB>), grid, dim3(kThreads), lds, st, a);
-    return h3d::launch_status("h3d_wgrad_x3");
+    if (a.conv_k > 0) hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, true>), grid, dim3(kThreads), lds, st, a);
+    else hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, false>), grid, dim3(kThreads), lds, st, a);
+    return h3d::launch_status(a.conv_k > 0 ? "h3d_conv_wgrad_x3" : "h3d_wgrad_x3");
 }
 
 }  // namespace
@@ -168,8 +186,8 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
                 "h3d_wgrad_x3: Co, Ci and the leading dimensions must be multiples of 4 (Co=%d Ci=%d ldy=%d ldx=%d)", Co, Ci, ldy, ldx);
     H3D_REQUIRE(h3d::aligned16(dY) && h3d::aligned16(X), "h3d_wgrad_x3: operands must be 16-byte aligned");
     H3D_REQUIRE(slices >= 1 && slices <= 65535 * 16, "h3d_wgrad_x3: slices=%d out of range", slices);
-    Args a;
-    a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx;
+    Args a{};
+    a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx; a.slices = slices;
     const int64_t per = (M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -179,5 +197,29 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
     H3D_CASE(1, 4); H3D_CASE(1, 2); H3D_CASE(1, 1);
 #undef H3D_CASE
     h3d::set_error("h3d_wgrad_x3: no kernel for tile counts %d x %d", na, nb);
+    return H3D_EUNSUPPORTED;
+}
+
+// Weight gradient of a k x k convolution (stride 1, zero padding k/2) of channels-last activations:
+//   partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co]^T X[p + tap, Ci]      (the caller sums the slices)
+// dY [B*H*W, Co], X [B*H*W, Ci] fp32; Co, Ci multiples of 4; slices as h3d_wgrad_x3_slices(B*H*W / k^2 ..) -- any >= 1.
+extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
+                                 int slices, h3d_stream_t stream) {
+    H3D_REQUIRE(dY && X && partial, "h3d_conv_wgrad_x3: null pointer");
+    H3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Co >= 1 && Ci >= 1 && (k == 1 || k == 3), "h3d_conv_wgrad_x3: bad shape");
+    H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0, "h3d_conv_wgrad_x3: Co, Ci must be multiples of 4 (Co=%d Ci=%d)", Co, Ci);
+    H3D_REQUIRE(h3d::aligned16(dY) && h3d::aligned16(X), "h3d_conv_wgrad_x3: operands must be 16-byte aligned");
+    H3D_REQUIRE(slices >= 1 && (int64_t)slices * k * k <= 65535 * 16, "h3d_conv_wgrad_x3: slices=%d out of range", slices);
+    Args a{};
+    a.dY = dY; a.X = X; a.partial = partial; a.M = (int64_t)B * H * W; a.Co = Co; a.Ci = Ci; a.ldy = Co; a.ldx = Ci;
+    a.conv_k = k; a.H = H; a.W = W; a.slices = slices;
+    const int64_t per = (a.M + slices - 1) / slices;
+    a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int na = tiles_for(Co), nb = tiles_for(Ci);
+#define H3D_CASE(NA, NB) if (na == NA && nb == NB) return launch<NA, NB>(a, slices, st)
+    H3D_CASE(4, 4); H3D_CASE(4, 2); H3D_CASE(4, 1); H3D_CASE(2, 4); H3D_CASE(2, 2); H3D_CASE(2, 1);
+    H3D_CASE(1, 4); H3D_CASE(1, 2); H3D_CASE(1, 1);
+#undef H3D_CASE
     return H3D_EUNSUPPORTED;
 }

@@ -1,0 +1,136 @@
+"""conv2d (3x3 / 1x1, stride 1, "same" padding) on the hand-written matrix-core kernels of csrc/conv_x3.hip / wgrad_x3.hip,
+differentiable to any order -- what the discriminator (lib/discriminators/unet_discriminators.py; reference ResBlock,
+unet_discriminators.py:8-72) runs its convolutions on, including the double backward of the R1 penalty
+(lib/trainers/phase_trainer.py:259-294).
+
+Three primitives, closed under differentiation (each backward is written with the other two, so autograd can differentiate
+the backward pass again -- no graph through a library convolution):
+    C (x, W)  = conv(x, W)                    dC/dx  = Ct(g, W)     dC/dW  = Cw(x, g)
+    Ct(g, W)  = conv_transpose(g, W)          dCt/dg = C (h, W)     dCt/dW = Cw(h, g)
+    Cw(x, g)  = weight gradient [Co,Ci,k,k]   dCw/dx = Ct(g, V)     dCw/dg = C (x, V)
+C and Ct are one kernel (h3d_conv_x3): Ct runs it on the flipped, transposed weights; Cw is h3d_conv_wgrad_x3.  Activations are
+channels-last fp32 (torch.channels_last memory format of the logical NCHW tensors); weights are packed per call on the device
+(a permute and two casts) -- they change every optimiser step and carry the spectral normalisation's graph.
+"""
+import ctypes
+
+import torch
+
+from .... import _lib
+
+
+def tiling(cin, cout):
+    """(NT, output blocks, k-steps per chunk, chunks) of h3d_conv_x3 for cin -> cout, or None when unsupported."""
+    out = (ctypes.c_int * 4)()
+    if _lib.load().h3d_conv_x3_tiling(int(cin), int(cout), out):
+        return None
+    return tuple(out)
+
+
+def supported(x, weight):
+    """The native path takes fp32 CUDA tensors, k in {1, 3} (square), channel counts that are multiples of 64."""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 4):
+        return False
+    co, ci, kh, kw = weight.shape
+    return kh == kw and kh in (1, 3) and x.shape[1] == ci and ci % 64 == 0 and co % 64 == 0 and tiling(ci, co) is not None
+
+
+def pack_stream(w):
+    """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns), see include/h3d.h."""
+    co, ci, k, _ = w.shape
+    NT, nblk, KSC, nch = tiling(ci, co)
+    t = w.detach().reshape(nblk, NT, 32, nch, KSC, 2, 8, k * k)          # ob, nt, j, chunk, ks, h, e, tap
+    t = t.permute(0, 7, 3, 4, 1, 5, 2, 6)                                 # ob, tap, chunk, ks, nt, h, j, e
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=5).contiguous().view(torch.int16)    # ob, tap, chunk, ks, nt, (hi|lo), h, j, e
+
+
+def _cl(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _run_conv(x, w, bias=None):
+    """x [B, Ci, H, W] (any layout) , w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd."""
+    x = _cl(x.detach())
+    B, ci, H, W = x.shape
+    co, _, k, _ = w.shape
+    stream = pack_stream(w)
+    out = torch.empty((B, co, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    b = None if bias is None else bias.detach().contiguous()
+    rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, _lib.stream_handle())
+    _lib.check(rc, "h3d_conv_x3")
+    return out
+
+
+def _run_wgrad(x, g, k):
+    """x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k]; no autograd."""
+    x, g = _cl(x.detach()), _cl(g.detach())
+    B, ci, H, W = x.shape
+    co = g.shape[1]
+    lib = _lib.load()
+    slices = max(1, lib.h3d_wgrad_x3_slices(B * H * W, co, ci) // (k * k) if k > 1 else lib.h3d_wgrad_x3_slices(B * H * W, co, ci))
+    partial = torch.empty((k * k, slices, co, ci), device=x.device, dtype=torch.float32)
+    rc = lib.h3d_conv_wgrad_x3(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, slices, _lib.stream_handle())
+    _lib.check(rc, "h3d_conv_wgrad_x3")
+    return partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
+
+
+def _transposed(w):
+    return w.flip(2, 3).transpose(0, 1).contiguous()
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _run_conv(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = _ConvT.apply(g, w) if ctx.needs_input_grad[0] else None
+        gw = _ConvW.apply(x, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _ConvT(torch.autograd.Function):
+    """conv_transpose(g, w): g [B, Co, H, W], w [Co, Ci, k, k] -> [B, Ci, H, W] (the data gradient of _Conv)."""
+
+    @staticmethod
+    def forward(ctx, g, w):
+        ctx.save_for_backward(g, w)
+        return _run_conv(g, _transposed(w.detach()))
+
+    @staticmethod
+    def backward(ctx, h):
+        g, w = ctx.saved_tensors
+        gg = _Conv.apply(h, w) if ctx.needs_input_grad[0] else None
+        gw = _ConvW.apply(h, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        return gg, gw
+
+
+class _ConvW(torch.autograd.Function):
+    """weight gradient of _Conv: x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k]."""
+
+    @staticmethod
+    def forward(ctx, x, g, k):
+        ctx.save_for_backward(x, g)
+        return _run_wgrad(x, g, k)
+
+    @staticmethod
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        gx = _ConvT.apply(g, v) if ctx.needs_input_grad[0] else None
+        gg = _Conv.apply(x, v) if ctx.needs_input_grad[1] else None
+        return gx, gg, None
+
+
+def conv2d(x, weight, bias=None):
+    """F.conv2d(x, weight, bias, stride=1, padding=k // 2) on the native kernels (see `supported`); the bias is a broadcast add."""
+    _lib.need_cuda(x, weight, bias)
+    if x.requires_grad or weight.requires_grad:
+        y = _Conv.apply(x, weight)
+    else:
+        return _run_conv(x, weight, bias)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)

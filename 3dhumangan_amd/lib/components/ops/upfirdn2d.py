@@ -1,5 +1,7 @@
 """upfirdn2d family with the reference's Python signatures (lib/components/ops/upfirdn2d.py:69-161, 276-386),
-executed by the HIP kernel behind h3d_upfirdn2d.  Forward only."""
+executed by the HIP kernel behind h3d_upfirdn2d.  Differentiable in x to any order: the adjoint of upfirdn2d is upfirdn2d with
+up / down swapped, the filter flipped and the complementary padding (reference upfirdn2d.py:230-264, Upfirdn2dCuda.backward), so
+the backward pass runs on the same kernel."""
 import ctypes
 
 import numpy as np
@@ -76,6 +78,41 @@ def _launch(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain):
     return y
 
 
+def _forward(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain):
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+        x = x.contiguous()
+    if f.ndim == 2:
+        return _launch(x, f.contiguous(), upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain)
+    # separable: the reference's kernel wrapper runs a [1,n] pass then an [n,1] pass, each with gain**0.5
+    g = float(gain) ** 0.5
+    y = _launch(x, f.unsqueeze(0).contiguous(), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
+    return _launch(y, f.unsqueeze(1).contiguous(), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
+
+
+class _Upfirdn2d(torch.autograd.Function):
+    """x -> upfirdn2d(x); the gradient w.r.t. x is upfirdn2d of dy with up / down swapped, the filter flipped and the
+    complementary padding (reference Upfirdn2dCuda.backward, upfirdn2d.py:248-262) -- itself differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, f, params):
+        ctx.params, ctx.x_shape = params, x.shape
+        ctx.save_for_backward(f)
+        return _forward(x, f, *params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, = ctx.saved_tensors
+        upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain = ctx.params
+        _, _, ih, iw = ctx.x_shape
+        _, _, oh, ow = dy.shape
+        fw, fh = _filter_size(f)
+        p = [fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1, fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = upfirdn2d(dy, f, up=(downx, downy), down=(upx, upy), padding=p, flip_filter=not flip_filter, gain=gain)
+        return dx, None, None
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="hip"):
     """Pad, upsample, filter, and downsample a batch of 2D images (reference upfirdn2d.py:117-161).
     ``impl`` is accepted for compatibility; everything runs on the HIP kernel."""
@@ -89,15 +126,11 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="hi
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
     assert f.dtype == torch.float32 and f.ndim in (1, 2)
-    if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
-        x = x.contiguous()
     f = f.to(x.device)
-    if f.ndim == 2:
-        return _launch(x, f.contiguous(), upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, gain)
-    # separable: the reference's kernel wrapper runs a [1,n] pass then an [n,1] pass, each with gain**0.5
-    g = float(gain) ** 0.5
-    y = _launch(x, f.unsqueeze(0).contiguous(), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
-    return _launch(y, f.unsqueeze(1).contiguous(), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
+    params = (upx, upy, downx, downy, px0, px1, py0, py1, bool(flip_filter), gain)
+    if x.requires_grad and torch.is_grad_enabled():
+        return _Upfirdn2d.apply(x, f, params)
+    return _forward(x.detach(), f, *params)
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl="hip"):

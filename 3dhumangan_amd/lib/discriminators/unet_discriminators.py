@@ -2,19 +2,24 @@
 
 Same constructor kwargs (the whole config dict is splatted in), same state_dict schema (spectral-norm convs store
 bias / weight_orig / weight_u / weight_v under the reference's module paths, so `*_discriminator` checkpoints load with
-strict=True) and the same output dict.  SURVEY 8f.1 ranks this row "next" with library convolutions first: the 3x3 / 1x1
-convolutions go through torch (MIOpen / rocBLAS on the device) so that autograd -- including the double backward the R1
-penalty needs -- is available; nothing here is on the generator hot path.
+strict=True) and the same output dict.  The 3x3 / 1x1 convolutions with channel counts that are multiples of 64 -- all of the
+network's arithmetic but the RGB stem, the three heads and the latent layer -- run on the hand-written matrix-core kernels
+of csrc/conv_x3.hip / wgrad_x3.hip through lib/components/ops/conv.py (forward, backward-data, weight gradient, and the double
+backward of the R1 penalty as compositions of the same three kernels); the remaining small convolutions and any CPU / autocast
+call go through torch (MIOpen).  `H3D_DISC_CONV=torch` forces the library path everywhere (A/B measurements).
 
 Module layout note: the reference wraps its convs in nn.Sequential(LeakyReLU, [Upsample,] conv), which fixes the state_dict
 index of the conv (conv1.1 / conv1.2 / conv2.1).  Here the activations and resampling are plain functional calls and a
 `_Slot` holds the conv under that same index, so only parameters live in modules.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ..components.ops import conv as conv_ops
 
 
 class _Slot(nn.Module):
@@ -29,8 +34,19 @@ class _Slot(nn.Module):
         return getattr(self, self.index)(x)
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (stride 1, padding k // 2) that runs on the native kernels when they cover the call; same parameters, same
+    state_dict, works under nn.utils.spectral_norm (the hook sets `weight` before forward)."""
+
+    def forward(self, x):
+        if (os.environ.get("H3D_DISC_CONV", "hip") != "torch" and not torch.is_autocast_enabled()
+                and conv_ops.supported(x, self.weight)):
+            return conv_ops.conv2d(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _conv(cin, cout, k, spectral):
-    conv = nn.Conv2d(cin, cout, k, 1, k // 2)
+    conv = Conv2d(cin, cout, k, 1, k // 2)
     return nn.utils.spectral_norm(conv) if spectral else conv
 
 

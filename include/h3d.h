@@ -163,6 +163,24 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
                         int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * the discriminator's convolutions == nn.Conv2d(fin, fout, 3, 1, 1) / (fin, fout, 1) of ResBlock
+ * (lib/discriminators/unet_discriminators.py:8-72), channels-last fp32, on the bf16 matrix cores with split (x3) operands.
+ *   h3d_conv_x3        out[p, o] = bias[o] + sum_{tap, i} W[o, i, tap] x[p + tap, i]   (x [B,H,W,Cin] -> out [B,H,W,Cout]; stride 1,
+ *                      zero padding k/2, k = 1 or 3).  Forward and backward-data are the same kernel: backward-data runs it on the
+ *                      flipped, transposed weights.  `stream` = the weights packed by the caller in consumption order
+ *                      [output block][tap][chunk][k-step][tile][hi|lo][64 lanes][8 bf16]: element (lane, e) of tile nt, k-step ks,
+ *                      chunk c, tap t, block ob = W[o = 32*(NT*ob + nt) + (lane&31)][i = 16*(KSC*c + ks) + 8*(lane>>5) + e][t],
+ *                      hi = bf16(w), lo = bf16(w - hi); NT, blocks, KSC, chunks from h3d_conv_x3_tiling (lib/components/ops/conv.py
+ *                      packs it with a handful of tensor ops on the device).  Cin, Cout multiples of 64.
+ *   h3d_conv_wgrad_x3  partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co] * X[p + tap, Ci]; the caller sums the slices.
+ */
+int h3d_conv_x3_tiling(int Cin, int Cout, int* out /* [4]: NT, blocks, KSC, chunks */);
+int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be NULL */, float* out, int B, int H, int W,
+                int Cin, int Cout, int k, h3d_stream_t stream_handle);
+int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int slices,
+                      h3d_stream_t stream_handle);
+
+/* ------------------------------------------------------------------------
  * A5 / A5+A6 in the "x2" arithmetic (csrc/x3_common.hpp): the hidden-layer contractions evaluate W.x as one f16 product
  * hi*hi plus ONE block-scaled fp6 (e2m3) matrix instruction for the two cross terms hi*lo + lo*hi, which are 2^-11 of the
  * main term -- half the matrix-pipe time and 55 % of the energy of three f16 products; inputs (K = 3 / 31 / view direction)

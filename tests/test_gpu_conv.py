@@ -1,0 +1,101 @@
+"""The discriminator's native convolutions (csrc/conv_x3.hip, wgrad_x3.hip through lib/components/ops/conv.py) against
+torch's F.conv2d in float64 on the CPU: forward, first-order gradients, and the second-order gradients of an R1-style
+penalty ||d out / d x||^2 (the double backward is a composition of the same three kernels)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+TOL = 1e-3          # split bf16 (16 mantissa bits per operand): measured ~2e-5
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,k", [(2, 16, 8, 128, 128, 3), (1, 9, 7, 64, 64, 3), (3, 5, 11, 256, 64, 3), (1, 8, 4, 512, 512, 3),
+                                            (2, 6, 6, 1024, 256, 3), (2, 16, 8, 128, 256, 1), (1, 33, 17, 64, 128, 3),
+                                            (1, 4, 2, 512, 512, 1)])
+def test_conv_forward_and_first_order_gradients(B, H, W, ci, co, k):
+    g = torch.Generator().manual_seed(ci + co + k)
+    x = torch.randn(B, ci, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(co, ci, k, k, generator=g, dtype=torch.float64) / (ci * k * k) ** 0.5
+    b = torch.randn(co, generator=g, dtype=torch.float64)
+    proj = torch.randn(B, co, H, W, generator=g, dtype=torch.float64)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=k // 2)
+    (ref * proj).sum().backward()
+    xd, wd, bd = (t.float().to(DEV).requires_grad_(True) for t in (x, w, b))
+    assert conv.supported(xd, wd)
+    got = conv.conv2d(xd, wd, bd)
+    assert got.shape == ref.shape
+    assert rel_err(got.detach().cpu(), ref.detach()) < TOL
+    (got * proj.float().to(DEV)).sum().backward()
+    assert rel_err(xd.grad.cpu(), xr.grad) < TOL
+    assert rel_err(wd.grad.cpu(), wr.grad) < TOL
+    assert rel_err(bd.grad.cpu(), br.grad) < TOL
+    # no-grad fast path with the bias fused
+    with torch.no_grad():
+        assert rel_err(conv.conv2d(xd.detach(), wd.detach(), bd.detach()).cpu(), ref.detach()) < TOL
+
+
+def test_conv_double_backward_of_an_r1_style_penalty():
+    g = torch.Generator().manual_seed(7)
+    B, H, W, c = 2, 12, 6, 64
+    x = torch.randn(B, c, H, W, generator=g, dtype=torch.float64)
+    w1 = torch.randn(128, c, 3, 3, generator=g, dtype=torch.float64) / (c * 9) ** 0.5
+    w2 = torch.randn(64, 128, 3, 3, generator=g, dtype=torch.float64) / (128 * 9) ** 0.5
+    w3 = torch.randn(64, 64, 1, 1, generator=g, dtype=torch.float64) / 8.0
+
+    def net(cv, x, w1, w2, w3):
+        h = F.leaky_relu(cv(x, w1), 0.2)
+        h = cv(F.leaky_relu(cv(h, w2) + cv(x, w3), 0.2), w3)
+        return h
+
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w1, w2, w3)]
+    out = net(lambda a, b: F.conv2d(a, b, padding=b.shape[2] // 2), *ref_in)
+    (gx,) = torch.autograd.grad(out.sum(), ref_in[0], create_graph=True)
+    pen = gx.pow(2).sum() + out.pow(2).mean()
+    ref_g = torch.autograd.grad(pen, ref_in[1:])
+    dev_in = [t.float().to(DEV).requires_grad_(True) for t in (x, w1, w2, w3)]
+    out_d = net(conv.conv2d, *dev_in)
+    assert rel_err(out_d.detach().cpu(), out.detach()) < TOL
+    (gxd,) = torch.autograd.grad(out_d.sum(), dev_in[0], create_graph=True)
+    assert rel_err(gxd.detach().cpu(), gx.detach()) < TOL
+    pen_d = gxd.pow(2).sum() + out_d.pow(2).mean()
+    assert abs(float(pen_d) - float(pen)) < TOL * abs(float(pen))
+    got_g = torch.autograd.grad(pen_d, dev_in[1:])
+    for a, b, name in zip(got_g, ref_g, ("w1", "w2", "w3")):
+        assert rel_err(a.cpu(), b) < TOL, name
+
+
+def test_discriminator_uses_the_native_convolutions_and_matches_the_library_path(monkeypatch):
+    """UNetDiscriminator at a config-4-like geometry: the native path is taken for the 64-multiple convolutions, and outputs,
+    weight gradients and the R1 double backward agree with the torch / MIOpen path on the same weights."""
+    disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+    trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+    torch.manual_seed(5)
+    D = disc.UNetDiscriminator(latent_dim=64, gen_height=64, gen_width=32, label_dim=5, discriminator_blocks=4).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    real = torch.randn(2, 3, 64, 32, generator=g).clamp(-1, 1).to(DEV)
+    fake = torch.randn(2, 3, 64, 32, generator=g).clamp(-1, 1).to(DEV)
+    gt = torch.randint(0, 5, (2, 64, 32), generator=g).to(DEV)
+    meta = dict(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, label_dim=5)
+    calls = []
+    real_run = conv._run_conv
+    monkeypatch.setattr(conv, "_run_conv", lambda *a, **k: (calls.append(1), real_run(*a, **k))[1])
+    res, grads = {}, {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("H3D_DISC_CONV", mode)
+        calls.clear()
+        res[mode] = trainers.discriminator_step(D, torch.optim.SGD(D.parameters(), lr=0.0), real, fake, gt, meta, do_r1=True,
+                                                r1_mode="per_sample")
+        grads[mode] = {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}
+        assert (len(calls) > 40) == (mode == "hip"), (mode, len(calls))
+    for k in ("loss", "gan", "r1", "segmentation"):
+        assert abs(float(res["hip"][k]) - float(res["torch"][k])) < TOL * (abs(float(res["torch"][k])) + 1e-6), k
+    assert set(grads["hip"]) == set(grads["torch"])
+    worst = max(rel_err(grads["hip"][n], grads["torch"][n]) for n in grads["torch"] if float(grads["torch"][n].abs().max()) > 1e-6)
+    assert worst < 5e-3, worst        # both sides carry their own rounding (MIOpen fp32 Winograd vs split bf16)

@@ -149,7 +149,7 @@ def test_x3t_synthesis_geometries_vs_oracle(width, gh, gw, rh, rw, mode):
     # and the fp32 engine on the same weights agrees to rounding
     plan.engine = "f32"
     out32 = G.forward(z.to(DEV), cond_to(cond), jitter=jit.to(DEV), **cfg)
-    assert rel_err(out["rgbs"].cpu(), out32["rgbs"].cpu()) < (1e-4 if engine == "bf16x3" else 5e-4)
+    assert rel_err(out["rgbs"].cpu(), out32["rgbs"].cpu()) < 1e-4
 
 
 def test_wide_configs_default_to_the_x3t_engines():

@@ -284,3 +284,39 @@ def test_upfirdn2d_tiled_kernel_vs_oracle(up, down, pad, taps, dtype, tol):
     cl = upfirdn_mod.upfirdn2d(dev(x.to(dtype)).contiguous(memory_format=torch.channels_last), dev(f), up=up, down=down, padding=pad,
                                gain=1.5)
     assert rel_err(cl.cpu(), ref) < tol
+
+
+@pytest.mark.parametrize("up,down,pad,taps,flip", [(2, 1, [2, 1, 2, 1], [1, 3, 3, 1], False), (1, 2, [1, 1, 1, 1], [1, 3, 3, 1], True),
+                                                   (1, 1, [2, 1, 1, 2], [1, 2, 5, 1], False), (2, 2, [3, 0, 1, 2], [1, 4, 2, 1, 3], True),
+                                                   ((2, 1), (1, 2), [1, 2, 2, 1], [1, 3, 3, 1], False)])
+def test_upfirdn2d_gradients_vs_oracle_autograd(up, down, pad, taps, flip):
+    """First and second order: dx of the op (the reference's Upfirdn2dCuda.backward = upfirdn2d with up / down swapped, the
+    filter flipped, the complementary padding) and the gradient of a function of dx, against torch autograd through the
+    oracle's pure-torch restatement in float64."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 11, 9, generator=g, dtype=torch.float64)
+    f = torch.tensor(taps, dtype=torch.float32)
+    f2 = torch.outer(f, f[: max(2, len(taps) - 1)]) / 7.0                   # asymmetric 2-D filter
+    xr = x.clone().requires_grad_(True)
+    ref = O.upfirdn2d(xr, f2.double(), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
+    proj = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (gr,) = torch.autograd.grad((ref * proj).sum(), xr, create_graph=True)
+    (gr2,) = torch.autograd.grad((gr * gr).sum(), xr)
+    xd = dev(x.float()).requires_grad_(True)
+    got = upfirdn_mod.upfirdn2d(xd, dev(f2), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
+    assert rel_err(got.detach().cpu(), ref.detach()) < 3e-6
+    (gg,) = torch.autograd.grad((got * dev(proj.float())).sum(), xd, create_graph=True)
+    assert gg.shape == xd.shape and rel_err(gg.detach().cpu(), gr.detach()) < 1e-5
+    # the penalty ||dx||^2 is independent of x for a linear op: its x-gradient is exactly zero in both
+    (gg2,) = torch.autograd.grad((gg * gg).sum(), xd, allow_unused=True)
+    assert float(gr2.abs().max()) == 0.0 and (gg2 is None or float(gg2.abs().max()) == 0.0)
+    # double backward proper: d/d(proj) of ||dx||^2 -- runs the op's backward-of-backward
+    pd = dev(proj.float()).requires_grad_(True)
+    (g1,) = torch.autograd.grad((upfirdn_mod.upfirdn2d(xd, dev(f2), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5) * pd).sum(),
+                                xd, create_graph=True)
+    (gp,) = torch.autograd.grad((g1 * g1).sum(), pd)
+    pr = proj.clone().requires_grad_(True)
+    (r1,) = torch.autograd.grad((O.upfirdn2d(xr, f2.double(), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5) * pr).sum(),
+                                xr, create_graph=True)
+    (rp,) = torch.autograd.grad((r1 * r1).sum(), pr)
+    assert rel_err(gp.cpu(), rp) < 1e-5
