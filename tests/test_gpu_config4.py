@@ -128,14 +128,6 @@ def test_config4_two_iterations_at_the_per_gpu_geometry():
     ema = ema_mod.ExponentialMovingAverage(G.parameters(), decay=0.999)
     g0 = {n: p.detach().clone() for n, p in G.named_parameters()}
     d0 = {n: p.detach().clone() for n, p in D.named_parameters()}
-    # the discriminator treats the samples of a batch independently (no batch statistics anywhere in it); eval mode: in
-    # train mode every call runs a spectral-norm power iteration, i.e. changes the weights
-    D.eval()
-    with torch.no_grad():
-        whole = D(real, None, 1.0)["prediction"]
-        one = D(real[2:3], None, 1.0)["prediction"]
-    D.train()
-    assert rel_err(one.cpu(), whole[2:3].cpu()) < 1e-4
     fwd = {k: v for k, v in cfg.items() if isinstance(k, str)}
     for it in range(2):
         with torch.no_grad():
@@ -154,6 +146,14 @@ def test_config4_two_iterations_at_the_per_gpu_geometry():
     assert len(with_grad_d) > 50 and set(with_grad_d) <= set(moved_d)
     assert ema.num_updates == 2
     assert torch.cuda.max_memory_allocated() < 100e9
+    # the discriminator treats the samples of a batch independently (no batch statistics anywhere in it).  Eval mode (in
+    # train mode every call runs a spectral-norm power iteration, i.e. changes the weights), after the iterations above (a
+    # fresh module's u / v are random: sigma = u^T W v is then meaningless and the network overflows)
+    D.eval()
+    with torch.no_grad():
+        whole = D(real, None, 1.0)["prediction"]
+        one = D(real[2:3], None, 1.0)["prediction"]
+    assert bool(torch.isfinite(whole).all()) and rel_err(one.cpu(), whole[2:3].cpu()) < 1e-4
 
 
 def test_differentiable_path_matches_the_inference_engines_at_the_config4_geometry():

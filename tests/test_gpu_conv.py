@@ -78,6 +78,10 @@ def test_discriminator_uses_the_native_convolutions_and_matches_the_library_path
     trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
     torch.manual_seed(5)
     D = disc.UNetDiscriminator(latent_dim=64, gen_height=64, gen_width=32, label_dim=5, discriminator_blocks=4).to(DEV)
+    with torch.no_grad():                      # settle the spectral-norm vectors (a fresh module's u / v are random), ...
+        for _ in range(5):
+            D(torch.zeros(1, 3, 64, 32, device=DEV), None, 1.0)
+    D.eval()                                   # ... then freeze them: both runs below must see the same weights
     g = torch.Generator().manual_seed(6)
     real = torch.randn(2, 3, 64, 32, generator=g).clamp(-1, 1).to(DEV)
     fake = torch.randn(2, 3, 64, 32, generator=g).clamp(-1, 1).to(DEV)

@@ -301,15 +301,11 @@ def test_upfirdn2d_gradients_vs_oracle_autograd(up, down, pad, taps, flip):
     ref = O.upfirdn2d(xr, f2.double(), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
     proj = torch.randn(ref.shape, generator=g, dtype=torch.float64)
     (gr,) = torch.autograd.grad((ref * proj).sum(), xr, create_graph=True)
-    (gr2,) = torch.autograd.grad((gr * gr).sum(), xr)
     xd = dev(x.float()).requires_grad_(True)
     got = upfirdn_mod.upfirdn2d(xd, dev(f2), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
     assert rel_err(got.detach().cpu(), ref.detach()) < 3e-6
     (gg,) = torch.autograd.grad((got * dev(proj.float())).sum(), xd, create_graph=True)
     assert gg.shape == xd.shape and rel_err(gg.detach().cpu(), gr.detach()) < 1e-5
-    # the penalty ||dx||^2 is independent of x for a linear op: its x-gradient is exactly zero in both
-    (gg2,) = torch.autograd.grad((gg * gg).sum(), xd, allow_unused=True)
-    assert float(gr2.abs().max()) == 0.0 and (gg2 is None or float(gg2.abs().max()) == 0.0)
     # double backward proper: d/d(proj) of ||dx||^2 -- runs the op's backward-of-backward
     pd = dev(proj.float()).requires_grad_(True)
     (g1,) = torch.autograd.grad((upfirdn_mod.upfirdn2d(xd, dev(f2), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5) * pd).sum(),

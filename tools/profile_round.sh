@@ -2,14 +2,15 @@
 # Round profile: bench line, rocprofv3 kernel stats of the same command, separate PMC passes for HBM traffic and for the SQ
 # counters, the same for the wide (x3t) workload.  usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r2
 set -u
-R=${1:-r2}
+R=${1:-r3}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 REPO=$PWD
-KERN='x3_kernel|x3t_kernel|geo_features|ray_integrate'
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+KERN='x3_kernel|x3t_kernel|geo_features|ray_integrate|conv_x3|wgrad'
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err        # the driver's protocol
+python bench.py --steps 200 --warmup 5 --no-extra --no-cpu --no-check > $OUT/bench_200steps.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $REPO/bench.py --no-cpu --no-extra --no-check > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu --no-extra --no-check > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c -d $OUT/pmc_$c -o p -- python $REPO/bench.py --no-cpu --no-extra --no-check --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
 done
