@@ -27,6 +27,7 @@ struct Args {
     float* out;                    // [P, Cout]
     int64_t P;                     // B * H * W
     int H, W, Cin, Cout, k, n_chunks, stages_per_oblk;
+    int ldx, ldo;                  // row strides (floats) of x and out: >= Cin / Cout (channel slices of wider tensors)
 };
 
 // this lane's 8 consecutive channels (16 ks + 8 h ..) of its shifted pixel for the KSC k-steps of one chunk: 2 float4 per k-step
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
         const int ty = tap / A.k - pad, tx = tap - (tap / A.k) * A.k - pad;
         valid = okp && (unsigned)(y + ty) < (unsigned)A.H && (unsigned)(x + tx) < (unsigned)A.W;
         const int64_t q = valid ? pc + (int64_t)ty * A.W + tx : pc;
-        return A.x + q * A.Cin + chunk * (16 * KSC);
+        return A.x + q * A.ldx + chunk * (16 * KSC);
     };
     {
         bool valid;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
     ring.drain();
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
     if (okp) {
-        float* __restrict__ o = A.out + p * A.Cout + oblk * (NT * 32);
+        float* __restrict__ o = A.out + p * A.ldo + oblk * (NT * 32);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
@@ -152,11 +153,12 @@ extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
 }
 
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
-                           int Cout, int k, h3d_stream_t stream_) {
+                           int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
     H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
                 "h3d_conv_x3: operands must be 16-byte aligned");
+    H3D_REQUIRE(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0, "h3d_conv_x3: row strides must be multiples of 4 and cover the channels (ldx=%d ldo=%d)", ldx, ldo);
     int til[4];
     if (h3d_conv_x3_tiling(Cin, Cout, til)) {
         h3d::set_error("h3d_conv_x3: channel counts must be multiples of 64 (got %d -> %d)", Cin, Cout);
@@ -166,7 +168,7 @@ extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias
     Args A{};
     A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out;
     A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
-    A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * til[2];
+    A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * til[2]; A.ldx = ldx; A.ldo = ldo;
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const int NT = til[0], KSC = til[2];

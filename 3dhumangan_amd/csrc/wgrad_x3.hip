@@ -202,16 +202,18 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
 
 // Weight gradient of a k x k convolution (stride 1, zero padding k/2) of channels-last activations:
 //   partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co]^T X[p + tap, Ci]      (the caller sums the slices)
-// dY [B*H*W, Co], X [B*H*W, Ci] fp32; Co, Ci multiples of 4; slices as h3d_wgrad_x3_slices(B*H*W / k^2 ..) -- any >= 1.
+// dY [B*H*W, Co], X [B*H*W, Ci] fp32 with row strides ldy, ldx (channel slices of wider tensors); Co, Ci multiples of 4;
+// slices: any >= 1.
 extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
-                                 int slices, h3d_stream_t stream) {
+                                 int ldy, int ldx, int slices, h3d_stream_t stream) {
     H3D_REQUIRE(dY && X && partial, "h3d_conv_wgrad_x3: null pointer");
     H3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Co >= 1 && Ci >= 1 && (k == 1 || k == 3), "h3d_conv_wgrad_x3: bad shape");
-    H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0, "h3d_conv_wgrad_x3: Co, Ci must be multiples of 4 (Co=%d Ci=%d)", Co, Ci);
+    H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
+                "h3d_conv_wgrad_x3: Co, Ci and the row strides must be multiples of 4 (Co=%d Ci=%d ldy=%d ldx=%d)", Co, Ci, ldy, ldx);
     H3D_REQUIRE(h3d::aligned16(dY) && h3d::aligned16(X), "h3d_conv_wgrad_x3: operands must be 16-byte aligned");
     H3D_REQUIRE(slices >= 1 && (int64_t)slices * k * k <= 65535 * 16, "h3d_conv_wgrad_x3: slices=%d out of range", slices);
     Args a{};
-    a.dY = dY; a.X = X; a.partial = partial; a.M = (int64_t)B * H * W; a.Co = Co; a.Ci = Ci; a.ldy = Co; a.ldx = Ci;
+    a.dY = dY; a.X = X; a.partial = partial; a.M = (int64_t)B * H * W; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx;
     a.conv_k = k; a.H = H; a.W = W; a.slices = slices;
     const int64_t per = (a.M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);

@@ -27,12 +27,19 @@ def tiling(cin, cout):
     return tuple(out)
 
 
+def _native(ci, co):
+    return ci % 64 == 0 and co % 64 == 0 and tiling(ci, co) is not None
+
+
 def supported(x, weight):
-    """The native path takes fp32 CUDA tensors, k in {1, 3} (square), channel counts that are multiples of 64."""
+    """The native path takes fp32 CUDA tensors, k in {1, 3} (square).  Channel counts that are multiples of 64 run as they are;
+    a side with fewer than 64 channels (the RGB stem, the 1- and label_dim-channel heads) is zero-padded to 64 by conv2d."""
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 4):
         return False
     co, ci, kh, kw = weight.shape
-    return kh == kw and kh in (1, 3) and x.shape[1] == ci and ci % 64 == 0 and co % 64 == 0 and tiling(ci, co) is not None
+    if not (kh == kw and kh in (1, 3) and x.shape[1] == ci):
+        return False
+    return _native(ci if ci >= 64 else 64, co if co >= 64 else 64)
 
 
 def pack_stream(w):
@@ -46,32 +53,43 @@ def pack_stream(w):
     return torch.stack([hi, lo], dim=5).contiguous().view(torch.int16)    # ob, tap, chunk, ks, nt, (hi|lo), h, j, e
 
 
-def _cl(x):
-    return x.contiguous(memory_format=torch.channels_last)
+def _rows(x):
+    """x [B, C, H, W] -> (tensor whose memory is pixel-major rows of C floats, row stride in floats).  Channels-last tensors and
+    channel slices of channels-last tensors (what the backward of a skip concatenation hands out) are taken as they are;
+    anything else is copied to channels-last."""
+    x = x.detach()
+    B, C, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    ld = sw
+    if (sc == 1 and ld >= C and ld % 4 == 0 and sh == W * ld and (sb == H * W * ld or B == 1)
+            and (x.storage_offset() * 4 + x.untyped_storage().data_ptr()) % 16 == 0):
+        return x, ld
+    return x.contiguous(memory_format=torch.channels_last), C
 
 
 def _run_conv(x, w, bias=None):
     """x [B, Ci, H, W] (any layout) , w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd."""
-    x = _cl(x.detach())
+    x, ldx = _rows(x)
     B, ci, H, W = x.shape
     co, _, k, _ = w.shape
     stream = pack_stream(w)
     out = torch.empty((B, co, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     b = None if bias is None else bias.detach().contiguous()
-    rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, _lib.stream_handle())
+    rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
+                                 _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3")
     return out
 
 
 def _run_wgrad(x, g, k):
     """x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k]; no autograd."""
-    x, g = _cl(x.detach()), _cl(g.detach())
+    (x, ldx), (g, ldg) = _rows(x), _rows(g)
     B, ci, H, W = x.shape
     co = g.shape[1]
     lib = _lib.load()
-    slices = max(1, lib.h3d_wgrad_x3_slices(B * H * W, co, ci) // (k * k) if k > 1 else lib.h3d_wgrad_x3_slices(B * H * W, co, ci))
+    slices = max(1, lib.h3d_wgrad_x3_slices(B * H * W, co, ci) // (k * k))
     partial = torch.empty((k * k, slices, co, ci), device=x.device, dtype=torch.float32)
-    rc = lib.h3d_conv_wgrad_x3(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, slices, _lib.stream_handle())
+    rc = lib.h3d_conv_wgrad_x3(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_wgrad_x3")
     return partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
 
@@ -127,10 +145,23 @@ class _ConvW(torch.autograd.Function):
 
 
 def conv2d(x, weight, bias=None):
-    """F.conv2d(x, weight, bias, stride=1, padding=k // 2) on the native kernels (see `supported`); the bias is a broadcast add."""
+    """F.conv2d(x, weight, bias, stride=1, padding=k // 2) on the native kernels (see `supported`); the bias is a broadcast add.
+    A side with fewer than 64 channels is zero-padded to 64 (differentiably: a concatenation / a slice), which costs little
+    where it happens -- 3 -> 128 at full resolution becomes the work of a 64 -> 128 layer, the heads that of 64 -> 64 1x1."""
     _lib.need_cuda(x, weight, bias)
+    co, ci = weight.shape[:2]
+    if ci < 64:
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = torch.cat([x, x.new_zeros((x.shape[0], 64 - ci) + tuple(x.shape[2:])).contiguous(memory_format=torch.channels_last)], dim=1)
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 64 - ci))
+    if co < 64:
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 64 - co))
     if x.requires_grad or weight.requires_grad:
         y = _Conv.apply(x, weight)
-    else:
+    elif co >= 64:
         return _run_conv(x, weight, bias)
+    else:
+        y = _run_conv(x, weight)
+    if co < 64:
+        y = y[:, :co]
     return y if bias is None else y + bias.view(1, -1, 1, 1)

@@ -112,8 +112,8 @@ class UNetDiscriminator(nn.Module):
         ups += [ResBlock(2 * ch[n - i], ch[n - i - 1], 1, **kwargs) for i in range(1, n - 1)]
         ups.append(ResBlock(2 * ch[1], 64, 1, **kwargs))
         self.body_up = nn.ModuleList(ups)
-        self.layer_up_last = nn.Conv2d(64, 1, 1)
-        self.output_layer = nn.Conv2d(64, self.output_dim, 1)
+        self.layer_up_last = Conv2d(64, 1, 1)
+        self.output_layer = Conv2d(64, self.output_dim, 1)
         self.latent_layer = nn.Conv2d(ch[n], self.latent_dim, (H // 2 ** n, W // 2 ** n))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -126,6 +126,8 @@ class UNetDiscriminator(nn.Module):
         """images [B, 3|6, H, W] -> {"prediction" [B,1,H,W], "latents" [B,latent_dim], "segments" [B,label_dim,H,W]
         (, "semantics" [B,semantic_dim,H,W])}.  `conditions` and `alpha` are accepted and unused, as in the reference."""
         x, skips = images, []
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)        # the native convolutions are channels-last throughout
         for blk in self.body_down:
             x = blk(x)
             skips.append(x)

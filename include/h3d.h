@@ -176,9 +176,10 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
  */
 int h3d_conv_x3_tiling(int Cin, int Cout, int* out /* [4]: NT, blocks, KSC, chunks */);
 int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be NULL */, float* out, int B, int H, int W,
-                int Cin, int Cout, int k, h3d_stream_t stream_handle);
-int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int slices,
-                      h3d_stream_t stream_handle);
+                int Cin, int Cout, int k, int ldx, int ldo /* row strides in floats: channel slices of wider tensors */,
+                h3d_stream_t stream_handle);
+int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
+                      int ldy, int ldx, int slices, h3d_stream_t stream_handle);
 
 /* ------------------------------------------------------------------------
  * A5 / A5+A6 in the "x2" arithmetic (csrc/x3_common.hpp): the hidden-layer contractions evaluate W.x as one f16 product

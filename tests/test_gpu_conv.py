@@ -17,7 +17,8 @@ TOL = 1e-3          # split bf16 (16 mantissa bits per operand): measured ~2e-5
 
 @pytest.mark.parametrize("B,H,W,ci,co,k", [(2, 16, 8, 128, 128, 3), (1, 9, 7, 64, 64, 3), (3, 5, 11, 256, 64, 3), (1, 8, 4, 512, 512, 3),
                                             (2, 6, 6, 1024, 256, 3), (2, 16, 8, 128, 256, 1), (1, 33, 17, 64, 128, 3),
-                                            (1, 4, 2, 512, 512, 1)])
+                                            (1, 4, 2, 512, 512, 1), (2, 16, 8, 3, 128, 3), (1, 9, 5, 64, 1, 1), (2, 8, 8, 64, 26, 1),
+                                            (1, 6, 6, 6, 128, 1)])
 def test_conv_forward_and_first_order_gradients(B, H, W, ci, co, k):
     g = torch.Generator().manual_seed(ci + co + k)
     x = torch.randn(B, ci, H, W, generator=g, dtype=torch.float64)
@@ -39,6 +40,26 @@ def test_conv_forward_and_first_order_gradients(B, H, W, ci, co, k):
     # no-grad fast path with the bias fused
     with torch.no_grad():
         assert rel_err(conv.conv2d(xd.detach(), wd.detach(), bd.detach()).cpu(), ref.detach()) < TOL
+
+
+def test_conv_takes_channel_slices_without_copying():
+    """Backward of a skip concatenation hands the convolutions channel slices of a wider channels-last tensor: they are read
+    in place through the row stride (no dense copy), with the same results."""
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(2, 192, 10, 6, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 128, 3, 3, generator=g) / 34.0).to(DEV)
+    sl = wide[:, 64:]
+    rows, ld = conv._rows(sl)
+    assert ld == 192 and rows.data_ptr() == sl.data_ptr()
+    ref = F.conv2d(sl.double().cpu(), w.double().cpu(), padding=1)
+    assert rel_err(conv.conv2d(sl, w).cpu(), ref) < TOL
+    gy = torch.randn(2, 128, 10, 6, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)[:, 32:96]
+    xr = sl.double().cpu().requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    (F.conv2d(xr, wr, padding=1) * gy.double().cpu()).sum().backward()
+    xd, wd = sl.detach().requires_grad_(True), w.clone().requires_grad_(True)
+    (conv.conv2d(xd, wd) * gy).sum().backward()
+    assert rel_err(xd.grad.cpu(), xr.grad) < TOL and rel_err(wd.grad.cpu(), wr.grad) < TOL
 
 
 def test_conv_double_backward_of_an_r1_style_penalty():
