@@ -45,6 +45,8 @@ _SIGNATURES = {
                                       _i, _i, _p]),
     "h3d_conv_x3_tiling": (C.c_int, [_i, _i, C.POINTER(C.c_int)]),
     "h3d_conv_x3": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_wgrad_x3_slices": (C.c_int, [_i, _i, _i, _i, _i, _i]),
+    "h3d_conv_wgrad_x3_fused": (C.c_int, [_i, _i, _i, _i, _i]),
     "h3d_conv_wgrad_x3": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_field_pack_x2_size": (C.c_int64, [_i, _i]),
     "h3d_field_pack_x2": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),

@@ -59,6 +59,42 @@ __device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restri
     }
 }
 
+// x-fused conv variant: the X band of one filter row ty for 16 output pixels = the 18 source rows r0 - 1 + ty W .. r0 + 16 + ty W
+// (tx = -1, 0, +1 read rows e, e + 1, e + 2 of it).  W % 16 == 0 and r0 % 16 == 0, so the 16 pixels lie in one image row y:
+// the band is zero when y + ty leaves the image, its first row is zero when the pixels start an image row (x = 0 has no left
+// neighbour; that band row is only ever read as the tx = -1 neighbour of pixel 0) and its last row when they end one.
+template <int NT>
+__device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const float* __restrict__ src, int ld, int64_t r0, int64_t r_end,
+                                          int col0, int ncols, int t, int ty, int H, int W) {
+    constexpr int W4 = 16 * NT;               // float4 per band row
+    constexpr int NJ = NT + (NT + 7) / 8;     // 18 rows = 16 + 2: ceil(18 * W4 / 256) float4 per thread
+    const int64_t HW = (int64_t)H * W;
+    const int rem = (int)(r0 % HW);
+    const int y = rem / W, x0 = rem - y * W;
+    const bool band_ok = r0 < r_end && (unsigned)(y + ty) < (unsigned)H;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int idx = j * kThreads + t;
+        const int row = idx / W4, c = (idx - row * W4) * 4;          // band row 0..17 <-> source pixel r0 - 1 + row (+ ty W)
+        bool ok = band_ok && row < 18 && col0 + c < ncols;
+        if (row == 0 && x0 == 0) ok = false;
+        if (row == 17 && x0 + 16 == W) ok = false;
+        // pixels of this k-step past the end of the slice contribute nothing through dY (zero rows); their X rows are in range
+        const int64_t q = r0 - 1 + row + (int64_t)ty * W;
+        r[j] = ok ? *reinterpret_cast<const float4*>(src + q * ld + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void park_band(const float4 (&r)[NT + (NT + 7) / 8], float* lds, int t) {
+    constexpr int W4 = 16 * NT, NJ = NT + (NT + 7) / 8;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int idx = j * kThreads + t;
+        if (idx < 18 * W4) *reinterpret_cast<float4*>(lds + idx * 4) = r[j];
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void park_slab(const float4 (&r)[NT], float* lds, int t) {
 #pragma unroll
@@ -67,8 +103,8 @@ __device__ __forceinline__ void park_slab(const float4 (&r)[NT], float* lds, int
 
 // bf16 hi / lo fragments of column `col` of an LDS slab of width W: element e <-> row 8 * (lane >> 5) + e
 template <int W>
-__device__ __forceinline__ void read_frag(const float* lds, int col, int lane, BF16::vec8& hi, BF16::vec8& lo) {
-    const float* p = lds + (8 * (lane >> 5)) * W + col;
+__device__ __forceinline__ void read_frag(const float* lds, int col, int lane, BF16::vec8& hi, BF16::vec8& lo, int row0 = 0) {
+    const float* p = lds + (row0 + 8 * (lane >> 5)) * W + col;
     unsigned h[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[e] = h3d::split2_bf16(p[(2 * e) * W], p[(2 * e + 1) * W], l[e]);
@@ -150,6 +186,98 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         }
 }
 
+// 3x3 convolution weight gradient with the three taps of a filter row fused: a workgroup owns a K-slice of pixels, one filter
+// row ty and a [64 NA x 64 NB] block of dW for tx = -1, 0, +1 (3 NA NB accumulator tiles per wave, NA, NB <= 2), so dY and X are
+// read three times (once per ty) instead of nine.  partial[3 ty + tx][slice][Co][Ci].
+template <int NA, int NB>
+__global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
+    constexpr int WA = 64 * NA, WB = 64 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kBuf = kKS * WA + 18 * WB;     // floats per buffer: the dY slab (16 rows), then the X band (18 rows)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int co0 = blockIdx.y * WA, ci0 = blockIdx.z * WB;
+    const int tyi = blockIdx.x / A.slices, slice = blockIdx.x - tyi * A.slices;
+    const int ty = tyi - 1;
+    const int64_t r_begin = (int64_t)slice * A.rows_per_wg;
+    const int64_t r_end = r_begin + A.rows_per_wg < A.M ? r_begin + A.rows_per_wg : A.M;
+    const int n_steps = r_end > r_begin ? (int)((r_end - r_begin + kKS - 1) / kKS) : 0;
+
+    f32x16 acc[3][NA][NB];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[x][a][b][i] = 0.f;
+
+    float4 ra[NA], rb[NB + (NB + 7) / 8];
+    load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_band<NB>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+    park_slab<NA>(ra, smem, t);
+    park_band<NB>(rb, smem + kKS * WA, t);
+    __syncthreads();
+
+    for (int s = 0; s < n_steps; ++s) {
+        const float* curA = smem + (s & 1) * kBuf;
+        const float* curB = curA + kKS * WA;
+        float* nxtA = smem + ((s + 1) & 1) * kBuf;
+        if (s + 1 < n_steps) {
+            const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
+            load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
+            load_band<NB>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+        }
+        BF16::vec8 ah[NA], al[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) read_frag<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane, ah[a], al[a]);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            BF16::vec8 bh[NB], bl[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) read_frag<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane, bh[b], bl[b], x);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc[x][a][b] = BF16::mfma(al[a], bh[b], acc[x][a][b]);
+                    acc[x][a][b] = BF16::mfma(ah[a], bl[b], acc[x][a][b]);
+                    acc[x][a][b] = BF16::mfma(ah[a], bh[b], acc[x][a][b]);
+                }
+        }
+        if (s + 1 < n_steps) {
+            park_slab<NA>(ra, nxtA, t);
+            park_band<NB>(rb, nxtA + kKS * WA, t);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        float* out = A.partial + ((int64_t)(tyi * 3 + x) * A.slices + slice) * A.Co * A.Ci;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int ci = ci0 + (wx * NB + b) * 32 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int co = co0 + (wy * NA + a) * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+                    if (co < A.Co && ci < A.Ci) out[(int64_t)co * A.Ci + ci] = acc[x][a][b][i];
+                }
+            }
+    }
+}
+
+template <int NA, int NB>
+int launch_conv3(const Args& a, hipStream_t st) {
+    constexpr size_t lds = 2 * (kKS * 64 * NA + 18 * 64 * NB) * sizeof(float);
+    const dim3 grid((unsigned)(a.slices * 3), (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
+    h3d::pre_launch();
+    hipLaunchKernelGGL((wgrad_conv3_kernel<NA, NB>), grid, dim3(kThreads), lds, st, a);
+    return h3d::launch_status("h3d_conv_wgrad_x3");
+}
+
 int tiles_for(int c) { return c > 128 ? 4 : c > 64 ? 2 : 1; }
 
 template <int NA, int NB>
@@ -200,6 +328,33 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
     return H3D_EUNSUPPORTED;
 }
 
+// 1 when h3d_conv_wgrad_x3 runs a 3x3 problem on the x-fused kernel (three passes over the operands instead of nine): image rows
+// that are multiples of 16 pixels and enough pixels for the operand traffic to matter (the low-resolution layers' operands fit
+// the caches, and their 256 x 256 blocks do more work per byte).
+extern "C" int h3d_conv_wgrad_x3_fused(int B, int H, int W, int Co, int Ci) {
+    (void)Co; (void)Ci;
+    return W % 16 == 0 && (int64_t)B * H * W >= 32768;
+}
+
+// K-slices for h3d_conv_wgrad_x3: about two workgroups per compute unit over (slices x filter rows or taps x output blocks),
+// at least 256 pixels per slice.
+extern "C" int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int k) {
+    const int64_t M = (int64_t)B * H * W;
+    if (M <= 0 || Co <= 0 || Ci <= 0) return 0;
+    int64_t per_slice_wgs;
+    if (k == 3 && h3d_conv_wgrad_x3_fused(B, H, W, Co, Ci)) {
+        per_slice_wgs = 3 * (int64_t)((Co + 127) / 128) * ((Ci + 127) / 128);
+    } else {
+        const int na = tiles_for(Co), nb = tiles_for(Ci);
+        per_slice_wgs = (int64_t)k * k * ((Co + 64 * na - 1) / (64 * na)) * ((Ci + 64 * nb - 1) / (64 * nb));
+    }
+    int64_t want = (2 * (int64_t)h3d::compute_units() + per_slice_wgs - 1) / per_slice_wgs;
+    const int64_t most = (M + 255) / 256;
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
 // Weight gradient of a k x k convolution (stride 1, zero padding k/2) of channels-last activations:
 //   partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co]^T X[p + tap, Ci]      (the caller sums the slices)
 // dY [B*H*W, Co], X [B*H*W, Ci] fp32 with row strides ldy, ldx (channel slices of wider tensors); Co, Ci multiples of 4;
@@ -218,6 +373,14 @@ extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial
     const int64_t per = (a.M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k == 3 && W % 16 == 0 && h3d_conv_wgrad_x3_fused(B, H, W, Co, Ci)) {
+        // the three taps of a filter row share one pass over dY and X (blocks of <= 128 x 128 so that 3 accumulator sets fit)
+        const int na = Co > 64 ? 2 : 1, nb = Ci > 64 ? 2 : 1;
+        if (na == 2 && nb == 2) return launch_conv3<2, 2>(a, st);
+        if (na == 2 && nb == 1) return launch_conv3<2, 1>(a, st);
+        if (na == 1 && nb == 2) return launch_conv3<1, 2>(a, st);
+        return launch_conv3<1, 1>(a, st);
+    }
     const int na = tiles_for(Co), nb = tiles_for(Ci);
 #define H3D_CASE(NA, NB) if (na == NA && nb == NB) return launch<NA, NB>(a, slices, st)
     H3D_CASE(4, 4); H3D_CASE(4, 2); H3D_CASE(4, 1); H3D_CASE(2, 4); H3D_CASE(2, 2); H3D_CASE(2, 1);

@@ -13,6 +13,7 @@ channels-last fp32 (torch.channels_last memory format of the logical NCHW tensor
 (a permute and two casts) -- they change every optimiser step and carry the spectral normalisation's graph.
 """
 import ctypes
+import os
 
 import torch
 
@@ -53,6 +54,9 @@ def pack_stream(w):
     return torch.stack([hi, lo], dim=5).contiguous().view(torch.int16)    # ob, tap, chunk, ks, nt, (hi|lo), h, j, e
 
 
+_copied = {}          # H3D_CONV_DEBUG=1: (shape, strides) of tensors that had to be copied to channels-last, with counts
+
+
 def _rows(x):
     """x [B, C, H, W] -> (tensor whose memory is pixel-major rows of C floats, row stride in floats).  Channels-last tensors and
     channel slices of channels-last tensors (what the backward of a skip concatenation hands out) are taken as they are;
@@ -64,6 +68,9 @@ def _rows(x):
     if (sc == 1 and ld >= C and ld % 4 == 0 and sh == W * ld and (sb == H * W * ld or B == 1)
             and (x.storage_offset() * 4 + x.untyped_storage().data_ptr()) % 16 == 0):
         return x, ld
+    if os.environ.get("H3D_CONV_DEBUG"):
+        key = (tuple(x.shape), tuple(x.stride()))
+        _copied[key] = _copied.get(key, 0) + 1
     return x.contiguous(memory_format=torch.channels_last), C
 
 
@@ -87,7 +94,7 @@ def _run_wgrad(x, g, k):
     B, ci, H, W = x.shape
     co = g.shape[1]
     lib = _lib.load()
-    slices = max(1, lib.h3d_wgrad_x3_slices(B * H * W, co, ci) // (k * k))
+    slices = max(1, lib.h3d_conv_wgrad_x3_slices(B, H, W, co, ci, k))
     partial = torch.empty((k * k, slices, co, ci), device=x.device, dtype=torch.float32)
     rc = lib.h3d_conv_wgrad_x3(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_wgrad_x3")

@@ -180,6 +180,10 @@ int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be 
                 h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
                       int ldy, int ldx, int slices, h3d_stream_t stream_handle);
+/* K-slices to ask for (HOST helper), and whether a 3x3 problem runs on the kernel that fuses the three taps of a filter row
+ * (three passes over dY and X instead of nine; image rows must be multiples of 16 pixels). */
+int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int k);
+int h3d_conv_wgrad_x3_fused(int B, int H, int W, int Co, int Ci);
 
 /* ------------------------------------------------------------------------
  * A5 / A5+A6 in the "x2" arithmetic (csrc/x3_common.hpp): the hidden-layer contractions evaluate W.x as one f16 product

@@ -18,7 +18,8 @@ TOL = 1e-3          # split bf16 (16 mantissa bits per operand): measured ~2e-5
 @pytest.mark.parametrize("B,H,W,ci,co,k", [(2, 16, 8, 128, 128, 3), (1, 9, 7, 64, 64, 3), (3, 5, 11, 256, 64, 3), (1, 8, 4, 512, 512, 3),
                                             (2, 6, 6, 1024, 256, 3), (2, 16, 8, 128, 256, 1), (1, 33, 17, 64, 128, 3),
                                             (1, 4, 2, 512, 512, 1), (2, 16, 8, 3, 128, 3), (1, 9, 5, 64, 1, 1), (2, 8, 8, 64, 26, 1),
-                                            (1, 6, 6, 6, 128, 1)])
+                                            (1, 6, 6, 6, 128, 1), (2, 128, 128, 64, 128, 3), (3, 96, 128, 128, 64, 3), (1, 256, 128, 64, 64, 3),
+                                            (2, 128, 128, 192, 192, 3)])
 def test_conv_forward_and_first_order_gradients(B, H, W, ci, co, k):
     g = torch.Generator().manual_seed(ci + co + k)
     x = torch.randn(B, ci, H, W, generator=g, dtype=torch.float64)
