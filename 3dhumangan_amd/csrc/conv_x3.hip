@@ -145,8 +145,7 @@ int launch(const Args& A, int n_oblk, hipStream_t st) {
 // per channel chunk (4 or 8), out[3] = chunks.  -1 when the channel counts are not supported (both must be multiples of 64).
 extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
     if (!out || Cin < 64 || Cout < 64 || Cin % 64 || Cout % 64) return -1;
-    const int NT = Cout >= 256 ? 8 : Cout >= 128 ? 4 : 2;
-    if (Cout % (32 * NT)) return -1;
+    const int NT = Cout % 256 == 0 ? 8 : Cout % 128 == 0 ? 4 : 2;
     const int KSC = Cin % 128 == 0 ? 8 : 4;
     out[0] = NT; out[1] = Cout / (32 * NT); out[2] = KSC; out[3] = Cin / (16 * KSC);
     return 0;

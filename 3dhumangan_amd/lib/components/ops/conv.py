@@ -151,6 +151,23 @@ class _ConvW(torch.autograd.Function):
         return gx, gg, None
 
 
+class _NarrowChannels(torch.autograd.Function):
+    """y[:, :co] whose gradient stays channels-last (torch's slice backward builds an NCHW-contiguous zero-padded tensor, which the
+    next convolution would have to copy); differentiable again (a concatenation)."""
+
+    @staticmethod
+    def forward(ctx, y, co):
+        ctx.extra = y.shape[1] - co
+        return y[:, :co]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous(memory_format=torch.channels_last)
+        pad = torch.empty((g.shape[0], ctx.extra) + tuple(g.shape[2:]), device=g.device, dtype=g.dtype,
+                          memory_format=torch.channels_last).zero_()
+        return torch.cat([g, pad], dim=1), None
+
+
 def conv2d(x, weight, bias=None):
     """F.conv2d(x, weight, bias, stride=1, padding=k // 2) on the native kernels (see `supported`); the bias is a broadcast add.
     A side with fewer than 64 channels is zero-padded to 64 (differentiably: a concatenation / a slice), which costs little
@@ -170,5 +187,5 @@ def conv2d(x, weight, bias=None):
     else:
         y = _run_conv(x, weight)
     if co < 64:
-        y = y[:, :co]
+        y = _NarrowChannels.apply(y, co) if y.requires_grad else y[:, :co]
     return y if bias is None else y + bias.view(1, -1, 1, 1)
