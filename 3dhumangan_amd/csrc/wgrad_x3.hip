@@ -30,6 +30,7 @@ struct Args {
     int64_t M;
     int Co, Ci, ldy, ldx, rows_per_wg;
     int conv_k, H, W, slices;     // conv_k > 0: weight gradient of a k x k convolution over [B, H, W] pixels (rows of X shifted per tap)
+    float* colsum;                // optional [slices][Co]: column sums of dY over the slice's rows (the bias gradient), or null
 };
 
 // row of X that pairs with row rr of dY for filter tap (ty, tx): the shifted pixel, or -1 outside the image (zero padding)
@@ -135,9 +136,20 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     float4 ra[NA], rb[NB];
+    // bias gradient riding along (first column block of X, first tap only): a thread's slab positions (row, 4 columns) are the
+    // same in every k-step, so it keeps NA running float4 sums; the 16 rows are folded through LDS at the end
+    const bool do_colsum = A.colsum != nullptr && blockIdx.z == 0 && tap == 0;
+    float4 cs[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_colsum = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { cs[j].x += ra[j].x; cs[j].y += ra[j].y; cs[j].z += ra[j].z; cs[j].w += ra[j].w; }
+    };
     // rows past r_end must not leak into this slice: the loaders clip at min(M, r_end) through the `M` argument
     load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
     load_slab<NB, CONV>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
+    if (do_colsum) add_colsum();
     park_slab<NA>(ra, smem, t);
     park_slab<NB>(rb, smem + kKS * WA, t);
     __syncthreads();
@@ -150,6 +162,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
             load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
             load_slab<NB, CONV>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
+            if (do_colsum) add_colsum();
         }
         BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
 #pragma unroll
@@ -171,6 +184,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         __syncthreads();
     }
 
+    if (do_colsum) {            // fold the 16 slab rows: thread (row, c) parks its sums, the first WA threads add the rows up
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<float4*>(smem + (j * kThreads + t) * 4) = cs[j];
+        __syncthreads();
+        if (t < WA && co0 + t < A.Co) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < kKS; ++r) v += smem[r * WA + t];
+            A.colsum[(int64_t)slice * A.Co + co0 + t] = v;
+        }
+    }
     // accumulator tile (a, b): lane holds column ci = lane & 31, rows co = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)
     float* out = A.partial + (int64_t)blockIdx.x * A.Co * A.Ci;
 #pragma unroll
@@ -306,8 +331,18 @@ extern "C" int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci) {
     return (int)want;
 }
 
+extern "C" int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                                 int ldx, int slices, h3d_stream_t stream);
+
 extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx,
                             int slices, h3d_stream_t stream) {
+    return h3d_wgrad_x3_bias(dY, X, partial, nullptr, M, Co, Ci, ldy, ldx, slices, stream);
+}
+
+// h3d_wgrad_x3 that also writes colsum[slice][Co] = the column sums of dY over the slice's rows (the bias gradient of the same
+// layer; the caller sums the slices): dY is streamed anyway, so the separate reduction pass over it disappears.
+extern "C" int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                                 int ldx, int slices, h3d_stream_t stream) {
     H3D_REQUIRE(dY && X && partial, "h3d_wgrad_x3: null pointer");
     H3D_REQUIRE(M >= 1 && Co >= 1 && Ci >= 1, "h3d_wgrad_x3: bad shape M=%lld Co=%d Ci=%d", (long long)M, Co, Ci);
     H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
@@ -316,6 +351,7 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
     H3D_REQUIRE(slices >= 1 && slices <= 65535 * 16, "h3d_wgrad_x3: slices=%d out of range", slices);
     Args a{};
     a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx; a.slices = slices;
+    a.colsum = colsum;
     const int64_t per = (M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);

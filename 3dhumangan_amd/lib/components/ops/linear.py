@@ -15,18 +15,21 @@ MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this th
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 
 
-def wgrad_x3(dy, x):
-    """dy [M, Co], x [M, Ci] fp32 row-major (row stride >= width, multiple of 4) -> dy^T x [Co, Ci] fp32."""
+def wgrad_x3(dy, x, with_bias=False):
+    """dy [M, Co], x [M, Ci] fp32 row-major (row stride >= width, multiple of 4) -> dy^T x [Co, Ci] fp32; with_bias: also the
+    column sums of dy [Co] (the bias gradient of the same layer, from the same pass over dy) -> (dw, db)."""
     _lib.need_cuda(dy, x)
     M, Co = dy.shape
     Ci = x.shape[1]
     lib = _lib.load()
     slices = lib.h3d_wgrad_x3_slices(M, Co, Ci)
     partial = torch.empty((slices, Co, Ci), device=dy.device, dtype=torch.float32)
-    rc = lib.h3d_wgrad_x3(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), M, Co, Ci, dy.stride(0), x.stride(0), slices,
-                          _lib.stream_handle())
+    colsum = torch.empty((slices, Co), device=dy.device, dtype=torch.float32) if with_bias else None
+    rc = lib.h3d_wgrad_x3_bias(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), _lib.ptr(colsum), M, Co, Ci, dy.stride(0), x.stride(0),
+                               slices, _lib.stream_handle())
     _lib.check(rc, "h3d_wgrad_x3")
-    return partial.sum(dim=0) if slices > 1 else partial[0]
+    dw = partial.sum(dim=0) if slices > 1 else partial[0]
+    return (dw, colsum.sum(dim=0)) if with_bias else dw
 
 
 def wgrad_narrow(wide, narrow):
@@ -72,9 +75,11 @@ class _LinearX3(torch.autograd.Function):
                 dw = wgrad_narrow(_rows(x), dy2)                     # [Co, Ci]
             elif Ci <= 4:
                 dw = wgrad_narrow(dy2, _rows(x)).t()                 # [Ci, Co] -> [Co, Ci]
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
+                dw, db = wgrad_x3(dy2, _rows(x), with_bias=True)      # the bias gradient rides along: no second pass over dy
             else:
                 dw = wgrad_x3(dy2, _rows(x))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0)
         return dx, dw, db
 

@@ -414,6 +414,10 @@ int h3d_ray_integrate_bwd(const float* field, const float* z_vals, const float* 
 int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci);
 int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx, int slices,
                  h3d_stream_t stream);
+/* h3d_wgrad_x3 that also writes colsum[slice][Co] = column sums of dY over each slice's rows (the bias gradient; the caller
+ * sums the slices).  colsum may be NULL. */
+int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                      int ldx, int slices, h3d_stream_t stream_handle);
 
 /* Weight gradient with one narrow side: out[j][c] = sum_r narrow[r][j] * wide[r][c], j < nn <= 4 (ToRGB 3 x C, density /
  * colour heads, the coordinate layer transposed).  wide [M, C] fp32 with leading dimension ldw, narrow [M, nn] fp32 contiguous;

@@ -168,6 +168,12 @@ def test_wgrad_x3_vs_fp64(M, Co, Ci):
     assert got.shape == (Co, Ci)
     err = ((got.cpu().double() - ref).abs().amax(1) / ref.abs().amax(1)).max()      # per output row: each has its own scale
     assert float(err) < 2e-4, float(err)
+    # the bias gradient riding along (column sums of dY from the same pass): exact fp32 sums, same dW
+    dw2, db = lin.wgrad_x3(dy.to(DEV), wide.to(DEV)[:, 4:4 + Ci], with_bias=True)
+    assert torch.equal(dw2, got)
+    ref_b = dy.double().sum(dim=0)
+    scale = dy.double().abs().sum(dim=0).clamp_min(1e-300)
+    assert float(((db.cpu().double() - ref_b).abs() / scale).max()) < 1e-5
 
 
 @pytest.mark.parametrize("M,C,n", [(5000, 256, 3), (70001, 420, 1), (3000, 30, 4), (2000, 1028, 2)])
