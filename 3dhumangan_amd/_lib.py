@@ -56,6 +56,7 @@ _SIGNATURES = {
                                       _i, _i, _p]),
     "h3d_field_pack_x3t_size": (C.c_int64, [_i, _i]),
     "h3d_field_pack_x3t": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
+    "h3d_field_pack_x2t": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
     "h3d_field_x3t_layout": (C.c_int, [_i, _i, C.POINTER(C.c_int64), _i]),
     "h3d_neural_field_x3t": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),
     "h3d_render_fused_x3t": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i,

@@ -93,10 +93,13 @@ __device__ __forceinline__ float density(float x, int clamp_mode) {
 
 // P: partial products per operand pair of the hidden GEMMs (x3t_common.hpp): 3 = fp32-class (the default engine), 1 = plain
 // f16 matrix-core arithmetic (the "f16 MFMA" tier of BASELINE config 5; the K=3 / K=31 input layers always run with 3).
+// P = 4: the x2 arithmetic (x3_common.hpp / x3t_common.hpp: one f16 product + one block-scaled fp6 product per contraction; the
+// blob must come from h3d_field_pack_x2t).
 template <int NTF, int NX, bool FUSED, int P>
 __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     constexpr int NU = 2 * NTF + NX;
     constexpr bool LO = P == 3;            // activations carry a lo half
+    constexpr bool X2 = P == 4;            // activations carry the K-tile's fp6 record in the lo planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const LayoutT& L = A.L;
     const int KS = L.KS, HdP = L.HdP;
@@ -212,14 +215,18 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                     for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_sinf(fmaf(v[q], t1[sl][rg][q], t0[sl][rg][q]));
                     return y;
                 };
+                auto store = [&](const f32x16& v, int mt) __attribute__((always_inline)) {
+                    if constexpr (X2) x3t_store_unit_x2<false>(v, actT, KS, U.nt[i], mt, lane, film);      // sines: static scale
+                    else x3t_store_unit<LO>(v, actT, KS, U.nt[i], mt, lane, split, film);
+                };
                 if constexpr (i < NTF) {
                     pin1(acc[2 * i]);
-                    x3t_store_unit<LO>(acc[2 * i], actT, KS, U.nt[i], 0, lane, split, film);
+                    store(acc[2 * i], 0);
                     pin1(acc[2 * i + 1]);
-                    x3t_store_unit<LO>(acc[2 * i + 1], actT, KS, U.nt[i], 1, lane, split, film);
+                    store(acc[2 * i + 1], 1);
                 } else {
                     pin1(acc[2 * NTF]);
-                    x3t_store_unit<LO>(acc[2 * NTF], actT, KS, U.nt[i], U.xmt, lane, split, film);
+                    store(acc[2 * NTF], U.xmt);
                 }
                 // bound the scheduler's hoisting to one tile (all tiles at once cost > 200 registers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -230,6 +237,58 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         // part[w][head][sample] (rows 0..3 of the tile are registers 0..3 of the lanes with h == 0).  All weight fragments
         // of the wave are requested up front (<= 7 k-steps), so their latency overlaps instead of adding up.
         auto heads = [&]() __attribute__((always_inline)) {
+            if constexpr (X2) {
+                // x2: wave w contracts K-tiles w, w+4, .. (k-steps 2T, 2T+1): two f16 instructions + one fp6 instruction per
+                // K-tile and sample tile; the head tile's "lo" planes hold its record halves like every other matrix
+                constexpr int MAXT = 4;                                 // KS <= 28 -> 14 K-tiles
+                u32x4 wh[MAXT][2], wr[MAXT][2];
+                const unsigned char* wsrc = headw + opaque + lane * 16;
+#pragma unroll
+                for (int i = 0; i < MAXT; ++i) {
+                    const int T = wave + 4 * i;
+                    if (2 * T < KS) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            wh[i][j] = *reinterpret_cast<const u32x4*>(wsrc + (2 * T + j) * 2048);
+                            wr[i][j] = *reinterpret_cast<const u32x4*>(wsrc + (2 * T + j) * 2048 + 1024);
+                        }
+                    }
+                }
+                f32x16 ha[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ha[mt][r] = 0.f;
+#pragma unroll
+                for (int i = 0; i < MAXT; ++i) {
+                    const int T = wave + 4 * i;
+                    if (2 * T < KS) {
+                        const i32x8 w6 = {(int)wr[i][0][0], (int)wr[i][0][1], (int)wr[i][0][2], (int)wr[i][0][3],
+                                          (int)wr[i][1][0], (int)wr[i][1][1], (int)wr[i][1][2], (int)wr[i][1][3]};
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            u32x4 xr[2];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const unsigned char* q = actT + x3t_frag(KS, mt, 2 * T + j, 0) + lane * 16;
+                                const half8 xh_ = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(q));
+                                xr[j] = *reinterpret_cast<const u32x4*>(q + 1024);
+                                ha[mt] = F16::mfma(__builtin_bit_cast(half8, wh[i][j]), xh_, ha[mt]);
+                            }
+                            const i32x8 x6 = {(int)xr[0][0], (int)xr[0][1], (int)xr[0][2], (int)xr[0][3],
+                                              (int)xr[1][0], (int)xr[1][1], (int)xr[1][2], (int)xr[1][3]};
+                            ha[mt] = mm6<false>(w6, x6, ha[mt]);
+                        }
+                    }
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int hd = 0; hd < 4; ++hd) part[(wave * 4 + hd) * 64 + mt * 32 + m] = ha[mt][hd];
+                }
+                return;
+            }
             constexpr int MAXK = 7;                                     // KS <= 28
             u32x4 wh[MAXK], wl[MAXK];
             const unsigned char* wsrc = headw + opaque + lane * 16;
@@ -624,6 +683,8 @@ int check_x3t(const void* packed, const float* points, const float* geo, const f
     return H3D_OK;
 }
 
+int field_pack_t(const h3d_field_params* p, int Hd, int F, void* blob_, bool x2);
+
 }  // namespace
 
 extern "C" int64_t h3d_field_pack_x3t_size(int Hd, int F) {
@@ -643,7 +704,13 @@ extern "C" int h3d_field_x3t_layout(int Hd, int F, int64_t* out, int n_out) {
     return H3D_OK;
 }
 
-extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void* blob_) {
+extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void* blob) { return field_pack_t(p, Hd, F, blob, false); }
+/* the x2 tier's blob (products = 4 of the _tier entry points): same layout and size; the matrices fed by accumulators and the
+ * head tile carry f16 hi fragments + fp6 records instead of hi + lo fragments */
+extern "C" int h3d_field_pack_x2t(const h3d_field_params* p, int Hd, int F, void* blob) { return field_pack_t(p, Hd, F, blob, true); }
+
+namespace {
+int field_pack_t(const h3d_field_params* p, int Hd, int F, void* blob_, bool x2) {
     H3D_REQUIRE(p && blob_, "h3d_field_pack_x3t: null pointer");
     H3D_REQUIRE(widths_ok(Hd, F), "h3d_field_pack_x3t: widths up to 448 (got %d, %d)", Hd, F);
     const LayoutT L = make_layout(Hd, F);
@@ -652,6 +719,11 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     float* invs = reinterpret_cast<float*>(blob + L.inv_scale);
     const float target = 8192.f;
     auto dst = [&](int wi) { return reinterpret_cast<uint16_t*>(blob + L.w[wi]); };
+    // accumulator-order matrices: x3 (hi + lo fragments) or x2 (hi fragments + fp6 records)
+    auto pack_acc = [&](const float* w, int ld, int in_begin, int in_count, int n_out, int KStot, int ks0, int KSm, float sc, int wi) {
+        if (x2) x3t_pack_x2(w, ld, in_begin, in_count, n_out, L.NT, KStot, ks0, KSm, sc, blob + L.w[wi]);
+        else x3t_pack_f16(w, ld, in_begin, in_count, n_out, L.NT, KStot, ks0, KSm, sc, dst(wi), true);
+    };
     // input layers: natural K order
     {
         const float sc = pow2_scale(p->w_coord, (int64_t)Hd * 3, target);
@@ -666,26 +738,26 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     // FiLM 0: both K halves accumulate into the same registers -> one scale; k-steps [0, KS) coordinate half, [KS, 2KS) geometry half
     {
         const float sc = pow2_scale(p->w_film[0], (int64_t)Hd * 2 * Hd, target);
-        x3t_pack_f16(p->w_film[0], 2 * Hd, 0, Hd, Hd, L.NT, 2 * L.KS, 0, L.KS, sc, dst(W_F0), true);
-        x3t_pack_f16(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.NT, 2 * L.KS, L.KS, L.KS, sc, dst(W_F0), true);
+        pack_acc(p->w_film[0], 2 * Hd, 0, Hd, Hd, 2 * L.KS, 0, L.KS, sc, W_F0);
+        pack_acc(p->w_film[0], 2 * Hd, Hd, Hd, Hd, 2 * L.KS, L.KS, L.KS, sc, W_F0);
         invs[W_F0] = 1.f / sc;
     }
     for (int l = 1; l < 4; ++l) {
         const float sc = pow2_scale(p->w_film[l], (int64_t)Hd * Hd, target);
-        x3t_pack_f16(p->w_film[l], Hd, 0, Hd, Hd, L.NT, L.KS, 0, L.KS, sc, dst(W_F0 + l), true);
+        pack_acc(p->w_film[l], Hd, 0, Hd, Hd, L.KS, 0, L.KS, sc, W_F0 + l);
         invs[W_F0 + l] = 1.f / sc;
     }
     // colour layer: KS k-steps over the hidden features (columns 3..), one k-step over the view direction (columns
     // 0..2, natural order); one scale for the whole matrix (same accumulators), both inputs unscaled
     {
         const float sc = pow2_scale(p->w_color, (int64_t)Hd * (Hd + 3), target);
-        x3t_pack_f16(p->w_color, Hd + 3, 3, Hd, Hd, L.NT, L.KS + 1, 0, L.KS, sc, dst(W_COLOR), true);
+        pack_acc(p->w_color, Hd + 3, 3, Hd, Hd, L.KS + 1, 0, L.KS, sc, W_COLOR);
         x3t_pack_f16(p->w_color, Hd + 3, 0, 3, Hd, L.NT, L.KS + 1, L.KS, 1, sc, dst(W_COLOR), false);
         invs[W_COLOR] = 1.f / sc;
     }
     {
         const float sc = pow2_scale(p->w_feat, (int64_t)F * Hd, target);
-        x3t_pack_f16(p->w_feat, Hd, 0, Hd, F, L.NT, L.KS, 0, L.KS, sc, dst(W_FEAT), true);
+        pack_acc(p->w_feat, Hd, 0, Hd, F, L.KS, 0, L.KS, sc, W_FEAT);
         invs[W_FEAT] = 1.f / sc;
     }
     float* bias = reinterpret_cast<float*>(blob + L.bias);
@@ -704,6 +776,31 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     for (int hd = 0; hd < 4; ++hd) {
         const float* w = hd == 0 ? p->w_sigma : p->w_rgb + (int64_t)(hd - 1) * Hd;
         const float sc = pow2_scale(w, Hd, target);
+        hinv[hd] = 1.f / sc;
+        hb[hd] = hd == 0 ? p->b_sigma[0] : p->b_rgb[hd - 1];
+        if (x2) {      // rows 0..3 of the head tile as hi fragments + records (lane = 32 * hh + row)
+            unsigned char* hbase = blob + L.head_w;
+            for (int T = 0; T < L.KS / 2; ++T)
+                for (int hh = 0; hh < 2; ++hh) {
+                    float hi[16], lo[16];
+                    const int lane = 32 * hh + hd;
+                    for (int j = 0; j < 2; ++j)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = x3t_acc_k(2 * T + j, hh, e);
+                            const float v = k < Hd ? w[k] * sc : 0.f;
+                            const uint16_t h16 = x3t_f32_to_f16_rn(v);
+                            hi[8 * j + e] = x3t_f16_to_f32(h16);
+                            lo[8 * j + e] = v - hi[8 * j + e];
+                            reinterpret_cast<uint16_t*>(hbase + (int64_t)(2 * T + j) * 2048)[lane * 8 + e] = h16;
+                        }
+                    unsigned rec[8];
+                    x2_make_record(hi, lo, rec);
+                    for (int j = 0; j < 2; ++j)
+                        for (int d = 0; d < 4; ++d)
+                            reinterpret_cast<unsigned*>(hbase + (int64_t)(2 * T + j) * 2048 + 1024)[lane * 4 + d] = rec[4 * j + d];
+                }
+            continue;
+        }
         for (int ks = 0; ks < L.KS; ++ks)
             for (int hh = 0; hh < 2; ++hh)
                 for (int e = 0; e < 8; ++e) {
@@ -719,13 +816,15 @@ extern "C" int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void
     }
     return H3D_OK;
 }
+}  // namespace
 
 extern "C" int h3d_neural_field_x3t_tier(const void* packed, const float* points, const float* geo, const float* dirs,
                                          const float* freq, const float* phase, float* out, int B, int64_t N, int Hd, int F,
                                          int geo_stride, float input_scaler, int products, h3d_stream_t stream) {
     int rc = check_x3t(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
-    H3D_REQUIRE(products == 1 || products == 3, "h3d_neural_field_x3t_tier: products must be 1 (plain f16) or 3 (split f16)");
+    H3D_REQUIRE(products == 1 || products == 3 || products == 4,
+                "h3d_neural_field_x3t_tier: products must be 1 (plain f16), 3 (split f16) or 4 (x2: blob from h3d_field_pack_x2t)");
     H3D_REQUIRE(out, "h3d_neural_field_x3t: null output");
     if (B == 0 || N == 0) return H3D_OK;
     Args A{};
@@ -736,6 +835,7 @@ extern "C" int h3d_neural_field_x3t_tier(const void* packed, const float* points
     const int64_t groups = (N + 63) / 64;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_neural_field_x3t: N too large");
     return products == 3 ? launch<false, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+         : products == 4 ? launch<false, 4>(A, B, groups, static_cast<hipStream_t>(stream))
                          : launch<false, 1>(A, B, groups, static_cast<hipStream_t>(stream));
 }
 
@@ -753,7 +853,8 @@ extern "C" int h3d_render_fused_x3t_tier(const void* packed, const float* points
     const int64_t N = (int64_t)R * S;
     int rc = check_x3t(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
-    H3D_REQUIRE(products == 1 || products == 3, "h3d_render_fused_x3t_tier: products must be 1 (plain f16) or 3 (split f16)");
+    H3D_REQUIRE(products == 1 || products == 3 || products == 4,
+                "h3d_render_fused_x3t_tier: products must be 1 (plain f16), 3 (split f16) or 4 (x2: blob from h3d_field_pack_x2t)");
     H3D_REQUIRE(z_vals && feats && depth && weights, "h3d_render_fused_x3t: null pointer");
     H3D_REQUIRE(clamp_mode == 0 || clamp_mode == 1, "h3d_render_fused_x3t: clamp_mode must be 0 (relu) or 1 (softplus)");
     H3D_REQUIRE(R >= 0 && S >= 1, "h3d_render_fused_x3t: bad R=%d S=%d", R, S);
@@ -781,6 +882,7 @@ extern "C" int h3d_render_fused_x3t_tier(const void* packed, const float* points
         (void)hipMemset(tb, 0, 4096 * 8);
         A.out = reinterpret_cast<float*>(tb);
         const int rc2 = products == 3 ? launch<true, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+                      : products == 4 ? launch<true, 4>(A, B, groups, static_cast<hipStream_t>(stream))
                                       : launch<true, 1>(A, B, groups, static_cast<hipStream_t>(stream));
         (void)hipDeviceSynchronize();
         static unsigned long long host[4096];
@@ -800,6 +902,7 @@ extern "C" int h3d_render_fused_x3t_tier(const void* packed, const float* points
     }
 #endif
     return products == 3 ? launch<true, 3>(A, B, groups, static_cast<hipStream_t>(stream))
+         : products == 4 ? launch<true, 4>(A, B, groups, static_cast<hipStream_t>(stream))
                          : launch<true, 1>(A, B, groups, static_cast<hipStream_t>(stream));
 }
 

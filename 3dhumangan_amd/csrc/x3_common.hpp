@@ -325,6 +325,30 @@ __device__ __forceinline__ f32x16 mm6(const i32x8& w, const i32x8& x, const f32x
                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 2, 2, 0, sw, 0, sx);
 }
 
+// two fp32 -> packed f16 hi halves (returned) and packed f16 halves of lo * 2^12 (plain VALU only, see split2_act)
+__device__ __forceinline__ unsigned split2_x2(float a, float b, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 hv = __builtin_convertvector(f2{a, b}, h2);
+    const float fa = (float)hv.x, fb = (float)hv.y;
+    float la, lb;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(la) : "v"(la), "v"(kX2Rho));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(lb) : "v"(lb), "v"(kX2Rho));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{la, lb}, h2));
+    return __builtin_bit_cast(unsigned, hv);
+}
+
+// The fp6 record of a K-tile whose largest |activation| of this lane is amax = m * 2^e (1 <= m < 2): codes = q6(y / cs) with
+// cs = 2^(e-2) when m < 1.875 (largest hi code < 7.5: no saturation) and 2^(e-1) otherwise.  lo' = lo * 2^12 <= 2^(e+1) can
+// reach code 8 in the first case and is then clipped to 7.5 (an error of 2^-4 of a term that is 2^-12 of the product).
+__device__ __forceinline__ i32x8 x2_record_dyn(const F16::vec8& l0, const F16::vec8& l1, const F16::vec8& h0, const F16::vec8& h1, float amax) {
+    unsigned eb = (__builtin_bit_cast(unsigned, amax) + 0x100000u) >> 23;   // biased exponent, + 1 when m >= 1.875 (amax >= 0)
+    eb = eb < 16u ? 16u : eb;                                               // all-zero / tiny tiles: any in-range scale
+    return x2_record(l0, l1, h0, h1, __builtin_bit_cast(float, (eb - 2u) << 23), (int)eb - 2);
+}
+
 // acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3
 // k-steps (B operands xh[s], xl3[s - KS2]: fragments assembled from memory, lo unscaled).  Same ring protocol, look-ahead
 // and hook convention as gemm_x3_roll; a section carries 2 (even x2 k-step), 4 (odd) or 6 (x3) MFMAs.

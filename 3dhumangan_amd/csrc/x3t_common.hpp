@@ -121,14 +121,23 @@ __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigne
 //      3  hi*hi + hi*lo + lo*hi   fp32-class (22 / 16 significant bits per operand with f16 / bf16 halves)
 //      2  hi*hi + lo*hi           weights to full precision, activations rounded to ONE 16-bit value
 //      1  hi*hi                   plain f16 / bf16 matrix-core arithmetic
+//      4  "x2" (x3_common.hpp)    hi*hi on the f16 matrix cores + ONE block-scaled fp6 instruction per K-tile (two k-steps) for
+//                                 both cross terms.  The "lo" planes of weights and activations then hold the halves of the
+//                                 K-tile's fp6 records (dwords 0-3 with the even k-step, 4-7 with the odd one): an even k-step
+//                                 issues NU f16 instructions, an odd one NU fp6 instructions (which read the record halves of
+//                                 this AND the previous k-step) followed by NU f16 instructions.  The previous k-step's ring
+//                                 slots are the ones this k-step refills, so every load / read into a record half is pinned
+//                                 behind the last fp6 instruction (operation order: weight hi, fragment hi, fragment lo, weight lo).
 template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false, bool PRE = false, int P = 3>
 __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsigned char* bT, int mt_stride,
                                          const unsigned char* __restrict__ W, int KStot, int ks0, int KS,
                                          const X3tUnits<NTF, NX>& U, int lane, X3tRing<NTF + NX>& R) {
     constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
-    constexpr bool WLO = P >= 2, XLO = P == 3;       // which lo planes are read
+    constexpr bool X2 = P == 4;
+    constexpr bool WLO = P >= 2, XLO = P >= 3;       // which lo planes are read
     constexpr int NLA = (WLO ? 2 : 1) * NA;          // weight loads per k-step
-    static_assert(P >= 1 && P <= 3, "1, 2 or 3 partial products");
+    static_assert(P >= 1 && P <= 4, "1, 2 or 3 partial products, or 4 = x2");
+    static_assert(!X2 || (D % 2 == 0 && !GUARD), "x2: k-step parity follows the ring slot; short phases stay on three products");
     static_assert(!(GUARD && PRE), "short phases load everything themselves");
     typedef typename X3tRing<NA>::AF AF;
     struct BF { u32x4 h[2], l[2], xh, xl; };
@@ -161,52 +170,94 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         }
     };
     // MFMA j of a k-step, j = 0 .. P*NU-1: pass j / NU (hi*hi, then lo*hi, then hi*lo) over all units -- consecutive MFMAs
-    // never share an accumulator
-    auto mfma1 = [&](auto jc, const AF& a, const BF& b) __attribute__((always_inline)) {
-        constexpr int j = decltype(jc)::value, p = j / NU, u = j % NU, sl = u < 2 * NTF ? u / 2 : NTF;
-        const u32x4 wv = p == 1 ? a.l[sl] : a.h[sl];
-        const u32x4 xv = u < 2 * NTF ? (p == 2 ? b.l[u & 1] : b.h[u & 1]) : (p == 2 ? b.xl : b.xh);
-        acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
+    // never share an accumulator.  x2 (ODD k-step): j < NU are the fp6 instructions of the K-tile (record halves of the
+    // previous k-step ap / bp and of this one), j >= NU the f16 ones; even k-step: f16 only.
+    auto mfma1 = [&](auto jc, auto oddc, const AF& a, const BF& b, const AF& ap, const BF& bp) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr bool ODD = decltype(oddc)::value != 0;
+        if constexpr (X2) {
+            if constexpr (ODD && j < NU) {
+                constexpr int u = j, sl = u < 2 * NTF ? u / 2 : NTF;
+                const u32x4 w0 = ap.l[sl], w1 = a.l[sl];
+                const u32x4 x0 = u < 2 * NTF ? bp.l[u & 1] : bp.xl, x1 = u < 2 * NTF ? b.l[u & 1] : b.xl;
+                const i32x8 w6 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                const i32x8 x6 = {(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+                acc[u] = mm6<SWAP>(w6, x6, acc[u]);
+            } else {
+                constexpr int u = ODD ? j - NU : j, sl = u < 2 * NTF ? u / 2 : NTF;
+                const u32x4 xv = u < 2 * NTF ? b.h[u & 1] : b.xh;
+                acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, a.h[sl]), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
+            }
+        } else {
+            constexpr int p = j / NU, u = j % NU, sl = u < 2 * NTF ? u / 2 : NTF;
+            const u32x4 wv = p == 1 ? a.l[sl] : a.h[sl];
+            const u32x4 xv = u < 2 * NTF ? (p == 2 ? b.l[u & 1] : b.h[u & 1]) : (p == 2 ? b.xl : b.xh);
+            acc[u] = mm<T, SWAP>(__builtin_bit_cast(typename T::vec8, wv), __builtin_bit_cast(typename T::vec8, xv), acc[u]);
+        }
     };
-    auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {
-        static_for<0, P * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, a, b); });
+    auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {      // short (GUARD) phases: never x2
+        static_for<0, P * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, IC<0>{}, a, b, a, b); });
     };
     // One k-step with its memory traffic in the shadow of the matrix pipe (one wave per SIMD: whatever is issued between
     // two MFMAs is free, whatever is issued before the first one leaves the pipe idle): after MFMA j comes weight load j
     // (tile j/2, plane j%2) of k-step `ka`, then the LDS reads of k-step `kb`, one per MFMA.  Every position is pinned.
     // (LA / LB: whether this k-step still requests weights / fragments; references, never pointers: taking the address of a
     // ring element would move the whole ring to scratch memory)
-    auto kstep = [&](auto la, auto lb, const AF& a_cur, const BF& b_cur, AF& a_nxt, int ka, BF& b_nxt, int kb) __attribute__((always_inline)) {
-        constexpr bool LA = decltype(la)::value != 0, LB = decltype(lb)::value != 0;
+    // x2: a_nxt / b_nxt are the slots of the PREVIOUS k-step; an odd k-step reads their record halves in its fp6 instructions
+    // before anything is loaded into them (operation order below).
+    auto kstep = [&](auto la, auto lb, auto oddc, const AF& a_cur, const BF& b_cur, AF& a_nxt, int ka, BF& b_nxt, int kb) __attribute__((always_inline)) {
+        constexpr bool LA = decltype(la)::value != 0, LB = decltype(lb)::value != 0, ODD = decltype(oddc)::value != 0;
         constexpr int XP = XLO ? 2 : 1;                            // fragment planes read per sample tile
-        constexpr int NBF = NTF > 0 ? 2 * XP : 0, NB = NBF + (NX ? XP : 0), NOPS = NLA + NB, NM = P * NU;
-        // memory operation i = 0 .. NOPS-1: the NLA weight loads first (tile-major, hi then lo), then the NB fragment reads
-        auto memop = [&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i < NLA) {
-                if constexpr (LA) {
-                    constexpr int tile = WLO ? i / 2 : i, plane = WLO ? i % 2 : 0;
-                    const unsigned char* q = wp[tile] + ka * 2048;
-                    if constexpr (plane == 0) x3t_gload<0>(a_nxt.h[tile], q, lane_off);
-                    else x3t_gload<1024>(a_nxt.l[tile], q, lane_off);
-                }
-            } else if constexpr (LB) {
-                constexpr int r = i - NLA;
-                if constexpr (r < NBF) {
-                    constexpr int mt = r / XP, plane = r % XP;
-                    const unsigned char* q = bp + mt * mt_stride + kb * 2048 + plane * 1024;
-                    if constexpr (plane == 0) b_nxt.h[mt] = *reinterpret_cast<const u32x4*>(q);
-                    else b_nxt.l[mt] = *reinterpret_cast<const u32x4*>(q);
+        constexpr int NBF = NTF > 0 ? 2 * XP : 0, NB = NBF + (NX ? XP : 0), NOPS = NLA + NB;
+        constexpr int NM = X2 ? (ODD ? 2 * NU : NU) : P * NU;
+        constexpr int NBH = (NTF > 0 ? 2 : 0) + (NX ? 1 : 0);      // x2: fragment hi reads (= lo reads)
+        auto wload = [&](auto tc, auto pc) __attribute__((always_inline)) {
+            constexpr int tile = decltype(tc)::value, plane = decltype(pc)::value;
+            if constexpr (LA) {
+                const unsigned char* q = wp[tile] + ka * 2048;
+                if constexpr (plane == 0) x3t_gload<0>(a_nxt.h[tile], q, lane_off);
+                else x3t_gload<1024>(a_nxt.l[tile], q, lane_off);
+            }
+        };
+        auto bread = [&](auto rc, auto pc) __attribute__((always_inline)) {     // r: 0, 1 = sample tiles of the full units, 2 = extra unit
+            constexpr int r = decltype(rc)::value, plane = decltype(pc)::value;
+            if constexpr (LB) {
+                if constexpr (r < 2) {
+                    const unsigned char* q = bp + r * mt_stride + kb * 2048 + plane * 1024;
+                    if constexpr (plane == 0) b_nxt.h[r] = *reinterpret_cast<const u32x4*>(q);
+                    else b_nxt.l[r] = *reinterpret_cast<const u32x4*>(q);
                 } else {
-                    constexpr int k = r - NBF;
-                    if constexpr (k == 0) b_nxt.xh = *reinterpret_cast<const u32x4*>(bx + kb * 2048);
+                    if constexpr (plane == 0) b_nxt.xh = *reinterpret_cast<const u32x4*>(bx + kb * 2048);
                     else b_nxt.xl = *reinterpret_cast<const u32x4*>(bx + kb * 2048 + 1024);
                 }
             }
         };
+        // memory operation i = 0 .. NOPS-1
+        auto memop = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (X2) {
+                // weight hi (NA), fragment hi (NBH), fragment lo (NBH), weight lo (NA): the first half of the operations touches
+                // no record half
+                if constexpr (i < NA) wload(IC<i>{}, IC<0>{});
+                else if constexpr (i < NA + NBH) {
+                    constexpr int r = i - NA;
+                    bread(IC<(NTF > 0 ? r : 2)>{}, IC<0>{});
+                } else if constexpr (i < NA + 2 * NBH) {
+                    constexpr int r = i - NA - NBH;
+                    bread(IC<(NTF > 0 ? r : 2)>{}, IC<1>{});
+                } else wload(IC<i - NA - 2 * NBH>{}, IC<1>{});
+            } else if constexpr (i < NLA) {
+                constexpr int tile = WLO ? i / 2 : i, plane = WLO ? i % 2 : 0;
+                wload(IC<tile>{}, IC<plane>{});
+            } else {
+                constexpr int r = i - NLA;
+                if constexpr (r < NBF) bread(IC<r / XP>{}, IC<r % XP>{});
+                else bread(IC<2>{}, IC<r - NBF>{});
+            }
+        };
         static_for<0, NM>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            mfma1(jc, a_cur, b_cur);
+            mfma1(jc, oddc, a_cur, b_cur, a_nxt, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
             // operations [j*NOPS/NM, (j+1)*NOPS/NM) ride behind MFMA j: spread evenly over the k-step (with one product
             // per operand pair there are more memory operations than MFMAs: some gaps carry two)
@@ -243,7 +294,8 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
             for (int d = 0; d < D; ++d) {
                 x3t_wait_frags<(D - 2) * NLA, NA, WLO>(a[d].h, a[d].l);
                 __builtin_amdgcn_sched_barrier(0);
-                kstep(IC<1>{}, IC<1>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
+                if (d & 1) kstep(IC<1>{}, IC<1>{}, IC<1>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
+                else kstep(IC<1>{}, IC<1>{}, IC<0>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
             }
         }
         // the last D k-steps: one more request, then the ring drains
@@ -251,7 +303,7 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
             constexpr int d = decltype(dc)::value;
             x3t_wait_frags<(d == 0 ? D - 2 : D - 1 - d) * NLA, NA, WLO>(a[d].h, a[d].l);
             __builtin_amdgcn_sched_barrier(0);
-            kstep(IC<(d == 0)>{}, IC<(d < D - 1)>{}, a[d], b[d & 1], a[D - 1], KS - 1, b[(d + 1) & 1], KS - D + d + 1);
+            kstep(IC<(d == 0)>{}, IC<(d < D - 1)>{}, IC<(d & 1)>{}, a[d], b[d & 1], a[(d + D - 1) % D], KS - 1, b[(d + 1) & 1], KS - D + d + 1);
         });
     }
 }
@@ -278,6 +330,38 @@ __device__ __forceinline__ void x3t_store_unit(const f32x16& v, unsigned char* a
         unsigned char* p = actT + x3t_frag(KS, mt, 2 * nt + j, 0) + lane * 16;
         *reinterpret_cast<u32x4*>(p) = hi;
         if constexpr (LO) *reinterpret_cast<u32x4*>(p + 1024) = lo;
+    }
+}
+
+// x2 epilogue of one unit: f16 hi fragments of k-steps 2*nt, 2*nt+1 into the hi planes, and the K-tile's fp6 record (codes of
+// lo * 2^12 and hi, the lane's block scale in dword 6; x3_common.hpp) split over the two "lo" planes.
+// DYN: per-lane scale from the largest of the 16 values (unbounded activations); otherwise the static scale for |y| <= 1.
+template <bool DYN, typename F>
+__device__ __forceinline__ void x3t_store_unit_x2(const f32x16& v, unsigned char* actT, int KS, int nt, int mt, int lane, F f) {
+    u32x4 hi[2], lo[2];
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rg = 2 * j + q;
+            const f32x4 y = f(rg, f32x4{v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]});
+            if (DYN) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+            unsigned l0, l1;
+            hi[j][2 * q + 0] = split2_x2(y[0], y[1], l0);
+            hi[j][2 * q + 1] = split2_x2(y[2], y[3], l1);
+            lo[j][2 * q + 0] = l0;
+            lo[j][2 * q + 1] = l1;
+        }
+    const F16::vec8 l0v = __builtin_bit_cast(F16::vec8, lo[0]), l1v = __builtin_bit_cast(F16::vec8, lo[1]);
+    const F16::vec8 h0v = __builtin_bit_cast(F16::vec8, hi[0]), h1v = __builtin_bit_cast(F16::vec8, hi[1]);
+    i32x8 rec = DYN ? x2_record_dyn(l0v, l1v, h0v, h1v, amax) : x2_record(l0v, l1v, h0v, h1v);
+    rec[7] = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned char* p = actT + x3t_frag(KS, mt, 2 * nt + j, 0) + lane * 16;
+        *reinterpret_cast<u32x4*>(p) = hi[j];
+        *reinterpret_cast<u32x4*>(p + 1024) = u32x4{(unsigned)rec[4 * j], (unsigned)rec[4 * j + 1], (unsigned)rec[4 * j + 2], (unsigned)rec[4 * j + 3]};
     }
 }
 
@@ -362,6 +446,69 @@ inline void x3t_pack_f16(const float* w, int ld, int in_begin, int in_count, int
                     dst[base + lane * 8 + e] = hi;
                     dst[base + 64 * 8 + lane * 8 + e] = lo;
                 }
+}
+
+// ---- x2 packing (host): fp6 (e2m3) codes and block scales -----------------------------------------------------------
+inline unsigned x2_e2m3_code(float v) {            // round-to-nearest-even on the code grid, saturating at 7.5
+    const unsigned sign = v < 0.f ? 32u : 0u;
+    const float a = fminf(fabsf(v), 7.5f);
+    const float step = a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f;
+    const float q = nearbyintf(a / step) * step;   // default rounding mode: ties to even; spacing doubles exactly at 2 and 4
+    unsigned c;
+    if (q < 2.f) c = (unsigned)(q * 8.f);
+    else if (q < 4.f) c = 16u + (unsigned)((q - 2.f) * 4.f);
+    else c = 24u + (unsigned)((q - 4.f) * 2.f);
+    return sign | c;
+}
+
+// 32 B record of one lane and K-tile from its 16 (already scaled) weights' f16 hi values and fp32 residuals
+inline void x2_make_record(const float (&hi)[16], const float (&lo)[16], unsigned (&rec)[8]) {
+    float mx = 0.f;
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fabsf(hi[i]));
+    int ea = mx > 0.f ? (int)floorf(log2f(7.5f / mx)) : 0;
+    if (ea > 100) ea = 100;
+    if (ea < -100) ea = -100;
+    for (int i = 0; i < 16; ++i)
+        if (fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f) { --ea; break; }
+    const float alpha = ldexpf(1.f, ea);
+    for (int d = 0; d < 8; ++d) rec[d] = 0;
+    for (int sl = 0; sl < 32; ++sl) {
+        const float v = sl < 16 ? hi[sl] * alpha : lo[sl - 16] * alpha * kX2Rho;
+        const uint64_t code = x2_e2m3_code(v);
+        const int bit = 6 * sl;
+        rec[bit / 32] |= (unsigned)(code << (bit & 31));
+        if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
+    }
+    rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+}
+
+// x3t_pack_f16 for the x2 tier: accumulator-order matrices only (KSm even); hi planes as x3t_pack_f16, the "lo" planes hold
+// the record halves.  head_rows > 0: a head tile (only rows < head_rows of the 32 are real: w is [head_rows, ld]).
+inline void x3t_pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int KStot, int ks0, int KSm,
+                        float scale, unsigned char* dst) {
+    for (int nt = 0; nt < NT; ++nt)
+        for (int T = 0; T < KSm / 2; ++T)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int nn = 32 * nt + (lane & 31), hh = lane >> 5;
+                float hi[16], lo[16];
+                for (int j = 0; j < 2; ++j)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = x3t_acc_k(2 * T + j, hh, e);
+                        float v = 0.f;
+                        if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+                        const uint16_t h16 = x3t_f32_to_f16_rn(v);
+                        hi[8 * j + e] = x3t_f16_to_f32(h16);
+                        lo[8 * j + e] = v - hi[8 * j + e];
+                        uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)nt * KStot + ks0 + 2 * T + j) * 2) * 1024);
+                        hd[lane * 8 + e] = h16;
+                    }
+                unsigned rec[8];
+                x2_make_record(hi, lo, rec);
+                for (int j = 0; j < 2; ++j) {
+                    unsigned* cd = reinterpret_cast<unsigned*>(dst + (((int64_t)nt * KStot + ks0 + 2 * T + j) * 2 + 1) * 1024);
+                    for (int d = 0; d < 4; ++d) cd[lane * 4 + d] = rec[4 * j + d];
+                }
+            }
 }
 
 }  // namespace h3d

@@ -60,6 +60,7 @@ class COORDCONCATSIREN(nn.Module):
         # Arithmetic engine (all meet the 1e-3 parity budget):
         #   "f16x2"   as f16x3 with the two cross products of a contraction in one block-scaled fp6 instruction (widths <= 256)
         #   "f16x3"   split-operand f16 matrix cores, activations register-resident (widths <= 256)
+        #   "f16x2t"  the x2 arithmetic on the LDS-resident engine, any width <= 448
         #   "f16x3t"  split-operand f16 matrix cores, activations LDS-resident, any width <= 448 (MAP3DBN 384, MAP3DBN512L 420)
         #   "f32"     fp32 matrix cores (any width <= 512)
         # and, NOT within the 1e-3 budget (the "fp16 MFMA path" tier of BASELINE config 5, ~1e-2 on the render; opt-in):
@@ -81,6 +82,8 @@ class COORDCONCATSIREN(nn.Module):
         "f16x3t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t", "h3d_render_fused_x3t", 64, ()),
         "f16x1t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x3t", "h3d_neural_field_x3t_tier", "h3d_render_fused_x3t_tier",
                    64, (1,)),
+        "f16x2t": ("h3d_field_pack_x3t_size", "h3d_field_pack_x2t", "h3d_neural_field_x3t_tier", "h3d_render_fused_x3t_tier",
+                   64, (4,)),
         "f32": ("h3d_field_pack_size", "h3d_field_pack", "h3d_neural_field", "h3d_render_fused", 64, ()),
     }
 

@@ -219,6 +219,10 @@ int h3d_render_fused_x2(const void* packed, const float* points, const float* ge
  */
 int64_t h3d_field_pack_x3t_size(int Hd, int F);
 int h3d_field_pack_x3t(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+/* The same blob layout for the x2 tier (`products` = 4 of the _tier entry points below): the matrices fed by accumulators and
+ * the head tile carry f16 hi fragments + the K-tiles' fp6 records (dwords 0-3 in the even k-step's lo plane, 4-7 in the odd
+ * one's; record layout as h3d_field_pack_x2) instead of hi + lo fragments. */
+int h3d_field_pack_x2t(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
 /* HOST helper: out[0..17] = tiles NT (even, >= 4), k-steps KS = 2*NT, padded width 32*NT, then BYTE offsets of the eight
  * weight matrices (coord [1 k-step], geo [2], film0 [2*KS: coordinate half, geometry half], film1..3 [KS], colour
  * [KS + 1: the last k-step carries the view direction], feature head [KS]), of inv_scale float[8], bias float[7][HdP],

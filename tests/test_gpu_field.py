@@ -13,7 +13,7 @@ DEV = "cuda"
 FIELD_TOL = 1e-3      # north_star: within 1e-3 relative fp32; measured errors are ~1e-5
 
 
-ENGINES = ["f16x2", "f16x3", "f16x3t", "f32"]
+ENGINES = ["f16x2", "f16x2t", "f16x3", "f16x3t", "f32"]
 
 
 def make_field(state, hidden, feature, prefix="neural_field.", precision=None):
@@ -53,7 +53,7 @@ def test_field_golden(name, hidden, engine):
         assert rel_err(out.cpu()[..., sl], g["out"][..., sl]) < FIELD_TOL
 
 
-@pytest.mark.parametrize("hidden,engine", [(256, "f16x2"), (256, "f16x3"), (256, "f16x3t"), (256, "f32"), (384, "f16x3t"), (384, "f32"),
+@pytest.mark.parametrize("hidden,engine", [(256, "f16x2"), (256, "f16x3"), (256, "f16x3t"), (256, "f16x2t"), (256, "f32"), (384, "f16x3t"), (384, "f16x2t"), (384, "f32"), (420, "f16x2t"),
                                            (420, "f16x3t"), (420, "f32")])
 def test_field_reference_vectors_at_shipped_widths(hidden, engine):
     """The reference module's own output at the widths of MAP3DBN512 / MAP3DBN / MAP3DBN512L (not the oracle's)."""
@@ -89,7 +89,10 @@ def test_field_in_generator_fixture(name, engine):
                                                      (128, 96, 77, "f32"), (128, 96, 77, "f16x3"), (200, 256, 333, "f16x3"),
                                                      (384, 384, 130, "f16x3t"), (420, 420, 200, "f16x3t"), (256, 256, 65, "f16x3t"),
                                                      (32, 32, 1, "f16x3t"), (128, 96, 77, "f16x3t"), (200, 300, 333, "f16x3t"),
-                                                     (448, 448, 64, "f16x3t"), (170, 170, 100, "f16x3t")])
+                                                     (448, 448, 64, "f16x3t"), (170, 170, 100, "f16x3t"),
+                                                     (384, 384, 130, "f16x2t"), (420, 420, 200, "f16x2t"), (256, 256, 65, "f16x2t"),
+                                                     (32, 32, 1, "f16x2t"), (128, 96, 77, "f16x2t"), (200, 300, 333, "f16x2t"),
+                                                     (448, 448, 64, "f16x2t"), (170, 170, 100, "f16x2t")])
 def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
     state, net = random_state(hidden, feature, seed=hidden, precision=engine)
     g = torch.Generator().manual_seed(N)
@@ -114,7 +117,10 @@ def test_field_real_widths_vs_oracle(hidden, feature, N, engine):
                                                 (128, 3, 64, "f16x3"), (32, 7, 256, "f16x3"), (96, 3, 128, "f16x3"),
                                                 (8, 20, 32, "f16x3t"), (16, 30, 48, "f16x3t"), (32, 9, 64, "f16x3t"),
                                                 (64, 5, 420, "f16x3t"), (128, 3, 200, "f16x3t"), (32, 7, 384, "f16x3t"),
-                                                (64, 6, 384, "f16x3t"), (192, 2, 300, "f16x3t"), (16, 11, 420, "f16x3t")])
+                                                (64, 6, 384, "f16x3t"), (192, 2, 300, "f16x3t"), (16, 11, 420, "f16x3t"),
+                                                (8, 20, 32, "f16x2t"), (16, 30, 48, "f16x2t"), (32, 9, 64, "f16x2t"),
+                                                (64, 5, 420, "f16x2t"), (128, 3, 200, "f16x2t"), (32, 7, 384, "f16x2t"),
+                                                (64, 6, 384, "f16x2t"), (192, 2, 300, "f16x2t"), (16, 11, 420, "f16x2t")])
 @pytest.mark.parametrize("last_back,white_back,clamp", [(False, True, "relu"), (True, False, "softplus")])
 def test_fused_render_vs_oracle(S, R, hidden, engine, last_back, white_back, clamp):
     state, net = random_state(hidden, hidden, seed=S + hidden, precision=engine)

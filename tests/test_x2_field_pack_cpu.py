@@ -110,3 +110,94 @@ def test_field_x2_pack_is_the_emulated_arithmetic(Hd):
     # heads: third plane = hi * 2^-12
     hw = blob[lay[16]: lay[16] + 2 * 4 * 3 * KS * 16].view(torch.float16).double().view(4, 3, KS, 2, 8)
     assert torch.equal(hw[:, 2], f16(hw[:, 0] / 4096.0))
+
+
+def decode_x2t(blob, off, KStot, ks0, KS, NT):
+    """Tile-major x2 stages of the LDS-resident engine, [tile][KStot][hi fragment 1 KiB | record half 1 KiB] -> as decode_x2."""
+    st = blob[off: off + NT * KStot * 2048].view(NT, KStot, 2, 1024)[:, ks0: ks0 + KS]
+    Whi = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+    hi = st[:, :, 0].contiguous().view(torch.float16).double().view(NT, KS, 64, 8)
+    for ks in range(KS):
+        for h in range(2):
+            for e in range(8):
+                Whi[:, acc_k(ks, h, e)] = hi[:, ks, 32 * h: 32 * h + 32, e].reshape(-1)
+    recs = {}
+    half = st[:, :, 1].contiguous().view(torch.int32).view(NT, KS, 64, 4)
+    for T in range(KS // 2):
+        rec = torch.cat([half[:, 2 * T], half[:, 2 * T + 1]], dim=-1).numpy().astype(np.uint32)      # [NT, 64, 8]
+        bits = np.zeros((NT, 64, 32), dtype=np.int64)
+        for s in range(32):
+            b = 6 * s
+            v = rec[..., b // 32].astype(np.uint64) >> np.uint64(b & 31)
+            if (b & 31) > 26:
+                v |= rec[..., b // 32 + 1].astype(np.uint64) << np.uint64(32 - (b & 31))
+            bits[..., s] = (v & np.uint64(63)).astype(np.int64)
+        vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
+        sb = rec[..., 6]
+        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == 0)
+        recs[T] = (vals, torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127)))
+    return Whi, recs
+
+
+@pytest.mark.parametrize("Hd", [64, 420])
+def test_field_x2t_pack_is_the_emulated_arithmetic(Hd):
+    """h3d_field_pack_x2t (the x2 tier of the LDS-resident engine: same layout as h3d_field_pack_x3t, hi fragments + fp6 records)."""
+    F = Hd
+    torch.manual_seed(Hd + 2)
+    net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=Hd, hidden_dim=Hd, geo_feature_dim=31, output_dim=F + 4, feature_dim=F,
+                                num_blocks=4)
+    lib = L.load()
+    lins = net._params_for_pack()
+    host = [(l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous()) for l in lins]
+    P = L.FieldParams()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    P.w_coord, P.b_coord = vp(host[0][0]), vp(host[0][1])
+    P.w_geo, P.b_geo = vp(host[1][0]), vp(host[1][1])
+    for k in range(4):
+        P.w_film[k], P.b_film[k] = host[2 + k][0].data_ptr(), host[2 + k][1].data_ptr()
+    P.w_sigma, P.b_sigma = vp(host[6][0]), vp(host[6][1])
+    P.w_color, P.b_color = vp(host[7][0]), vp(host[7][1])
+    P.w_rgb, P.b_rgb = vp(host[8][0]), vp(host[8][1])
+    P.w_feat, P.b_feat = vp(host[9][0]), vp(host[9][1])
+    blob = torch.zeros(lib.h3d_field_pack_x3t_size(Hd, F), dtype=torch.uint8)
+    L.check(lib.h3d_field_pack_x2t(ctypes.byref(P), Hd, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack_x2t")
+    lay = (ctypes.c_int64 * 18)()
+    L.check(lib.h3d_field_x3t_layout(Hd, F, lay, 18), "h3d_field_x3t_layout")
+    NT, KS, HdP = lay[0:3]
+    woff = list(lay[3:11])                                    # coord, geo, f0, f1, f2, f3, color, feat
+    inv = blob[lay[11]: lay[11] + 32].view(torch.float32).double()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(19, Hd, generator=g, dtype=torch.float64) * 2 - 1).float().double()
+    cases = [("f1", woff[3], KS, 0, host[3][0], 3), ("f3", woff[5], KS, 0, host[5][0], 5), ("feat", woff[7], KS, 0, host[9][0], 7),
+             ("color", woff[6], KS + 1, 0, host[7][0][:, 3:], 6), ("f0 geometry half", woff[2], 2 * KS, KS, host[2][0][:, Hd:], 2)]
+    for name, off, KStot, ks0, Wsrc, wi in cases:
+        Whi, recs = decode_x2t(blob, off, KStot, ks0, KS, NT)
+        sc = 1.0 / float(inv[wi])
+        want = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
+        want[:Wsrc.shape[0], :Hd] = f16(Wsrc.double() * sc)
+        assert torch.equal(Whi, want), name
+        xp = torch.nn.functional.pad(x, (0, 16 * KS - Hd))
+        xh = f16(xp)
+        Bh, Bl = q_e2m3(xh * 4.0), q_e2m3(f16((xp - xh) * 4096.0) * 4.0)
+        y = xh @ Whi.t()
+        for T, (vals, scale) in recs.items():
+            for h in range(2):
+                feats = torch.tensor([acc_k(2 * T + j, h, e) for j in range(2) for e in range(8)])
+                a = vals[:, 32 * h: 32 * h + 32].reshape(32 * NT, 32)
+                s = scale[:, 32 * h: 32 * h + 32].reshape(32 * NT)
+                y = y + (Bl[:, feats] @ a[:, :16].t() + Bh[:, feats] @ a[:, 16:].t()) * s * 2.0 ** -14
+        y = (y / sc)[:, :Wsrc.shape[0]]
+        if name.startswith("f0"):
+            # FiLM 0's two halves share one matrix scale (the largest weight of the WHOLE matrix): emulate with it
+            from x2_emulation import weight_alpha, slot_groups
+            Ws = Wsrc.double() * sc
+            Wh = f16(Ws)
+            emu = f16(x) @ Wh.t()
+            for gi in slot_groups(Hd):
+                al = weight_alpha(Wh[:, gi], (Ws - Wh)[:, gi])
+                emu = emu + (q_e2m3(f16((x - f16(x)) * 4096.0) * 4.0)[:, gi] @ q_e2m3(Wh[:, gi] * al[:, None]).t()
+                             + q_e2m3(f16(x) * 4.0)[:, gi] @ q_e2m3((Ws - Wh)[:, gi] * 4096.0 * al[:, None]).t()) / (al * 4.0 * 4096.0)
+            emu = emu / sc
+        else:
+            emu = x2_matmul(x, Wsrc)
+        assert float((y - emu).abs().max() / emu.abs().max()) < 1e-12, name
