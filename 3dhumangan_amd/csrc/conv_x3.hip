@@ -130,6 +130,25 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
     }
 }
 
+// Weight stream of h3d_conv_x3 from OIHW fp32 weights, one launch: thread <-> (o, i, tap) of the convolution that will RUN
+// (transposed: the backward-data convolution of w, W'[o][i][tap] = w[i][o][k*k - 1 - tap]).
+__global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ stream, int Cout, int Cin, int kk, int NT,
+                                 int KSC, int n_chunks, int transposed, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int tap = (int)(idx % kk);
+    const int i = (int)((idx / kk) % Cin), o = (int)(idx / ((int64_t)kk * Cin));
+    const float v = transposed ? w[((int64_t)i * Cout + o) * kk + (kk - 1 - tap)] : w[((int64_t)o * Cin + i) * kk + tap];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int ob = o / (32 * NT), nt = (o / 32) % NT, j = o & 31;
+    const int chunk = i / (16 * KSC), ks = (i / 16) % KSC, h = (i >> 3) & 1, e = i & 7;
+    // [ob][tap][chunk][ks][nt][hi|lo][64 lanes = 32 h + j][8]
+    const int64_t base = (((((int64_t)ob * kk + tap) * n_chunks + chunk) * KSC + ks) * NT + nt) * 2;
+    stream[(base * 64 + 32 * h + j) * 8 + e] = __builtin_bit_cast(unsigned short, hi);
+    stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = __builtin_bit_cast(unsigned short, lo);
+}
+
 template <int NT, int KSC>
 int launch(const Args& A, int n_oblk, hipStream_t st) {
     H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC>));
@@ -149,6 +168,23 @@ extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
     const int KSC = Cin % 128 == 0 ? 8 : 4;
     out[0] = NT; out[1] = Cout / (32 * NT); out[2] = KSC; out[3] = Cin / (16 * KSC);
     return 0;
+}
+
+// Pack OIHW fp32 weights `w` (device) into the stream h3d_conv_x3 reads (2 * Cout * Cin * k * k bf16, device).  transposed = 0:
+// w is [Cout, Cin, k, k], the forward convolution; transposed = 1: w is [Cin, Cout, k, k] and the stream is that of its
+// backward-data convolution (Cout <- Cin channels, flipped taps).
+extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
+    H3D_REQUIRE(w && stream && (k == 1 || k == 3), "h3d_conv_x3_pack: null pointer / kernel size");
+    int til[4];
+    if (h3d_conv_x3_tiling(Cin, Cout, til)) {
+        h3d::set_error("h3d_conv_x3_pack: channel counts must be multiples of 64 (got %d -> %d)", Cin, Cout);
+        return H3D_EUNSUPPORTED;
+    }
+    const int64_t total = (int64_t)Cout * Cin * k * k;
+    h3d::pre_launch();
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w,
+                       static_cast<unsigned short*>(stream), Cout, Cin, k * k, til[0], til[2], til[3], transposed, total);
+    return h3d::launch_status("h3d_conv_x3_pack");
 }
 
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,

@@ -48,10 +48,13 @@ __device__ __forceinline__ float linspace_pm1(int n, int i) {   // torch.linspac
 // T / P: operand type and partial products per operand pair (x3t_common.hpp): BF16 / 3 is the fp32-class default; F16 / 2
 // (weights hi + lo, activations one f16 value) and F16 / 1 (plain f16 matrix-core arithmetic) are the reduced-precision
 // tiers of BASELINE config 5 -- f16 because one bf16 value (8 significant bits) per activation is too coarse.
+// F16 / 4 is the x2 arithmetic (x3_common.hpp: one f16 product + one block-scaled fp6 product per contraction; fragments' "lo"
+// planes hold the K-tiles' fp6 records, each pixel's record with its own power-of-two scale).
 template <int NTF, int NX, typename T, int P>
 struct Block {
     static constexpr int NU = 2 * NTF + NX;
     static constexpr bool LO = P == 3;          // activations carry a lo half
+    static constexpr bool X2 = P == 4;          // activations carry fp6 records
     typedef typename std::conditional<std::is_same<T, F16>::value, SplitF16, SplitBF16>::type Split;
     const Args& A;
     X3tUnits<NTF, NX> U;
@@ -75,6 +78,11 @@ struct Block {
         });
     }
     __device__ __forceinline__ int unit_mt(int u) const { return U.mt(u); }
+    template <typename F>
+    __device__ __forceinline__ void store_unit(const f32x16& v, int nt, int mt, F f) const {
+        if constexpr (X2) x3t_store_unit_x2<true>(v, actT, KS, nt, mt, lane, f);
+        else x3t_store_unit<LO>(v, actT, KS, nt, mt, lane, split, f);
+    }
 
     // constant-style SPADE of `src`: y = lrelu(x * a + b) (per-(sample, channel) affine from the host) -> actT
     __device__ __forceinline__ void store_const(f32x16 (&src)[NU], const h3d_spade_desc& Sp) const {
@@ -96,7 +104,7 @@ struct Block {
                 if (k < nu) {
                     const int u = u0 + k;
                     pin1(src[u]);       // accumulator sets live in AGPRs; VALU code reads / writes them one unit at a time
-                    x3t_store_unit<LO>(src[u], actT, KS, nt, unit_mt(u), lane, split, [&](int rg, f32x4 v) {
+                    store_unit(src[u], nt, unit_mt(u), [&](int rg, f32x4 v) {
                         f32x4 y;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) y[q] = lrelu(fmaf(v[q], sa[sl][rg][q], sb[sl][rg][q]));
@@ -147,6 +155,8 @@ struct Block {
             const float* g01 = Gb + (int64_t)tap[px * 4 + 1] * A.g_channels;
             const float* g10 = Gb + (int64_t)tap[px * 4 + 2] * A.g_channels;
             const float* g11 = Gb + (int64_t)tap[px * 4 + 3] * A.g_channels;
+            u32x4 qh[4], ql[4];                            // x2: the K-tile's four fragments of this pixel (q = 2 j + hh)
+            float amax[2] = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                  // (k-step, half) = (2w + q/2, q%2): 8 channels each
                 const int ks = 2 * wave + (q >> 1), hh = q & 1, k0 = 16 * ks + 8 * hh;
@@ -161,12 +171,37 @@ struct Block {
                         v[4 * j + i] = fmaxf((a[i] * tx1 + bq[i] * tx) * ty1 + (c[i] * tx1 + d[i] * tx) * ty + k4[i], 0.f);
                 }
                 u32x4 hi, lo;
+                if constexpr (X2) {
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) { unsigned l2; hi[e / 2] = split(v[e], v[e + 1], l2); lo[e / 2] = l2; }
-                unsigned char* dst = aT + x3t_frag(kKSA, mt, ks, 0) + (32 * hh + pm) * 16;
-                *reinterpret_cast<u32x4*>(dst) = hi;
-                *reinterpret_cast<u32x4*>(dst + 1024) = lo;
+                    for (int e = 0; e < 8; e += 2) {
+                        unsigned l2;
+                        hi[e / 2] = split2_x2(v[e], v[e + 1], l2);
+                        lo[e / 2] = l2;
+                        amax[hh] = fmaxf(amax[hh], fmaxf(v[e], v[e + 1]));       // relu outputs: non-negative
+                    }
+                    qh[q] = hi; ql[q] = lo;
+                    *reinterpret_cast<u32x4*>(aT + x3t_frag(kKSA, mt, ks, 0) + (32 * hh + pm) * 16) = hi;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) { unsigned l2; hi[e / 2] = split(v[e], v[e + 1], l2); lo[e / 2] = l2; }
+                    unsigned char* dst = aT + x3t_frag(kKSA, mt, ks, 0) + (32 * hh + pm) * 16;
+                    *reinterpret_cast<u32x4*>(dst) = hi;
+                    *reinterpret_cast<u32x4*>(dst + 1024) = lo;
+                }
                 __builtin_amdgcn_sched_barrier(0);         // 10 x 16-byte loads in flight per step are plenty
+            }
+            if constexpr (X2) {
+                // the records of fragment lanes (pm, hh = 0) and (pm, hh = 1) of K-tile `wave`: this pixel's k-steps 2w, 2w+1
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    i32x8 rec = x2_record_dyn(__builtin_bit_cast(F16::vec8, ql[hh]), __builtin_bit_cast(F16::vec8, ql[2 + hh]),
+                                              __builtin_bit_cast(F16::vec8, qh[hh]), __builtin_bit_cast(F16::vec8, qh[2 + hh]), amax[hh]);
+                    rec[7] = 0;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        *reinterpret_cast<u32x4*>(aT + x3t_frag(kKSA, mt, 2 * wave + j, 1) + (32 * hh + pm) * 16) =
+                            u32x4{(unsigned)rec[4 * j], (unsigned)rec[4 * j + 1], (unsigned)rec[4 * j + 2], (unsigned)rec[4 * j + 3]};
+                }
             }
         }
         __syncthreads();
@@ -200,7 +235,7 @@ struct Block {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             pin1(g[u]);
-            x3t_store_unit<LO>(g[u], actT, KS, U.tile(u), U.mt(u), lane, split, [&](int, f32x4 v) {
+            store_unit(g[u], U.tile(u), U.mt(u), [&](int, f32x4 v) {
                 f32x4 y;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = lrelu(v[i]);
@@ -428,8 +463,9 @@ extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, co
                                       int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
                                       float* rgb, int B, int H, int W, int dtype, int products, h3d_stream_t stream) {
     H3D_REQUIRE(wblob && tables && desc && rgb, "h3d_synthesis_x3t: null pointer");
-    H3D_REQUIRE((dtype == 0 && products == 3) || (dtype == 1 && (products == 1 || products == 2)),
-                "h3d_synthesis_x3t_tier: (dtype, products) must be (0 bf16, 3), (1 f16, 2) or (1 f16, 1)");
+    H3D_REQUIRE((dtype == 0 && products == 3) || (dtype == 1 && (products == 1 || products == 2 || products == 4)),
+                "h3d_synthesis_x3t_tier: (dtype, products) must be (0 bf16, 3), (1 f16, 2), (1 f16, 1) or (1 f16, 4 = x2: f16 hi fragments "
+                "+ fp6 records)");
     H3D_REQUIRE(h3d::aligned16(wblob) && h3d::aligned16(tables), "h3d_synthesis_x3t: weights / tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3t: n_blocks=%d", desc->n_blocks);
     H3D_REQUIRE(B >= 0 && B <= 65535 && H >= 1 && W >= 1, "h3d_synthesis_x3t: bad output shape");
@@ -486,7 +522,7 @@ extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, co
     H3D_REQUIRE(lds_bytes(NT) <= 160 * 1024, "h3d_synthesis_x3t: width %d does not fit the 160 KB LDS", desc->C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == 0) return launch<BF16, 3>(A, B, tiles, st);
-    return products == 2 ? launch<F16, 2>(A, B, tiles, st) : launch<F16, 1>(A, B, tiles, st);
+    return products == 4 ? launch<F16, 4>(A, B, tiles, st) : products == 2 ? launch<F16, 2>(A, B, tiles, st) : launch<F16, 1>(A, B, tiles, st);
 }
 
 extern "C" int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,

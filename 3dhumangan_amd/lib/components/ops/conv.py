@@ -43,8 +43,21 @@ def supported(x, weight):
     return _native(ci if ci >= 64 else 64, co if co >= 64 else 64)
 
 
-def pack_stream(w):
-    """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns), see include/h3d.h."""
+def pack_stream(w, transposed=False):
+    """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
+    kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
+    taps flipped) instead."""
+    w = w.detach().contiguous()
+    co, ci, k, _ = w.shape
+    out = torch.empty(2 * w.numel(), device=w.device, dtype=torch.int16)
+    rc = _lib.load().h3d_conv_x3_pack(_lib.ptr(w), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
+                                      _lib.stream_handle())
+    _lib.check(rc, "h3d_conv_x3_pack")
+    return out
+
+
+def pack_stream_torch(w):
+    """The same stream with tensor operations (reference for tests/test_gpu_conv.py)."""
     co, ci, k, _ = w.shape
     NT, nblk, KSC, nch = tiling(ci, co)
     t = w.detach().reshape(nblk, NT, 32, nch, KSC, 2, 8, k * k)          # ob, nt, j, chunk, ks, h, e, tap
@@ -74,12 +87,14 @@ def _rows(x):
     return x.contiguous(memory_format=torch.channels_last), C
 
 
-def _run_conv(x, w, bias=None):
-    """x [B, Ci, H, W] (any layout) , w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd."""
+def _run_conv(x, w, bias=None, transposed=False):
+    """x [B, Ci, H, W] (any layout), w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd.  transposed: w is
+    [Ci, Co, k, k] and the backward-data convolution of w runs instead (x has w's OUTPUT channel count)."""
     x, ldx = _rows(x)
     B, ci, H, W = x.shape
-    co, _, k, _ = w.shape
-    stream = pack_stream(w)
+    k = w.shape[2]
+    co = w.shape[1] if transposed else w.shape[0]
+    stream = pack_stream(w, transposed)
     out = torch.empty((B, co, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     b = None if bias is None else bias.detach().contiguous()
     rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
@@ -125,7 +140,7 @@ class _ConvT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, w):
         ctx.save_for_backward(g, w)
-        return _run_conv(g, _transposed(w.detach()))
+        return _run_conv(g, w, transposed=True)
 
     @staticmethod
     def backward(ctx, h):

@@ -1,9 +1,12 @@
-"""y = x W^T + b with the weight gradient on the hand-written split-K matrix-core kernel (csrc/wgrad_x3.hip).
+"""y = x W^T + b on hand-written matrix-core kernels: the weight gradient on the split-K kernel of csrc/wgrad_x3.hip, and (round
+3) forward and data gradient on h3d_conv_x3 as a 1x1 convolution over the rows.
 
-Forward and the data gradient are library GEMMs ([M, C] x [C, C'] with M ~ 0.5 M rows: the shape hipBLASLt is good at, 83 % of the
-fp32 matrix peak measured); the WEIGHT gradient dW = dY^T X contracts over the M rows and produces a tiny output -- the library
-runs it at ~50 TFLOP/s, h3d_wgrad_x3 streams both operands once (HBM-bound).  Used by lib/generators/differentiable.py for every
-layer with enough rows; anything else (few rows, half-precision autocast inputs, odd widths, CPU tensors) is F.linear."""
+Forward / data gradient ([M, C] x [C, C'] with M ~ 0.5 M rows): hipBLASLt runs them in fp32 at 131 TFLOP/s (83 % of the fp32 matrix
+peak); h3d_conv_x3 evaluates the same contraction with split bf16 operands (three 16-bit products, ~2e-5) at ~230 TFLOP/s, bias
+fused, when both widths are multiples of 64 (`H3D_LINEAR=library` keeps the library GEMM).  The WEIGHT gradient dW = dY^T X
+contracts over the M rows and produces a tiny output -- the library runs it at ~50 TFLOP/s, h3d_wgrad_x3 streams both operands once
+(HBM-bound) and returns the bias gradient from the same pass.  Used by lib/generators/differentiable.py for every layer with enough
+rows; anything else (few rows, half-precision autocast inputs, odd widths, CPU tensors) is F.linear."""
 import os
 
 import torch
@@ -13,6 +16,26 @@ from .... import _lib
 
 MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this the library GEMM is as good
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
+NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
+
+
+def _as_image(t2):
+    """[M, C] rows (unit column stride) -> the same memory as a [1, C, 1, M] channels-last "image" for h3d_conv_x3."""
+    M, C = t2.shape
+    ld = t2.stride(0)
+    return torch.as_strided(t2, (1, C, 1, M), (M * ld, 1, M * ld, ld))
+
+
+def gemm_x3(x2, w, bias=None, transposed=False):
+    """x2 [M, Ci] @ w[Co, Ci]^T (+ bias) -> [M, Co]; transposed: x2 [M, Co] @ w[Co, Ci] -> [M, Ci].  Split-bf16 matrix-core kernel."""
+    from . import conv
+    y = conv._run_conv(_as_image(x2), w.detach()[:, :, None, None], bias, transposed=transposed)
+    return y.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
+
+
+def _native_ok(Co, Ci):
+    from . import conv
+    return NATIVE_GEMM and Co % 64 == 0 and Ci % 64 == 0 and conv.tiling(Ci, Co) is not None and conv.tiling(Co, Ci) is not None
 
 
 def wgrad_x3(dy, x, with_bias=False):
@@ -59,6 +82,8 @@ class _LinearX3(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        if _native_ok(*w.shape):
+            return gemm_x3(_rows(x), w, b).view(*x.shape[:-1], w.shape[0])
         return F.linear(x, w, b)
 
     @staticmethod
@@ -66,9 +91,9 @@ class _LinearX3(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = dy @ w
         dy2 = _rows(dy)
+        if ctx.needs_input_grad[0]:
+            dx = gemm_x3(dy2, w, transposed=True).view(*dy.shape[:-1], w.shape[1]) if _native_ok(*w.shape) else dy @ w
         if ctx.needs_input_grad[1]:
             Co, Ci = w.shape
             if Co <= 4:
@@ -93,4 +118,7 @@ def linear(x, w, b=None):
             and ((Co % 4 == 0 and Ci % 4 == 0 and Co >= 32 and Ci >= 32)           # h3d_wgrad_x3
                  or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):             # h3d_wgrad_narrow (heads, ToRGB, coordinates)
         return _LinearX3.apply(x, w, b)
+    if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled() and rows >= MIN_ROWS
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and _native_ok(Co, Ci)):
+        return gemm_x3(_rows(x), w, b).view(*x.shape[:-1], Co)          # nothing to record (the D step's generator forward)
     return F.linear(x, w, b)

@@ -155,7 +155,7 @@ class SynthesisPlan:
         # register-resident activations (C <= 256); "bf16x3" split-bf16 matrix cores, register-resident activations (C <= 256);
         # "bf16x3t" split-bf16 matrix cores, LDS-resident activations (C <= 448: MAP3DBN 384, MAP3DBN512L 420);
         # "f32" fp32 matrix cores (anything else).  Opt-in reduced-precision tiers on the bf16x3t kernel (NOT within the
-        # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16x2t" weights f16 hi + lo, activations one f16 value (two
+        # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16w2t" weights f16 hi + lo, activations one f16 value (two
         # products); "f16x1t" plain f16 products.
         default = "f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
@@ -227,7 +227,7 @@ class SynthesisPlan:
         return code | ((v < 0).to(torch.int64) << 5)
 
     @classmethod
-    def pack_stream_x2(cls, w_out_in, KS, NT):
+    def pack_stream_x2(cls, w_out_in, KS, NT, acc_order=True):
         """[n_out, n_in] -> weight-stream stages of the x2 engines, [KS][NT][1 KiB f16 hi fragment | 1 KiB half of the fp6
         records] as int16 bit patterns (csrc/x3_common.hpp).  K in accumulator-register order.  The fp6 record of a lane
         (output row n = 32 nt + lane % 32, half h = lane // 32) and K-tile T holds, for the lane's 16 input features (k-steps
@@ -243,7 +243,9 @@ class SynthesisPlan:
         hh = torch.arange(2, device=dev).view(1, 2, 1)
         e = torch.arange(8, device=dev).view(1, 1, 8)
         k = 32 * (ks // 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh          # [KS, 2, 8]
-        wp = wp[:, k.reshape(-1)]                                                      # columns now [ks][h][e]
+        if acc_order:
+            wp = wp[:, k.reshape(-1)]                                                  # columns now [ks][h][e]
+        # (natural order, k = 16 ks + 8 h + e, already is [ks][h][e])
         hi16 = wp.to(torch.float16)
         hi = hi16.float()
         lo = wp - hi
@@ -287,24 +289,29 @@ class SynthesisPlan:
                 return False
         return True
 
-    X3T_TIERS = {"bf16x3t": (torch.bfloat16, 0, 3), "f16x2t": (torch.float16, 1, 2), "f16x1t": (torch.float16, 1, 1)}
+    # engine -> (element type of the hi halves, dtype code, products code of h3d_synthesis_x3t_tier, weight format)
+    X3T_TIERS = {"bf16x3t": (torch.bfloat16, 0, 3, "x3"), "f16x2t": (torch.float16, 1, 4, "x2"),
+                 "f16w2t": (torch.float16, 1, 2, "x3"), "f16x1t": (torch.float16, 1, 1, "x3")}
 
-    def build_x3t(self, dtype=torch.bfloat16):
+    def build_x3t(self, dtype=torch.bfloat16, fmt="x3"):
         """Weights as bf16 (f16 for the reduced-precision tiers) hi/lo MFMA A fragments, tile-major [tile][k-step][hi|lo][64 lanes][8] (conv matrices with K in
         accumulator-register order, gamma / beta in natural order: their input is assembled from memory), fp32 tables
         padded to the engine's width 32 * tiles, and a descriptor whose w_* offsets are BYTES into the fragment blob and
         whose vec / b_conv / w_rgb / w_in / b_in offsets are FLOATS into the tables."""
         if self._x3t is None:
             self._x3t = {}
-        if dtype in self._x3t:
-            return self._x3t[dtype]
+        if (dtype, fmt) in self._x3t:
+            return self._x3t[(dtype, fmt)]
         C = self.C
         NT = _lib.load().h3d_synthesis_x3t_tiles(C)
         HdP, KS = 32 * NT, 2 * NT
         wchunks, woff, tchunks, toff = [], [0], [], [0]
 
         def add_w(w_out_in, ks, acc_order):
-            frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order, dtype=dtype).view(ks, NT, 2 * 64 * 8)
+            if fmt == "x2":        # f16 hi fragments + fp6 records (same bytes per stage)
+                frag = self.pack_stream_x2(w_out_in, ks, NT, acc_order=acc_order).view(ks, NT, 2 * 64 * 8)
+            else:
+                frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order, dtype=dtype).view(ks, NT, 2 * 64 * 8)
             o = woff[0]
             wchunks.append(frag.transpose(0, 1).contiguous().flatten())          # [NT][ks][2][64][8]
             woff[0] += wchunks[-1].numel() * 2
@@ -341,9 +348,9 @@ class SynthesisPlan:
             if dst.to_rgb:
                 wr, br = self._rgb[k]
                 dst.w_rgb = add_t(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
-        self._x3t[dtype] = dict(desc=desc, wblob=torch.cat(wchunks).contiguous(), tables=torch.cat(tchunks).contiguous(),
+        self._x3t[(dtype, fmt)] = dict(desc=desc, wblob=torch.cat(wchunks).contiguous(), tables=torch.cat(tchunks).contiguous(),
                                 NT=NT, HdP=HdP)
-        return self._x3t[dtype]
+        return self._x3t[(dtype, fmt)]
 
     # Optional split of the network into several launches whose weight streams each fit the 4 MB L2 of an XCD
     # (H3D_SYNTH_SEGMENT_BYTES=2359296).  Measured on MI355X: the single-launch stream (6.3 MB, 63 % L2 hit rate) is
@@ -478,10 +485,12 @@ class SynthesisPlan:
         x2 = self.engine == "f16x2"
         x3 = self.build_x3(x2) if self.engine in ("bf16x3", "f16x2") else None
         tier = self.X3T_TIERS.get(self.engine, self.X3T_TIERS["bf16x3t"])
-        x3t = self.build_x3t(tier[0]) if self.engine in self.X3T_TIERS else None
+        x3t = self.build_x3t(tier[0], tier[3]) if self.engine in self.X3T_TIERS else None
         if x3 and self.pixel_ids and not _lib.load().h3d_synthesis_x3_geometry_ok(H, W, Hr, Wr):
             # the x3 engine's matrix-core resize does not cover this geometry: the LDS-resident engine does
-            x3, x3t = None, (self.build_x3t() if self.x3t_supported() else None)
+            # (f16x2 falls back to the x2 tier of that engine, bf16x3 to its three-product tier)
+            tier = self.X3T_TIERS["f16x2t" if x2 else "bf16x3t"]
+            x3, x3t = None, (self.build_x3t(tier[0], tier[3]) if self.x3t_supported() else None)
         with stage(owner, "synthesis_tables"):
             if x3:
                 G, cst, ab = self.x3_forward_tables(feature_maps.float(), fixed_style.float(), x2)

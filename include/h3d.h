@@ -175,6 +175,9 @@ int h3d_render_fused_x3(const void* packed, const float* points, const float* ge
  *   h3d_conv_wgrad_x3  partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co] * X[p + tap, Ci]; the caller sums the slices.
  */
 int h3d_conv_x3_tiling(int Cin, int Cout, int* out /* [4]: NT, blocks, KSC, chunks */);
+/* Device-side packer of that stream (one launch): w OIHW fp32 [Cout, Cin, k, k] -> stream (2 * Cout * Cin * k * k bf16);
+ * transposed = 1: w is [Cin, Cout, k, k] and the stream is the one of its backward-data convolution. */
+int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_handle);
 int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be NULL */, float* out, int B, int H, int W,
                 int Cin, int Cout, int k, int ldx, int ldo /* row strides in floats: channel slices of wider tensors */,
                 h3d_stream_t stream_handle);

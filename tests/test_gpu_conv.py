@@ -43,6 +43,35 @@ def test_conv_forward_and_first_order_gradients(B, H, W, ci, co, k):
         assert rel_err(conv.conv2d(xd.detach(), wd.detach(), bd.detach()).cpu(), ref.detach()) < TOL
 
 
+@pytest.mark.parametrize("co,ci,k", [(128, 64, 3), (512, 1024, 3), (192, 256, 1), (64, 64, 1)])
+def test_device_packer_equals_the_tensor_op_packer(co, ci, k):
+    w = torch.randn(co, ci, k, k, generator=torch.Generator().manual_seed(co + k)).to(DEV)
+    assert torch.equal(conv.pack_stream(w).view(-1), conv.pack_stream_torch(w).reshape(-1))
+    assert torch.equal(conv.pack_stream(w, transposed=True).view(-1), conv.pack_stream_torch(conv._transposed(w)).reshape(-1))
+
+
+@pytest.mark.parametrize("M,ci,co", [(20000, 256, 256), (33333, 128, 768), (16400, 768, 128), (70000, 64, 256)])
+def test_linear_on_the_convolution_kernel(M, ci, co):
+    """ops.linear: forward and data gradient as a 1x1 convolution over the rows (h3d_conv_x3), weight + bias gradient on
+    h3d_wgrad_x3_bias, against float64."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, ci, generator=g, dtype=torch.float64)
+    w = torch.randn(co, ci, generator=g, dtype=torch.float64) / ci ** 0.5
+    b = torch.randn(co, generator=g, dtype=torch.float64)
+    p = torch.randn(M, co, generator=g, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    (F.linear(xr, wr, br) * p).sum().backward()
+    xd, wd, bd = (t.float().to(DEV).requires_grad_(True) for t in (x, w, b))
+    assert lin._native_ok(co, ci)
+    y = lin.linear(xd, wd, bd)
+    assert rel_err(y.detach().cpu(), F.linear(x, w, b)) < TOL
+    (y * p.float().to(DEV)).sum().backward()
+    assert rel_err(xd.grad.cpu(), xr.grad) < TOL and rel_err(wd.grad.cpu(), wr.grad) < TOL and rel_err(bd.grad.cpu(), br.grad) < TOL
+    with torch.no_grad():
+        assert rel_err(lin.linear(xd.detach(), wd.detach(), bd.detach()).cpu(), F.linear(x, w, b)) < TOL
+
+
 def test_conv_takes_channel_slices_without_copying():
     """Backward of a skip concatenation hands the convolutions channel slices of a wider channels-last tensor: they are read
     in place through the row stride (no dense copy), with the same results."""

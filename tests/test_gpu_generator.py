@@ -16,7 +16,7 @@ DEV = "cuda"
 TOL = 1e-3          # north_star: generator outputs within 1e-3 relative of the reference CPU path
 
 
-ENGINES = [("f16x2", "f16x2"), ("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f32", "f32")]      # (field engine, synthesis engine)
+ENGINES = [("f16x2", "f16x2"), ("f16x2t", "f16x2t"), ("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f32", "f32")]      # (field engine, synthesis engine)
 
 
 def build(meta, state=None, engines=None):
@@ -127,17 +127,18 @@ def test_x3_synthesis_geometries_vs_oracle(width, gh, gw, rh, rw, engine):
 @pytest.mark.parametrize("width,gh,gw,rh,rw,mode", [(64, 41, 31, 7, 6, "mixed"), (300, 40, 24, 9, 5, "isolated"),
                                                      (384, 32, 64, 6, 12, "mixed"), (420, 64, 32, 12, 6, "isolated"),
                                                      (448, 16, 16, 16, 16, "mixed"), (170, 33, 96, 9, 18, "mixed")])
-def test_x3t_synthesis_geometries_vs_oracle(width, gh, gw, rh, rw, mode):
-    """The LDS-resident split-bf16 synthesis engine: every tile count (4..14, with and without the extra unit), ragged last
-    workgroup, arbitrary resize geometry (incl. the ones the register-resident engine refuses), both style modes."""
+@pytest.mark.parametrize("engines", [("f16x3t", "bf16x3t"), ("f16x2t", "f16x2t")])
+def test_x3t_synthesis_geometries_vs_oracle(width, gh, gw, rh, rw, mode, engines):
+    """The LDS-resident synthesis engine (split bf16, and its x2 tier): every tile count (4..14, with and without the extra
+    unit), ragged last workgroup, arbitrary resize geometry (incl. the ones the register-resident engine refuses), both style
+    modes."""
     meta = dict(load_golden("gen_tiny_mixed")["meta"])
     meta.update(hidden_dim=width, latent_dim=width, feature_dim=width, gen_height=gh, gen_width=gw, render_height=rh,
                 render_width=rw, num_steps=8, map3d_mode=mode)
     torch.manual_seed(width + gh)
     G, cfg = build(meta)
     plan = G.synthesis_plan(DEV)
-    plan.engine = "bf16x3t"
-    G.neural_field.precision = "f16x3t"
+    G.neural_field.precision, plan.engine = engines
     sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
     cond = synthetic.make_conditions(2, n_vertices=100, seed=5)
     z = torch.randn(2, width)
@@ -149,7 +150,7 @@ def test_x3t_synthesis_geometries_vs_oracle(width, gh, gw, rh, rw, mode):
     # and the fp32 engine on the same weights agrees to rounding
     plan.engine = "f32"
     out32 = G.forward(z.to(DEV), cond_to(cond), jitter=jit.to(DEV), **cfg)
-    assert rel_err(out["rgbs"].cpu(), out32["rgbs"].cpu()) < 1e-4
+    assert rel_err(out["rgbs"].cpu(), out32["rgbs"].cpu()) < (1e-4 if engines[1] == "bf16x3t" else 1e-3)
 
 
 def test_wide_configs_default_to_the_x3t_engines():

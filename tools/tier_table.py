@@ -18,7 +18,7 @@ import h3d_oracle as O                                    # noqa: E402  (checker
 from conftest import rel_err_channels                      # noqa: E402
 import bench                                               # noqa: E402
 
-COMBOS = [("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f16x3", "f16x2t"), ("f16x1t", "bf16x3"), ("f16x1t", "f16x2t"),
+COMBOS = [("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f16x3", "f16w2t"), ("f16x1t", "bf16x3"), ("f16x1t", "f16w2t"),
           ("f16x1t", "f16x1t"), ("f32", "f32")]
 WORK = {"cfg3_512sq_b16_s64": ("MAP3DBN512", (512, 512), (96, 96), 64, 16),
         "cfg5_1024sq_b4_s128": ("MAP3DBN512", (1024, 1024), (192, 192), 128, 4)}
