@@ -157,7 +157,7 @@ class SynthesisPlan:
         # "f32" fp32 matrix cores (anything else).  Opt-in reduced-precision tiers on the bf16x3t kernel (NOT within the
         # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16w2t" weights f16 hi + lo, activations one f16 value (two
         # products); "f16x1t" plain f16 products.
-        default = "f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported() else "bf16x3t" if self.x3t_supported() else "f32"
+        default = "f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported() else "f16x2t" if self.x3t_supported() else "f32"
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine

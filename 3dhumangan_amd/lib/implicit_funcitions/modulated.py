@@ -66,7 +66,7 @@ class COORDCONCATSIREN(nn.Module):
         # and, NOT within the 1e-3 budget (the "fp16 MFMA path" tier of BASELINE config 5, ~1e-2 on the render; opt-in):
         #   "f16x1t"  plain f16 matrix-core products on the f16x3t engine (one product instead of three)
         widest = max(hidden_dim, feature_dim)
-        default = "f16x2" if widest <= 256 else "f16x3t" if widest <= 448 else "f32"
+        default = "f16x2" if widest <= 256 else "f16x2t" if widest <= 448 else "f32"
         self.precision = os.environ.get("H3D_FIELD_PRECISION", default)
 
     # ---- weight packing (host, once per weight version)

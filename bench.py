@@ -250,7 +250,7 @@ def kernel_rooflines(G, cfg, batch, stage_ms):
         """engine: the arithmetic of the kernel's contractions.  Matrix-pipe time issued per algorithmic f16-rate product:
         x3 = three f16/bf16 products; x2 = one f16 product + one block-scaled fp6 instruction per two k-steps that takes the
         time of one f16 instruction (both cross terms) = 1.5; f32 = the fp32 matrix instruction (its own peak)."""
-        kind = "x2" if engine.endswith("x2") else "x3" if engine.endswith("x3") or engine.endswith("x3t") else "f32"
+        kind = "x2" if engine in ("f16x2", "f16x2t") else "x3" if engine.endswith("x3") or engine.endswith("x3t") else "f32"
         peak = MFMA_F32_PEAK_TF if kind == "f32" else MFMA_F16_PEAK_TF
         factor = {"x3": 3.0, "x2": 1.5, "f32": 1.0}[kind]
         label = {"x3": "split f16/bf16 x3: hi*hi + hi*lo + lo*hi, three 16-bit MFMA products (fp32-class)",

@@ -159,7 +159,7 @@ def test_wide_configs_default_to_the_x3t_engines():
         cfg.update(dataset_length=4)
         cfg["neural_field_cls"] = impl.COORDCONCATSIREN
         G = gens.Map3DGenerator(**cfg).to(DEV).eval()
-        assert G.neural_field.precision == "f16x3t" and G.synthesis_plan(DEV).engine == "bf16x3t", name
+        assert G.neural_field.precision == "f16x2t" and G.synthesis_plan(DEV).engine == "f16x2t", name
 
 
 def test_engine_override_is_seen_by_forward_under_any_device_spelling():

@@ -95,7 +95,7 @@ def test_x3t_plan_matches_oracle(mode, width):
     plan = sp.SynthesisPlan(sd, "synthesis_network", "synthesis_input", meta["synthesis_blocks"], tuple(meta["mod_blocks"]), mode,
                             torch.device("cpu"))
     assert plan.x3t_supported()
-    assert plan.engine == ("f16x2" if width <= 256 else "bf16x3t")        # the default follows the width
+    assert plan.engine == ("f16x2" if width <= 256 else "f16x2t")         # the default follows the width
     B, Hr, Wr, H, W = 2, 3, 2, 6, 4
     fmap = torch.randn(B, Hr * Wr, width)
     style = torch.randn(B, width)

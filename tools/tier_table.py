@@ -2,7 +2,7 @@
 same batch; error = per-channel max-norm relative deviation of the image / render from the CPU oracle on a pixel / ray subset
 (oracle/h3d_oracle.py: generator_forward_subset).  Writes profiles/<tag>_precision_tiers.json.
 
-    python tools/tier_table.py r2"""
+    python tools/tier_table.py r3"""
 import json
 import os
 import sys
@@ -18,7 +18,7 @@ import h3d_oracle as O                                    # noqa: E402  (checker
 from conftest import rel_err_channels                      # noqa: E402
 import bench                                               # noqa: E402
 
-COMBOS = [("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f16x3", "f16w2t"), ("f16x1t", "bf16x3"), ("f16x1t", "f16w2t"),
+COMBOS = [("f16x2", "f16x2"), ("f16x2", "bf16x3"), ("f16x2t", "f16x2t"), ("f16x3", "bf16x3"), ("f16x3t", "bf16x3t"), ("f16x3", "f16w2t"), ("f16x1t", "bf16x3"), ("f16x1t", "f16w2t"),
           ("f16x1t", "f16x1t"), ("f32", "f32")]
 WORK = {"cfg3_512sq_b16_s64": ("MAP3DBN512", (512, 512), (96, 96), 64, 16),
         "cfg5_1024sq_b4_s128": ("MAP3DBN512", (1024, 1024), (192, 192), 128, 4)}
