@@ -158,7 +158,7 @@ def discriminator_step_bench(a, rank, world, dist_on, dev):
             "metric": "discriminator-step images/sec at 512x256 (G forward + D fwd/bwd + R1)", "value": a.batch * world * a.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "generator: split f16/bf16 (fp32-class); discriminator: fp32 (torch / MIOpen convolutions)", "data": "synthetic",
+            "dtype": "generator: x2 engines (f16 + fp6 cross terms); discriminator: split-bf16 convolution kernels (fp32 in / out)", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4, discriminator half: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; "
                                    "UNetDiscriminator 6 blocks; R1 every step; generator backward NOT included (not built)",
                        "global_batch": a.batch * world,
@@ -218,7 +218,8 @@ def train_step_bench(a, rank, world, dist_on, dev, emit=True):
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp32" if a.amp == "none" else f"AMP {a.amp} autocast (GEMMs / convolutions in {a.amp}, HIP kernels fp32)") +
-                     " (library GEMMs + HIP activation / integration / SPADE kernels; discriminator: torch / MIOpen convolutions)",
+                     " (generator: split-bf16 matrix-core GEMMs / weight gradients + HIP activation / integration / SPADE kernels; discriminator: "
+                     "hand-written split-bf16 convolution kernels, forward / backward-data / weight gradient / R1 double backward)",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; UNetDiscriminator "
                                    "6 blocks; R1 every step; GAN + segmentation losses; Adam on both networks; EMA",
