@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ..generators.synthesis_pack import pack_matrix
+from .ops.recompute import with_recomputed_grad
 
 
 def _pad_rows(v, n):
@@ -54,19 +55,48 @@ class StyleModLayer(nn.Module):
             self._packed = (key, dict(w=torch.cat(taps).contiguous(), w2sum=(w * w).sum(dim=(2, 3)), bias=bias))
         return self._packed[1]
 
-    @torch.no_grad()
     def forward(self, x, style):
-        """x [B,Cin,H,W] | [B,Cin] | [B,N,Cin]; style [B,S]  ->  same layout with Cout channels."""
+        """x [B,Cin,H,W] | [B,Cin] | [B,N,Cin]; style [B,S]  ->  same layout with Cout channels.  Differentiable (backward by
+        recomputation: ops/recompute.py)."""
         _lib.need_cuda(x, style)
         assert x.shape[0] == style.shape[0]
-        if x.dim() == 2:
-            inp = x[:, :, None, None]
-        elif x.dim() == 3:
-            inp = x.permute(0, 2, 1).unsqueeze(-1)
-        elif x.dim() == 4:
-            inp = x
-        else:
+        if x.dim() not in (2, 3, 4):
             raise Exception("wrong input size")
+        return with_recomputed_grad(self._launch, self._restate, x, style, self.weight, self.bias, self.geo_feature.weight,
+                                    self.geo_feature.bias)
+
+    @staticmethod
+    def _to_image(x):
+        if x.dim() == 2:
+            return x[:, :, None, None]
+        if x.dim() == 3:
+            return x.permute(0, 2, 1).unsqueeze(-1)
+        return x
+
+    @staticmethod
+    def _from_image(out, dim):
+        if dim == 2:
+            return out[:, :, 0, 0]
+        if dim == 3:
+            return out[:, :, :, 0].permute(0, 2, 1).contiguous()
+        return out
+
+    def _oikk(self, weight):
+        if self.use_group_conv:
+            return weight[0]
+        return weight[0].t().reshape(self.out_channel, self.in_channel, 1, 1)
+
+    def _restate(self, x, style, weight, bias, gw, gb):
+        """The grouped convolution as tensor algebra: modulate the input, shared-weight convolution, demodulate the output."""
+        w = self._oikk(weight).float()
+        s = torch.nn.functional.linear(style.float(), gw, gb) + 1.0
+        y = torch.nn.functional.conv2d(self._to_image(x).float() * s[:, :, None, None], w, padding=self.padding)
+        if self.demodulate:
+            y = y * torch.rsqrt((s * s) @ (w * w).sum(dim=(2, 3)).t() + self.eps)[:, :, None, None]
+        return self._from_image(y + bias.view(1, -1, 1, 1), x.dim())
+
+    def _launch(self, x, style, *_):
+        inp = self._to_image(x)
         B, Cin, H, W = inp.shape
         pk = self._pack(x.device)
         r32 = lambda n: (n + 31) // 32 * 32
@@ -81,8 +111,4 @@ class StyleModLayer(nn.Module):
         rc = _lib.load().h3d_modconv2d(_lib.ptr(xin), _lib.ptr(smod), _lib.ptr(dmod), _lib.ptr(pk["w"]), _lib.ptr(pk["bias"]),
                                        _lib.ptr(out), B, Cin, self.out_channel, H, W, self.kernel_size, _lib.stream_handle())
         _lib.check(rc, "h3d_modconv2d")
-        if x.dim() == 2:
-            return out[:, :, 0, 0]
-        if x.dim() == 3:
-            return out[:, :, :, 0].permute(0, 2, 1).contiguous()
-        return out
+        return self._from_image(out, x.dim())

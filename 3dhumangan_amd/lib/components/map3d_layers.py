@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ..generators.synthesis_pack import pack_matrix
+from .ops.recompute import with_recomputed_grad
 
 
 def _pad_vec(v, n):
@@ -47,13 +48,25 @@ class SpatialStyleModLayer(nn.Module):
                 bias=_pad_vec(self.bias.detach().to(device), r32(Cout))))
         return self._packed[1]
 
-    @torch.no_grad()
     def forward(self, x, style):
-        """x [B,P,Cin]; style [B,P,S] or [B,S,H,W]  ->  [B,P,Cout]"""
+        """x [B,P,Cin]; style [B,P,S] or [B,S,H,W]  ->  [B,P,Cout].  Differentiable (backward by recomputation: ops/recompute.py)."""
         _lib.need_cuda(x, style)
         if style.dim() > 3:
             B, C, H, W = style.shape
             style = style.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        return with_recomputed_grad(self._launch, self._restate, x, style, self.weight, self.bias, self.affine.weight,
+                                    self.affine.bias)
+
+    def _restate(self, x, style, weight, bias, aw, ab):
+        """The same function as tensor algebra: ((x m) W) d + b with m = affine(style) + 1, d = rsqrt(m^2 W^2 + eps)."""
+        m = torch.nn.functional.linear(style.float(), aw, ab) + 1.0
+        w = weight[0, 0]
+        y = (x.float() * m) @ w
+        if self.demodulate:
+            y = y * torch.rsqrt((m * m) @ (w * w) + self.eps)
+        return y + bias[0]
+
+    def _launch(self, x, style, *_):
         B, P, Cin = x.shape
         pk = self._pack(x.device)
         xin = x.contiguous().float()

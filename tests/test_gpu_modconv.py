@@ -64,3 +64,61 @@ def test_modconv2d_vs_oracle(cin, cout, k, hw):
                                    layer.bias.detach().cpu().double(), layer.geo_feature.weight.detach().cpu().double(),
                                    layer.geo_feature.bias.detach().cpu().double())[:, :, 0, 0]
         assert rel_err(layer(x2.to(DEV), st.to(DEV)).cpu(), ref2) < 2e-5
+
+
+def _grads(out, cot, tensors):
+    return torch.autograd.grad(out, tensors, cot)
+
+
+@pytest.mark.parametrize("cin,cout,s,rows,demod", [(64, 96, 48, 65, True), (33, 7, 5, 3, False)])
+def test_modconv1x1_gradients_vs_oracle(cin, cout, s, rows, demod):
+    """Every input and parameter gets the gradient of the oracle's float64 restatement (forward value from the kernel)."""
+    torch.manual_seed(cin)
+    layer = m3.SpatialStyleModLayer(in_channel=cin, out_channel=cout, style_dim=s, demodulate=demod)
+    x, st = torch.randn(2, rows, cin), torch.randn(2, rows, s)
+    cot = torch.randn(2, rows, cout)
+    names = ["weight", "bias", "affine.weight", "affine.bias"]
+    ps = dict(layer.named_parameters())
+    ref_leaves = [t.detach().double().requires_grad_() for t in (x, st, *[ps[n] for n in names])]
+    rx, rst, rw, rb, raw, rab = ref_leaves
+    ref = O.modconv1x1_pixelwise(rx, rst, rw[0, 0], rb[0, 0], raw, rab, demodulate=demod)
+    ref_g = _grads(ref, cot.double(), ref_leaves)
+    layer = layer.to(DEV)
+    ps = dict(layer.named_parameters())
+    xd, sd = x.to(DEV).requires_grad_(), st.to(DEV).requires_grad_()
+    out = layer(xd, sd)
+    assert out.requires_grad and rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    got = _grads(out, cot.to(DEV), [xd, sd] + [ps[n] for n in names])
+    for name, a, b in zip(["x", "style"] + names, got, ref_g):
+        assert rel_err(a.cpu(), b) < 5e-5, name
+    # only some inputs need a gradient / none does
+    out = layer(x.to(DEV), sd)
+    (g_s,) = _grads(out, cot.to(DEV), [sd])
+    assert rel_err(g_s.cpu(), ref_g[1]) < 5e-5
+    with torch.no_grad():
+        assert not layer(xd, sd).requires_grad
+
+
+@pytest.mark.parametrize("cin,cout,k,hw,dim", [(64, 64, 3, (9, 7), 4), (40, 72, 1, (5, 6), 4), (32, 48, 1, None, 2), (32, 48, 1, 11, 3)])
+def test_modconv2d_gradients_vs_oracle(cin, cout, k, hw, dim):
+    torch.manual_seed(cin + k + dim)
+    layer = cips.StyleModLayer(in_channel=cin, out_channel=cout, kernel_size=k, style_dim=16)
+    x = torch.randn(2, cin, *hw) if dim == 4 else torch.randn(2, cin) if dim == 2 else torch.randn(2, hw, cin)
+    st = torch.randn(2, 16)
+    names = ["weight", "bias", "geo_feature.weight", "geo_feature.bias"]
+    ps = dict(layer.named_parameters())
+    ref_leaves = [t.detach().double().requires_grad_() for t in (x, st, *[ps[n] for n in names])]
+    rx, rst, rw, rb, rgw, rgb = ref_leaves
+    img = rx if dim == 4 else rx[:, :, None, None] if dim == 2 else rx.permute(0, 2, 1).unsqueeze(-1)
+    ref = O.modconv2d_grouped(img, rst, rw, rb, rgw, rgb)
+    ref = ref if dim == 4 else ref[:, :, 0, 0] if dim == 2 else ref[:, :, :, 0].permute(0, 2, 1)
+    cot = torch.randn(ref.shape)
+    ref_g = _grads(ref, cot.double(), ref_leaves)
+    layer = layer.to(DEV)
+    ps = dict(layer.named_parameters())
+    xd, sd = x.to(DEV).requires_grad_(), st.to(DEV).requires_grad_()
+    out = layer(xd, sd)
+    assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    got = _grads(out, cot.to(DEV), [xd, sd] + [ps[n] for n in names])
+    for name, a, b in zip(["x", "style"] + names, got, ref_g):
+        assert rel_err(a.cpu(), b) < 5e-5, name

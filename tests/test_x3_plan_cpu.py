@@ -36,9 +36,11 @@ CODES = torch.tensor([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1
                       2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5], dtype=torch.float64)
 
 
-def decode_x2(stream_i16, stage0, KS, NT):
+def decode_x2(stream_i16, stage0, KS, NT, order=None):
     """x2 stages [KS][NT][1 KiB f16 hi fragment | 1 KiB record halves] -> (Whi [32 NT, 16 KS] in feature order, groups for
-    x2_emulation.x2_operands_matmul: (features [16], codes_hi [N, 16], codes_lo [N, 16], block scale [N]))."""
+    x2_emulation.x2_operands_matmul: (features [16], codes_hi [N, 16], codes_lo [N, 16], block scale [N])).
+    order(ks, lane half, element) -> feature (default: accumulator-register order)."""
+    order = order or acc_k
     n = KS * NT * 1024                                                # int16 elements
     st = stream_i16[stage0 * NT * 1024: stage0 * NT * 1024 + n].view(KS, NT, 2, 512)
     hi = st[:, :, 0].contiguous().view(torch.float16).double().view(KS, NT, 64, 8)
@@ -46,7 +48,7 @@ def decode_x2(stream_i16, stage0, KS, NT):
     for ks in range(KS):
         for h in range(2):
             for e in range(8):
-                Whi[:, acc_k(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
+                Whi[:, order(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
     half = st[:, :, 1].contiguous().view(torch.uint8).view(KS, NT, 64, 16).to(torch.int64)
     groups = []
     for T in range(KS // 2):
@@ -58,7 +60,7 @@ def decode_x2(stream_i16, stage0, KS, NT):
         assert torch.equal(rec[..., 24:28], rec[..., 24:25].expand(-1, -1, 4)) and int(rec[..., 28:].abs().max()) == 0
         scale = torch.exp2((rec[..., 24] - 127).double())
         for h in range(2):
-            feats = torch.tensor([acc_k(2 * T + j, h, e) for j in range(2) for e in range(8)])
+            feats = torch.tensor([order(2 * T + j, h, e) for j in range(2) for e in range(8)])
             v = vals[:, 32 * h: 32 * h + 32].reshape(32 * NT, 32)
             groups.append((feats, v[:, :16], v[:, 16:], scale[:, 32 * h: 32 * h + 32].reshape(32 * NT)))
     return Whi, groups
