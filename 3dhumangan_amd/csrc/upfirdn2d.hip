@@ -4,7 +4,13 @@
 // sample of the zero-stuffed signal are visited, so the cost is ceil(fw/upx)*ceil(fh/upy) MACs per output.
 // Strides are explicit (NCHW or channels_last).  The filter (<= 1 K taps) is staged in LDS once per workgroup.
 //
-// Two kernels:
+// Three kernels:
+//   upfirdn2d_poly     the StyleGAN resampling filters on dense NCHW planes: 4-tap filters (4x4, or the 4x1 / 1x4 passes of a
+//                      separable one) with 2x up, 2x down or neither.  Every resampling constant is a template parameter, so the
+//                      polyphase structure is resolved at compile time: a thread owns a 4 x 2 output patch, pulls the
+//                      (at most 4 x 3 for 2x up) input samples it touches from the LDS tile into registers once and runs only
+//                      the taps that land on a real sample (2 x 2 of the 4 x 4 for 2x up), no integer division anywhere,
+//                      filter coefficients in scalar registers, 16-byte stores.
 //   upfirdn2d_tiled    dense NCHW planes (the usual case): a workgroup owns a 64 x 16 output tile of one (b, c) plane, stages
 //                      the input samples the tile touches in LDS once (zero-filled outside the image: the padding) and every
 //                      thread gathers its taps from there -- each input sample is read from HBM once per tile instead of
@@ -12,6 +18,7 @@
 //   upfirdn2d_kernel   any strides / very large resampling footprints: one thread per output element, global gathers.
 #include "common.hpp"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 namespace {
 
@@ -127,6 +134,138 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
     }
 }
 
+// ---- polyphase kernel: compile-time resampling constants -------------------------------------------------------------------
+// Output o reads padded / zero-stuffed coordinate u = o*D - pad0 + k for tap k (correlation order), which is the real input
+// sample (u / U) when U divides u.  A thread's patch starts at an output index that is a multiple of V with V*D % U == 0, so
+// u = (q*U + R) + v*D + k with the launch-uniform phase R = (-pad0) mod U: tap k of patch output v is live iff
+// (R + v*D + k) % U == 0 and reads register (R + v*D + k) / U of the thread's window, all compile-time.
+template <int UX_, int UY_, int DX_, int DY_, int FW_, int FH_, int RX_, int RY_>
+struct Poly {
+    static constexpr int UX = UX_, UY = UY_, DX = DX_, DY = DY_, FW = FW_, FH = FH_, RX = RX_, RY = RY_;
+    static constexpr int VX = 4, VY = 2, TW = 64, TH = 32;                          // patch per thread, tile per workgroup
+    static constexpr int WX = (RX + (VX - 1) * DX + FW - 1) / UX + 1;                 // register window of a thread
+    static constexpr int WY = (RY + (VY - 1) * DY + FH - 1) / UY + 1;
+    static constexpr int IN_W = (RX + (TW - 1) * DX + FW - 1) / UX + 1;               // LDS tile of a workgroup
+    static constexpr int IN_H = (RY + (TH - 1) * DY + FH - 1) / UY + 1;
+    static constexpr int LD = (IN_W + 3) / 4 * 4 + 4;                                  // row stride: multiple of 4, rows 4 banks apart
+    static_assert((VX * DX) % UX == 0 && (VY * DY) % UY == 0, "patch origin must keep the phase");
+};
+
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void upfirdn2d_poly(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
+                                                      Params p, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float tile[P::IN_H * P::LD];
+    float c[P::FH][P::FW];                                                           // correlation order; uniform -> scalar registers
+#pragma unroll
+    for (int ky = 0; ky < P::FH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < P::FW; ++kx)
+            c[ky][kx] = f[(p.flip ? ky : P::FH - 1 - ky) * P::FW + (p.flip ? kx : P::FW - 1 - kx)];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ox0 = blockIdx.x * P::TW, oy0 = blockIdx.y * P::TH;
+    const int ix0 = floor_div(ox0 * P::DX - p.padx0, P::UX), iy0 = floor_div(oy0 * P::DY - p.pady0, P::UY);
+    const T* __restrict__ xb = x + (int64_t)blockIdx.z * p.H * p.W;
+    for (int ly = wave; ly < P::IN_H; ly += 4) {                                     // a wave stages whole rows: no index division
+        const int iy = iy0 + ly;
+        const bool row_ok = iy >= 0 && iy < p.H;
+        const T* __restrict__ xr = xb + (int64_t)iy * p.W;
+        for (int lx = lane; lx < P::IN_W; lx += 64) {
+            const int ix = ix0 + lx;
+            tile[ly * P::LD + lx] = (row_ok && ix >= 0 && ix < p.W) ? (float)xr[ix] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int txg = t & 15, ty = t >> 4;
+    const int ox = ox0 + P::VX * txg, oy = oy0 + P::VY * ty;
+    if (ox >= p.outW || oy >= p.outH) return;
+    const float* __restrict__ wp = tile + (P::VY * ty * P::DY / P::UY) * P::LD + P::VX * txg * P::DX / P::UX;
+    float win[P::WY][P::WX];
+#pragma unroll
+    for (int j = 0; j < P::WY; ++j)
+#pragma unroll
+        for (int i = 0; i < P::WX; ++i) win[j][i] = wp[j * P::LD + i];
+    T* __restrict__ yb = y + (int64_t)blockIdx.z * p.outH * p.outW;
+#pragma unroll
+    for (int vy = 0; vy < P::VY; ++vy) {
+        if (oy + vy >= p.outH) break;
+        float acc[P::VX];
+#pragma unroll
+        for (int vx = 0; vx < P::VX; ++vx) {
+            float a = 0.f;                                                           // ky outer, kx inner: the order of the other kernels
+#pragma unroll
+            for (int ky = 0; ky < P::FH; ++ky) {
+                if ((P::RY + vy * P::DY + ky) % P::UY) continue;
+#pragma unroll
+                for (int kx = 0; kx < P::FW; ++kx) {
+                    if ((P::RX + vx * P::DX + kx) % P::UX) continue;
+                    a += win[(P::RY + vy * P::DY + ky) / P::UY][(P::RX + vx * P::DX + kx) / P::UX] * c[ky][kx];
+                }
+            }
+            acc[vx] = a * p.gain;                                                    // gain last, as upfirdn2d.cu
+        }
+        T* o = yb + (int64_t)(oy + vy) * p.outW + ox;
+        if (vec_ok && ox + P::VX <= p.outW) {
+            typedef T vecT __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<vecT*>(o) = vecT{(T)acc[0], (T)acc[1], (T)acc[2], (T)acc[3]};
+        } else {
+#pragma unroll
+            for (int vx = 0; vx < P::VX; ++vx)
+                if (ox + vx < p.outW) o[vx] = (T)acc[vx];
+        }
+    }
+}
+
+inline int pos_mod(int a, int m) { return ((a % m) + m) % m; }
+
+template <typename T, typename P>
+int launch_poly(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    const int64_t planes = (int64_t)p.B * p.C;
+    const int vec_ok = (p.outW % 4 == 0) && (reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T)) == 0);
+    for (int64_t z0 = 0; z0 < planes; z0 += 65535) {
+        const unsigned nz = (unsigned)((planes - z0) < 65535 ? (planes - z0) : 65535);
+        h3d::pre_launch();
+        hipLaunchKernelGGL((upfirdn2d_poly<T, P>), dim3((p.outW + P::TW - 1) / P::TW, (p.outH + P::TH - 1) / P::TH, nz), dim3(256), 0, st,
+                           (const T*)x + z0 * p.H * p.W, f, (T*)y + z0 * p.outH * p.outW, p, vec_ok);
+        const int rc = h3d::launch_status("h3d_upfirdn2d");
+        if (rc) return rc;
+    }
+    return H3D_OK;
+}
+
+// one resampling geometry, every phase of it
+template <typename T, int UX, int UY, int DX, int DY, int FW, int FH>
+int poly_phases(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    const int rx = pos_mod(-p.padx0, UX), ry = pos_mod(-p.pady0, UY);
+    if constexpr (UX == 2 && UY == 2) {
+        if (rx == 0 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
+        if (rx == 1 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0>>(x, f, y, p, st);
+        if (rx == 0 && ry == 1) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 1>>(x, f, y, p, st);
+    } else if constexpr (UX == 2) {
+        if (rx == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0>>(x, f, y, p, st);
+    } else if constexpr (UY == 2) {
+        if (ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1>>(x, f, y, p, st);
+    } else {
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
+    }
+}
+
+// -> H3D_OK / error when the geometry is one of the compiled ones (handled), -1 when it is not
+template <typename T>
+int try_poly(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    if ((int64_t)p.H * p.W >= (1ll << 31) || (int64_t)p.outH * p.outW >= (1ll << 31)) return -1;
+#define H3D_POLY(UX, UY, DX, DY, FW, FH)                                                                              \
+    if (p.upx == UX && p.upy == UY && p.downx == DX && p.downy == DY && p.fw == FW && p.fh == FH)                    \
+        return poly_phases<T, UX, UY, DX, DY, FW, FH>(x, f, y, p, st);
+    H3D_POLY(2, 2, 1, 1, 4, 4) H3D_POLY(1, 1, 2, 2, 4, 4) H3D_POLY(1, 1, 1, 1, 4, 4)      // 2-D filter
+    H3D_POLY(2, 1, 1, 1, 4, 1) H3D_POLY(1, 1, 2, 1, 4, 1) H3D_POLY(1, 1, 1, 1, 4, 1)      // separable: the row pass
+    H3D_POLY(1, 2, 1, 1, 1, 4) H3D_POLY(1, 1, 1, 2, 1, 4) H3D_POLY(1, 1, 1, 1, 1, 4)      //            the column pass
+#undef H3D_POLY
+    return -1;
+}
+
 bool dense_nchw(const Params& p) {
     return p.xs[3] == 1 && p.xs[2] == p.W && p.xs[1] == (int64_t)p.H * p.W && p.xs[0] == (int64_t)p.C * p.H * p.W &&
            p.ys[3] == 1 && p.ys[2] == p.outW && p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
@@ -134,6 +273,12 @@ bool dense_nchw(const Params& p) {
 
 template <typename T, typename A>
 int launch(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
+    if constexpr (!std::is_same<T, double>::value) {
+        if (dense_nchw(p)) {
+            const int rc = try_poly<T>(x, f, y, p, st);
+            if (rc >= 0) return rc;
+        }
+    }
     const TileGeom g = tile_geom(p);
     const int64_t planes = (int64_t)p.B * p.C;
     const size_t lds = sizeof(A) * g.in_w * g.in_h + sizeof(float) * p.fh * p.fw;
@@ -179,6 +324,6 @@ extern "C" int h3d_upfirdn2d(const void* x, const float* f, void* y, int dtype, 
     for (int i = 0; i < 4; ++i) { p.xs[i] = xs[i]; p.ys[i] = ys[i]; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == 0) return launch<float, float>(x, f, y, p, st);
-    if (dtype == 1) return launch<__half, float>(x, f, y, p, st);
+    if (dtype == 1) return launch<_Float16, float>(x, f, y, p, st);
     return launch<double, double>(x, f, y, p, st);
 }

@@ -116,7 +116,7 @@ def test_conv_double_backward_of_an_r1_style_penalty():
     (gxd,) = torch.autograd.grad(out_d.sum(), dev_in[0], create_graph=True)
     assert rel_err(gxd.detach().cpu(), gx.detach()) < TOL
     pen_d = gxd.pow(2).sum() + out_d.pow(2).mean()
-    assert abs(float(pen_d) - float(pen)) < TOL * abs(float(pen))
+    assert abs(float(pen_d.detach()) - float(pen.detach())) < TOL * abs(float(pen.detach()))
     got_g = torch.autograd.grad(pen_d, dev_in[1:])
     for a, b, name in zip(got_g, ref_g, ("w1", "w2", "w3")):
         assert rel_err(a.cpu(), b) < TOL, name

@@ -185,7 +185,9 @@ def test_geo_features_ties_across_chunks_and_near_tie_overflow():
 # ------------------------------------------------------------------ A7
 
 @pytest.mark.parametrize("shape", [(2, 5, 64, 32, 256, 128), (1, 3, 96, 48, 512, 256), (2, 4, 6, 5, 20, 12),
-                                   (1, 2, 8, 4, 17, 9), (1, 1, 5, 7, 5, 7), (1, 2, 16, 16, 8, 8)])
+                                   (1, 2, 8, 4, 17, 9), (1, 1, 5, 7, 5, 7), (1, 2, 16, 16, 8, 8),
+                                   # the row-caching kernel (W >= 128): ragged width / height, down-scaling, one source row
+                                   (1, 2, 40, 50, 70, 130), (2, 2, 300, 200, 41, 132), (1, 3, 1, 9, 33, 257), (1, 2, 96, 96, 512, 512)])
 def test_bilinear(shape):
     B, C, h, w, H, W = shape
     x = torch.randn(B, C, h, w, generator=torch.Generator().manual_seed(h * w))
@@ -284,6 +286,32 @@ def test_upfirdn2d_tiled_kernel_vs_oracle(up, down, pad, taps, dtype, tol):
     cl = upfirdn_mod.upfirdn2d(dev(x.to(dtype)).contiguous(memory_format=torch.channels_last), dev(f), up=up, down=down, padding=pad,
                                gain=1.5)
     assert rel_err(cl.cpu(), ref) < tol
+
+
+@pytest.mark.parametrize("hw", [(37, 70), (33, 35), (64, 128)])
+@pytest.mark.parametrize("up,down,pad", [(2, 1, (2, 1, 2, 1)), (2, 1, (1, 2, 1, 2)), (2, 1, (1, 2, 2, 1)), (2, 1, (3, 0, -1, 4)), (1, 2, (1, 1, 1, 1)),
+                                         (1, 2, (2, 1, 0, 3)), (1, 1, (2, 1, 2, 1)), (1, 1, (-2, 5, 3, 0))])
+def test_upfirdn2d_polyphase_kernel_vs_oracle(up, down, pad, hw):
+    """The compile-time polyphase kernel (4-tap filters, 2x up / 2x down / neither, dense NCHW): every phase of the padding, sizes
+    that are / are not multiples of its 64 x 32 tile and of the 4-wide vector store, 2-D and separable filters, flipped, fp16."""
+    g = torch.Generator().manual_seed(up * 10 + down + hw[0])
+    x = torch.randn(2, 3, *hw, generator=g, dtype=torch.float64)
+    f = torch.randn(4, 4, generator=g)
+    for flip in (False, True):
+        ref = O.upfirdn2d(x, f.double(), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
+        got = upfirdn_mod.upfirdn2d(dev(x.float()), dev(f), up=up, down=down, padding=pad, flip_filter=flip, gain=1.5)
+        assert got.shape == ref.shape and rel_err(got.cpu(), ref) < 1e-5
+    got16 = upfirdn_mod.upfirdn2d(dev(x.half()), dev(f), up=up, down=down, padding=pad, gain=1.5)
+    assert rel_err(got16.float().cpu(), O.upfirdn2d(x, f.double(), up=up, down=down, padding=pad, gain=1.5)) < 2e-3
+    f1 = torch.randn(4, generator=g)                                         # separable: a row pass and a column pass
+    ref = O.upfirdn2d(x, torch.outer(f1, f1).double(), up=up, down=down, padding=pad, gain=1.5)
+    got = upfirdn_mod.upfirdn2d(dev(x.float()), dev(f1), up=up, down=down, padding=pad, gain=1.5)
+    assert got.shape == ref.shape and rel_err(got.cpu(), ref) < 1e-5
+    # a view with a storage offset that breaks the 16-byte alignment of the output is not produced by the wrapper, but an
+    # input one is legal: the staging loads are scalar
+    xo = dev(torch.cat([torch.zeros(1), x.float().flatten()]))[1:].view(x.shape)
+    assert rel_err(upfirdn_mod.upfirdn2d(xo, dev(f), up=up, down=down, padding=pad, gain=1.5).cpu(),
+                   O.upfirdn2d(x, f.double(), up=up, down=down, padding=pad, gain=1.5)) < 1e-5
 
 
 @pytest.mark.parametrize("up,down,pad,taps,flip", [(2, 1, [2, 1, 2, 1], [1, 3, 3, 1], False), (1, 2, [1, 1, 1, 1], [1, 3, 3, 1], True),
