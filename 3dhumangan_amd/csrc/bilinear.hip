@@ -112,7 +112,108 @@ __global__ __launch_bounds__(256) void bilinear_rows(const float* __restrict__ i
     }
 }
 
+// ---- channels-last maps [B, h, w, C] (the training path's layout; C % 4 == 0) ------------------------------------------------
+// forward: a thread writes 4 channels of one output pixel (16-byte store; the four taps are 16-byte loads from the small source)
+__global__ __launch_bounds__(256) void bilinear_cl_fwd(const float* __restrict__ in, float* __restrict__ out, int h, int w, int H, int W,
+                                                       int C4, float ry, float rx) {
+    const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int X = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c4 >= C4 || X >= W) return;
+    const int Y = blockIdx.z % H, b = blockIdx.z / H;
+    int y0, y1, x0, x1;
+    float ty, tx;
+    src_index(Y, ry, h, y0, y1, ty);
+    src_index(X, rx, w, x0, x1, tx);
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(in) + (int64_t)b * h * w * C4 + c4;
+    const float4 a = src[((int64_t)y0 * w + x0) * C4], bq = src[((int64_t)y0 * w + x1) * C4];
+    const float4 c = src[((int64_t)y1 * w + x0) * C4], d = src[((int64_t)y1 * w + x1) * C4];
+    auto mix = [&](float a_, float b_, float c_, float d_) {
+        const float top = a_ * (1.f - tx) + b_ * tx, bot = c_ * (1.f - tx) + d_ * tx;       // same association as bilinear_kernel
+        return top * (1.f - ty) + bot * ty;
+    };
+    reinterpret_cast<float4*>(out)[(((int64_t)b * H + Y) * W + X) * C4 + c4] =
+        make_float4(mix(a.x, bq.x, c.x, d.x), mix(a.y, bq.y, c.y, d.y), mix(a.z, bq.z, c.z, d.z), mix(a.w, bq.w, c.w, d.w));
+}
+
+// adjoint along ONE axis: dst[o, i, r] = sum_I weight(I -> i) src[o, I, r] for src [O, N, R4] float4 rows, dst [O, n, R4].
+// A thread owns (o, r) and walks I = 0 .. N-1 once: the source index i0(I) is non-decreasing, so two running sums (rows i0 and
+// i0 + 1) are enough and each finished row is written exactly once -- the source is read once, coalesced over r, no atomics.
+__global__ __launch_bounds__(256) void bilinear_cl_adjoint_axis(const float* __restrict__ src, float* __restrict__ dst, int N, int n,
+                                                                int64_t R4, int64_t total, float ratio) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t o = idx / R4, r = idx - o * R4;
+    const float4* __restrict__ s = reinterpret_cast<const float4*>(src) + o * N * R4 + r;
+    float4* __restrict__ d = reinterpret_cast<float4*>(dst) + o * n * R4 + r;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    int cur = 0;
+    float4 v = s[0];
+    for (int I = 0; I < N; ++I) {
+        const float4 nxt = I + 1 < N ? s[(int64_t)(I + 1) * R4] : v;                       // one row ahead of the arithmetic
+        int i0, i1;
+        float t;
+        src_index(I, ratio, n, i0, i1, t);
+        while (cur < i0) {
+            d[(int64_t)cur * R4] = acc0;
+            acc0 = acc1;
+            acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            ++cur;
+        }
+        const float w0 = 1.f - t;
+        acc0.x += w0 * v.x; acc0.y += w0 * v.y; acc0.z += w0 * v.z; acc0.w += w0 * v.w;
+        if (i1 == i0) { acc0.x += t * v.x; acc0.y += t * v.y; acc0.z += t * v.z; acc0.w += t * v.w; }
+        else          { acc1.x += t * v.x; acc1.y += t * v.y; acc1.z += t * v.z; acc1.w += t * v.w; }
+        v = nxt;
+    }
+    for (; cur < n; ++cur) {
+        d[(int64_t)cur * R4] = acc0;
+        acc0 = acc1;
+        acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 }  // namespace
+
+// Channels-last variant: in [B,h,w,C] -> out [B,H,W,C] (C a multiple of 4, 16-byte aligned), same arithmetic as h3d_bilinear_resize.
+extern "C" int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream) {
+    H3D_REQUIRE(in && out, "h3d_bilinear_resize_cl: null pointer");
+    H3D_REQUIRE(B >= 0 && C >= 4 && C % 4 == 0 && h >= 1 && w >= 1 && H >= 1 && W >= 1, "h3d_bilinear_resize_cl: bad shape (C must be a multiple of 4)");
+    H3D_REQUIRE(h3d::aligned16(in) && h3d::aligned16(out), "h3d_bilinear_resize_cl: operands must be 16-byte aligned");
+    H3D_REQUIRE((int64_t)B * H < 65536, "h3d_bilinear_resize_cl: B * H must be below 65536");
+    if (B == 0) return H3D_OK;
+    const int C4 = C / 4;
+    h3d::pre_launch();
+    hipLaunchKernelGGL(bilinear_cl_fwd, dim3((C4 + 63) / 64, (W + 3) / 4, B * H), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       h, w, H, W, C4, (float)h / (float)H, (float)w / (float)W);
+    return h3d::launch_status("h3d_bilinear_resize_cl");
+}
+
+// Adjoint of h3d_bilinear_resize_cl: dout [B,H,W,C] -> din [B,h,w,C]; tmp: B*h*W*C floats of scratch (rows first, then columns).
+extern "C" int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
+                                          h3d_stream_t stream) {
+    H3D_REQUIRE(dout && tmp && din, "h3d_bilinear_resize_cl_bwd: null pointer");
+    H3D_REQUIRE(B >= 0 && C >= 4 && C % 4 == 0 && h >= 1 && w >= 1 && H >= 1 && W >= 1, "h3d_bilinear_resize_cl_bwd: bad shape (C must be a multiple of 4)");
+    H3D_REQUIRE(h3d::aligned16(dout) && h3d::aligned16(tmp) && h3d::aligned16(din), "h3d_bilinear_resize_cl_bwd: operands must be 16-byte aligned");
+    if (B == 0) return H3D_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t C4 = C / 4;
+    {   // rows: [B][H][W*C4] -> [B][h][W*C4]
+        const int64_t R4 = (int64_t)W * C4, total = (int64_t)B * R4;
+        H3D_REQUIRE((total + 255) / 256 < (int64_t(1) << 31), "h3d_bilinear_resize_cl_bwd: tensor too large");
+        h3d::pre_launch();
+        hipLaunchKernelGGL(bilinear_cl_adjoint_axis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout, tmp, H, h, R4, total,
+                           (float)h / (float)H);
+        const int rc = h3d::launch_status("h3d_bilinear_resize_cl_bwd");
+        if (rc) return rc;
+    }
+    {   // columns: [B*h][W][C4] -> [B*h][w][C4]
+        const int64_t R4 = C4, total = (int64_t)B * h * R4;
+        h3d::pre_launch();
+        hipLaunchKernelGGL(bilinear_cl_adjoint_axis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, din, W, w, R4, total,
+                           (float)w / (float)W);
+        return h3d::launch_status("h3d_bilinear_resize_cl_bwd");
+    }
+}
 
 extern "C" int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w, int H, int W,
                                    h3d_stream_t stream) {

@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include <hip/hip_fp16.h>
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -139,10 +140,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
 // sample (u / U) when U divides u.  A thread's patch starts at an output index that is a multiple of V with V*D % U == 0, so
 // u = (q*U + R) + v*D + k with the launch-uniform phase R = (-pad0) mod U: tap k of patch output v is live iff
 // (R + v*D + k) % U == 0 and reads register (R + v*D + k) / U of the thread's window, all compile-time.
-template <int UX_, int UY_, int DX_, int DY_, int FW_, int FH_, int RX_, int RY_>
+template <int UX_, int UY_, int DX_, int DY_, int FW_, int FH_, int RX_, int RY_, int VY_ = 2>
 struct Poly {
     static constexpr int UX = UX_, UY = UY_, DX = DX_, DY = DY_, FW = FW_, FH = FH_, RX = RX_, RY = RY_;
-    static constexpr int VX = 4, VY = 2, TW = 64, TH = 32;                          // patch per thread, tile per workgroup
+    static constexpr int VX = 4, VY = VY_, TW = 64, TH = 16 * VY_;                          // patch per thread, tile per workgroup
     static constexpr int WX = (RX + (VX - 1) * DX + FW - 1) / UX + 1;                 // register window of a thread
     static constexpr int WY = (RY + (VY - 1) * DY + FH - 1) / UY + 1;
     static constexpr int IN_W = (RX + (TW - 1) * DX + FW - 1) / UX + 1;               // LDS tile of a workgroup
@@ -233,22 +234,22 @@ int launch_poly(const void* x, const float* f, void* y, const Params& p, hipStre
 }
 
 // one resampling geometry, every phase of it
-template <typename T, int UX, int UY, int DX, int DY, int FW, int FH>
+template <typename T, int UX, int UY, int DX, int DY, int FW, int FH, int VY>
 int poly_phases(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
     const int rx = pos_mod(-p.padx0, UX), ry = pos_mod(-p.pady0, UY);
     if constexpr (UX == 2 && UY == 2) {
-        if (rx == 0 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
-        if (rx == 1 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0>>(x, f, y, p, st);
-        if (rx == 0 && ry == 1) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1>>(x, f, y, p, st);
-        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 1>>(x, f, y, p, st);
+        if (rx == 0 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0, VY>>(x, f, y, p, st);
+        if (rx == 1 && ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0, VY>>(x, f, y, p, st);
+        if (rx == 0 && ry == 1) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1, VY>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 1, VY>>(x, f, y, p, st);
     } else if constexpr (UX == 2) {
-        if (rx == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
-        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0>>(x, f, y, p, st);
+        if (rx == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0, VY>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 1, 0, VY>>(x, f, y, p, st);
     } else if constexpr (UY == 2) {
-        if (ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
-        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1>>(x, f, y, p, st);
+        if (ry == 0) return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0, VY>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 1, VY>>(x, f, y, p, st);
     } else {
-        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0>>(x, f, y, p, st);
+        return launch_poly<T, Poly<UX, UY, DX, DY, FW, FH, 0, 0, VY>>(x, f, y, p, st);
     }
 }
 
@@ -256,9 +257,10 @@ int poly_phases(const void* x, const float* f, void* y, const Params& p, hipStre
 template <typename T>
 int try_poly(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
     if ((int64_t)p.H * p.W >= (1ll << 31) || (int64_t)p.outH * p.outW >= (1ll << 31)) return -1;
+    static const bool vy4 = getenv("H3D_UPFIRDN_VY4") != nullptr;
 #define H3D_POLY(UX, UY, DX, DY, FW, FH)                                                                              \
     if (p.upx == UX && p.upy == UY && p.downx == DX && p.downy == DY && p.fw == FW && p.fh == FH)                    \
-        return poly_phases<T, UX, UY, DX, DY, FW, FH>(x, f, y, p, st);
+        return vy4 ? poly_phases<T, UX, UY, DX, DY, FW, FH, 4>(x, f, y, p, st) : poly_phases<T, UX, UY, DX, DY, FW, FH, 2>(x, f, y, p, st);
     H3D_POLY(2, 2, 1, 1, 4, 4) H3D_POLY(1, 1, 2, 2, 4, 4) H3D_POLY(1, 1, 1, 1, 4, 4)      // 2-D filter
     H3D_POLY(2, 1, 1, 1, 4, 1) H3D_POLY(1, 1, 2, 1, 4, 1) H3D_POLY(1, 1, 1, 1, 4, 1)      // separable: the row pass
     H3D_POLY(1, 2, 1, 1, 1, 4) H3D_POLY(1, 1, 1, 2, 1, 4) H3D_POLY(1, 1, 1, 1, 1, 4)      //            the column pass

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from ..components.ops.film import film_sin
 from ..components.ops.linear import linear
 from ..components.ops.spade import spade_norm_act
+from ..components.resample import bilinear_resize_cl
 
 
 # ------------------------------------------------------------------------------------------------ A5: the implicit function
@@ -89,6 +90,8 @@ def _resize_channels_last(t, render_hw, gen_hw):
     """Bilinear (align_corners=False) resize of a channels-last map [B, Hr*Wr, C] -> [B, H*W, C] without leaving the
     channels-last layout (F.interpolate on the NCHW *view* of the same memory)."""
     B, _, C = t.shape
+    if t.is_cuda and t.dtype == torch.float32 and C % 4 == 0 and not torch.is_autocast_enabled() and B * gen_hw[0] < 65536:
+        return bilinear_resize_cl(t, render_hw, gen_hw)        # own kernels: the backward reads the gradient once, no atomics
     nchw = t.reshape(B, render_hw[0], render_hw[1], C).permute(0, 3, 1, 2)
     up = F.interpolate(nchw, gen_hw, mode="bilinear", align_corners=False)
     return up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)
@@ -122,8 +125,9 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
     if pix:
         w_all = torch.cat([getattr(sn.network[n], s).mlp_shared[0].weight.flatten(1) for n, s in pix], dim=0)
         up = _resize_channels_last(linear(fmap_low, w_all), render_hw, gen_hw)                  # [B, P, 128 * len(pix)]
-        for k, key in enumerate(pix):
-            shared_up[key] = up[..., 128 * k:128 * (k + 1)]
+        # split, not slices: the backward of a split is ONE concatenation of the pieces' gradients; slices would each
+        # zero-fill a full-width gradient and add them up (6 x 1.6 GB at config 4)
+        shared_up = dict(zip(pix, torch.split(up, 128, dim=-1)))
 
     def modulation(blk_name, spade_name, idx):
         sp = getattr(sn.network[blk_name], spade_name)

@@ -133,6 +133,13 @@ int h3d_render_fused(const void* packed, const float* points, const float* geo, 
  */
 int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w, int H, int W,
                         h3d_stream_t stream);
+/* The same resize on channels-last maps (the layout of the differentiable path, lib/generators/differentiable.py):
+ * in [B,h,w,C] -> out [B,H,W,C], C a multiple of 4; and its adjoint (the backward of F.interpolate at
+ * map3d_generator.py:244-245): dout [B,H,W,C] -> din [B,h,w,C], tmp = B*h*W*C floats of scratch.  The adjoint reads dout
+ * once (a running two-row accumulation per output column, no atomics). */
+int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream);
+int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
+                               h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A5 / A5+A6 on the f16 matrix cores with split ("x3") operands: every fp32 operand is carried as hi + lo f16

@@ -196,6 +196,35 @@ def test_bilinear(shape):
     assert rel_err(got.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 6, 5, 20, 12), (1, 768, 12, 6, 64, 32), (2, 4, 5, 7, 5, 7), (1, 12, 16, 16, 8, 9), (1, 4, 1, 3, 7, 2),
+                                   (3, 260, 9, 4, 50, 23)])
+def test_bilinear_channels_last_forward_adjoint_and_double_backward(shape):
+    """h3d_bilinear_resize_cl and its adjoint against F.interpolate (float64) and its autograd: values, gradient (up- and
+    down-scaling, a single source row), and the gradient of the gradient (the adjoint's backward is the resize again)."""
+    B, C, h, w, H, W = shape
+    g = torch.Generator().manual_seed(h * W + C)
+    x = torch.randn(B, h * w, C, generator=g)
+    cot = torch.randn(B, H * W, C, generator=g)
+    xr = x.double().requires_grad_()
+    ref = torch.nn.functional.interpolate(xr.view(B, h, w, C).permute(0, 3, 1, 2), (H, W), mode="bilinear")
+    ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    (gref,) = torch.autograd.grad(ref, xr, cot.double())
+    xd = dev(x).requires_grad_()
+    got = resample.bilinear_resize_cl(xd, (h, w), (H, W))
+    assert rel_err(got.detach().cpu(), ref.detach()) < 2e-6
+    cd = dev(cot).requires_grad_()
+    (ggot,) = torch.autograd.grad(got, xd, cd, create_graph=True)
+    assert rel_err(ggot.detach().cpu(), gref) < 5e-6
+    # <adjoint(cot), u> differentiated w.r.t. cot is the resize of u
+    u = torch.randn(B, h * w, C, generator=g)
+    (back,) = torch.autograd.grad((ggot * dev(u)).sum(), cd)
+    uref = torch.nn.functional.interpolate(u.double().view(B, h, w, C).permute(0, 3, 1, 2), (H, W), mode="bilinear")
+    assert rel_err(back.cpu(), uref.permute(0, 2, 3, 1).reshape(B, H * W, C)) < 2e-6
+    # same bits as the NCHW kernel on the same data
+    nchw = resample.bilinear_resize(dev(x).view(B, h, w, C).permute(0, 3, 1, 2).contiguous(), (H, W))
+    assert torch.equal(nchw.permute(0, 2, 3, 1).reshape(B, H * W, C), got.detach())
+
+
 # ------------------------------------------------------------------ P1 / P2
 
 def test_bias_act_golden():
