@@ -455,6 +455,12 @@ def op_rooflines():
                     ms=ms, bytes=by, shape=shape, note="time includes the wrapper's output allocation")
 
     out = {}
+    x = torch.empty(8, 64, 512, 512, device="cuda")
+    ms = timeit(lambda: x.fill_(1.0))
+    out["hbm_write_only_reference"] = dict(achieved=x.numel() * 4.0 / ms / 1e6, unit="GB/s", ms=ms, bytes=x.numel() * 4.0,
+                                           note="a plain fill of a 537 MB tensor: what a write-only stream reaches on this box (context for "
+                                                "the write-dominated resampling kernels below; the 8 TB/s peak is read + write)")
+    del x
     x = torch.randn(8, 256, 512, 256, device="cuda")
     b = torch.randn(256, device="cuda")
     out["h3d_bias_act"] = entry(2.0 * x.numel() * 4, timeit(lambda: ba.bias_act(x, b, act="lrelu")), "lrelu [8,256,512,256] f32")
