@@ -140,17 +140,7 @@ __device__ __forceinline__ unsigned split2_act(float a, float b, unsigned& lo) {
 }
 
 // x2: the lo halves travel multiplied by rho = 2^12 (they only feed the fp6 conversion and the heads' scaled plane)
-__device__ __forceinline__ unsigned split2_act_x2(float a, float b, unsigned& lo) {
-    const half2v h2 = __builtin_convertvector(f32x2{a, b}, half2v);
-    const float fa = (float)h2.x, fb = (float)h2.y;
-    float la, lb;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(fa));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(fb));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(la) : "v"(la), "v"(kX2Rho));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(lb) : "v"(lb), "v"(kX2Rho));
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{la, lb}, half2v));
-    return __builtin_bit_cast(unsigned, h2);
-}
+__device__ __forceinline__ unsigned split2_act_x2(float a, float b, unsigned& lo) { return split2_x2(a, b, lo); }
 
 // two fp32 (already scaled) -> packed f16 hi halves (returned) and packed f16 lo halves
 __device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {

@@ -45,7 +45,7 @@ struct Args {
     int load_state, store_state;
 };
 
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
+__device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
 
 __device__ __forceinline__ float linspace_pm1(int n, int i) {
     if (n == 1) return -1.f;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void make_frags(V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i
             const float4 y = val(nt, rg);
             unsigned l0, l1, h0, h1;
             if constexpr (X2) {
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
+                amax = vmax3_abs2(vmax3_abs2(amax, y.x, y.y), y.z, y.w);
                 h0 = split2_x2(y.x, y.y, l0); h1 = split2_x2(y.z, y.w, l1);
             } else {
                 h0 = split2_bf16(y.x, y.y, l0); h1 = split2_bf16(y.z, y.w, l1);
@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned split2_plain(float a, float b, unsigned& lo)
 __device__ __forceinline__ float lrelu_plain(float v) {
     float t;
     asm("v_mul_f32 %0, 0x3e4ccccd, %1" : "=v"(t) : "v"(v));      // 0.2 * v, kept out of the SLP vectoriser's reach
-    return fmaxf(v, t);
+    return vmax(v, t);
 }
 
 // Producer of a conv's B fragments from a feature-major accumulator set, one 32-channel tile in eight chunks of two
@@ -173,7 +173,7 @@ struct SpadeProducer {
         unsigned lo, hi;
         const float z0 = lrelu_plain(y0), z1 = lrelu_plain(y1);
         if constexpr (X2) {
-            amax = C == 0 ? fmaxf(fabsf(z0), fabsf(z1)) : fmaxf(amax, fmaxf(fabsf(z0), fabsf(z1)));
+            amax = C == 0 ? vmax_abs2(z0, z1) : vmax3_abs2(amax, z0, z1);
             hi = split2_x2(z0, z1, lo);
         } else {
             hi = split2_plain(z0, z1, lo);
@@ -419,10 +419,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 make_frags<4, X2>(ah, al, a6, d, [&](int nt, int rg) {
                     const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
                     float4 y;
-                    y.x = fmaxf(d[nt][rg * 4 + 0] + k4.x, 0.f);
-                    y.y = fmaxf(d[nt][rg * 4 + 1] + k4.y, 0.f);
-                    y.z = fmaxf(d[nt][rg * 4 + 2] + k4.z, 0.f);
-                    y.w = fmaxf(d[nt][rg * 4 + 3] + k4.w, 0.f);
+                    y.x = vrelu(d[nt][rg * 4 + 0] + k4.x);
+                    y.y = vrelu(d[nt][rg * 4 + 1] + k4.y);
+                    y.z = vrelu(d[nt][rg * 4 + 2] + k4.z);
+                    y.w = vrelu(d[nt][rg * 4 + 3] + k4.w);
                     return y;
                 });
             }

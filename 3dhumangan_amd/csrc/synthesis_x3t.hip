@@ -33,7 +33,7 @@ struct Args {
     int g_channels, Hr, Wr, n_cst, n_ab, H, W, NT, first_skip;
 };
 
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
+__device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
 
 __device__ __forceinline__ float linspace_pm1(int n, int i) {   // torch.linspace(-1, 1, n)[i]
     if (n == 1) return -1.f;
@@ -168,7 +168,7 @@ struct Block {
                     // same association as F.interpolate: lerp in x on both rows, then lerp in y
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        v[4 * j + i] = fmaxf((a[i] * tx1 + bq[i] * tx) * ty1 + (c[i] * tx1 + d[i] * tx) * ty + k4[i], 0.f);
+                        v[4 * j + i] = vrelu((a[i] * tx1 + bq[i] * tx) * ty1 + (c[i] * tx1 + d[i] * tx) * ty + k4[i]);
                 }
                 u32x4 hi, lo;
                 if constexpr (X2) {
@@ -177,7 +177,7 @@ struct Block {
                         unsigned l2;
                         hi[e / 2] = split2_x2(v[e], v[e + 1], l2);
                         lo[e / 2] = l2;
-                        amax[hh] = fmaxf(amax[hh], fmaxf(v[e], v[e + 1]));       // relu outputs: non-negative
+                        amax[hh] = vmax3_abs2(amax[hh], v[e], v[e + 1]);
                     }
                     qh[q] = hi; ql[q] = lo;
                     *reinterpret_cast<u32x4*>(aT + x3t_frag(kKSA, mt, ks, 0) + (32 * hh + pm) * 16) = hi;

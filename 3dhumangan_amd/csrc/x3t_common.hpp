@@ -346,7 +346,7 @@ __device__ __forceinline__ void x3t_store_unit_x2(const f32x16& v, unsigned char
         for (int q = 0; q < 2; ++q) {
             const int rg = 2 * j + q;
             const f32x4 y = f(rg, f32x4{v[rg * 4 + 0], v[rg * 4 + 1], v[rg * 4 + 2], v[rg * 4 + 3]});
-            if (DYN) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+            if (DYN) amax = vmax3_abs2(vmax3_abs2(amax, y[0], y[1]), y[2], y[3]);
             unsigned l0, l1;
             hi[j][2 * q + 0] = split2_x2(y[0], y[1], l0);
             hi[j][2 * q + 1] = split2_x2(y[2], y[3], l1);

@@ -121,17 +121,20 @@ def _transposed(w):
 
 
 class _Conv(torch.autograd.Function):
+    """conv(x, w) (+ b, added by the kernel's epilogue: no separate pass over the output)."""
+
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, b=None):
         ctx.save_for_backward(x, w)
-        return _run_conv(x, w)
+        return _run_conv(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         gx = _ConvT.apply(g, w) if ctx.needs_input_grad[0] else None
         gw = _ConvW.apply(x, g, w.shape[2]) if ctx.needs_input_grad[1] else None
-        return gx, gw
+        gb = g.sum(dim=(0, 2, 3)) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
 
 
 class _ConvT(torch.autograd.Function):
@@ -195,7 +198,9 @@ def conv2d(x, weight, bias=None):
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 64 - ci))
     if co < 64:
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 64 - co))
-    if x.requires_grad or weight.requires_grad:
+    if (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)) and torch.is_grad_enabled():
+        if co >= 64:
+            return _Conv.apply(x, weight, bias)
         y = _Conv.apply(x, weight)
     elif co >= 64:
         return _run_conv(x, weight, bias)
