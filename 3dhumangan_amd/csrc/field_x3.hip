@@ -302,7 +302,10 @@ struct NoProducer {
     template <int TILE> __device__ __forceinline__ void convert() {}
 };
 
-constexpr int kRingX2 = 8;       // x2: one more buffer, the refill lags one stage (WeightRing LAG = 1)
+#ifndef H3D_FIELD_RINGX2
+#define H3D_FIELD_RINGX2 8
+#endif
+constexpr int kRingX2 = H3D_FIELD_RINGX2;       // x2: one more buffer, the refill lags one stage (WeightRing LAG = 1)
 
 template <int NT, bool FUSED, bool X2>
 __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
@@ -373,11 +376,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int64_t unit_ray = (int64_t)b * A.R + ((int64_t)blockIdx.x * 4 + wave);
     auto ray_of = [&](int64_t nn) -> int64_t { return A.log2S < 0 ? unit_ray : (int64_t)b * A.R + (nn >> A.log2S); };
 
-#ifdef H3D_EXPERIMENT_TRACE
-    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.out); g_trace_n = 0; }
-    __syncthreads();
+    H3D_TRACE_INIT();
     H3D_TRACE(0);
-#endif
     typedef typename std::conditional<X2, WeightRing<NT, kRingX2, 1>, WeightRing<NT>>::type Ring;
     Ring ring;
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     }
     ring.drain();
     H3D_TRACE(9);
+    H3D_TRACE_DUMP(A.out);
 }
 
 size_t lds_bytes(const LayoutX3& L) {
@@ -780,7 +781,7 @@ void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int 
                     rec[bit / 32] |= (unsigned)(code << (bit & 31));
                     if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
                 }
-                rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+                rec[6] = rec[7] = (unsigned)(127 - ea) * 0x01010101u;      // dword 7: the copy gemm_x2_roll reads (x3_common.hpp)
                 for (int j = 0; j < 2; ++j) {
                     unsigned* cd = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2 + 1) * 1024);
                     for (int d = 0; d < 4; ++d) cd[lane * 4 + d] = rec[4 * j + d];

@@ -155,11 +155,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         }
     }
 
-#ifdef H3D_EXPERIMENT_TRACE
-    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.out); g_trace_n = 0; }
-    __syncthreads();
+    H3D_TRACE_INIT();
     H3D_TRACE(0);
-#endif
     const int group_pts = FUSED ? (S > 64 ? S : 64) : 64;
     const int tiles = group_pts / 64;
     const int64_t g0 = (int64_t)blockIdx.x * group_pts;
@@ -630,6 +627,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         __syncthreads();     // actT / inT / part / wgt are rewritten by the next tile
         H3D_TRACE(29);
     }
+    H3D_TRACE_DUMP(A.out);
 }
 
 size_t lds_bytes(const LayoutT& L) {

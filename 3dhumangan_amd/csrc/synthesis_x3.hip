@@ -28,9 +28,17 @@ namespace {
 
 typedef BF16::vec8 bf8;
 constexpr int kShared = 128;
-constexpr int kRingDepth = 4;
+#ifndef H3D_SYNTH_RING
+#define H3D_SYNTH_RING 4
+#endif
+constexpr int kRingDepth = H3D_SYNTH_RING;
+constexpr int kDescInts = 12;       // descriptor fields per block kept in LDS (multiple of 4: the ring behind them stays 16-byte aligned)
 constexpr int kValuPerMfma = 5;    // VALU instructions slotted behind each MFMA of a section that carries epilogue work
-constexpr int kLook = 2;           // weight-fragment look-ahead in tile pairs (gemm_x3_roll)      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
+#ifndef H3D_SYNTH_LOOK_X2
+#define H3D_SYNTH_LOOK_X2 2
+#endif
+constexpr int kLook = 2;           // weight-fragment look-ahead in tile pairs (gemm_x3_roll)
+template <int NT> constexpr int look_x2() { return H3D_SYNTH_LOOK_X2 < NT / 2 ? H3D_SYNTH_LOOK_X2 : NT / 2; }   // x2: sections are shorter      // 4 x 16 KB: leaves ~96 KB of LDS for the per-layer tables
 
 struct Args {
     const unsigned char* stream;
@@ -112,6 +120,13 @@ __device__ __forceinline__ unsigned split2_plain(float a, float b, unsigned& lo)
     return hb;
 }
 
+// lrelu(t) from u = 0.4 t (the constant-style affine tables arrive pre-multiplied): 0.6 t + 0.4 |t| = 1.5 u + |u|, one instruction
+__device__ __forceinline__ float lrelu_from_scaled(float u) {
+    float z;
+    asm("v_fma_f32 %0, %1, %2, |%1|" : "=v"(z) : "v"(u), "s"(1.5f));
+    return z;
+}
+
 __device__ __forceinline__ float lrelu_plain(float v) {
     float t;
     asm("v_mul_f32 %0, 0x3e4ccccd, %1" : "=v"(t) : "v"(v));      // 0.2 * v, kept out of the SLP vectoriser's reach
@@ -120,8 +135,8 @@ __device__ __forceinline__ float lrelu_plain(float v) {
 
 // Producer of a conv's B fragments from a feature-major accumulator set, one 32-channel tile in eight chunks of two
 // activations (so that the consuming GEMM hides one chunk behind each tile-pair section of k-steps 2t, 2t+1):
-//   AFFINE  y = lrelu(v * sc + sh)   tables [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1] (constant-style SPADE with the
-//           conv bias of v folded into sh);  otherwise y = lrelu(v) (per-pixel style: v is already modulated)
+//   AFFINE  y = lrelu(v * sc + sh)   tables [HdP/2][4] = 0.4 * (sc[n], sc[n+1], sh[n], sh[n+1]) (constant-style SPADE with the
+//           conv bias of v folded into sh; the 0.4: lrelu_from_scaled);  otherwise y = lrelu(v) (per-pixel style: v is already modulated)
 //   RGB     also accumulates the ToRGB of v (the previous block's output) into rgb[3]: wr = LDS [3][HdP]
 // Source values are read from the AGPRs eight at a time: a v_accvgpr_read between MFMAs waits for the matrix pipe.
 template <int NT, bool AFFINE, bool RGB, bool X2, typename V8>
@@ -171,7 +186,7 @@ struct SpadeProducer {
         if constexpr (C < 7) fetch<TILE, C + 1>();
         else if constexpr (TILE + 1 < NT) fetch<TILE + 1, 0>();
         unsigned lo, hi;
-        const float z0 = lrelu_plain(y0), z1 = lrelu_plain(y1);
+        const float z0 = AFFINE ? lrelu_from_scaled(y0) : lrelu_plain(y0), z1 = AFFINE ? lrelu_from_scaled(y1) : lrelu_plain(y1);
         if constexpr (X2) {
             amax = C == 0 ? vmax_abs2(z0, z1) : vmax3_abs2(amax, z0, z1);
             hi = split2_x2(z0, z1, lo);
@@ -196,6 +211,7 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
     prod.prime();
     static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
     __builtin_amdgcn_sched_barrier(0);
+    H3D_TRACE(30);
     constexpr int W = NT, PER = 8 / W;          // sections per 2-k-step window, chunks per section
     auto hook = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
@@ -207,7 +223,7 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
     };
     if constexpr (X2) {
         const F16::vec8 none[1] = {};
-        gemm_x2_roll<NT, 2 * NT, 0, 2 * NT, NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, b6, none, ring, hook);
+        gemm_x2_roll<NT, 2 * NT, 0, 2 * NT, NT, false, look_x2<NT>(), kValuPerMfma, ZERO>(dst, xh, b6, none, ring, hook);
     } else {
         gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, hook);
     }
@@ -224,14 +240,33 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     float* ab0 = tab0 + ((A.table_floats + 3) & ~3);         // [n_ab][2][HdP] this sample's constant-style affines
     float* cst0 = ab0 + A.n_ab * 2 * HdP;                    // [n_cst][128]   this sample's shared-MLP constants
     float* zero0 = cst0 + A.n_cst * kShared;                 // [3][HdP] zeros: ToRGB weights of "no ToRGB"
-    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(zero0 + 3 * HdP);
+    int* dtab = reinterpret_cast<int*>(zero0 + 3 * HdP);     // [H3D_MAX_BLOCKS + 1][kDescInts] the descriptor fields the block loops read
+    unsigned char* ring_lds = reinterpret_cast<unsigned char*>(dtab + (H3D_MAX_BLOCKS + 1) * kDescInts);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int64_t HW = (int64_t)A.H * A.W;
-    const h3d_synth_desc& D = A.D;
+    // The descriptor is a kernel argument: it lives in the (host-visible) kernarg segment, and a scalar load from there that misses
+    // the scalar cache deep inside the kernel was measured at ~50 000 cycles (cycle trace: 57 % of every skip block went into the
+    // two loads of "to_rgb / w_rgb" behind the second convolution).  All lanes fetch their block's fields once, here, in parallel;
+    // the loops read the copy in LDS (dget: wave-uniform).
+    if (t <= H3D_MAX_BLOCKS) {
+        int* d = dtab + t * kDescInts;
+        if (t < H3D_MAX_BLOCKS) {
+            const h3d_block_desc& bd = A.D.block[t];
+            d[0] = bd.to_rgb; d[1] = (int)bd.w_rgb; d[2] = bd.skip;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                d[3 + 4 * q] = bd.spade[q].ab_index; d[4 + 4 * q] = bd.spade[q].cst_index;
+                d[5 + 4 * q] = bd.spade[q].g_offset; d[6 + 4 * q] = (int)bd.spade[q].vec;
+            }
+        } else {
+            d[0] = A.D.n_blocks; d[1] = (int)A.D.w_in; d[2] = (int)A.D.b_in;
+        }
+    }
+    auto dget = [&](int blk, int k) { return __builtin_amdgcn_readfirstlane(dtab[blk * kDescInts + k]); };
 
     for (int i = t; i < A.table_floats; i += 256) tab0[i] = A.tables[i];
     for (int i = t; i < A.n_ab * 2 * HdP; i += 256) ab0[i] = A.ab[(int64_t)b * A.n_ab * 2 * HdP + i];
@@ -239,15 +274,18 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     for (int i = t; i < 3 * HdP; i += 256) zero0[i] = 0.f;
     __syncthreads();
 
-#ifdef H3D_EXPERIMENT_TRACE
-    if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) { g_trace = reinterpret_cast<unsigned long long*>(A.state); g_trace_n = 0; }
-    __syncthreads();
+    H3D_TRACE_INIT();
     H3D_TRACE(0);
-#endif
     WeightRing<NT, DEPTH + (X2 ? 1 : 0), X2 ? 1 : 0> ring;        // x2: the fp6 records span two stages (LAG = 1)
     ring.init(A.stream, ring_lds, A.total_stages, wave, lane);
 
     // ---- this lane's pixel: synthesis-input coordinates and bilinear taps into the low-res maps
+    const int n_blocks = dget(H3D_MAX_BLOCKS, 0);
+    // kernel arguments used late in the kernel, pinned in scalar registers now (the compiler would otherwise re-load them from the
+    // kernarg segment where they are used -- see above)
+    int first_skip = A.first_skip, n_pixel_blocks = A.n_pixel_blocks;
+    float* rgb_out = A.rgb;
+    asm volatile("" : "+s"(first_skip), "+s"(n_pixel_blocks), "+s"(rgb_out));
     const int64_t p_tile = ((int64_t)blockIdx.x * 4 + wave) * 32;
     int64_t p = p_tile + m;
     const bool okp = p < HW;
@@ -258,7 +296,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     float sx = fmaxf(((float)X + 0.5f) * ((float)A.Wr / (float)A.W) - 0.5f, 0.f);
     const int y0 = min((int)sy, A.Hr - 1), x0 = min((int)sx, A.Wr - 1);
     const float ty = sy - (float)y0, tx = sx - (float)x0;
-    const float* __restrict__ Gb = A.G + (int64_t)b * A.Hr * A.Wr * A.g_channels;
+    const float* Gb_ = A.G + (int64_t)b * A.Hr * A.Wr * A.g_channels;
+    asm volatile("" : "+s"(Gb_));                  // loaded from the kernarg segment here, not where it is first used
+    const float* __restrict__ Gb = Gb_;
     // Bilinear resize of the low-res maps as a matrix product (the usual case: the wave's 32 pixels lie in one image
     // row and touch at most 8 low-res columns): D[ch][px] = sum_k T[k][ch] * wi[k][px] over the 16 texels
     // k = 8*r + e <-> (row ya + r, column xa + e), wi = the pixel's bilinear weights (<= 4 non-zeros).  Edge clamping
@@ -303,8 +343,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         rgb_acc[0] = r.x; rgb_acc[1] = r.y; rgb_acc[2] = r.z;
     } else {
         // ---- A8: x0 = sin(w0*i + w1*j + b) in accumulator layout
-        const float* win = tab0 + D.w_in;
-        const float* bin = tab0 + D.b_in;
+        const float* win = tab0 + dget(H3D_MAX_BLOCKS, 1);
+        const float* bin = tab0 + dget(H3D_MAX_BLOCKS, 2);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -329,10 +369,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             const int n = nt * 32 + rg * 8 + 4 * h;
             const f32x4 ta = ld4(ab + 2 * n), tb = ld4(ab + 2 * n + 4);
             float4 y;
-            y.x = lrelu(fmaf(v[nt][rg * 4 + 0], ta.x, ta.z));
-            y.y = lrelu(fmaf(v[nt][rg * 4 + 1], ta.y, ta.w));
-            y.z = lrelu(fmaf(v[nt][rg * 4 + 2], tb.x, tb.z));
-            y.w = lrelu(fmaf(v[nt][rg * 4 + 3], tb.y, tb.w));
+            y.x = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 0], ta.x, ta.z));
+            y.y = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 1], ta.y, ta.w));
+            y.z = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 2], tb.x, tb.z));
+            y.w = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 3], tb.y, tb.w));
             return y;
         });
     };
@@ -380,8 +420,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     // SPADE hipcc could not keep both accumulator sets in the 256 AGPRs and spilled three tiles (48 registers, 5 GB of
     // scratch stores per launch at 512^2 x 16) at every SPADE.
 #pragma unroll 1
-    for (int blk = 0; blk < A.n_pixel_blocks; ++blk) {
-        const h3d_block_desc& Bk = D.block[blk];
+    for (int blk = 0; blk < n_pixel_blocks; ++blk) {
         int opaque = 0;                       // keeps the loop-invariant LDS table loads inside the body
         asm volatile("" : "+s"(opaque));
         const float* tab = tab0 + opaque;
@@ -390,19 +429,19 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         (void)abt;
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
-            const h3d_spade_desc& Sp = Bk.spade[s];
             f32x16 acc[NT];
             // ---- shared-MLP activations a = relu(resize(G) + cst) of this lane's pixel as B fragments
             frag8 ah[8], al[8];
             i32x8 a6[4];
-            const float* cs = cstt + Sp.cst_index * kShared;
+            const float* cs = cstt + dget(blk, 4 + 4 * s) * kShared;
+            const int g_off = dget(blk, 5 + 4 * s);
             {
                 float tq[4][8];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        tq[tt][e] = trow[(int64_t)min(xa + e, A.Wr - 1) * A.g_channels + Sp.g_offset + 32 * tt];
+                        tq[tt][e] = trow[(int64_t)min(xa + e, A.Wr - 1) * A.g_channels + g_off + 32 * tt];
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 f32x16 (&d)[4] = reinterpret_cast<f32x16(&)[4]>(acc);
 #pragma unroll
@@ -426,13 +465,13 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     return y;
                 });
             }
-            const float* vec = tab + Sp.vec;
+            const float* vec = tab + dget(blk, 6 + 4 * s);
             // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
             set_bias(acc, vec);
             pin_agpr<NT>(x); pin_agpr<NT>(acc);
             const F16::vec8 none[1] = {};
             (void)none;
-            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, kLook>(acc, ah, a6, none, ring);
+            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, look_x2<NT>()>(acc, ah, a6, none, ring);
             else gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
             pin_agpr<NT>(x); pin_agpr<NT>(acc);
 #pragma unroll
@@ -454,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             }
             // beta:   y = lrelu(acc + beta)
             pin_agpr<NT>(acc);
-            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, kLook>(acc, ah, a6, none, ring);
+            if constexpr (X2) gemm_x2_roll<NT, 8, 0, 8, 4, false, look_x2<NT>()>(acc, ah, a6, none, ring);
             else gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
             pin_agpr<NT>(acc);
             {
@@ -463,11 +502,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             }
             pin_agpr<NT>(x);
         }
-        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
+        if (dget(blk, 0)) to_rgb(tab + dget(blk, 1), true);
     }
 #pragma unroll 1
-    for (int blk = A.n_pixel_blocks; blk < A.first_skip; ++blk) {
-        const h3d_block_desc& Bk = D.block[blk];
+    for (int blk = n_pixel_blocks; blk < first_skip; ++blk) {
         int opaque = 0;                       // keeps the loop-invariant LDS table loads inside the body
         asm volatile("" : "+s"(opaque));
         const float* tab = tab0 + opaque;
@@ -476,54 +514,60 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         (void)cstt;
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
-            const h3d_spade_desc& Sp = Bk.spade[s];
             // constant style before the first skip block: x is both source and destination, so the fragments
             // are completed before the conv starts
-            const_frags(x, abt + Sp.ab_index * 2 * HdP);
+            const_frags(x, abt + dget(blk, 3 + 4 * s) * 2 * HdP);
             if constexpr (X2) {
                 const F16::vec8 none[1] = {};
-                gemm_x2_roll<NT, KS, 0, KS, NT, false, kLook, 0, true>(x, xh, b6, none, ring);
+                gemm_x2_roll<NT, KS, 0, KS, NT, false, look_x2<NT>(), 0, true>(x, xh, b6, none, ring);
             } else {
                 gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
             }
             pin_agpr<NT>(x);
         }
-        if (Bk.to_rgb) to_rgb(tab + Bk.w_rgb, true);
+        if (dget(blk, 0)) to_rgb(tab + dget(blk, 1), true);
     }
 
     // ================= blocks from the first skip connection on (constant style only) ============================
     // conv 0 goes x -> acc (x stays live as the residual), conv 1 goes acc -> x accumulating onto the residual
     // (conv biases are folded into the consumers' tables by the host: build_x3 in synthesis_pack.py).
+    H3D_TRACE_RESET();
 #pragma unroll 1
-    for (int blk = A.first_skip; blk < D.n_blocks; ++blk) {
-        const h3d_block_desc& Bk = D.block[blk];
+    for (int blk = first_skip; blk < n_blocks; ++blk) {
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         const float* tab = tab0 + opaque;
         const float* abt = ab0 + opaque;
         f32x16 acc[NT];
         pin_agpr<NT>(x);
+        H3D_TRACE(20);
         {   // conv 0, with the ToRGB of the previous skip block's output (this block's input x) riding along
-            const float* wr_prev = (blk > A.first_skip && D.block[blk - 1].to_rgb) ? tab + D.block[blk - 1].w_rgb : zero0 + opaque;
-            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, abt + Bk.spade[0].ab_index * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+            const float* wr_prev = (blk > first_skip && dget(blk - 1, 0)) ? tab + dget(blk - 1, 1) : zero0 + opaque;
+#ifdef H3D_EXPERIMENT_NO_RGB
+            SpadeProducer<NT, true, false, X2, frag8> prod{x, xh, xl, b6, abt + dget(blk, 3) * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+#else
+            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, abt + dget(blk, 3) * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+#endif
             conv_progressive<NT, true, X2>(acc, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x); pin_agpr<NT>(acc);
+        H3D_TRACE(21);
         {
-            SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, abt + Bk.spade[1].ab_index * 2 * HdP, nullptr, rgb_acc, h, HdP};
+            SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, abt + dget(blk, 7) * 2 * HdP, nullptr, rgb_acc, h, HdP};
             conv_progressive<NT, false, X2>(x, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x);
-        if (Bk.to_rgb && h == 0) {          // bias of this block's ToRGB; its weights ride in the next block's conv 0
-            const float* wb = tab + Bk.w_rgb + 3 * HdP;
+        if (dget(blk, 0) && h == 0) {          // bias of this block's ToRGB; its weights ride in the next block's conv 0
+            const float* wb = tab + dget(blk, 1) + 3 * HdP;
             rgb_acc[0] += wb[0]; rgb_acc[1] += wb[1]; rgb_acc[2] += wb[2];
         }
     }
     H3D_TRACE(5);
-    if (D.n_blocks > A.first_skip && D.block[D.n_blocks - 1].to_rgb) to_rgb(tab0 + D.block[D.n_blocks - 1].w_rgb, false);
+    if (n_blocks > first_skip && dget(n_blocks - 1, 0)) to_rgb(tab0 + dget(n_blocks - 1, 1), false);
     H3D_TRACE(6);
     ring.drain();
     H3D_TRACE(9);
+    H3D_TRACE_DUMP(A.state);
     if (SEG && A.store_state) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -536,12 +580,12 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = rgb_acc[c] + __shfl_xor(rgb_acc[c], 32, 64);
-        if (okp && h == 0) A.rgb[((int64_t)b * 3 + c) * HW + p] = v;
+        if (okp && h == 0) rgb_out[((int64_t)b * 3 + c) * HW + p] = v;
     }
 }
 
 size_t lds_bytes(const Args& A, int NT, int depth) {
-    return sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared + 3 * (size_t)A.HdP) +
+    return sizeof(int) * (H3D_MAX_BLOCKS + 1) * kDescInts + sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared + 3 * (size_t)A.HdP) +
            (size_t)depth * NT * 2048;
 }
 

@@ -110,6 +110,9 @@ struct WeightRing {
         ring = lds;
         ring_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
         total = total_stages;
+#ifdef H3D_EXPERIMENT_SMALL_STREAM
+        total = total < 8 ? total : 8;        // timing experiment: the stream wraps inside 128 KB (always L2 hits; wrong results)
+#endif
         issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
 #pragma unroll
         for (int i = 0; i < kBuf - 1 - LAG; ++i) issue();
@@ -182,16 +185,35 @@ __device__ __forceinline__ f32x16 mm(const typename T::vec8& w, const typename T
 // s+1 and after the last read of stage s was issued; each acquire is followed by exactly one refill, one DMA chunk
 // after each of the next NT/2 tile pairs.  acc is accumulated into (initialise it with the bias / residual).
 #ifdef H3D_EXPERIMENT_TRACE
-__device__ unsigned long long* g_trace;
-__device__ int g_trace_n;
+// Development: cycle trace of workgroup (1000, 3), kept in LDS while the kernel runs (a global store per event would wait on
+// vmcnt and drain the weight ring's DMA queue) and copied out at the end (H3D_TRACE_DUMP).
+constexpr int kTraceMax = 500;
+__shared__ unsigned long long h3d_tr_buf[kTraceMax];
+__shared__ int h3d_tr_cnt;
 #define H3D_TRACE(tag)                                                                         \
     do {                                                                                       \
-        if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0 && g_trace_n < 4000) {   \
-            g_trace[g_trace_n++] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag); \
+        if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) {                       \
+            const int n_ = h3d_tr_cnt;                                                         \
+            if (n_ < kTraceMax) {                                                              \
+                h3d_tr_buf[n_] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag); \
+                h3d_tr_cnt = n_ + 1;                                                           \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+#define H3D_TRACE_INIT() do { if (threadIdx.x == 0) h3d_tr_cnt = 0; __syncthreads(); } while (0)
+#define H3D_TRACE_RESET() do { if (threadIdx.x == 0) h3d_tr_cnt = 0; } while (0)
+#define H3D_TRACE_DUMP(dst)                                                                    \
+    do {                                                                                       \
+        if (blockIdx.x == 1000 && blockIdx.y == 3 && threadIdx.x == 0) {                       \
+            unsigned long long* d_ = reinterpret_cast<unsigned long long*>(dst);               \
+            for (int i_ = 0; i_ < h3d_tr_cnt; ++i_) d_[i_] = h3d_tr_buf[i_];                   \
         }                                                                                      \
     } while (0)
 #else
 #define H3D_TRACE(tag) do { } while (0)
+#define H3D_TRACE_INIT() do { } while (0)
+#define H3D_TRACE_RESET() do { } while (0)
+#define H3D_TRACE_DUMP(dst) do { } while (0)
 #endif
 
 struct NoHook {
@@ -286,7 +308,8 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
 //   operand slots of the fp6 instruction (verified by tools/probes/{mfma_scale,fp6_cvt}_probe.hip): lane half h of A
 //   contracts slot s (bits [6s, 6s+6) of the lane's 6 dwords) with slot s of lane half h of B; per-lane e8m0 scales.
 //   A record (weights, 32 B per lane and K-tile): slots 0-15 = q6(hi(W)) of the lane's 16 features (acc order: slot 8j+e =
-//   element e of k-step 2T+j), slots 16-31 = q6(lo(W)); dword 6 = the lane's block scale (all four bytes), dword 7 = 0.
+//   element e of k-step 2T+j), slots 16-31 = q6(lo(W)); dword 6 = the lane's block scale (all four bytes), dword 7 = the same
+//   (gemm_x2_roll reads the scale from dword 7: a separate 32-bit load next to the 64-bit load of code dwords 4-5, see there).
 //   B record (activations): v_cvt_scalef32_pk32_fp6_f16 of [lo'(k-step 2T), lo'(2T+1), hi(2T), hi(2T+1)] (lo' = lo * 2^12).
 //   Stream: a stage is still one k-step, [tile][1 KiB f16 hi fragment][1 KiB]; the second KiB of an x2 k-step holds dwords
 //   0-3 (even k-step) / 4-7 (odd k-step) of the K-tile's A records, of an x3 k-step (inputs assembled from memory) the f16
@@ -397,7 +420,11 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
     constexpr int KS = KS2 + KS3, P = NT / 2, G = KS * P, NB = L + 1;
     static_assert(NT % 2 == 0 && KS2 % 2 == 0 && KS <= KSA && KS2 / 2 <= KT && L >= 1 && L <= P, "look-ahead is at most one k-step");
     static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
-    struct Pair { typename T::vec8 h[2], l[2]; u32x4 c[2][2]; } buf[NB];
+    // record halves: dwords 0-3 (stage s - 1) and 4-6 (stage s: codes 4, 5 and the scale) -- the second as a 64-bit and a 32-bit
+    // load, so that the code dwords land in sub-registers of the instruction's ONE 6-register operand (a 128-bit second half
+    // cannot: the compiler then copies two dwords per fp6 instruction)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    struct Pair { typename T::vec8 h[2], l[2]; u32x4 c0[2]; u32x2 c1[2]; unsigned sc[2]; } buf[NB];
     const unsigned char* st[2];
     auto load_pair = [&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value, s = q / P;
@@ -410,8 +437,9 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
                 b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 1) * 1024));
             } else if constexpr (s % 2 == 1) {
                 const unsigned char* bp = st[(s - 1) & 1] + (q % P) * 4096;
-                b.c[i][0] = *reinterpret_cast<const u32x4*>(bp + (i * 2 + 1) * 1024);
-                b.c[i][1] = *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 1) * 1024);
+                b.c0[i] = *reinterpret_cast<const u32x4*>(bp + (i * 2 + 1) * 1024);
+                b.c1[i] = *reinterpret_cast<const u32x2*>(b0 + (i * 2 + 1) * 1024);
+                b.sc[i] = *reinterpret_cast<const unsigned*>(b0 + (i * 2 + 1) * 1024 + 12);      // the scale again in dword 7: not mergeable into a 96-bit load
             }
         }
     };
@@ -425,6 +453,7 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
             st[(s + 1) & 1] = ring.acquire();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (p == 0) H3D_TRACE(100 + s);
         if constexpr (g + L < G) load_pair(IC<g + L>{});
         hook(gc);
         const Pair& b = buf[g % NB];
@@ -446,8 +475,8 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
         } else if constexpr (s % 2 == 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const i32x8 w6 = {(int)b.c[i][0][0], (int)b.c[i][0][1], (int)b.c[i][0][2], (int)b.c[i][0][3],
-                                  (int)b.c[i][1][0], (int)b.c[i][1][1], (int)b.c[i][1][2], (int)b.c[i][1][3]};
+                const i32x8 w6 = {(int)b.c0[i][0], (int)b.c0[i][1], (int)b.c0[i][2], (int)b.c0[i][3],
+                                  (int)b.c1[i][0], (int)b.c1[i][1], (int)b.sc[i], 0};
                 acc[n0 + i] = mm6<SWAP>(w6, b6[s / 2], acc[n0 + i]);
             }
         }

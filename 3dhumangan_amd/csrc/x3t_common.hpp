@@ -479,7 +479,7 @@ inline void x2_make_record(const float (&hi)[16], const float (&lo)[16], unsigne
         rec[bit / 32] |= (unsigned)(code << (bit & 31));
         if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
     }
-    rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+    rec[6] = rec[7] = (unsigned)(127 - ea) * 0x01010101u;
 }
 
 // x3t_pack_f16 for the x2 tier: accumulator-order matrices only (KSm even); hi planes as x3t_pack_f16, the "lo" planes hold

@@ -265,7 +265,7 @@ class SynthesisPlan:
         b2 = (c[..., 2] >> 4) | (c[..., 3] << 2)
         rec = torch.zeros(N, T, 2, 32, dtype=torch.uint8, device=dev)
         rec[..., :24] = torch.stack([b0, b1, b2], dim=-1).reshape(N, T, 2, 24).to(torch.uint8)
-        rec[..., 24:28] = (127 - ea).to(torch.uint8).unsqueeze(-1)
+        rec[..., 24:32] = (127 - ea).to(torch.uint8).unsqueeze(-1)      # dword 6, and again in dword 7 (the register engine reads it there)
         # [N = (nt, j32), T, h, (half, 16 B)] -> stage [ks = 2T + half][nt][lane = 32 h + j32][16 B]
         rec = rec.view(NT, 32, T, 2, 2, 16).permute(2, 4, 0, 3, 1, 5).reshape(KS, NT, 64 * 16)
         out = torch.empty(KS, NT, 2, 1024, dtype=torch.uint8, device=dev)
@@ -466,11 +466,13 @@ class SynthesisPlan:
     def x3_forward_tables(self, feature_maps, fixed_style, x2=False):
         """per_forward_tables for the x3 engine: the conv biases folded into the constant-style shifts (build_x3) and
         `ab` in the kernel's layout [B, n_ab, HdP/2, 4] = sc[n], sc[n+1], sh[n], sh[n+1] (one 16-byte LDS read per two
-        channels)."""
+        channels), both times 0.4: the kernel evaluates lrelu(t) = 0.6 t + 0.4 |t| as fma(u, 1.5, |u|) on u = 0.4 t (two
+        instructions per activation instead of three)."""
         x3 = self.build_x3(x2)
         G, cst, ab = self.per_forward_tables(feature_maps, fixed_style, x3["HdP"])
         if ab is not None:
             ab[:, :, 1] += ab[:, :, 0] * x3["ab_carry"][None, : ab.shape[1]]
+            ab = ab * 0.4
             Bq, nq, _, Hq = ab.shape
             ab = ab.view(Bq, nq, 2, Hq // 2, 2).permute(0, 1, 3, 2, 4).contiguous()
         return G, cst, ab

@@ -316,8 +316,9 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * registers of the producing layer are then its B-fragment elements; every matrix of this engine is fed that way);
  * tiles = 4 (C <= 128) or 8 (C <= 256), HdP = 32*tiles.  `tables`: fp32, the descriptor's vec / b_conv / w_rgb /
  * w_in / b_in offsets index it (vectors HdP long); w_gamma / w_beta / w_conv of the descriptor are ignored.
- * `ab` for THIS entry point is [B, n_ab, HdP/2, 4] = (scale[n], scale[n+1], shift[n], shift[n+1]) -- one 16-byte read per
- * two channels -- not the [B, n_ab, 2, HdP] of h3d_synthesis.
+ * `ab` for THIS entry point is [B, n_ab, HdP/2, 4] = 0.4 * (scale[n], scale[n+1], shift[n], shift[n+1]) -- one 16-byte read per
+ * two channels -- not the [B, n_ab, 2, HdP] of h3d_synthesis; the factor 0.4 because the kernel evaluates
+ * lrelu(t) = 0.6 t + 0.4 |t| as 1.5 u + |u| on u = 0.4 t (one instruction after the affine).
  * The conv biases are NOT read by this engine: the caller folds them into the consumers' tables (the activations it
  * carries are the true ones minus a per-channel carry c; SPADE shift sh' = sh + sc*c in `ab` / `vec`, ToRGB bias
  * br' = br + Wr*c -- see SynthesisPlan.build_x3 in lib/generators/synthesis_pack.py).

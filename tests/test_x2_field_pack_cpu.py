@@ -64,7 +64,7 @@ def decode_x2(blob, off, KS, NT):
             bits[..., s] = (v & np.uint64(63)).astype(np.int64)
         vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
         sb = rec[..., 6]
-        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == 0)
+        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == sb)        # the scale again in dword 7
         scale = torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127))
         recs[T] = (vals, scale)                        # vals [NT, 64, 32]; lanes = 32 * h + (row % 32)
     return Whi, recs
@@ -134,7 +134,7 @@ def decode_x2t(blob, off, KStot, ks0, KS, NT):
             bits[..., s] = (v & np.uint64(63)).astype(np.int64)
         vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
         sb = rec[..., 6]
-        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == 0)
+        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == sb)        # the scale again in dword 7
         recs[T] = (vals, torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127)))
     return Whi, recs
 

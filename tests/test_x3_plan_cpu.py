@@ -57,7 +57,7 @@ def decode_x2(stream_i16, stage0, KS, NT, order=None):
         c = torch.stack([b[..., 0] & 63, (b[..., 0] >> 6) | ((b[..., 1] & 15) << 2), (b[..., 1] >> 4) | ((b[..., 2] & 3) << 4),
                          b[..., 2] >> 2], dim=-1).reshape(NT, 64, 32)
         vals = CODES[c & 31] * torch.where((c & 32) > 0, -1.0, 1.0)
-        assert torch.equal(rec[..., 24:28], rec[..., 24:25].expand(-1, -1, 4)) and int(rec[..., 28:].abs().max()) == 0
+        assert torch.equal(rec[..., 24:32], rec[..., 24:25].expand(-1, -1, 8))          # the scale byte fills dwords 6 and 7
         scale = torch.exp2((rec[..., 24] - 127).double())
         for h in range(2):
             feats = torch.tensor([order(2 * T + j, h, e) for j in range(2) for e in range(8)])
@@ -112,7 +112,8 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
                 t4 = ab[:, d.ab_index].double()                       # [B, HdP/2, 2 (sc | sh), 2 (channel pair)]
                 sc = t4[:, :, 0, :].reshape(B, 1, HdP)
                 sh = t4[:, :, 1, :].reshape(B, 1, HdP)
-                y = lrelu(x * sc + sh)
+                u = x * sc + sh                                      # the tables carry 0.4 * (sc, sh): lrelu(t) = 1.5 u + |u|
+                y = 1.5 * u + u.abs()
             Wc = decode(stream, stage, 2 * NT, NT); stage += 2 * NT
             x = mm(y, Wc) + (x_in if (s == 1 and bk.skip) else 0.0)
         if bk.to_rgb:

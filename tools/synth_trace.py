@@ -22,7 +22,8 @@ st = torch.randn(16, 1, 256, device="cuda")
 for _ in range(3):
     G._synthesize(fmap, st, (96, 96))
 torch.cuda.synchronize()
-tr = G.synthesis_plan(fmap.device).build_x3()["trace"].cpu().tolist()
+plan = G.synthesis_plan(fmap.device)
+tr = plan.build_x3(plan.engine == "f16x2")["trace"].cpu().tolist()
 ev = [(t >> 8, t & 255) for t in tr if t]
 t0 = ev[0][0]
 prev = t0
