@@ -37,6 +37,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 
 using namespace h3d;
 
@@ -117,6 +118,7 @@ struct Args {
     int64_t N;
     int Hd, F, geo_stride, S, clamp_mode, last_back, white_back;
     int R, log2S;        // fused: rays per batch item; log2(S) when S <= 32 (a power of two), else -1
+    int n_groups;        // unit groups (4 wave units each) per sample; a workgroup walks blockIdx.x, + gridDim.x, ..
     float input_scaler;
     LayoutX3 L;
 };
@@ -371,16 +373,22 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int unit = FUSED ? (S > 32 ? S : 32) : 32;          // samples a wave walks per unit (whole rays when fused)
     const int steps = unit / 32;
     const int seglen = FUSED ? (S < 32 ? S : 32) : 32;
-    const int64_t u0 = ((int64_t)blockIdx.x * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
-    // ray of sample n (fused): no 64-bit division -- S > 32: one ray per wave unit; S <= 32: S is a power of two
-    const int64_t unit_ray = (int64_t)b * A.R + ((int64_t)blockIdx.x * 4 + wave);
-    auto ray_of = [&](int64_t nn) -> int64_t { return A.log2S < 0 ? unit_ray : (int64_t)b * A.R + (nn >> A.log2S); };
-
     H3D_TRACE_INIT();
     H3D_TRACE(0);
     typedef typename std::conditional<X2, WeightRing<NT, kRingX2, 1>, WeightRing<NT>>::type Ring;
     Ring ring;
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
+    int n_groups = A.n_groups;
+    asm volatile("" : "+s"(n_groups));           // pinned: not re-loaded from the kernarg segment inside the loop
+
+    // Persistent workgroups: the sample's tables above are built once, then the workgroup walks the unit groups blockIdx.x,
+    // blockIdx.x + gridDim.x, .. with the weight ring running across them (the stream wraps at the end of every step).
+#pragma unroll 1
+    for (int ug = blockIdx.x; ug < n_groups; ug += gridDim.x) {
+    const int64_t u0 = ((int64_t)ug * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
+    // ray of sample n (fused): no 64-bit division -- S > 32: one ray per wave unit; S <= 32: S is a power of two
+    const int64_t unit_ray = (int64_t)b * A.R + ((int64_t)ug * 4 + wave);
+    auto ray_of = [&](int64_t nn) -> int64_t { return A.log2S < 0 ? unit_ray : (int64_t)b * A.R + (nn >> A.log2S); };
 
     float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
     float rayacc[NT];
@@ -620,6 +628,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    }   // unit groups
     ring.drain();
     H3D_TRACE(9);
     H3D_TRACE_DUMP(A.out);
@@ -631,10 +640,20 @@ size_t lds_bytes(const LayoutX3& L) {
 }
 
 template <int NT, bool FUSED, bool X2>
-int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+int launch_one(Args A, int B, int64_t groups, hipStream_t st) {
     H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED, X2>));
+    A.n_groups = (int)groups;
+    // about four persistent workgroups per CU in total (one resident per CU: registers): tables once per many unit groups, short tail
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    static const int per_cu = getenv("H3D_FIELD_WG_PER_CU") ? atoi(getenv("H3D_FIELD_WG_PER_CU")) : 4;      // 0: one unit group per workgroup
+    const int64_t per_sample = per_cu <= 0 ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2>), dim3((unsigned)per_sample, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
     return h3d::launch_status(FUSED ? (X2 ? "h3d_render_fused_x2" : "h3d_render_fused_x3") : (X2 ? "h3d_neural_field_x2" : "h3d_neural_field_x3"));
 }
 

@@ -20,6 +20,8 @@
 // (= per-pixel) power-of-two scale taken from the largest of the lane's 16 values.  The bilinear resize product keeps three
 // bf16 products (12 small MFMAs per SPADE).
 #include "x3_common.hpp"
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace h3d;
@@ -51,6 +53,7 @@ struct Args {
     int table_floats, total_stages, g_channels, Hr, Wr, n_cst, n_ab, H, W, HdP, C, first_skip, n_pixel_blocks;
     float* state;          // [wave tiles][NT*4 + 1][64 lanes] float4: activations (+ rgb partial sums) between segments
     int load_state, store_state;
+    int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
 };
 
 __device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
@@ -283,10 +286,15 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     const int n_blocks = dget(H3D_MAX_BLOCKS, 0);
     // kernel arguments used late in the kernel, pinned in scalar registers now (the compiler would otherwise re-load them from the
     // kernarg segment where they are used -- see above)
-    int first_skip = A.first_skip, n_pixel_blocks = A.n_pixel_blocks;
+    int first_skip = A.first_skip, n_pixel_blocks = A.n_pixel_blocks, n_tiles = A.n_tiles;
     float* rgb_out = A.rgb;
-    asm volatile("" : "+s"(first_skip), "+s"(n_pixel_blocks), "+s"(rgb_out));
-    const int64_t p_tile = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    asm volatile("" : "+s"(first_skip), "+s"(n_pixel_blocks), "+s"(rgb_out), "+s"(n_tiles));
+    // Persistent workgroups: a workgroup walks the 128-pixel tiles blockIdx.x, blockIdx.x + gridDim.x, .. of its sample with the
+    // tables above staged once and the weight ring running across tile boundaries (the stream wraps exactly at the end of the
+    // network, so the first stages of the next tile are prefetched under the last layers of this one).
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t p_tile = ((int64_t)tile * 4 + wave) * 32;
     int64_t p = p_tile + m;
     const bool okp = p < HW;
     if (!okp) p = min(p_tile, HW - 1);          // lanes past the image shadow the tile's first pixel (never stored)
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     i32x8 b6[NT];
     float rgb_acc[3] = {0.f, 0.f, 0.f};
 
-    const int64_t wtile = (int64_t)b * gridDim.x * 4 + (int64_t)blockIdx.x * 4 + wave;
+    const int64_t wtile = (int64_t)b * n_tiles * 4 + (int64_t)tile * 4 + wave;
     float4* st_io = reinterpret_cast<float4*>(A.state) + wtile * (NT * 4 + 1) * 64 + lane;
     if (SEG && A.load_state) {
         // ---- resume: activations (lane-linear, as the previous segment left them) and the ToRGB partial sums
@@ -565,9 +573,6 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     H3D_TRACE(5);
     if (n_blocks > first_skip && dget(n_blocks - 1, 0)) to_rgb(tab0 + dget(n_blocks - 1, 1), false);
     H3D_TRACE(6);
-    ring.drain();
-    H3D_TRACE(9);
-    H3D_TRACE_DUMP(A.state);
     if (SEG && A.store_state) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -575,13 +580,17 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             for (int rg = 0; rg < 4; ++rg)
                 st_io[(nt * 4 + rg) * 64] = make_float4(x[nt][rg * 4 + 0], x[nt][rg * 4 + 1], x[nt][rg * 4 + 2], x[nt][rg * 4 + 3]);
         st_io[NT * 4 * 64] = make_float4(rgb_acc[0], rgb_acc[1], rgb_acc[2], 0.f);
-        return;
+        continue;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = rgb_acc[c] + __shfl_xor(rgb_acc[c], 32, 64);
         if (okp && h == 0) rgb_out[((int64_t)b * 3 + c) * HW + p] = v;
     }
+    }   // tiles
+    ring.drain();
+    H3D_TRACE(9);
+    H3D_TRACE_DUMP(A.state);
 }
 
 size_t lds_bytes(const Args& A, int NT, int depth) {
@@ -590,10 +599,21 @@ size_t lds_bytes(const Args& A, int NT, int depth) {
 }
 
 template <int NT, int DEPTH, bool SEG, bool X2>
-int launch_seg(const Args& A, int B, int64_t groups, hipStream_t st) {
+int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
     H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2>));
+    A.n_tiles = (int)groups;
+    // persistent workgroups (one per CU at a time: registers and LDS): about four per CU in total, so that the tables are staged
+    // once per ~n_tiles * B / (4 CUs) tiles while the tail of the launch stays short; segmented runs keep one tile per workgroup
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    static const int per_cu = getenv("H3D_SYNTH_WG_PER_CU") ? atoi(getenv("H3D_SYNTH_WG_PER_CU")) : 4;      // 0: one tile per workgroup
+    const int64_t per_sample = (SEG || per_cu <= 0) ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2>), dim3((unsigned)groups, (unsigned)B), dim3(256),
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH + (X2 ? 1 : 0)), st, A);
     return h3d::launch_status(X2 ? "h3d_synthesis_x2" : "h3d_synthesis_x3");
 }
