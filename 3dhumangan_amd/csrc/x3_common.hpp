@@ -167,6 +167,24 @@ struct WeightRing {
         cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
         return r;
     }
+    // Two consecutive stages (t, t + 1) behind ONE wait + barrier (the x2 GEMM consumes stages in pairs: an fp6 record spans an
+    // even / odd pair): half the workgroup barriers of acquire() per stage.  One stage fewer stays in flight while waiting.  The
+    // write-after-read argument of acquire() carries over: the refills issued during the two k-steps that follow land in the
+    // buffers of stages t - 1 - LAG and t - LAG, whose last reads every wave issued before it arrived here.
+    __device__ __forceinline__ void acquire2(const unsigned char*& r0, const unsigned char*& r1) {
+        static_assert(kBuf - 3 - LAG >= 0, "ring too shallow for paired acquires");
+        constexpr int kKeep = (kBuf - 3 - LAG) * kChunks;
+#ifndef H3D_EXPERIMENT_NO_BARRIER
+        __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
+        __builtin_amdgcn_s_barrier();
+#endif
+        const int nxt = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
+        int off0 = cur_buf * kStage + lane * 16, off1 = nxt * kStage + lane * 16;
+        asm volatile("" : "+v"(off0), "+v"(off1));
+        r0 = ring + off0;
+        r1 = ring + off1;
+        cur_buf = nxt + 1 == kBuf ? 0 : nxt + 1;
+    }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
@@ -413,6 +431,9 @@ __device__ __forceinline__ i32x8 x2_record_dyn(const F16::vec8& l0, const F16::v
 // acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3
 // k-steps (B operands xh[s], xl3[s - KS2]: fragments assembled from memory, lo unscaled).  Same ring protocol, look-ahead
 // and hook convention as gemm_x3_roll; a section carries 2 (even x2 k-step), 4 (odd) or 6 (x3) MFMAs.
+#ifndef H3D_X2_PAIRED_ACQUIRE
+#define H3D_X2_PAIRED_ACQUIRE 1
+#endif
 template <int NT, int KS2, int KS3, int KSA, int KT, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 (&xh)[KSA], const i32x8 (&b6)[KT],
                                              const F16::vec8 (&xl3)[KS3 > 0 ? KS3 : 1], RING& ring, HOOK hook = HOOK()) {
@@ -443,14 +464,20 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
             }
         }
     };
-    st[0] = ring.acquire();
+    // stages are acquired in pairs (one barrier per two k-steps): (0, 1) here, (s + 1, s + 2) inside every odd k-step s
+    if constexpr (KS >= 2 && H3D_X2_PAIRED_ACQUIRE) ring.acquire2(st[0], st[1]);
+    else st[0] = ring.acquire();
     ring.issue();
     static_for<0, L>(load_pair);
     static_for<0, G>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int s = g / P, p = g % P;
         if constexpr (p == P - L && s + 1 < KS) {
-            st[(s + 1) & 1] = ring.acquire();
+            if constexpr (!H3D_X2_PAIRED_ACQUIRE) st[(s + 1) & 1] = ring.acquire();
+            else if constexpr (s % 2 == 1) {
+                if constexpr (s + 2 < KS) ring.acquire2(st[(s + 1) & 1], st[s & 1]);
+                else st[(s + 1) & 1] = ring.acquire();
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (p == 0) H3D_TRACE(100 + s);
