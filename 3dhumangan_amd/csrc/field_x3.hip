@@ -57,6 +57,7 @@ constexpr float kSIn = 64.f;       // input scale (coords / geometry features, |
 #define H3D_FIELD_VALU 4
 #endif
 constexpr int kLookF = H3D_FIELD_LOOK;          // weight-fragment look-ahead in tile pairs
+constexpr int kValuF2 = 0;                      // x2: no forced VALU / MFMA interleave (measured: 17.19 -> 16.86 ms vs 4; 3 and 8 in between)
 constexpr int kValuF = H3D_FIELD_VALU;          // VALU instructions slotted behind each MFMA of a section carrying epilogue work
 
 // per-step activation tables (A1, A0) in LDS
@@ -283,7 +284,7 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
     if constexpr (X2) {
         constexpr int KS3 = KSG - KS;
         const half8 tail[1] = {xl[KS]};                 // view direction k-step: assembled from memory, lo unscaled
-        gemm_x2_roll<NT, KS, KS3, 2 * NT + 1, NT, SWAP, kLookF, kValuF, ZERO>(dst, xh, b6, tail, ring, hook);
+        gemm_x2_roll<NT, KS, KS3, 2 * NT + 1, NT, SWAP, kLookF, kValuF2, ZERO>(dst, xh, b6, tail, ring, hook);
     } else {
         gemm_x3_roll<F16, NT, KSG, 2 * NT + 1, SWAP, kLookF, kValuF, ZERO>(dst, xh, xl, ring, hook);
     }

@@ -35,7 +35,11 @@ constexpr int kShared = 128;
 #endif
 constexpr int kRingDepth = H3D_SYNTH_RING;
 constexpr int kDescInts = 12;       // descriptor fields per block kept in LDS (multiple of 4: the ring behind them stays 16-byte aligned)
-constexpr int kValuPerMfma = 5;    // VALU instructions slotted behind each MFMA of a section that carries epilogue work
+#ifndef H3D_SYNTH_VALU
+#define H3D_SYNTH_VALU 5
+#endif
+constexpr int kValuPerMfma = H3D_SYNTH_VALU;
+constexpr int kValuPerMfmaX2 = 0;  // x2: the scheduler places the producers' VALU work itself (24.27 -> 24.11 ms vs 5)    // VALU instructions slotted behind each MFMA of a section that carries epilogue work
 #ifndef H3D_SYNTH_LOOK_X2
 #define H3D_SYNTH_LOOK_X2 2
 #endif
@@ -226,7 +230,7 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
     };
     if constexpr (X2) {
         const F16::vec8 none[1] = {};
-        gemm_x2_roll<NT, 2 * NT, 0, 2 * NT, NT, false, look_x2<NT>(), kValuPerMfma, ZERO>(dst, xh, b6, none, ring, hook);
+        gemm_x2_roll<NT, 2 * NT, 0, 2 * NT, NT, false, look_x2<NT>(), kValuPerMfmaX2, ZERO>(dst, xh, b6, none, ring, hook);
     } else {
         gemm_x3_roll<BF16, NT, 2 * NT, 2 * NT, false, kLook, kValuPerMfma, ZERO>(dst, xh, xl, ring, hook);
     }

@@ -59,7 +59,7 @@ def h3d():
 
 def rel_err(a, b):
     a, b = a.double(), b.double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return float(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).detach())
 
 
 def rel_err_channels(a, b, dim=1):
