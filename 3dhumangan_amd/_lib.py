@@ -76,6 +76,7 @@ _SIGNATURES = {
     "h3d_modconv1x1": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _f, _p]),
     "h3d_modconv2d": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_synthesis_x3_geometry_ok": (C.c_int, [_i, _i, _i, _i]),
+    "h3d_synthesis_x3_lds_bytes": (C.c_int64, [_i, _i, _i, _i, _i]),
     "h3d_sample_pdf": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _f, _p]),
     "h3d_ray_points": (C.c_int, [_p, _p, _p, _p, _i, _l, _i, _p]),
     "h3d_merge_samples": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),

@@ -741,5 +741,14 @@ extern "C" int h3d_synthesis_x2(const void* stream, int64_t total_stages, const 
     return synthesis_x(true, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
                        state, load_state, store_state, stream_);
 }
+/* HOST helper: LDS bytes of the x3 (x2 = 0) / x2 (x2 = 1) kernel at its minimum ring depth for a network of width C with
+ * `table_floats` static table floats, n_ab constant-style and n_cst per-pixel SPADEs -- the planner's fit test (<= 160 KiB). */
+extern "C" int64_t h3d_synthesis_x3_lds_bytes(int table_floats, int n_ab, int n_cst, int C, int x2) {
+    Args A{};
+    A.table_floats = table_floats; A.n_ab = n_ab; A.n_cst = n_cst;
+    const int NT = C > 128 ? 8 : 4;
+    A.HdP = NT * 32;
+    return (int64_t)lds_bytes(A, NT, kRingDepth + (x2 ? 1 : 0));
+}
 /* LDS the x2 variant needs beyond the x3 one, for host-side planning (one more ring buffer) */
 extern "C" int h3d_synthesis_x2_extra_lds(int C) { return (C > 128 ? 8 : 4) * 2048; }

@@ -177,18 +177,20 @@ class SynthesisPlan:
             if any(px) and (seen_const or not all(px)):          # per-pixel styles: a leading run of whole blocks
                 return False
             seen_const = seen_const or not any(px)
-        # LDS budget of csrc/synthesis_x3.hip: static tables + per-sample tables + 4-deep weight ring <= 160 KB
+        # LDS budget of csrc/synthesis_x3.hip (tables, per-sample tables, descriptor copy, 4-deep weight ring): the kernel's own count
+        return self._x3_fits(False)
+
+    def _x3_fits(self, x2):
         x3 = self.build_x3()
-        per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED
-        return all(4 * (seg["tables"].numel() + per_sample) + 4 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
+        need = _lib.load().h3d_synthesis_x3_lds_bytes
+        return all(need(seg["tables"].numel(), len(self.const_ids), len(self.pixel_ids), self.C, int(x2)) <= 160 * 1024
+                   for seg in x3["segments"])
 
     def x2_supported(self):
         """x3_supported with room for the x2 kernel's fifth ring buffer."""
         if not self.x3_supported():
             return False
-        x3 = self.build_x3()
-        per_sample = len(self.const_ids) * 2 * x3["HdP"] + len(self.pixel_ids) * SHARED
-        return all(4 * (seg["tables"].numel() + per_sample) + 5 * x3["NT"] * 2048 <= 160 * 1024 for seg in x3["segments"])
+        return self._x3_fits(True)
 
     @staticmethod
     def pack_stream_bf16(w_out_in, KS, NT, acc_order=True, dtype=torch.bfloat16):

@@ -334,6 +334,9 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
 /* 1 when the x3 engine's matrix-core bilinear resize covers this geometry (only needed with per-pixel-style blocks):
  * W a multiple of 32 and 32 consecutive output pixels touching at most 8 low-res columns (31*Wr < 6*W). */
 int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr);
+/* HOST helper: LDS bytes h3d_synthesis_x3 (x2 = 0) / h3d_synthesis_x2 (x2 = 1) needs for a network of width C with
+ * `table_floats` floats of static tables, n_ab constant-style and n_cst per-pixel-style SPADEs (must be <= 160 KiB). */
+int64_t h3d_synthesis_x3_lds_bytes(int table_floats, int n_ab, int n_cst, int C, int x2);
 
 int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,

@@ -155,3 +155,16 @@ def test_x3_plan_matches_oracle(mode, width, x2):
     ref = O.synthesis_network(sd, x0, fm_up, style.view(B, 1, width), mode, tuple(meta["mod_blocks"]), meta["synthesis_blocks"])["final"]
     # bf16 hi + lo carries 16 significant bits of every weight: 1e-4 covers it comfortably
     assert rel_err(got.float(), ref) < 1e-4
+
+
+def test_planner_uses_the_kernels_own_lds_count():
+    """x3_supported / x2_supported ask the library how much LDS the kernel needs (tables + per-sample tables + descriptor copy +
+    weight ring) instead of restating the formula: the x2 kernel needs exactly one more ring buffer, and a table set that leaves
+    no room for it makes the plan fall back to the x3 engine, not fail at launch."""
+    lib = importlib.import_module("3dhumangan_amd._lib").load()
+    base = lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 0)
+    assert lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 1) - base == lib.h3d_synthesis_x2_extra_lds(256) == 8 * 2048
+    assert lib.h3d_synthesis_x3_lds_bytes(11544 + 4, 12, 6, 256, 0) - base == 16          # 4 more table floats
+    assert lib.h3d_synthesis_x3_lds_bytes(11544, 13, 6, 256, 0) - base == 2 * 256 * 4     # one more constant-style SPADE
+    assert lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 1) <= 160 * 1024             # MAP3DBN512 (the bench workload) fits x2
+    assert lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 1) > 160 * 1024 >= lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 0)
