@@ -1,0 +1,81 @@
+"""Host logic of the native convolution path (lib/components/ops/conv.py, ops/linear.py) on the CPU: tilings from the library's
+host helper, the torch restatement of the weight stream (decoded back and run as an implicit GEMM against F.conv2d), the
+channels-last row view the kernels are handed, and the channel-narrowing Function.  No kernel launch."""
+import importlib
+
+import pytest
+import torch
+
+conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+linear = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+
+
+def test_tilings_follow_the_channel_counts():
+    assert conv.tiling(256, 256) == (8, 1, 8, 2)            # NT, output blocks, k-steps per chunk, chunks
+    assert conv.tiling(128, 512) == (8, 2, 8, 1)
+    assert conv.tiling(64, 128) == (4, 1, 4, 1)
+    assert conv.tiling(192, 192) == (2, 3, 4, 3)            # 192 = 3 x 64: two-tile output blocks, 64-channel chunks
+    assert conv.tiling(64, 64) == (2, 1, 4, 1)
+    for bad in ((3, 64), (64, 1), (100, 128), (128, 96 + 1)):
+        assert conv.tiling(*bad) is None
+    assert linear._native_ok(256, 256) and linear._native_ok(128, 768) and not linear._native_ok(3, 256) and not linear._native_ok(256, 100)
+
+
+def _decode(stream_i16, co, ci, k):
+    """[ob][tap][chunk][ks][nt][hi|lo][h][j][e] of bf16 bit patterns -> dense [Co, Ci, k, k] (hi + lo)."""
+    NT, nblk, KSC, nch = conv.tiling(ci, co)
+    t = stream_i16.view(torch.bfloat16).double().view(nblk, k * k, nch, KSC, NT, 2, 2, 32, 8)
+    t = t[:, :, :, :, :, 0] + t[:, :, :, :, :, 1]                          # ob, tap, chunk, ks, nt, h, j, e
+    t = t.permute(0, 4, 6, 2, 3, 5, 7, 1)                                  # ob, nt, j, chunk, ks, h, e, tap
+    return t.reshape(co, ci, k, k)
+
+
+@pytest.mark.parametrize("co,ci,k", [(64, 64, 3), (128, 192, 1), (256, 128, 3)])
+def test_weight_stream_restatement_decodes_to_the_weights(co, ci, k):
+    w = torch.randn(co, ci, k, k, generator=torch.Generator().manual_seed(co + ci + k))
+    s = conv.pack_stream_torch(w)
+    assert s.dtype == torch.int16 and s.numel() == 2 * w.numel()
+    back = _decode(s, co, ci, k)
+    assert float((back - w.double()).abs().max()) < 2.0 ** -16 * float(w.abs().max())        # bf16 hi + lo: 16 significant bits
+    x = torch.randn(2, ci, 5, 6, generator=torch.Generator().manual_seed(1)).double()
+    ref = torch.nn.functional.conv2d(x, w.double(), padding=k // 2)
+    got = torch.nn.functional.conv2d(x, back, padding=k // 2)
+    assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
+def test_rows_view_takes_channels_last_tensors_and_channel_slices_as_they_are():
+    x = torch.randn(2, 64, 4, 8).contiguous(memory_format=torch.channels_last)
+    r, ld = conv._rows(x)
+    assert ld == 64 and r.data_ptr() == x.data_ptr()
+    wide = torch.randn(2, 192, 4, 8).contiguous(memory_format=torch.channels_last)
+    sl = wide[:, 64:128]                                                     # what the backward of a skip concatenation hands out
+    r, ld = conv._rows(sl)
+    assert ld == 192 and r.data_ptr() == sl.data_ptr()
+    r, ld = conv._rows(torch.randn(2, 64, 4, 8))                             # NCHW: copied
+    assert ld == 64 and r.is_contiguous(memory_format=torch.channels_last)
+    r, ld = conv._rows(wide[:, 2:66])                                        # misaligned slice: copied
+    assert ld == 64
+
+
+def test_narrow_channels_keeps_gradients_channels_last_and_is_differentiable_again():
+    y = torch.randn(2, 64, 3, 5, dtype=torch.float64).contiguous(memory_format=torch.channels_last).requires_grad_()
+    out = conv._NarrowChannels.apply(y, 3)
+    assert out.shape == (2, 3, 3, 5) and torch.equal(out, y[:, :3])
+    g = torch.randn(2, 3, 3, 5, dtype=torch.float64, requires_grad=True)
+    (gy,) = torch.autograd.grad(out, y, g, create_graph=True)
+    assert gy.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(gy[:, :3].detach(), g.detach()) and float(gy[:, 3:].detach().abs().max()) == 0.0
+    (gg,) = torch.autograd.grad((gy * gy).sum(), g)                          # through the backward: d/dg sum(pad(g)^2) = 2 g
+    assert torch.allclose(gg, 2 * g)
+
+
+def test_linear_rows_as_image_is_a_view_of_the_same_memory():
+    t = torch.arange(6 * 64, dtype=torch.float32).view(6, 64)
+    img = linear._as_image(t)
+    assert img.shape == (1, 64, 1, 6) and img.data_ptr() == t.data_ptr()
+    assert torch.equal(img[0, :, 0, :].t(), t)
+    wide = torch.arange(6 * 128, dtype=torch.float32).view(6, 128)[:, :64]  # row stride 128
+    img = linear._as_image(wide)
+    assert torch.equal(img[0, :, 0, :].t(), wide)
+    r, ld = conv._rows(img)
+    assert ld == 128 and r.data_ptr() == wide.data_ptr()
