@@ -457,7 +457,8 @@ def op_rooflines():
     out = {}
     x = torch.empty(8, 64, 512, 512, device="cuda")
     ms = timeit(lambda: x.fill_(1.0))
-    out["hbm_write_only_reference"] = dict(achieved=x.numel() * 4.0 / ms / 1e6, unit="GB/s", ms=ms, bytes=x.numel() * 4.0,
+    out["hbm_write_only_reference"] = dict(bound="hbm", achieved=x.numel() * 4.0 / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
+                                           frac=x.numel() * 4.0 / ms / 1e6 / HBM_PEAK_GBS, ms=ms, bytes=x.numel() * 4.0,
                                            note="a plain fill of a 537 MB tensor: what a write-only stream reaches on this box (context for "
                                                 "the write-dominated resampling kernels below; the 8 TB/s peak is read + write)")
     del x
