@@ -8,11 +8,13 @@
 The pickled objects name classes under the reference's import paths (`lib.generators.map3d_generator.Map3DGenerator`,
 `lib.components.ema.ExponentialMovingAverage`, ...), which do not exist here.  They are restored WITHOUT the reference on
 the path: an unpickler maps every class under `lib.` / `configs` to a stand-in built on the fly (an nn.Module subclass when
-the pickled state has module dictionaries), which is all `state_dict()` needs; torch's own classes (spectral-norm hooks,
-parameters, tensors) resolve normally.  Only data is taken from the file: every other global a pickle may name is checked
-against an allow-list (torch's tensor / storage / parameter rebuild helpers, torch.nn classes, `collections.OrderedDict`,
-numpy's array reconstruction) and anything else -- `os.system`, `builtins.eval`, ... -- raises `UnpicklingError`, so a
-downloaded `*_generator.pth` cannot run code.  Plain state-dict files go through `weights_only=True` first.
+the pickled state has module dictionaries), which is all `state_dict()` needs.  Every other global a pickle names must be
+on an EXACT (module, name) allow-list (torch's tensor / storage / parameter rebuild helpers, the spectral-norm hook
+classes, `collections.OrderedDict`, numpy's array reconstruction) or resolve to a torch dtype / storage class or to an
+nn.Module class under `torch.nn.modules`; dotted names (`torch` + `os.system`), `builtins.getattr`, `functools.partial`,
+`copyreg._reconstructor` and everything else raise `UnpicklingError`.  This narrows what a file can name to constructors of
+data containers; it is a hardening of a pickle loader, not a sandbox -- prefer the `*_state_dict.pth` files (which go
+through torch's `weights_only=True` loader and never reach this unpickler) for files of unknown origin.
 """
 import io
 import pickle
@@ -22,32 +24,48 @@ import torch.nn as nn
 
 from .lib.components.ema import ExponentialMovingAverage
 
-# globals a trainer checkpoint legitimately names, besides the reference's own classes (which become stand-ins)
+# Globals a trainer checkpoint legitimately names, besides the reference's own classes (which become stand-ins).  The list is
+# EXACT (module, name) pairs plus two type-checked families; no module or prefix is allowed wholesale: pickle's find_class
+# resolves dotted names through attributes (`torch` + `os.system` is `torch.os.system`), so "anything in torch" is "anything".
 _ALLOWED_EXACT = {
     ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "set"), ("builtins", "frozenset"),
     ("builtins", "slice"), ("builtins", "complex"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
     ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
-    ("builtins", "object"), ("builtins", "getattr"),      # getattr: nn.utils.parametrize / bound-method pickles of torch hooks
-    ("copyreg", "_reconstructor"), ("functools", "partial"), ("_codecs", "encode"),   # _codecs.encode: bytes in protocol 2
+    ("_codecs", "encode"),                                                        # bytes objects in protocol 2
     ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
     ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    # tensor / parameter reconstruction
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor_v3"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch._utils", "_rebuild_qtensor"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch.nn.parameter", "Buffer"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.storage", "UntypedStorage"),
+    ("torch.storage", "TypedStorage"), ("torch.serialization", "_get_layout"),
+    # what a pickled module of the reference drags along: hooks of spectral_norm and the hook wrapper of nn.Module
+    ("torch.nn.modules.module", "_WrappedHook"),
+    ("torch.nn.utils.spectral_norm", "SpectralNorm"), ("torch.nn.utils.spectral_norm", "SpectralNormStateDictHook"),
+    ("torch.nn.utils.spectral_norm", "SpectralNormLoadStateDictPreHook"),
 }
-_ALLOWED_PREFIXES = ("torch.nn.", "torch.optim.", "torch.distributions.")
-_ALLOWED_TORCH_MODULES = {"torch", "torch._utils", "torch._tensor", "torch.storage", "torch.serialization", "torch.nn",
-                          "torch.nn.parameter", "torch.cuda.amp.grad_scaler", "torch.amp.grad_scaler", "torch.optim"}
-_DENIED_NAMES = {"eval", "exec", "compile", "__import__", "open", "system", "popen", "load", "loads"}
 
 
-def _allowed(module, name):
+def _allowed(module, name, resolve):
+    """`resolve()` performs the lookup; it is only called for candidates of the two type-checked families, and the object
+    it returns must BE a dtype / storage class (module `torch`) or an nn.Module class (module `torch.nn.modules.*`)."""
     if module == "__builtin__":                      # protocol-2 spelling, which pickle itself maps to builtins
         module = "builtins"
-    if name in _DENIED_NAMES and (module, name) not in _ALLOWED_EXACT:
+    if "." in name or not name.isidentifier():       # dotted names walk attributes: never
         return False
     if (module, name) in _ALLOWED_EXACT:
         return True
-    if module in _ALLOWED_TORCH_MODULES:
-        return True
-    return module.startswith(_ALLOWED_PREFIXES)
+    if module == "torch":                            # torch.float32, torch.FloatStorage, ...
+        obj = resolve()
+        return isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage") and
+                                                 issubclass(obj, (torch.storage._LegacyStorage, torch.storage.TypedStorage,
+                                                                  torch.storage.UntypedStorage)))
+    if module.startswith("torch.nn.modules."):       # Linear, Conv2d, SyncBatchNorm, Sequential, ...
+        obj = resolve()
+        return isinstance(obj, type) and issubclass(obj, nn.Module) and obj.__module__.startswith("torch.nn.modules.")
+    return False
 
 
 class _Bag:
@@ -82,7 +100,7 @@ class _RefUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "lib" or module.startswith("lib.") or module == "configs" or module.startswith("configs."):
             return _stub_for(module, name)
-        if not _allowed(module, name):
+        if not _allowed(module, name, lambda: pickle.Unpickler.find_class(self, module, name)):
             raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}, which is not on the allow-list of "
                                          "3dhumangan_amd.checkpoints (only tensors, torch.nn classes and plain containers load)")
         return super().find_class(module, name)

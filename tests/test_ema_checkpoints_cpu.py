@@ -111,3 +111,46 @@ def test_unpickler_refuses_globals_outside_the_allow_list(tmp_path):
     ok = tmp_path / "ok_state_dict.pth"
     torch.save({"w": torch.arange(3.0)}, str(ok))
     assert torch.equal(ck.load_reference_pickle(str(ok))["w"], torch.arange(3.0))
+
+
+def _raw_pickle_file(tmp_path, name, payload):
+    """A torch.save-style zip whose data.pkl is the given hand-written pickle (what an attacker controls)."""
+    import zipfile
+    path = tmp_path / name
+    with zipfile.ZipFile(str(path), "w") as z:
+        z.writestr("archive/data.pkl", payload)
+        z.writestr("archive/version", "3\n")
+        z.writestr("archive/byteorder", "little")
+    return str(path)
+
+
+@pytest.mark.parametrize("module,name", [
+    ("torch", "os.system"),                       # dotted name through an allow-listed module (ADVICE r3, reproduced there)
+    ("torch.nn.modules.module", "torch.os.system"),
+    ("torch", "os"),                              # a module object, to be walked with getattr
+    ("builtins", "getattr"), ("functools", "partial"), ("copyreg", "_reconstructor"),
+    ("torch.serialization", "load"), ("torch", "load"), ("torch.nn.modules.module", "warnings"),
+    ("torch._utils", "_import_dotted_name"), ("torch", "_C"), ("builtins", "eval"), ("posix", "system"),
+])
+def test_unpickler_gadget_chains_are_refused(tmp_path, module, name):
+    """Protocol-4 pickles `<module> <name> STACK_GLOBAL ('echo',) REDUCE`: every spelling that reaches a callable which is
+    not a data constructor must fail in find_class, before anything is called."""
+    import pickle
+    marker = tmp_path / "pwned"
+    arg = f"touch {marker}".encode()
+    payload = (b"\x80\x04" + b"\x8c" + bytes([len(module)]) + module.encode() + b"\x8c" + bytes([len(name)]) + name.encode() +
+               b"\x93" + b"\x8c" + bytes([len(arg)]) + arg + b"\x85R.")
+    path = _raw_pickle_file(tmp_path, "evil.pth", payload)
+    with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+        ck.load_reference_pickle(path)
+    assert not marker.exists()
+
+
+def test_unpickler_allow_list_is_exact():
+    """The families that are resolved by type: dtypes / storages in `torch`, nn.Module classes under torch.nn.modules."""
+    ok = lambda m, n: ck._allowed(m, n, lambda: getattr(importlib.import_module(m), n))
+    assert ok("torch", "float32") and ok("torch", "FloatStorage") and ok("torch.nn.modules.linear", "Linear")
+    assert ok("torch._utils", "_rebuild_tensor_v2") and ok("__builtin__", "set")
+    assert not ok("torch", "load") and not ok("torch", "hub") and not ok("torch.nn.modules.module", "warnings")
+    assert not ok("torch.nn.modules.module", "register_module_forward_hook") and not ok("torch.optim", "Adam")
+    assert not ok("torch", "os.system") and not ok("builtins", "getattr")
