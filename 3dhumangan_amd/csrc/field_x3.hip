@@ -766,7 +766,8 @@ unsigned e2m3_code(float v) {            // round-to-nearest-even on the code gr
 }
 
 // W [n_out, ld] row-major; K range [in_begin, in_begin + in_count) in accumulator order over KSm (even) k-steps ->
-// stages [KSm][NT][hi fragment 1 KiB | fp6 half-record 1 KiB], weights scaled by `scale` (the f16 scale of the matrix)
+// stages [KSm][NT][hi fragment 1 KiB | fp6 half-record 1 KiB], weights scaled by `scale` (the f16 scale of the matrix);
+// the destination must be zero-initialised (the odd stages' half-records end in 256 B of padding)
 void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, unsigned char* dst) {
     for (int T = 0; T < KSm / 2; ++T)
         for (int nt = 0; nt < NT; ++nt)
@@ -790,8 +791,12 @@ void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int 
                 int ea = mx > 0.f ? (int)floorf(log2f(7.5f / mx)) : 0;
                 if (ea > 100) ea = 100;
                 if (ea < -100) ea = -100;
-                for (int i = 0; i < 16; ++i)
-                    if (fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f) { --ea; break; }
+                // (f16-subnormal hi values leave lo up to 2^-1 of hi instead of 2^-11: several steps then)
+                for (bool sat = true; sat && ea > -100;) {
+                    sat = false;
+                    for (int i = 0; i < 16; ++i) sat = sat || fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f;
+                    if (sat) --ea;
+                }
                 const float alpha = ldexpf(1.f, ea);
                 unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int sl = 0; sl < 32; ++sl) {
@@ -801,11 +806,15 @@ void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int 
                     rec[bit / 32] |= (unsigned)(code << (bit & 31));
                     if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
                 }
-                rec[6] = rec[7] = (unsigned)(127 - ea) * 0x01010101u;      // dword 7: the copy gemm_x2_roll reads (x3_common.hpp)
-                for (int j = 0; j < 2; ++j) {
-                    unsigned* cd = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2 + 1) * 1024);
-                    for (int d = 0; d < 4; ++d) cd[lane * 4 + d] = rec[4 * j + d];
-                }
+                rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+                // even stage: code dwords 0-3, 16 B per lane; odd stage: code dwords 4-5 as [64 lanes][8 B], then the scale dwords as
+                // [64 lanes][4 B], then 256 B of zeros -- dense, so that gemm_x2_roll's 64- and 32-bit reads are bank-conflict-free
+                unsigned* ev = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T) * NT + nt) * 2 + 1) * 1024);
+                unsigned* od = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + 1) * NT + nt) * 2 + 1) * 1024);
+                for (int d = 0; d < 4; ++d) ev[lane * 4 + d] = rec[d];
+                od[lane * 2 + 0] = rec[4];
+                od[lane * 2 + 1] = rec[5];
+                od[128 + lane] = rec[6];
             }
 }
 

@@ -58,7 +58,13 @@ struct Args {
     float* state;          // [wave tiles][NT*4 + 1][64 lanes] float4: activations (+ rgb partial sums) between segments
     int load_state, store_state;
     int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
+    int* ovf;              // x2: set to 1 when an activation leaves the range the f16 planes carry (nullable)
+    const int* run_if;     // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 engine
 };
+
+// x2 range guard: the hi plane is f16 and the lo plane travels as f16(lo * 2^12) with |lo| <= ulp(hi) / 2, so both planes are
+// finite exactly when |activation| < 2^15 (ulp 16 -> lo * 2^12 <= 2^15); beyond that the engine's result is not to be used.
+constexpr float kX2ActLimit = 32768.f;
 
 __device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
 
@@ -87,7 +93,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // SpadeProducer).  val(nt, rg) returns the 4 values of register group rg (rows 8rg + 4h + 0..3 of this lane's pixel).
 // X2: f16 hi fragments, lo' fragments and the fp6 record of every K-tile.
 template <int NT, bool X2, typename V8, typename F>
-__device__ __forceinline__ void make_frags(V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], f32x16 (&src)[NT], F val) {
+__device__ __forceinline__ void make_frags(V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], f32x16 (&src)[NT], float& gmax, F val) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         pin1(src[nt]);                       // the source tile sits in AGPRs until this iteration reads it
@@ -107,7 +113,17 @@ __device__ __forceinline__ void make_frags(V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i
             set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 0, l0);
             set_word(xl[2 * nt + (rg >> 1)], 2 * (rg & 1) + 1, l1);
         }
-        if constexpr (X2) b6[nt] = x2_record_dyn(xl[2 * nt], xl[2 * nt + 1], xh[2 * nt], xh[2 * nt + 1], amax);
+        if constexpr (X2) {
+            b6[nt] = x2_record_dyn(xl[2 * nt], xl[2 * nt + 1], xh[2 * nt], xh[2 * nt + 1], amax);
+            gmax = vmax(gmax, amax);
+            asm volatile("" : "+v"(b6[nt]), "+v"(xh[2 * nt]), "+v"(xh[2 * nt + 1]));
+        } else {
+            asm volatile("" : "+v"(xl[2 * nt]), "+v"(xl[2 * nt + 1]), "+v"(xh[2 * nt]), "+v"(xh[2 * nt + 1]));
+        }
+        // The launder above anchors this tile's arithmetic HERE: instruction selection schedules for register pressure and is
+        // free to sink pure arithmetic below later loads (nothing but data flow orders it against the sched_barrier), which
+        // with immediate-offset table reads meant: all 64 table reads of the eight tiles first (256 live registers, spilled),
+        // every tile's arithmetic afterwards.
         // bound the scheduler's load hoisting to one tile: the table reads of all tiles at once would cost
         // hundreds of registers on top of the resident activations
         __builtin_amdgcn_sched_barrier(0);
@@ -152,25 +168,25 @@ struct SpadeProducer {
     V8 (&xh)[2 * NT];
     V8 (&xl)[2 * NT];
     i32x8 (&b6)[NT];
-    const float* ab;
-    const float* wr;
+    lds_ptr ab;               // lane base (+ 32 h bytes) of the [HdP/2][4] affine table
+    lds_ptr wr;               // lane base (+ 16 h bytes) of the [3][HdP] ToRGB weights
     float (&rgb)[3];
-    int h, HdP;
+    float& gmax;              // x2: largest |activation| this lane has fed to the matrix cores (range guard)
     f32x4 tv;
     f32x2 w0, w1, w2;
     float sv[8];
     float amax;               // x2: largest |activation| of the tile in production (this lane)
 
     template <int TILE, int C>
-    __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
+    static constexpr int chan() { return TILE * 32 + (C / 2) * 8 + (C % 2) * 2; }      // + 4 h: in the lane bases
     template <int TILE, int C>
     __device__ __forceinline__ void fetch() {
-        const int n = chan<TILE, C>();
-        if constexpr (AFFINE) tv = ld4(ab + 2 * n);
+        constexpr int n = chan<TILE, C>(), HdP = NT * 32;
+        if constexpr (AFFINE) tv = ldt4(ab, 2 * n);
         if constexpr (RGB) {
-            w0 = *reinterpret_cast<const f32x2*>(wr + n);
-            w1 = *reinterpret_cast<const f32x2*>(wr + HdP + n);
-            w2 = *reinterpret_cast<const f32x2*>(wr + 2 * HdP + n);
+            w0 = lds_ld<f32x2>(wr + 4 * n);
+            w1 = lds_ld<f32x2>(wr + 4 * (HdP + n));
+            w2 = lds_ld<f32x2>(wr + 4 * (2 * HdP + n));
         }
     }
     __device__ __forceinline__ void prime() { fetch<0, 0>(); }
@@ -207,7 +223,10 @@ struct SpadeProducer {
     // x2: fp6 record of the finished tile (called before chunk<TILE + 1, 0> restarts the running maximum)
     template <int TILE>
     __device__ __forceinline__ void convert() {
-        if constexpr (X2) b6[TILE] = x2_record_dyn(xl[2 * TILE], xl[2 * TILE + 1], xh[2 * TILE], xh[2 * TILE + 1], amax);
+        if constexpr (X2) {
+            b6[TILE] = x2_record_dyn(xl[2 * TILE], xl[2 * TILE + 1], xh[2 * TILE], xh[2 * TILE + 1], amax);
+            gmax = vmax(gmax, amax);
+        }
     }
 };
 
@@ -238,7 +257,7 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
 
 template <int NT, int DEPTH, bool SEG, bool X2>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
-    constexpr int KS = 2 * NT;
+    constexpr int KS = 2 * NT, kHdP = NT * 32;       // the host sets A.HdP = 32 NT: table strides are compile-time
     typedef typename std::conditional<X2, F16, BF16>::type T;
     typedef typename T::vec8 frag8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -250,11 +269,14 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     int* dtab = reinterpret_cast<int*>(zero0 + 3 * HdP);     // [H3D_MAX_BLOCKS + 1][kDescInts] the descriptor fields the block loops read
     unsigned char* ring_lds = reinterpret_cast<unsigned char*>(dtab + (H3D_MAX_BLOCKS + 1) * kDescInts);
 
+    if (A.run_if && *A.run_if == 0) return;          // guarded fallback: nothing to redo
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int64_t HW = (int64_t)A.H * A.W;
+    float gmax = 0.f;                                // x2: running maximum of |activation| over everything this lane converts
+    (void)gmax;
     // The descriptor is a kernel argument: it lives in the (host-visible) kernarg segment, and a scalar load from there that misses
     // the scalar cache deep inside the kernel was measured at ~50 000 cycles (cycle trace: 57 % of every skip block went into the
     // two loads of "to_rgb / w_rgb" behind the second convolution).  All lanes fetch their block's fields once, here, in parallel;
@@ -355,16 +377,16 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         rgb_acc[0] = r.x; rgb_acc[1] = r.y; rgb_acc[2] = r.z;
     } else {
         // ---- A8: x0 = sin(w0*i + w1*j + b) in accumulator layout
-        const float* win = tab0 + dget(H3D_MAX_BLOCKS, 1);
-        const float* bin = tab0 + dget(H3D_MAX_BLOCKS, 2);
+        const lds_ptr win = lane_base(tab0 + dget(H3D_MAX_BLOCKS, 1), 16 * h);
+        const lds_ptr bin = lane_base(tab0 + dget(H3D_MAX_BLOCKS, 2), 16 * h);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = nt * 32 + rg * 8 + 4 * h;
-                const f32x4 w0 = ld4(win + n);
-                const f32x4 w1 = ld4(win + HdP + n);
-                const f32x4 bb = ld4(bin + n);
+                const int n = nt * 32 + rg * 8;
+                const f32x4 w0 = ldt4(win, n);
+                const f32x4 w1 = ldt4(win, kHdP + n);
+                const f32x4 bb = ldt4(bin, n);
                 x[nt][rg * 4 + 0] = sin_hw(w0.x * ci + w1.x * cj + bb.x);
                 x[nt][rg * 4 + 1] = sin_hw(w0.y * ci + w1.y * cj + bb.y);
                 x[nt][rg * 4 + 2] = sin_hw(w0.z * ci + w1.z * cj + bb.z);
@@ -376,10 +398,11 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     }
 
     // constant-style SPADE: y = lrelu(v * a + b) -> fragments
-    auto const_frags = [&](f32x16 (&v)[NT], const float* ab) {       // ab: [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]
-        make_frags<NT, X2>(xh, xl, b6, v, [&](int nt, int rg) {
-            const int n = nt * 32 + rg * 8 + 4 * h;
-            const f32x4 ta = ld4(ab + 2 * n), tb = ld4(ab + 2 * n + 4);
+    auto const_frags = [&](f32x16 (&v)[NT], const float* ab_) {      // ab: [HdP/2][4] = sc[n], sc[n+1], sh[n], sh[n+1]
+        const lds_ptr ab = lane_base(ab_, 32 * h);
+        make_frags<NT, X2>(xh, xl, b6, v, gmax, [&](int nt, int rg) {
+            const int n = nt * 32 + rg * 8;
+            const f32x4 ta = ldt4(ab, 2 * n), tb = ldt4(ab, 2 * n + 4);
             float4 y;
             y.x = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 0], ta.x, ta.z));
             y.y = lrelu_from_scaled(fmaf(v[nt][rg * 4 + 1], ta.y, ta.w));
@@ -389,12 +412,12 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         });
     };
     // accumulator initialisation with a per-channel vector (1 + gamma bias of the per-pixel SPADE)
-    auto set_bias = [&](f32x16 (&v)[NT], const float* bc) {
+    auto set_bias = [&](f32x16 (&v)[NT], lds_ptr bc) {               // bc: lane base (+ 16 h bytes)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 bb = ld4(bc + nt * 32 + rg * 8 + 4 * h);
+                const f32x4 bb = ldt4(bc, nt * 32 + rg * 8);
                 v[nt][rg * 4 + 0] = bb.x; v[nt][rg * 4 + 1] = bb.y; v[nt][rg * 4 + 2] = bb.z; v[nt][rg * 4 + 3] = bb.w;
             }
             pin1(v[nt]);
@@ -402,17 +425,19 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         }
     };
     // ToRGB: rgb += Wrgb * x + b, an fp32 dot product over this lane's half of the channels
-    auto to_rgb = [&](const float* wr, bool with_bias) {
+    auto to_rgb = [&](const float* wr_, bool with_bias) {
+        const lds_ptr wr = lane_base(wr_, 16 * h);
+        constexpr int HdP = kHdP;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             pin1(x[nt]);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = nt * 32 + rg * 8 + 4 * h;
-                const f32x4 w0 = ld4(wr + n);
-                const f32x4 w1 = ld4(wr + HdP + n);
-                const f32x4 w2 = ld4(wr + 2 * HdP + n);
+                const int n = nt * 32 + rg * 8;
+                const f32x4 w0 = ldt4(wr, n);
+                const f32x4 w1 = ldt4(wr, HdP + n);
+                const f32x4 w2 = ldt4(wr, 2 * HdP + n);
                 const float v0 = x[nt][rg * 4 + 0], v1 = x[nt][rg * 4 + 1], v2 = x[nt][rg * 4 + 2], v3 = x[nt][rg * 4 + 3];
                 s0 = fmaf(v3, w0.w, fmaf(v2, w0.z, fmaf(v1, w0.y, fmaf(v0, w0.x, s0))));
                 s1 = fmaf(v3, w1.w, fmaf(v2, w1.z, fmaf(v1, w1.y, fmaf(v0, w1.x, s1))));
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (h == 0 && with_bias) { s0 += wr[3 * HdP + 0]; s1 += wr[3 * HdP + 1]; s2 += wr[3 * HdP + 2]; }
+        if (h == 0 && with_bias) { s0 += wr_[3 * HdP + 0]; s1 += wr_[3 * HdP + 1]; s2 += wr_[3 * HdP + 2]; }
         rgb_acc[0] += s0; rgb_acc[1] += s1; rgb_acc[2] += s2;
     };
 
@@ -467,8 +492,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     d[tt] = BF16::mfma(th, wil, d[tt]);
                     d[tt] = BF16::mfma(tl, wih, d[tt]);
                 }
-                make_frags<4, X2>(ah, al, a6, d, [&](int nt, int rg) {
-                    const f32x4 k4 = ld4(cs + nt * 32 + rg * 8 + 4 * h);
+                const lds_ptr csl = lane_base(cs, 16 * h);
+                make_frags<4, X2>(ah, al, a6, d, gmax, [&](int nt, int rg) {
+                    const f32x4 k4 = ldt4(csl, nt * 32 + rg * 8);
                     float4 y;
                     y.x = vrelu(d[nt][rg * 4 + 0] + k4.x);
                     y.y = vrelu(d[nt][rg * 4 + 1] + k4.y);
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                     return y;
                 });
             }
-            const float* vec = tab + dget(blk, 6 + 4 * s);
+            const lds_ptr vec = lane_base(tab + dget(blk, 6 + 4 * s), 16 * h);
             // gamma:  acc = 1 + gamma ;  x <- (x*sc + sh) * acc + beta_bias   (beta accumulates on top of x)
             set_bias(acc, vec);
             pin_agpr<NT>(x); pin_agpr<NT>(acc);
@@ -491,10 +517,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 pin1(x[nt]); pin1(acc[nt]);
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int n = nt * 32 + rg * 8 + 4 * h;
-                    const f32x4 bt = ld4(vec + HdP + n);
-                    const f32x4 sc = ld4(vec + 2 * HdP + n);
-                    const f32x4 sh = ld4(vec + 3 * HdP + n);
+                    const int n = nt * 32 + rg * 8;
+                    const f32x4 bt = ldt4(vec, kHdP + n);
+                    const f32x4 sc = ldt4(vec, 2 * kHdP + n);
+                    const f32x4 sh = ldt4(vec, 3 * kHdP + n);
                     acc[nt][rg * 4 + 0] = fmaf(fmaf(x[nt][rg * 4 + 0], sc.x, sh.x), acc[nt][rg * 4 + 0], bt.x);
                     acc[nt][rg * 4 + 1] = fmaf(fmaf(x[nt][rg * 4 + 1], sc.y, sh.y), acc[nt][rg * 4 + 1], bt.y);
                     acc[nt][rg * 4 + 2] = fmaf(fmaf(x[nt][rg * 4 + 2], sc.z, sh.z), acc[nt][rg * 4 + 2], bt.z);
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
             else gemm_x3_roll<BF16, NT, 8, 8, false, kLook>(acc, ah, al, ring);
             pin_agpr<NT>(acc);
             {
-                SpadeProducer<NT, false, false, X2, frag8> prod{acc, xh, xl, b6, nullptr, nullptr, rgb_acc, h, HdP};
+                SpadeProducer<NT, false, false, X2, frag8> prod{acc, xh, xl, b6, nullptr, nullptr, rgb_acc, gmax};
                 conv_progressive<NT, true, X2>(x, xh, xl, b6, ring, prod);
             }
             pin_agpr<NT>(x);
@@ -556,16 +582,16 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         {   // conv 0, with the ToRGB of the previous skip block's output (this block's input x) riding along
             const float* wr_prev = (blk > first_skip && dget(blk - 1, 0)) ? tab + dget(blk - 1, 1) : zero0 + opaque;
 #ifdef H3D_EXPERIMENT_NO_RGB
-            SpadeProducer<NT, true, false, X2, frag8> prod{x, xh, xl, b6, abt + dget(blk, 3) * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+            SpadeProducer<NT, true, false, X2, frag8> prod{x, xh, xl, b6, lane_base(abt + dget(blk, 3) * 2 * HdP, 32 * h), lane_base(wr_prev, 16 * h), rgb_acc, gmax};
 #else
-            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, abt + dget(blk, 3) * 2 * HdP, wr_prev, rgb_acc, h, HdP};
+            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, lane_base(abt + dget(blk, 3) * 2 * HdP, 32 * h), lane_base(wr_prev, 16 * h), rgb_acc, gmax};
 #endif
             conv_progressive<NT, true, X2>(acc, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x); pin_agpr<NT>(acc);
         H3D_TRACE(21);
         {
-            SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, abt + dget(blk, 7) * 2 * HdP, nullptr, rgb_acc, h, HdP};
+            SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, lane_base(abt + dget(blk, 7) * 2 * HdP, 32 * h), nullptr, rgb_acc, gmax};
             conv_progressive<NT, false, X2>(x, xh, xl, b6, ring, prod);
         }
         pin_agpr<NT>(x);
@@ -592,6 +618,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         if (okp && h == 0) rgb_out[((int64_t)b * 3 + c) * HW + p] = v;
     }
     }   // tiles
+    if constexpr (X2) {
+        // sticky range flag: an activation beyond the f16 planes' range anywhere in this launch (NaN compares false below too)
+        if (A.ovf && !(gmax < kX2ActLimit)) atomicOr(A.ovf, 1);
+    }
     ring.drain();
     H3D_TRACE(9);
     H3D_TRACE_DUMP(A.state);
@@ -639,7 +669,8 @@ extern "C" int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr) {
 static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const float* tables, int table_floats,
                        const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                        const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
-                       float* state, int load_state, int store_state, h3d_stream_t stream_) {
+                       float* state, int load_state, int store_state, h3d_stream_t stream_, int* ovf = nullptr,
+                       const int* run_if = nullptr) {
     H3D_REQUIRE(stream && tables && desc && rgb, "h3d_synthesis_x3: null pointer");
     H3D_REQUIRE(h3d::aligned16(stream) && h3d::aligned16(tables), "h3d_synthesis_x3: stream/tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3: n_blocks=%d", desc->n_blocks);
@@ -705,6 +736,7 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     if (B == 0) return H3D_OK;
     Args A{};
     A.state = state; A.load_state = load_state; A.store_state = store_state;
+    A.ovf = ovf; A.run_if = run_if;
     A.stream = static_cast<const unsigned char*>(stream);
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
@@ -719,12 +751,17 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     const int64_t groups = ((int64_t)H * W + 127) / 128;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_synthesis_x3: image too large");
     hipStream_t st = static_cast<hipStream_t>(stream_);
+#ifdef H3D_DEV_ONLY_HOT       // development: compile only the instantiation the BASELINE cfg-3 bench runs (fast ISA / resource turnaround)
+    (void)deep;
+    return launch_seg<8, kRingDepth, false, true>(A, B, groups, st);
+#else
     if (x2) {
         if (NT == 8) return deep ? launch_one<8, 6, true>(A, B, groups, st) : launch_one<8, kRingDepth, true>(A, B, groups, st);
         return deep ? launch_one<4, 6, true>(A, B, groups, st) : launch_one<4, kRingDepth, true>(A, B, groups, st);
     }
     if (NT == 8) return deep ? launch_one<8, 6, false>(A, B, groups, st) : launch_one<8, kRingDepth, false>(A, B, groups, st);
     return deep ? launch_one<4, 6, false>(A, B, groups, st) : launch_one<4, kRingDepth, false>(A, B, groups, st);
+#endif
 }
 
 extern "C" int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
@@ -740,6 +777,27 @@ extern "C" int h3d_synthesis_x2(const void* stream, int64_t total_stages, const 
                                 float* state, int load_state, int store_state, h3d_stream_t stream_) {
     return synthesis_x(true, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
                        state, load_state, store_state, stream_);
+}
+/* Range-guarded pair (round 4).  h3d_synthesis_x2_guarded is h3d_synthesis_x2 that also ORs 1 into *overflow (device memory,
+ * zeroed by the caller) when any activation it converted to the f16 planes was >= 2^15 in magnitude or non-finite -- its image
+ * is then not to be used.  h3d_synthesis_x3_if is h3d_synthesis_x3 (bf16 planes: fp32 exponent range) that returns at once,
+ * leaving rgb untouched, when *run_if == 0.  Launched back to back on one stream with the same flag they give "x2, redone on
+ * x3 when out of range" without a host synchronisation. */
+extern "C" int h3d_synthesis_x2_guarded(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                        const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                        const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                        int* overflow, h3d_stream_t stream_) {
+    H3D_REQUIRE(overflow, "h3d_synthesis_x2_guarded: null flag");
+    return synthesis_x(true, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
+                       nullptr, 0, 0, stream_, overflow, nullptr);
+}
+extern "C" int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                   const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                   const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                   const int* run_if, h3d_stream_t stream_) {
+    H3D_REQUIRE(run_if, "h3d_synthesis_x3_if: null flag");
+    return synthesis_x(false, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
+                       nullptr, 0, 0, stream_, nullptr, run_if);
 }
 /* HOST helper: LDS bytes of the x3 (x2 = 0) / x2 (x2 = 1) kernel at its minimum ring depth for a network of width C with
  * `table_floats` static table floats, n_ab constant-style and n_cst per-pixel SPADEs -- the planner's fit test (<= 160 KiB). */

@@ -90,30 +90,64 @@ __device__ __forceinline__ void relayout_tile(const unsigned (&P)[4][2], typenam
     f1 = __builtin_bit_cast(typename T::vec8, r[1]);
 }
 
+// LDS pointers are carried as address-space-3 pointers built from integers (ring position + lane slot), so every access
+// through them is a ds_read whatever the optimiser can or cannot infer about their provenance.
+typedef const __attribute__((address_space(3))) unsigned char* lds_ptr;
+template <typename V>
+__device__ __forceinline__ V lds_ld(lds_ptr p) { return *reinterpret_cast<const __attribute__((address_space(3))) V*>(p); }
+
+// Per-lane base of an LDS table: the table's address plus this lane's `lane_bytes`, as ONE opaque register.  Reads then address
+// `base + compile-time constant`, which instruction selection folds into the DS instruction's 16-bit offset field.  Without the
+// launder LLVM re-associates "table + (lane part + constant)" into a loop-invariant (lane part + constant) per read site and
+// hoists it: round 3's synthesis kernel carried ~60 such registers per convolution and paid one v_add per table read.
+__device__ __forceinline__ lds_ptr lane_base(const void* table, unsigned lane_bytes) {
+    unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)table + lane_bytes;
+    asm volatile("" : "+v"(a));
+    return reinterpret_cast<lds_ptr>(a);
+}
+__device__ __forceinline__ f32x4 ldt4(lds_ptr base, int float_index) { return lds_ld<f32x4>(base + 4 * float_index); }
+
 // Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
 // ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
 // LAG = 1 keeps the buffer of stage t - 1 readable during stage t (the refill issued after acquire(t) is stage
 // t + kBuf - 2 and lands in the buffer of stage t - 2): the x2 engines read an fp6 record that spans two consecutive stages.
+//
+// Bookkeeping (round 4): the ring's state is three running ADDRESSES in scalar registers -- fill position in the stream,
+// fill and read position in the ring -- each advanced by one add / compare / select per stage; the DMA takes the stream
+// address as an SGPR pair (saddr form: global_load_lds_dwordx4 v_lane_slot, s[base:base+1] offset:imm) and an LDS pointer is
+// one v_lshl_add_u32 of the lane id onto the scalar ring position.  Every update is laundered through an empty asm volatile,
+// which is ordered against the (asm volatile) DMA issues: round 3's index arithmetic (stage index * 16 KiB as a 64-bit shift,
+// buffer index * 16 KiB, 64-bit vector adds per stage) was hoisted by the compiler to the head of each GEMM, sixteen stages
+// at a time, and spilled from there (v_writelane: 129 spilled SGPRs in synthesis_x3_kernel<8, 4, false, true>).
 template <int NT, int DEPTH = H3D_RING_DEPTH, int LAG = 0>
 struct WeightRing {
     static constexpr int kBuf = DEPTH;
     static_assert(DEPTH - LAG >= 3 && (DEPTH - 2 - LAG) * (NT * 2 / 4) < 64, "ring depth out of range for the 6-bit vmcnt field");
     static constexpr int kChunks = NT * 2 / 4;          // DMA instructions per wave per stage
     static constexpr int kStage = NT * 2048;
-    const unsigned char* gsrc;    // global stream + this lane's slot
-    unsigned char* ring;          // LDS ring base
-    const unsigned char* cur_g;   // global address of the stage being filled (this lane's slot of piece 0)
-    int total, issue_pos, issue_buf, cur_buf, wave, lane, ring_base, cur_m0;
+    static constexpr unsigned kRingBytes = (unsigned)kBuf * kStage;
+    // all scalar (wave-uniform); the three running positions are ABSOLUTE addresses, wrapped by compare-and-select
+    const unsigned char* fill_g;            // global address of the stage filled next
+    const unsigned char* g_begin;           // the weight stream
+    unsigned g_end_lo;                      // low word of the stream's end (the stream is far smaller than 4 GiB)
+    unsigned fill_m0, m0_begin, m0_end;     // LDS address (M0) of this wave's quarter of the buffer filled next / of buffer 0 / past the last
+    unsigned read_at, rd_begin, rd_end;     // LDS address of the buffer acquired next / of the ring / past it
+    int vslot;                              // vector: this lane's 16 bytes inside a stage = (wave * kChunks) KiB + lane * 16
+    int lane;
 
     __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
-        gsrc = stream + (w * kChunks) * 1024 + l * 16;
-        ring = lds;
-        ring_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-        total = total_stages;
 #ifdef H3D_EXPERIMENT_SMALL_STREAM
-        total = total < 8 ? total : 8;        // timing experiment: the stream wraps inside 128 KB (always L2 hits; wrong results)
+        total_stages = total_stages < 8 ? total_stages : 8;        // timing experiment: the stream wraps inside 128 KB (always L2 hits; wrong results)
 #endif
-        issue_pos = 0; issue_buf = 0; cur_buf = 0; wave = w; lane = l;
+        g_begin = fill_g = stream;
+        g_end_lo = (unsigned)(size_t)stream + (unsigned)total_stages * kStage;
+        rd_begin = read_at = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        rd_end = rd_begin + kRingBytes;
+        m0_begin = fill_m0 = __builtin_amdgcn_readfirstlane(rd_begin + w * kChunks * 1024);
+        m0_end = m0_begin + kRingBytes;
+        vslot = w * kChunks * 1024 + l * 16;
+        lane = l;
+        asm volatile("" : "+s"(fill_g), "+s"(fill_m0), "+s"(read_at));
 #pragma unroll
         for (int i = 0; i < kBuf - 1 - LAG; ++i) issue();
     }
@@ -123,23 +157,42 @@ struct WeightRing {
     // latency and each table read drains the whole weight prefetch queue.  The ring is synchronised by hand
     // (acquire()), so the compiler does not need to know about these writes.  The global and the LDS address advance
     // by the same 1 KB per piece, so the instruction's immediate offset serves both (one address per stage).
+    // M0 is written with the first piece of a stage only: the pieces of a stage are issued sections apart, but nothing the
+    // compiler generates for these kernels touches M0 in between (tests/test_abi.py disassembles the library and checks that
+    // every write of M0 in it is one of these).
     template <int C>
     __device__ __forceinline__ void issue_chunk() {           // C = 0 .. kChunks-1, in order
-#ifdef H3D_EXPERIMENT_NO_REFILL
-        if (issue_pos >= kBuf - 1 - LAG) { if (C == kChunks - 1) { issue_pos = issue_pos + 1 == total ? kBuf - 1 - LAG : issue_pos + 1; } return; }
+#ifndef H3D_RING_M0_PER_PIECE
+        if (C == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0" : : "s"(fill_m0), "v"(vslot), "s"(fill_g) : "m0");
+        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(vslot), "s"(fill_g), "n"(C * 1024));
+#else
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" : : "s"(fill_m0), "v"(vslot), "s"(fill_g), "n"(C * 1024) : "m0");
 #endif
-        if (C == 0) {
-            cur_g = gsrc + (int64_t)issue_pos * kStage;
-            cur_m0 = __builtin_amdgcn_readfirstlane(ring_base + issue_buf * kStage + wave * kChunks * 1024);
-        }
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off offset:%2" : : "s"(cur_m0), "v"(cur_g), "n"(C * 1024) : "m0");
         if (C == kChunks - 1) {
-            issue_pos = issue_pos + 1 == total ? 0 : issue_pos + 1;
-            issue_buf = issue_buf + 1 == kBuf ? 0 : issue_buf + 1;
+            fill_g += kStage;
+            fill_g = (unsigned)(size_t)fill_g == g_end_lo ? g_begin : fill_g;
+            fill_m0 += kStage;
+            fill_m0 = fill_m0 == m0_end ? m0_begin : fill_m0;
+            asm volatile("" : "+s"(fill_g), "+s"(fill_m0));   // ordered after the DMA above: the next stage's arithmetic stays here
         }
     }
     __device__ __forceinline__ void issue() {
         static_for<0, kChunks>([&](auto c) __attribute__((always_inline)) { issue_chunk<decltype(c)::value>(); });
+    }
+    // scalar LDS address of the buffer acquired next; advances the read position
+    __device__ __forceinline__ unsigned next_read() {
+        const unsigned at = read_at;
+        read_at += kStage;
+        read_at = read_at == rd_end ? rd_begin : read_at;
+        asm volatile("" : "+s"(read_at));
+        return at;
+    }
+    template <int SHIFT>
+    __device__ __forceinline__ lds_ptr slot(unsigned at) const {        // lane * 2^SHIFT bytes into the buffer at `at`
+        // the stage's ds_reads depend on this (opaque) address: they cannot be hoisted above the barrier
+        unsigned a = ((unsigned)lane << SHIFT) + at;
+        asm volatile("" : "+v"(a));
+        return reinterpret_cast<lds_ptr>(a);
     }
     // Make the next stage (t) readable by every wave.  The caller then issues stage t + kBuf - 1 with
     // issue_chunk(0..kChunks-1), one chunk after each tile pair's MFMAs of the k-step it computes next, so the DMA
@@ -148,42 +201,37 @@ struct WeightRing {
     // cycles after the barrier and its data lands an L2 round trip (>= 300 cycles) later still, whereas an LDS read
     // retires within ~130 cycles of issue -- the write-after-read distance is a few hundred cycles of margin on a
     // bounded-latency path.  (Waiting lgkmcnt(0) here instead costs ~15 % on the whole kernel.)
-    __device__ __forceinline__ const unsigned char* acquire() {
+    __device__ __forceinline__ lds_ptr acquire() {
         // vmcnt only (expcnt / lgkmcnt fields left at "no wait"): stages t+1 .. t+kBuf-2 may stay in flight
-#ifdef H3D_EXPERIMENT_NO_REFILL
-        constexpr int kKeep = 0;
-#else
         constexpr int kKeep = (kBuf - 2 - LAG) * kChunks;
-#endif
 #ifndef H3D_EXPERIMENT_NO_BARRIER
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
         __builtin_amdgcn_s_barrier();
 #endif
-        // the stage's ds_reads depend on this (opaque) offset: they cannot be hoisted above the barrier.  An integer
-        // is laundered, not the pointer, so the address space stays LDS (ds_read, not flat_load).
-        int off = cur_buf * kStage + lane * 16;
-        asm volatile("" : "+v"(off));
-        const unsigned char* r = ring + off;
-        cur_buf = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
-        return r;
+        return slot<4>(next_read());
     }
     // Two consecutive stages (t, t + 1) behind ONE wait + barrier (the x2 GEMM consumes stages in pairs: an fp6 record spans an
     // even / odd pair): half the workgroup barriers of acquire() per stage.  One stage fewer stays in flight while waiting.  The
     // write-after-read argument of acquire() carries over: the refills issued during the two k-steps that follow land in the
     // buffers of stages t - 1 - LAG and t - LAG, whose last reads every wave issued before it arrived here.
-    __device__ __forceinline__ void acquire2(const unsigned char*& r0, const unsigned char*& r1) {
+    // r0 / r1: lane * 16 into the even / odd stage (fragments, first record half); r1c / r1s: lane * 8 and lane * 4 into the odd
+    // stage (the dense second record half: code dwords 4-5 as [64 lanes][8 B], scale dwords as [64 lanes][4 B] behind them);
+    // r1d = r1c + one tile (2 KiB) as a register of its own -- the odd tile of a pair reads its code dwords through it, so that
+    // the two 64-bit reads of a pair have different base registers and are NOT merged into one ds_read2st64_b64 (whose four
+    // result registers would then have to be copied into the two 6-register operands: 4 v_mov per pair).
+    __device__ __forceinline__ void acquire2(lds_ptr& r0, lds_ptr& r1, lds_ptr& r1c, lds_ptr& r1d, lds_ptr& r1s) {
         static_assert(kBuf - 3 - LAG >= 0, "ring too shallow for paired acquires");
         constexpr int kKeep = (kBuf - 3 - LAG) * kChunks;
 #ifndef H3D_EXPERIMENT_NO_BARRIER
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
         __builtin_amdgcn_s_barrier();
 #endif
-        const int nxt = cur_buf + 1 == kBuf ? 0 : cur_buf + 1;
-        int off0 = cur_buf * kStage + lane * 16, off1 = nxt * kStage + lane * 16;
-        asm volatile("" : "+v"(off0), "+v"(off1));
-        r0 = ring + off0;
-        r1 = ring + off1;
-        cur_buf = nxt + 1 == kBuf ? 0 : nxt + 1;
+        r0 = slot<4>(next_read());
+        const unsigned odd = next_read();
+        r1 = slot<4>(odd);
+        r1c = slot<3>(odd);
+        r1d = slot<3>(odd + 2048);
+        r1s = slot<2>(odd);
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -249,18 +297,18 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
     static_assert(NT % 2 == 0 && KS <= KSA && L >= 1 && L <= P, "look-ahead is at most one k-step");
     static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
     struct Pair { typename T::vec8 h[2], l[2]; } buf[NB];
-    const unsigned char* st[2];
+    lds_ptr st[2];
     auto load_pair = [&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value;
-        const unsigned char* s = st[(q / P) & 1] + (q % P) * 4096;
+        const lds_ptr s = st[(q / P) & 1] + (q % P) * 4096;
         Pair& b = buf[q % NB];
 #ifdef H3D_EXPERIMENT_NO_WREAD
         if (q >= NB) return;
 #endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            b.h[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 0) * 1024));
-            b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(s + (i * 2 + 1) * 1024));
+            b.h[i] = __builtin_bit_cast(typename T::vec8, lds_ld<u32x4>(s + (i * 2 + 0) * 1024));
+            b.l[i] = __builtin_bit_cast(typename T::vec8, lds_ld<u32x4>(s + (i * 2 + 1) * 1024));
         }
     };
     H3D_TRACE(1);
@@ -312,6 +360,10 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
                 __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER_MFMA, 0);
             }
         }
+        // anchor the section: instruction selection orders pure instructions (MFMAs included) by register-pressure heuristics
+        // only, and has been seen to sink every MFMA of a GEMM below ALL its weight-fragment reads (which then spill); the
+        // empty asm consumes the section's accumulators, so the section's matrix instructions are issued before it
+        asm volatile("" : "+a"(acc[n0]), "+a"(acc[n1]));
         __builtin_amdgcn_sched_barrier(0);
     });
     H3D_TRACE(4);
@@ -431,9 +483,6 @@ __device__ __forceinline__ i32x8 x2_record_dyn(const F16::vec8& l0, const F16::v
 // acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3
 // k-steps (B operands xh[s], xl3[s - KS2]: fragments assembled from memory, lo unscaled).  Same ring protocol, look-ahead
 // and hook convention as gemm_x3_roll; a section carries 2 (even x2 k-step), 4 (odd) or 6 (x3) MFMAs.
-#ifndef H3D_X2_PAIRED_ACQUIRE
-#define H3D_X2_PAIRED_ACQUIRE 1
-#endif
 template <int NT, int KS2, int KS3, int KSA, int KT, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 (&xh)[KSA], const i32x8 (&b6)[KT],
                                              const F16::vec8 (&xl3)[KS3 > 0 ? KS3 : 1], RING& ring, HOOK hook = HOOK()) {
@@ -446,26 +495,32 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
     // cannot: the compiler then copies two dwords per fp6 instruction)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     struct Pair { typename T::vec8 h[2], l[2]; u32x4 c0[2]; u32x2 c1[2]; unsigned sc[2]; } buf[NB];
-    const unsigned char* st[2];
+    lds_ptr st[2];
+    lds_ptr stc[2] = {nullptr, nullptr}, sts = nullptr;   // the odd stage of the current pair at lane * 8 (even / odd tile) and lane * 4
     auto load_pair = [&](auto qc) __attribute__((always_inline)) {
         constexpr int q = decltype(qc)::value, s = q / P;
-        const unsigned char* b0 = st[s & 1] + (q % P) * 4096;
+        const lds_ptr b0 = st[s & 1] + (q % P) * 4096;
         Pair& b = buf[q % NB];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            b.h[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 0) * 1024));
+            b.h[i] = __builtin_bit_cast(typename T::vec8, lds_ld<u32x4>(b0 + (i * 2 + 0) * 1024));
             if constexpr (s >= KS2) {
-                b.l[i] = __builtin_bit_cast(typename T::vec8, *reinterpret_cast<const u32x4*>(b0 + (i * 2 + 1) * 1024));
+                b.l[i] = __builtin_bit_cast(typename T::vec8, lds_ld<u32x4>(b0 + (i * 2 + 1) * 1024));
             } else if constexpr (s % 2 == 1) {
-                const unsigned char* bp = st[(s - 1) & 1] + (q % P) * 4096;
-                b.c0[i] = *reinterpret_cast<const u32x4*>(bp + (i * 2 + 1) * 1024);
-                b.c1[i] = *reinterpret_cast<const u32x2*>(b0 + (i * 2 + 1) * 1024);
-                b.sc[i] = *reinterpret_cast<const unsigned*>(b0 + (i * 2 + 1) * 1024 + 12);      // the scale again in dword 7: not mergeable into a 96-bit load
+                // record halves: code dwords 0-3 from the even stage (16 B per lane: one conflict-free ds_read_b128), code dwords
+                // 4-5 and the scale dword from the odd stage, stored DENSE -- [64 lanes][8 B] then [64 lanes][4 B] -- so that the
+                // 64-bit and the 32-bit read are conflict-free as well (round 3 kept 16 B per lane there: the lanes of a half-wave
+                // then hit every fourth bank pair, a 2-way conflict on the b64 and a 4-way conflict on the b32 read, 1.6e9 conflict
+                // cycles per launch).  Two loads, not one of 96 bits: the code dwords must land in sub-registers of the
+                // instruction's ONE 6-register operand and the scale in a register of its own.
+                b.c0[i] = lds_ld<u32x4>(st[(s - 1) & 1] + (q % P) * 4096 + (i * 2 + 1) * 1024);
+                b.c1[i] = lds_ld<u32x2>(stc[i] + (q % P) * 4096 + 1024);
+                b.sc[i] = lds_ld<unsigned>(sts + (q % P) * 4096 + (i * 2 + 1) * 1024 + 512);
             }
         }
     };
     // stages are acquired in pairs (one barrier per two k-steps): (0, 1) here, (s + 1, s + 2) inside every odd k-step s
-    if constexpr (KS >= 2 && H3D_X2_PAIRED_ACQUIRE) ring.acquire2(st[0], st[1]);
+    if constexpr (KS2 >= 2) ring.acquire2(st[0], st[1], stc[0], stc[1], sts);
     else st[0] = ring.acquire();
     ring.issue();
     static_for<0, L>(load_pair);
@@ -473,11 +528,8 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
         constexpr int g = decltype(gc)::value;
         constexpr int s = g / P, p = g % P;
         if constexpr (p == P - L && s + 1 < KS) {
-            if constexpr (!H3D_X2_PAIRED_ACQUIRE) st[(s + 1) & 1] = ring.acquire();
-            else if constexpr (s % 2 == 1) {
-                if constexpr (s + 2 < KS) ring.acquire2(st[(s + 1) & 1], st[s & 1]);
-                else st[(s + 1) & 1] = ring.acquire();
-            }
+            if constexpr (s + 1 >= KS2) st[(s + 1) & 1] = ring.acquire();                            // x3 tail: single stages
+            else if constexpr (s % 2 == 1) ring.acquire2(st[(s + 1) & 1], st[s & 1], stc[0], stc[1], sts);      // x2: the pair (s + 1, s + 2)
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (p == 0) H3D_TRACE(100 + s);
@@ -516,6 +568,7 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
                 __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER_MFMA, 0);
             }
         }
+        asm volatile("" : "+a"(acc[n0]), "+a"(acc[n1]));          // anchor (see gemm_x3_roll)
         __builtin_amdgcn_sched_barrier(0);
     });
 }

@@ -468,8 +468,11 @@ inline void x2_make_record(const float (&hi)[16], const float (&lo)[16], unsigne
     int ea = mx > 0.f ? (int)floorf(log2f(7.5f / mx)) : 0;
     if (ea > 100) ea = 100;
     if (ea < -100) ea = -100;
-    for (int i = 0; i < 16; ++i)
-        if (fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f) { --ea; break; }
+    for (bool sat = true; sat && ea > -100;) {          // several steps when the hi values are f16 subnormals (|lo| up to |hi| / 2)
+        sat = false;
+        for (int i = 0; i < 16; ++i) sat = sat || fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f;
+        if (sat) --ea;
+    }
     const float alpha = ldexpf(1.f, ea);
     for (int d = 0; d < 8; ++d) rec[d] = 0;
     for (int sl = 0; sl < 32; ++sl) {

@@ -157,7 +157,10 @@ class SynthesisPlan:
         # "f32" fp32 matrix cores (anything else).  Opt-in reduced-precision tiers on the bf16x3t kernel (NOT within the
         # 1e-3 budget; BASELINE config 5's "fp16 MFMA path"): "f16w2t" weights f16 hi + lo, activations one f16 value (two
         # products); "f16x1t" plain f16 products.
-        default = "f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported() else "f16x2t" if self.x3t_supported() else "f32"
+        default = ("f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported()
+                   else ("f16x2t" if self.x2_weights_in_range() else "bf16x3t") if self.x3t_supported() else "f32")
+        self._x2_flag = None          # int32 [1] on the device: the x2 engine's range flag of the LAST run (see run())
+        self.x2_guard = os.environ.get("H3D_SYNTH_GUARD", "1") != "0"
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
@@ -186,11 +189,25 @@ class SynthesisPlan:
         return all(need(seg["tables"].numel(), len(self.const_ids), len(self.pixel_ids), self.C, int(x2)) <= 160 * 1024
                    for seg in x3["segments"])
 
+    # |x| < 2^15 keeps both f16 planes of the x2 arithmetic finite (hi = f16(x); lo * 2^12 <= ulp(hi) * 2^11): csrc/synthesis_x3.hip
+    X2_LIMIT = 32768.0
+
+    def x2_weights_in_range(self):
+        """Every matrix the x2 engines carry as f16 hi planes (conv, gamma, beta) is finite and below the f16 planes' range.
+        A network whose spectral-norm vectors were never normalised (sigma = u . W v can be tiny) fails this and
+        stays on the bf16 engines, which have the fp32 exponent range."""
+        for raw in self._raw:
+            for k in ("conv_w", "wgam", "wbet"):
+                w = raw[k]
+                if not bool(torch.isfinite(w).all()) or float(w.abs().max()) >= self.X2_LIMIT:
+                    return False
+        return True
+
     def x2_supported(self):
-        """x3_supported with room for the x2 kernel's fifth ring buffer."""
+        """x3_supported with room for the x2 kernel's fifth ring buffer and weights inside the f16 planes' range."""
         if not self.x3_supported():
             return False
-        return self._x3_fits(True)
+        return self._x3_fits(True) and self.x2_weights_in_range()
 
     @staticmethod
     def pack_stream_bf16(w_out_in, KS, NT, acc_order=True, dtype=torch.bfloat16):
@@ -229,13 +246,16 @@ class SynthesisPlan:
         return code | ((v < 0).to(torch.int64) << 5)
 
     @classmethod
-    def pack_stream_x2(cls, w_out_in, KS, NT, acc_order=True):
+    def pack_stream_x2(cls, w_out_in, KS, NT, acc_order=True, dense=True):
         """[n_out, n_in] -> weight-stream stages of the x2 engines, [KS][NT][1 KiB f16 hi fragment | 1 KiB half of the fp6
         records] as int16 bit patterns (csrc/x3_common.hpp).  K in accumulator-register order.  The fp6 record of a lane
         (output row n = 32 nt + lane % 32, half h = lane // 32) and K-tile T holds, for the lane's 16 input features (k-steps
         2T, 2T+1), slots 0-15 = q6(hi * alpha), slots 16-31 = q6(lo * 2^12 * alpha) (alpha the largest power of two with
-        max|hi| * alpha <= 7.5 and no saturated lo code), six bits per slot, then the e8m0 byte of 1 / alpha four times, then zero: 8 dwords, the first four
-        in the even k-step's stage, the last four in the odd one's."""
+        max|hi| * alpha <= 7.5 and no saturated lo code), six bits per slot, then the e8m0 byte of 1 / alpha four times: 7 dwords.
+        Code dwords 0-3 travel in the even k-step's stage, 16 B per lane.  The odd k-step's KiB holds, `dense` (the register
+        engine, csrc/x3_common.hpp: gemm_x2_roll reads it with one 64-bit and one 32-bit LDS load per lane, bank-conflict-free in
+        this layout), code dwords 4-5 as [64 lanes][8 B], the scale dwords as [64 lanes][4 B] and 256 B of zeros; otherwise (the
+        LDS-resident engine, which pulls 16 B per lane straight from L2) dwords 4-7 = codes, scale, scale at 16 B per lane."""
         assert KS % 2 == 0
         n_out, n_in = w_out_in.shape
         dev = w_out_in.device
@@ -258,7 +278,10 @@ class SynthesisPlan:
         gh, gl = grp(hi), grp(lo)
         mx = gh.abs().amax(dim=-1)
         ea = torch.where(mx > 0, torch.floor(torch.log2(7.5 / mx.clamp_min(1e-38))), torch.zeros_like(mx)).clamp(-100, 100)
-        ea = ea - ((gl.abs() * 4096.0 * torch.exp2(ea).unsqueeze(-1)).amax(dim=-1) > 7.5).to(ea.dtype)   # no saturated lo code
+        # no saturated lo code: one step for normal hi values (|lo| <= 2^-11 |hi|), several when hi is an f16 subnormal
+        lo_max = gl.abs().amax(dim=-1) * 4096.0
+        need = torch.where(lo_max > 0, torch.ceil(torch.log2(lo_max.clamp_min(1e-38) / 7.5)), torch.full_like(lo_max, -200.0))
+        ea = torch.minimum(ea, -need).clamp(-100, 100)
         alpha = torch.exp2(ea).unsqueeze(-1)
         codes = cls.e2m3_codes(torch.cat([gh * alpha, gl * alpha * 4096.0], dim=-1))    # [N, T, 2, 32]
         c = codes.view(N, T, 2, 8, 4)
@@ -270,6 +293,10 @@ class SynthesisPlan:
         rec[..., 24:32] = (127 - ea).to(torch.uint8).unsqueeze(-1)      # dword 6, and again in dword 7 (the register engine reads it there)
         # [N = (nt, j32), T, h, (half, 16 B)] -> stage [ks = 2T + half][nt][lane = 32 h + j32][16 B]
         rec = rec.view(NT, 32, T, 2, 2, 16).permute(2, 4, 0, 3, 1, 5).reshape(KS, NT, 64 * 16)
+        if dense:
+            odd = rec[1::2].reshape(T, NT, 64, 16)
+            rec[1::2] = torch.cat([odd[..., 0:8].reshape(T, NT, 512), odd[..., 8:12].reshape(T, NT, 256),
+                                   odd.new_zeros(T, NT, 256)], dim=-1)
         out = torch.empty(KS, NT, 2, 1024, dtype=torch.uint8, device=dev)
         out[:, :, 0] = hi_frag.reshape(KS, NT, 64 * 8).view(torch.uint8).reshape(KS, NT, 1024)
         out[:, :, 1] = rec
@@ -311,7 +338,7 @@ class SynthesisPlan:
 
         def add_w(w_out_in, ks, acc_order):
             if fmt == "x2":        # f16 hi fragments + fp6 records (same bytes per stage)
-                frag = self.pack_stream_x2(w_out_in, ks, NT, acc_order=acc_order).view(ks, NT, 2 * 64 * 8)
+                frag = self.pack_stream_x2(w_out_in, ks, NT, acc_order=acc_order, dense=False).view(ks, NT, 2 * 64 * 8)
             else:
                 frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order, dtype=dtype).view(ks, NT, 2 * 64 * 8)
             o = woff[0]
@@ -521,6 +548,24 @@ class SynthesisPlan:
                     state = x3["trace"]
                 lib, rc = _lib.load(), 0
                 entry = lib.h3d_synthesis_x2 if x2 else lib.h3d_synthesis_x3
+                if x2 and self.x2_guard and len(segs) == 1 and state is None:
+                    # Range-guarded x2: the kernel raises a device flag when an activation leaves the range its f16 planes carry
+                    # (|x| >= 2^15, inf, NaN upstream); the bf16 engine, launched right behind it on the same stream, returns at
+                    # once when the flag is clear and recomputes the image when it is set.  No host synchronisation; the x3
+                    # stream shares descriptor, tables and per-forward tables with the x2 one (only the weight format differs).
+                    seg, alt = segs[0], self.build_x3(False)["segments"][0]
+                    if self._x2_flag is None or self._x2_flag.device != fixed_style.device:
+                        self._x2_flag = torch.zeros(1, dtype=torch.int32, device=fixed_style.device)
+                    self._x2_flag.zero_()
+                    common = lambda sg: (_lib.ptr(sg["stream"]), sg["stages"], _lib.ptr(sg["tables"]), sg["tables"].numel(),
+                                         ctypes.byref(sg["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr, _lib.ptr(cst),
+                                         len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
+                                         _lib.ptr(self._x2_flag), _lib.stream_handle())
+                    rc = lib.h3d_synthesis_x2_guarded(*common(seg))
+                    if not rc:
+                        what = "h3d_synthesis_x3_if"
+                        rc = lib.h3d_synthesis_x3_if(*common(alt))
+                    segs = []
                 for i, seg in enumerate(segs):
                     rc = entry(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]),
                                               seg["tables"].numel(), ctypes.byref(seg["desc"]), _lib.ptr(G),
@@ -533,6 +578,11 @@ class SynthesisPlan:
                 rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
         _lib.check(rc, what)
         return rgb
+
+    def x2_fell_back(self):
+        """True when the last run() of the guarded x2 engine left its f16 range and the image came from the bf16 engine
+        (reads the device flag: synchronises; for tests and diagnostics)."""
+        return self._x2_flag is not None and bool(int(self._x2_flag.item()))
 
     def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):
         return _lib.load().h3d_synthesis(_lib.ptr(self.blob), ctypes.byref(self.desc), _lib.ptr(G), self.g_channels, Hr, Wr,

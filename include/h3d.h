@@ -346,8 +346,9 @@ int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tabl
 /* h3d_synthesis_x3 in the "x2" arithmetic (csrc/x3_common.hpp, see the _x2 field entry points): every conv / gamma /
  * beta contraction is one f16 product hi*hi plus one block-scaled fp6 (e2m3) matrix instruction for the two cross terms;
  * activations are not bounded here, so every pixel's K-tile record carries its own power-of-two scale (largest of its 16
- * values).  f16 hi halves: inputs of these convolutions must be f16-representable (|x| < 65504) -- the reference trains
- * them under fp16 autocast (lib/trainers/base_trainer.py:50-51).  Same arguments, limits and return codes as
+ * values).  f16 planes: inputs of these convolutions must stay below 2^15 in magnitude (hi = f16(x) and f16(lo * 2^12) both
+ * finite) -- the reference trains them under fp16 autocast (lib/trainers/base_trainer.py:50-51); h3d_synthesis_x2_guarded
+ * below detects a violation.  Same arguments, limits and return codes as
  * h3d_synthesis_x3; the stream holds, per stage, [tile][1 KiB f16 hi fragment][1 KiB half of the K-tile's fp6 records]
  * (record layout as for h3d_field_pack_x2; SynthesisPlan.pack_stream_x2), and the kernel needs
  * h3d_synthesis_x2_extra_lds(C) more bytes of LDS than h3d_synthesis_x3 (one more ring buffer). */
@@ -356,6 +357,23 @@ int h3d_synthesis_x2(const void* stream, int64_t total_stages, const float* tabl
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                      float* state, int load_state, int store_state, h3d_stream_t stream_handle);
 int h3d_synthesis_x2_extra_lds(int C);
+
+/* Range-guarded pair (round 4).  The x2 engine's operand planes are f16: hi = f16(x) and f16(lo * 2^12) with |lo| <= ulp(hi)/2
+ * are finite exactly for |x| < 2^15.  h3d_synthesis_x2_guarded is h3d_synthesis_x2 (single launch: no state) that also ORs 1
+ * into *overflow (int32 in device memory, zeroed by the caller on the same stream) when any activation it fed to the matrix
+ * cores was >= 2^15 in magnitude or not finite -- its image is then not to be used.  h3d_synthesis_x3_if is h3d_synthesis_x3
+ * (bf16 planes: fp32 exponent range; `stream` in the x3 format) that returns at once, leaving rgb untouched, when
+ * *run_if == 0.  Launched back to back on one stream with the same flag the pair is "x2, redone on x3 when out of range"
+ * without a host synchronisation (SynthesisPlan.run does exactly that; replaces nothing in the reference -- its fp32
+ * convolutions, lib/components/map3d_layers.py:193-238, have no range limit to guard). */
+int h3d_synthesis_x2_guarded(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                             const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                             const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                             int* overflow, h3d_stream_t stream_handle);
+int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                        const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                        const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                        const int* run_if, h3d_stream_t stream_handle);
 
 /* Same network, split-bf16 arithmetic as h3d_synthesis_x3, for widths up to 448 ("x3t": the activations of a 64-pixel
  * tile live in LDS as ready-made MFMA fragments, the channels are split over the four waves; csrc/x3t_common.hpp).

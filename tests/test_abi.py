@@ -60,3 +60,29 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "h3d_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_every_m0_write_in_the_library_is_a_weight_ring_dma(lib, tmp_path):
+    """WeightRing (csrc/x3_common.hpp) writes M0 once per stage and issues the stage's remaining LDS-DMA pieces sections later
+    WITHOUT rewriting it.  That is only sound while nothing the compiler generates touches M0: disassemble every gfx950 code
+    object of the library and require that each instruction naming m0 is `s_mov_b32 m0, sN` directly followed by a
+    global_load_lds (ours).  A compiler-generated M0 user (s_movrel, readlane by M0, ...) would show up here."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    build = importlib.import_module("3dhumangan_amd._build")
+    so = shutil.copy(build.LIB, str(tmp_path / "libh3d.so"))
+    subprocess.run([objdump, "--offloading", so], cwd=str(tmp_path), capture_output=True, check=True)
+    objs = [str(tmp_path / f) for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, "no gfx950 code objects in the library"
+    n_writes = 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", o], capture_output=True, text=True, check=True).stdout.split("\n")
+        for i, line in enumerate(text):
+            if re.search(r"\bm0\b", line.split("//")[0]):
+                assert re.search(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)\b", line), f"unexpected M0 user: {line.strip()}"
+                assert "global_load_lds_dwordx4" in text[i + 1], f"M0 write not followed by an LDS-DMA: {text[i + 1].strip()}"
+                n_writes += 1
+    assert n_writes > 100        # the register engines' rings are in there

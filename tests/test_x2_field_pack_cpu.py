@@ -52,9 +52,12 @@ def decode_x2(blob, off, KS, NT):
             for e in range(8):
                 Whi[:, acc_k(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
     recs = {}
-    half = st[:, :, 1].contiguous().view(torch.int32).view(KS, NT, 64, 4)
+    half = st[:, :, 1].contiguous().view(torch.int32).view(KS, NT, 256)
     for T in range(KS // 2):
-        rec = torch.cat([half[2 * T], half[2 * T + 1]], dim=-1).numpy().astype(np.uint32)      # [NT, 64, 8]
+        # even stage: dwords 0-3 at 16 B per lane; odd stage DENSE: dwords 4-5 as [64][2], scale dwords as [64], 64 zero dwords
+        ev, od = half[2 * T].view(NT, 64, 4), half[2 * T + 1]
+        assert not od[:, 192:].any()
+        rec = torch.cat([ev, od[:, :128].view(NT, 64, 2), od[:, 128:192].view(NT, 64, 1)], dim=-1).numpy().astype(np.uint32)  # [NT, 64, 7]
         bits = np.zeros((NT, 64, 32), dtype=np.int64)
         for s in range(32):
             b = 6 * s
@@ -64,7 +67,7 @@ def decode_x2(blob, off, KS, NT):
             bits[..., s] = (v & np.uint64(63)).astype(np.int64)
         vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
         sb = rec[..., 6]
-        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == sb)        # the scale again in dword 7
+        assert np.all(sb == (sb & 255) * 0x01010101)                                      # the e8m0 byte fills the scale dword
         scale = torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127))
         recs[T] = (vals, scale)                        # vals [NT, 64, 32]; lanes = 32 * h + (row % 32)
     return Whi, recs

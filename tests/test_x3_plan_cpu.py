@@ -36,7 +36,7 @@ CODES = torch.tensor([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1
                       2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5], dtype=torch.float64)
 
 
-def decode_x2(stream_i16, stage0, KS, NT, order=None):
+def decode_x2(stream_i16, stage0, KS, NT, order=None, dense=True):
     """x2 stages [KS][NT][1 KiB f16 hi fragment | 1 KiB record halves] -> (Whi [32 NT, 16 KS] in feature order, groups for
     x2_emulation.x2_operands_matmul: (features [16], codes_hi [N, 16], codes_lo [N, 16], block scale [N])).
     order(ks, lane half, element) -> feature (default: accumulator-register order)."""
@@ -49,10 +49,18 @@ def decode_x2(stream_i16, stage0, KS, NT, order=None):
         for h in range(2):
             for e in range(8):
                 Whi[:, order(ks, h, e)] = hi[ks, :, 32 * h: 32 * h + 32, e].reshape(-1)
-    half = st[:, :, 1].contiguous().view(torch.uint8).view(KS, NT, 64, 16).to(torch.int64)
+    half = st[:, :, 1].contiguous().view(torch.uint8).view(KS, NT, 1024).to(torch.int64)
     groups = []
     for T in range(KS // 2):
-        rec = torch.cat([half[2 * T], half[2 * T + 1]], dim=-1)                     # [NT, 64, 32 bytes]
+        # even stage: code dwords 0-3 at 16 B per lane; odd stage DENSE: code dwords 4-5 as [64 lanes][8 B], scale dwords as
+        # [64 lanes][4 B], 256 B of zeros (pack_stream_x2(dense=True): conflict-free 64- / 32-bit LDS reads)
+        ev, od = half[2 * T].view(NT, 64, 16), half[2 * T + 1]
+        if dense:
+            assert not od[:, 768:].any()
+            sd = od[:, 512:768].view(NT, 64, 4)
+            rec = torch.cat([ev, od[:, :512].view(NT, 64, 8), sd, sd], dim=-1)      # [NT, 64, 32 bytes] (scale dword twice)
+        else:                                                                       # the LDS-resident engine: 16 B per lane in both stages
+            rec = torch.cat([ev, od.view(NT, 64, 16)], dim=-1)
         b = rec[..., :24].reshape(NT, 64, 8, 3)
         c = torch.stack([b[..., 0] & 63, (b[..., 0] >> 6) | ((b[..., 1] & 15) << 2), (b[..., 1] >> 4) | ((b[..., 2] & 3) << 4),
                          b[..., 2] >> 2], dim=-1).reshape(NT, 64, 32)

@@ -40,7 +40,7 @@ def decode_x2(wblob_i16, byte_off, KS, NT, acc_order):
     from test_x3_plan_cpu import decode_x2 as decode_stream
     n = NT * KS * 1024
     st = wblob_i16[byte_off // 2: byte_off // 2 + n].view(NT, KS, 1024).transpose(0, 1).contiguous().flatten()
-    return decode_stream(st, 0, KS, NT, order=None if acc_order else (lambda ks, h, e: 16 * ks + 8 * h + e))
+    return decode_stream(st, 0, KS, NT, order=None if acc_order else (lambda ks, h, e: 16 * ks + 8 * h + e), dense=False)
 
 
 def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):

@@ -49,8 +49,11 @@ def weight_alpha(Wh_g, Wl_g, rho=4096.0):
     """Block scale of one slot group: Wh_g, Wl_g [N, 16] -> alpha [N] (see the module docstring)."""
     wmax = Wh_g.abs().amax(dim=1)
     a2 = torch.where(wmax > 0, 2.0 ** torch.floor(torch.log2(7.5 / wmax.clamp_min(1e-300))), torch.ones_like(wmax))
-    ok = (Wl_g.abs() * rho * a2[:, None]).amax(dim=1) <= 7.5
-    return torch.where(ok, a2, a2 / 2)
+    # ... lowered until no lo code saturates: one halving when the hi values are normal f16 numbers (|lo| <= 2^-11 |hi|), more
+    # when they are f16 subnormals (round 4: the packers iterate; they used to halve at most once)
+    lmax = (Wl_g.abs() * rho).amax(dim=1)
+    cap = torch.where(lmax > 0, 2.0 ** torch.floor(torch.log2(7.5 / lmax.clamp_min(1e-300))), torch.full_like(lmax, float("inf")))
+    return torch.minimum(a2, cap)
 
 
 def x2_matmul(x, W, x_scale_hi=4.0, rho=4096.0, w_target=8192.0):
