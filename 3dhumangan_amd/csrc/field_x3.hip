@@ -122,7 +122,22 @@ struct Args {
     int n_groups;        // unit groups (4 wave units each) per sample; a workgroup walks blockIdx.x, + gridDim.x, ..
     float input_scaler;
     LayoutX3 L;
+    // GEOIN (A4 inside the kernel): the nearest-vertex index of every sample and the pose tables the features are built from
+    const int* nn_index;         // [B, N]
+    const float* joints;         // [B, 24, 3]
+    const float* vertices;       // [B, V, 3]
+    const float* tpose;          // [B, V, 3]
+    const float* vertex_ik;      // [B, V, 16] blended inverse bone transforms
+    int V, legacy_mode;
 };
+
+constexpr int kJointRows = 40;     // GEOIN: LDS table of 3 + 24 + 13 float4 rows (joints at rows 3..26, zeros around them)
+
+// the oracle's squared distance, (dx*dx + dy*dy) + dz*dz without contraction (geo_features.hip: sqdist_exact)
+__device__ __forceinline__ float sqdist_exact(float px, float py, float pz, float vx, float vy, float vz) {
+    const float dx = __fsub_rn(px, vx), dy = __fsub_rn(py, vy), dz = __fsub_rn(pz, vz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
 
 __device__ __forceinline__ float density(float x, int clamp_mode) {
     if (clamp_mode == 1) return x > 20.f ? x : log1pf(expf(x));
@@ -182,16 +197,15 @@ struct FilmProducer {
     half8 (&xh)[2 * NT + 1];
     half8 (&xl)[2 * NT + 1];
     i32x8 (&b6)[NT];          // x2: the fp6 activation record of each K-tile
-    const float* tab;         // LDS [HdP/2][4]: A1[n], A1[n+1], A0[n], A0[n+1]
-    int h;
+    lds_ptr tab;              // lane base (+ 32 h bytes: lane_base) of the LDS table [HdP/2][4]: A1[n], A1[n+1], A0[n], A0[n+1]
     f32x4 tv;
     float sv[8];              // half a tile of the source accumulators, read from the AGPRs in one batch: a
                               // v_accvgpr_read issued between MFMAs waits for the matrix pipe, so 2 batches per tile
                               // instead of 8 pairs
 
     template <int TILE, int C>
-    __device__ __forceinline__ int chan() const { return TILE * 32 + (C / 2) * 8 + 4 * h + (C % 2) * 2; }
-    __device__ __forceinline__ void prime() { tv = ld4(tab + 2 * chan<0, 0>()); }
+    static constexpr int chan() { return TILE * 32 + (C / 2) * 8 + (C % 2) * 2; }      // + 4 h: in the lane base
+    __device__ __forceinline__ void prime() { tv = ldt4(tab, 2 * chan<0, 0>()); }
     template <int TILE, int C>
     __device__ __forceinline__ void chunk() {
         if constexpr (C == 0) pin1(src[TILE]);
@@ -203,8 +217,8 @@ struct FilmProducer {
         const float s0 = sv[(C % 4) * 2], s1 = sv[(C % 4) * 2 + 1];
         const float u0 = fmaf(s0, tv.x, tv.z);
         const float u1 = fmaf(s1, tv.y, tv.w);
-        if constexpr (C < 7) tv = ld4(tab + 2 * chan<TILE, C + 1>());
-        else if constexpr (TILE + 1 < NT) tv = ld4(tab + 2 * chan<TILE + 1, 0>());
+        if constexpr (C < 7) tv = ldt4(tab, 2 * chan<TILE, C + 1>());
+        else if constexpr (TILE + 1 < NT) tv = ldt4(tab, 2 * chan<TILE + 1, 0>());
         unsigned lo;
         const unsigned hi = X2 ? split2_act_x2(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo)
                                : split2_act(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo);
@@ -249,11 +263,11 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
     u32x4 hwh, hwl, hws;
     // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo (/ hi * 2^-12: the x2 lo
     // fragments are pre-multiplied by 2^12): [head][plane][KS][half][16 B]
-    const unsigned char* hbase = head_lds + ((((lane & 3) * PL) * KS) * 2 + (lane >> 5)) * 16;
+    const lds_ptr hbase = lane_base(head_lds, ((((lane & 3) * PL) * KS) * 2 + (lane >> 5)) * 16);
     auto load_head = [&](int s) __attribute__((always_inline)) {
-        hwh = *reinterpret_cast<const u32x4*>(hbase + s * 32);
-        hwl = *reinterpret_cast<const u32x4*>(hbase + (KS + s) * 32);
-        if constexpr (X2) hws = *reinterpret_cast<const u32x4*>(hbase + (2 * KS + s) * 32);
+        hwh = lds_ld<u32x4>(hbase + s * 32);
+        hwl = lds_ld<u32x4>(hbase + (KS + s) * 32);
+        if constexpr (X2) hws = lds_ld<u32x4>(hbase + (2 * KS + s) * 32);
     };
     if constexpr (HEAD) load_head(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -310,7 +324,7 @@ struct NoProducer {
 #endif
 constexpr int kRingX2 = H3D_FIELD_RINGX2;       // x2: one more buffer, the refill lags one stage (WeightRing LAG = 1)
 
-template <int NT, bool FUSED, bool X2>
+template <int NT, bool FUSED, bool X2, bool GEOIN = false>
 __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     constexpr int KS = 2 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -319,7 +333,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     float* tab0 = smem;                                 // [ST_COUNT][2][HdP]  A1 / A0 per step
     float* tfeat0 = tab0 + ST_COUNT * 2 * HdP;          // [HdP] feature-head bias
     float* scratch = tfeat0 + HdP;                      // [4 waves][64]: compositing weights, background terms
-    unsigned char* head0 = reinterpret_cast<unsigned char*>(scratch + 4 * 64);          // head A-fragment rows
+    float* joint0 = scratch + 4 * 64;                   // GEOIN: [kJointRows] float4 (x, y, z, 0): joints at rows 3 .. 26
+    unsigned char* head0 = reinterpret_cast<unsigned char*>(joint0 + (GEOIN ? kJointRows * 4 : 0));      // head A-fragment rows
     unsigned char* ring_lds = head0 + 4 * (X2 ? 3 : 2) * KS * 32;                        // [ring depth][NT*2 KB]
 
     const int t = threadIdx.x, lane = t & 63;
@@ -358,6 +373,12 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             q[2] = a0;
         }
         for (int idx = t; idx < HdP; idx += 256) tfeat0[idx] = idx < F ? bf[idx] : 0.f;
+        if constexpr (GEOIN) {
+            if (t < kJointRows * 4) {
+                const int row = t >> 2, c = t & 3, j = row - 3;
+                joint0[t] = (j >= 0 && j < 24 && c < 3) ? A.joints[((int64_t)b * 24 + j) * 3 + c] : 0.f;
+            }
+        }
         const u32x4* hsrc = reinterpret_cast<const u32x4*>(blob + L.head_w);
         u32x4* hdst = reinterpret_cast<u32x4*>(head0);
         for (int idx = t; idx < 4 * (X2 ? 3 : 2) * KS * 2; idx += 256) hdst[idx] = hsrc[idx];
@@ -426,26 +447,69 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < 3 && h == 0 && ok) ? p[e < 3 ? e : 0] * A.input_scaler : 0.f;
             split8(v, kSIn, ch, cl);
-            const float* __restrict__ g = A.geo + gi * A.geo_stride;
+            if constexpr (!GEOIN) {
+                const float* __restrict__ g = A.geo + gi * A.geo_stride;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = ks * 16 + h * 8 + e;
-                    v[e] = (k < 31 && ok) ? g[k < 31 ? k : 0] : 0.f;
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ks * 16 + h * 8 + e;
+                        v[e] = (k < 31 && ok) ? g[k < 31 ? k : 0] : 0.f;
+                    }
+                    split8(v, kSIn, gh[ks], gl[ks]);
                 }
-                split8(v, kSIn, gh[ks], gl[ks]);
+            } else {
+                // ---- A4 in place (lib/components/smpl.py:210-249; the arithmetic of geo_features.hip's tail): this lane's 16
+                // of the sample's 31 features, slot q = 8 ks + e <-> feature k = 16 ks + 8 h + e.  Feature order
+                // [cano 3 | joints 24 | T-pose vertex 3 | distance 1] (legacy_mode: joints first, then cano).
+                const float X = p[0], Y = p[1], Z = p[2];
+                const int vi = A.nn_index[gi];
+                const int64_t vrow = (int64_t)b * A.V + vi;
+                float f[16];
+                // every slot as a joint distance first: row k (+ 3 in legacy order) of the padded joint table, one broadcast
+                // ds_read_b128 per slot; the non-joint slots are overwritten below
+                const lds_ptr jb = lane_base(joint0 + opaque, (8 * h + (A.legacy_mode ? 3 : 0)) * 16);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 J = lds_ld<f32x4>(jb + ((q >> 3) * 16 + (q & 7)) * 16);
+                    const float ax = X - J.x, ay = Y - J.y, az = Z - J.z;
+                    // v_sqrt_f32 (1 ulp) and a reciprocal constant instead of the IEEE sqrt / divide sequences (~10 instructions
+                    // each, 16 times per lane and step); the features differ from h3d_geo_features' in the last bit at most
+                    f[q] = __builtin_amdgcn_sqrtf(ax * ax + ay * ay + az * az) * (1.f / 2.4f);
+                }
+                if (h == (A.legacy_mode ? 1 : 0)) {            // canonical coordinates: features 0..2 (legacy: 24..26)
+                    const float4* __restrict__ M = reinterpret_cast<const float4*>(A.vertex_ik + vrow * 16);
+                    const float4 r0 = M[0], r1 = M[1], r2 = M[2];
+                    const float cx = (r0.x * X + r0.y * Y + r0.z * Z + r0.w) * 0.5f;
+                    const float cy = ((r1.x * X + r1.y * Y + r1.z * Z + r1.w) + 0.2f) * 0.5f;
+                    const float cz = (r2.x * X + r2.y * Y + r2.z * Z + r2.w) * (1.f / 1.3f);
+                    if (A.legacy_mode) { f[8] = cx; f[9] = cy; f[10] = cz; }
+                    else { f[0] = cx; f[1] = cy; f[2] = cz; }
+                }
+                if (h == 1) {                                   // features 27..30 (+ the padding slot 31)
+                    const float* __restrict__ tv = A.tpose + vrow * 3;
+                    const float* __restrict__ vv = A.vertices + vrow * 3;
+                    f[11] = tv[0]; f[12] = tv[1]; f[13] = tv[2] * (1.f / 0.2f);
+                    f[14] = __builtin_amdgcn_sqrtf(sqdist_exact(X, Y, Z, vv[0], vv[1], vv[2])) * (1.f / 1.3f);
+                    f[15] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ok ? f[ks * 8 + e] : 0.f;
+                    split8(v, kSIn, gh[ks], gl[ks]);
+                }
             }
         }
         // ---- the layer chain.  Producers (FiLM epilogue of a layer's source accumulators) are created up front because the
         //      tile-0 chunks of producer l+1 run inside the last k-step of GEMM l.
-        FilmProducer<NT, X2> p_coord{Y, xh, xl, b6, tab + ST_COORD * 2 * HdP, h};
-        FilmProducer<NT, X2> p_geo{Y, xh, xl, b6, tab + ST_GEO * 2 * HdP, h};
-        FilmProducer<NT, X2> p_f0{X, xh, xl, b6, tab + ST_FILM0 * 2 * HdP, h};
-        FilmProducer<NT, X2> p_f1{Y, xh, xl, b6, tab + ST_FILM1 * 2 * HdP, h};
-        FilmProducer<NT, X2> p_f2{X, xh, xl, b6, tab + ST_FILM2 * 2 * HdP, h};
-        FilmProducer<NT, X2> p_f3{Y, xh, xl, b6, tab + ST_FILM3 * 2 * HdP, h};
-        FilmProducer<NT, X2> p_col{X, xh, xl, b6, tab + ST_COLOR * 2 * HdP, h};
+        FilmProducer<NT, X2> p_coord{Y, xh, xl, b6, lane_base(tab + ST_COORD * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_geo{Y, xh, xl, b6, lane_base(tab + ST_GEO * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_f0{X, xh, xl, b6, lane_base(tab + ST_FILM0 * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_f1{Y, xh, xl, b6, lane_base(tab + ST_FILM1 * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_f2{X, xh, xl, b6, lane_base(tab + ST_FILM2 * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_f3{Y, xh, xl, b6, lane_base(tab + ST_FILM3 * 2 * HdP, 32 * h)};
+        FilmProducer<NT, X2> p_col{X, xh, xl, b6, lane_base(tab + ST_COLOR * 2 * HdP, 32 * h)};
         // coordinate first layer -> Y ; FiLM 0, coordinate half: X = W0a * sin(30 * (Wc p + bc))
         {
             const half8 ih[2] = {ch, ch}, il[2] = {cl, cl};
@@ -591,7 +655,22 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             }
             const float wtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
             const float back = A.white_back ? wl_lds[32] : 0.f;
-            const int64_t ray0 = ray_of(n0);
+            // per-lane output addresses and background terms, once per step: the tile loop below then needs no scalar pointer,
+            // ray index or kernel argument (they were spilled SGPRs, reloaded with v_readlane in every tile iteration)
+            float* fout = A.feats + ray_of(n0) * C + 3 + m;                       // S >= 32: one ray per wave step
+            float* frg[4];
+            float brg[4];
+            bool okrg[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {                                      // S < 32: a ray per 8 / 16 rows
+                const int64_t n_first = n0 + rg * 8;
+                okrg[rg] = h == 0 && n_first < N;
+                frg[rg] = A.feats + ray_of(okrg[rg] ? n_first : n0) * C + 3 + m;
+                brg[rg] = A.white_back ? wl_lds[32 + rg * 8] : 0.f;
+            }
+            const bool store_ray = last_step && h == 0 && n0 < N;
+            const int g8 = S >> 3;                 // 8-row groups per ray when S < 32: 1 or 2
+            const bool long_rays = S >= 32;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int nn = nt * 32 + m;
@@ -606,22 +685,19 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                     s = fmaf(acc[nt][rg * 4 + 2], wr[rg * 4 + 2], s);
                     s4[rg] = fmaf(acc[nt][rg * 4 + 3], wr[rg * 4 + 3], s);
                 }
-                if (S >= 32) {
+                if (long_rays) {
                     float tot = fmaf((s4[0] + s4[1]) + (s4[2] + s4[3]), inv_f, bias * wtot);
                     tot += __shfl_xor(tot, 32, 64);
                     rayacc[nt] += tot;
-                    if (last_step && okn && h == 0 && n0 < N) A.feats[ray0 * C + 3 + nn] = rayacc[nt] + back;
+                    if (store_ray && okn) fout[nt * 32] = rayacc[nt] + back;
                 } else {
-                    const int g8 = S >> 3;                 // 8-row groups per ray: 1 or 2
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         if (rg % g8 != 0) continue;
                         float sv = fmaf(s4[rg], inv_f, bias * wsum[rg]);
                         if (g8 == 2) sv += fmaf(s4[rg + 1 < 4 ? rg + 1 : 3], inv_f, bias * wsum[rg + 1 < 4 ? rg + 1 : 3]);
                         sv += __shfl_xor(sv, 32, 64);
-                        const int64_t n_first = n0 + rg * 8;
-                        if (okn && h == 0 && n_first < N)
-                            A.feats[ray_of(n_first) * C + 3 + nn] = sv + (A.white_back ? wl_lds[32 + rg * 8] : 0.f);
+                        if (okn && okrg[rg]) frg[rg][nt * 32] = sv + brg[rg];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -635,14 +711,14 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     H3D_TRACE_DUMP(A.out);
 }
 
-size_t lds_bytes(const LayoutX3& L) {
-    return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64) + (size_t)4 * L.head_planes * L.KS * 32 +
-           (L.head_planes == 3 ? kRingX2 : H3D_RING_DEPTH) * (size_t)L.NT * 2048;
+size_t lds_bytes(const LayoutX3& L, bool geoin = false) {
+    return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64 + (geoin ? kJointRows * 4 : 0)) +
+           (size_t)4 * L.head_planes * L.KS * 32 + (L.head_planes == 3 ? kRingX2 : H3D_RING_DEPTH) * (size_t)L.NT * 2048;
 }
 
-template <int NT, bool FUSED, bool X2>
+template <int NT, bool FUSED, bool X2, bool GEOIN = false>
 int launch_one(Args A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED, X2>));
+    H3D_ALLOW_MAX_LDS((field_x3_kernel<NT, FUSED, X2, GEOIN>));
     A.n_groups = (int)groups;
     // about four persistent workgroups per CU in total (one resident per CU: registers): tables once per many unit groups, short tail
     static int cus = 0;
@@ -654,12 +730,19 @@ int launch_one(Args A, int B, int64_t groups, hipStream_t st) {
     static const int per_cu = getenv("H3D_FIELD_WG_PER_CU") ? atoi(getenv("H3D_FIELD_WG_PER_CU")) : 4;      // 0: one unit group per workgroup
     const int64_t per_sample = per_cu <= 0 ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2>), dim3((unsigned)per_sample, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2, GEOIN>), dim3((unsigned)per_sample, (unsigned)B), dim3(256), lds_bytes(A.L, GEOIN), st, A);
     return h3d::launch_status(FUSED ? (X2 ? "h3d_render_fused_x2" : "h3d_render_fused_x3") : (X2 ? "h3d_neural_field_x2" : "h3d_neural_field_x3"));
 }
 
 template <bool FUSED>
 int launch(const Args& A, int B, int64_t groups, hipStream_t st) {
+    if constexpr (FUSED) {
+        if (A.nn_index) {            // A4 inside the kernel
+            const bool x2 = A.L.head_planes == 3;
+            if (A.L.NT == 4) return x2 ? launch_one<4, true, true, true>(A, B, groups, st) : launch_one<4, true, false, true>(A, B, groups, st);
+            if (A.L.NT == 8) return x2 ? launch_one<8, true, true, true>(A, B, groups, st) : launch_one<8, true, false, true>(A, B, groups, st);
+        }
+    }
     if (A.L.head_planes == 3) {
         switch (A.L.NT) {
             case 4: return launch_one<4, FUSED, true>(A, B, groups, st);
@@ -975,12 +1058,24 @@ extern "C" int h3d_neural_field_x2(const void* packed, const float* points, cons
     return neural_field_x(true, packed, points, geo, dirs, freq, phase, out, B, N, Hd, F, geo_stride, input_scaler, stream);
 }
 
+struct GeoIn {            // A4 inside the fused kernel (h3d_render_fused_x2_geo / _x3_geo)
+    const int* nn_index;
+    const float *joints, *vertices, *tpose, *vertex_ik;
+    int V, legacy_mode;
+};
+
 static int render_fused_x(bool x2, const void* packed, const float* points, const float* geo, const float* dirs,
                           const float* freq, const float* phase, const float* z_vals, const float* noise,
                           float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
                           int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
-                          h3d_stream_t stream) {
+                          h3d_stream_t stream, const GeoIn* gin = nullptr) {
     const int64_t N = (int64_t)R * S;
+    if (gin) {
+        H3D_REQUIRE(gin->nn_index && gin->joints && gin->vertices && gin->tpose && gin->vertex_ik, "h3d_render_fused_x*_geo: null pointer");
+        H3D_REQUIRE(gin->V >= 1 && h3d::aligned16(gin->vertex_ik), "h3d_render_fused_x*_geo: V=%d, vertex_ik must be 16-byte aligned", gin->V);
+        geo = points;                // check_x3 wants a non-null geometry pointer; the kernel never reads it
+        geo_stride = 31;
+    }
     int rc = check_x3(packed, points, geo, freq, phase, B, N, Hd, F, geo_stride);
     if (rc) return rc;
     H3D_REQUIRE(z_vals && feats && depth && weights, "h3d_render_fused_x3: null pointer");
@@ -1002,6 +1097,10 @@ static int render_fused_x(bool x2, const void* packed, const float* points, cons
     A.log2S = -1;
     if (S <= 32) { A.log2S = 0; while ((1 << A.log2S) < S) ++A.log2S; }
     A.L = make_layout(Hd, F, x2);
+    if (gin) {
+        A.nn_index = gin->nn_index; A.joints = gin->joints; A.vertices = gin->vertices; A.tpose = gin->tpose;
+        A.vertex_ik = gin->vertex_ik; A.V = gin->V; A.legacy_mode = gin->legacy_mode;
+    }
     const int unit = S > 32 ? S : 32;
     const int64_t units = (N + unit - 1) / unit;
     const int64_t groups = (units + 3) / 4;
@@ -1048,4 +1147,31 @@ extern "C" int h3d_render_fused_x2(const void* packed, const float* points, cons
                                    h3d_stream_t stream) {
     return render_fused_x(true, packed, points, geo, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F,
                           geo_stride, input_scaler, clamp_mode, last_back, white_back, stream);
+}
+
+/* The fused render with A4 inside (round 4; north_star: "the ray-sample / MLP / alpha-composite loop is a fused kernel"): instead
+ * of a [B, N, 31] feature tensor the kernel takes every sample's nearest-vertex index (h3d_nearest_vertex) and the pose tables
+ * and builds the sample's geometry features in the prologue of its 32-sample step -- canonical coordinates through the gathered
+ * blended inverse transform, the 24 joint distances, the nearest T-pose vertex and the distance to the nearest vertex
+ * (lib/components/smpl.py:210-249) -- as the B fragments of the K = 31 input GEMM.  Same results as h3d_geo_features followed by
+ * h3d_render_fused_x2 / _x3 up to the rounding of the feature arithmetic. */
+extern "C" int h3d_render_fused_x2_geo(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                       const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                       int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                       const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                       int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                       int white_back, h3d_stream_t stream) {
+    const GeoIn g{nn_index, joints, vertices, tpose_vertices, vertex_ik, V, legacy_mode};
+    return render_fused_x(true, packed, points, nullptr, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F, 31,
+                          input_scaler, clamp_mode, last_back, white_back, stream, &g);
+}
+extern "C" int h3d_render_fused_x3_geo(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                       const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                       int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                       const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                       int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                       int white_back, h3d_stream_t stream) {
+    const GeoIn g{nn_index, joints, vertices, tpose_vertices, vertex_ik, V, legacy_mode};
+    return render_fused_x(false, packed, points, nullptr, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F, 31,
+                          input_scaler, clamp_mode, last_back, white_back, stream, &g);
 }

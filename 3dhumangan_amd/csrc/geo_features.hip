@@ -68,6 +68,9 @@ __device__ __forceinline__ void refine(const f4* vx4, const f4* vy4, const f4* v
     }
 }
 
+// FEATURES = false: the search only -- nn_index is the whole output (h3d_nearest_vertex; the features are then built in the field
+// kernel's prologue, csrc/field_x3.hip GEOIN).
+template <bool FEATURES>
 __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     const float* __restrict__ points, const float* __restrict__ joints, const float* __restrict__ vertices,
     const float* __restrict__ tpose, const float* __restrict__ vertex_ik, float* __restrict__ geo,
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
         if (ok) v2 = fmaxf(v2, x * x + y * y + z * z);
     }
     atomicMax(v2max_bits, __float_as_uint(v2));      // non-negative floats order like their bit patterns
-    if (t < kJoints * 3) jl[t] = joints[(int64_t)b * kJoints * 3 + t];
+    if (FEATURES && t < kJoints * 3) jl[t] = joints[(int64_t)b * kJoints * 3 + t];
     __syncthreads();
     const float v2max = __uint_as_float(*v2max_bits);
 
@@ -210,6 +213,10 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
         const int64_t n = wbase + (4 * hh + k) * 32 + m;
         if (n >= N) continue;
         const int idx = bi[k];
+        if constexpr (!FEATURES) {
+            nn_index[(int64_t)b * N + n] = idx;
+            continue;
+        }
         const float4* __restrict__ M = reinterpret_cast<const float4*>(vertex_ik + ((int64_t)b * V + idx) * 16);
         const float4 r0 = M[0], r1 = M[1], r2 = M[2];
         const float x = px[k], y = py[k], z = pz[k];
@@ -234,25 +241,46 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
 
 }  // namespace
 
-extern "C" int h3d_geo_features(const float* points, const float* joints, const float* vertices,
-                                const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
-                                int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
-    H3D_REQUIRE(points && joints && vertices && tpose_vertices && vertex_ik && geo, "h3d_geo_features: null pointer");
-    H3D_REQUIRE(B >= 0 && B <= 65535 && N >= 0, "h3d_geo_features: bad B=%d N=%lld", B, (long long)N);
-    H3D_REQUIRE(V >= 1, "h3d_geo_features: V=%d", V);
-    H3D_REQUIRE(geo_stride >= 31, "h3d_geo_features: geo_stride=%d must be >= 31", geo_stride);
-    H3D_REQUIRE(h3d::aligned16(vertex_ik), "h3d_geo_features: vertex_ik must be 16-byte aligned");
+static int geo_launch(bool features, const float* points, const float* joints, const float* vertices,
+                      const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
+                      int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
+    H3D_REQUIRE(B >= 0 && B <= 65535 && N >= 0, "h3d_geo_features / h3d_nearest_vertex: bad B=%d N=%lld", B, (long long)N);
+    H3D_REQUIRE(V >= 1, "h3d_geo_features / h3d_nearest_vertex: V=%d", V);
     if (B == 0 || N == 0) return H3D_OK;
     const int Vpad = (V + kChunk - 1) / kChunk * kChunk;
     const size_t lds = sizeof(float) * (3 * (size_t)Vpad + kJoints * 3 + 4);
     H3D_REQUIRE(lds <= 160 * 1024, "h3d_geo_features: mesh with V=%d vertices does not fit the 160 KB LDS", V);
-    H3D_ALLOW_MAX_LDS(geo_features_kernel);
+    H3D_ALLOW_MAX_LDS(geo_features_kernel<true>);
+    H3D_ALLOW_MAX_LDS(geo_features_kernel<false>);
     const int64_t per_block = (int64_t)kThreads * kPts;
     const int64_t gx = (N + per_block - 1) / per_block;
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_geo_features: N too large");
     h3d::pre_launch();
-    hipLaunchKernelGGL(geo_features_kernel, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
-                       points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
-                       legacy_mode);
-    return h3d::launch_status("h3d_geo_features");
+    if (features)
+        hipLaunchKernelGGL(geo_features_kernel<true>, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
+                           points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
+                           legacy_mode);
+    else
+        hipLaunchKernelGGL(geo_features_kernel<false>, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
+                           points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
+                           legacy_mode);
+    return h3d::launch_status(features ? "h3d_geo_features" : "h3d_nearest_vertex");
+}
+
+extern "C" int h3d_geo_features(const float* points, const float* joints, const float* vertices,
+                                const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
+                                int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
+    H3D_REQUIRE(points && joints && vertices && tpose_vertices && vertex_ik && geo, "h3d_geo_features: null pointer");
+    H3D_REQUIRE(geo_stride >= 31, "h3d_geo_features: geo_stride=%d must be >= 31", geo_stride);
+    H3D_REQUIRE(h3d::aligned16(vertex_ik), "h3d_geo_features: vertex_ik must be 16-byte aligned");
+    return geo_launch(true, points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, B, N, V, geo_stride, legacy_mode, stream);
+}
+
+/* The K = 1 nearest-vertex search of h3d_geo_features alone (same filter + exact refine, same arg-min bit for bit):
+ * nn_index [B, N] int32 is the only output.  The field kernels with GEOIN build the 31 features from it in their prologue
+ * (h3d_render_fused_x2_geo / _x3_geo), so the [B, N, 31] feature tensor is neither written nor read back. */
+extern "C" int h3d_nearest_vertex(const float* points, const float* vertices, int32_t* nn_index, int B, int64_t N, int V,
+                                  h3d_stream_t stream) {
+    H3D_REQUIRE(points && vertices && nn_index, "h3d_nearest_vertex: null pointer");
+    return geo_launch(false, points, nullptr, vertices, nullptr, nullptr, nullptr, nn_index, B, N, V, 31, 0, stream);
 }

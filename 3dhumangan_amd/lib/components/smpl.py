@@ -40,3 +40,17 @@ def get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, l
                                       _lib.stream_handle())
     _lib.check(rc, "h3d_geo_features")
     return (geo, idx) if return_index else geo
+
+
+def nearest_vertex(points, vertices):
+    """K = 1 nearest mesh vertex of every point (the search inside get_geo_features; pytorch3d.ops.knn_points at
+    lib/components/smpl.py:220 of the reference): points [B,N,3], vertices [B,V,3] -> int32 [B,N].  Feeds the fused render
+    kernels that build the geometry features themselves (COORDCONCATSIREN.render_geo)."""
+    _lib.need_cuda(points, vertices)
+    B, N, _ = points.shape
+    pts = points.contiguous().float()
+    vt = vertices.contiguous().float()
+    idx = torch.empty((B, N), device=pts.device, dtype=torch.int32)
+    rc = _lib.load().h3d_nearest_vertex(_lib.ptr(pts), _lib.ptr(vt), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())
+    _lib.check(rc, "h3d_nearest_vertex")
+    return idx

@@ -14,6 +14,7 @@ The reference forward is stochastic.  The draws happen here at t
 RNG; ``jitter=`` / ``noise=`` kwargs inject explicit tensors instead (used by the parity tests).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -270,6 +271,9 @@ class Map3DGenerator(nn.Module):
         self.gen_height, self.gen_width = k["gen_height"], k["gen_width"]
         self.disable_modulation = k.get("disable_modulation", False)
         self.legacy_mode = k.get("legacy_mode", False)
+        # eval-mode render: nearest-vertex search + fused field kernel that builds the geometry features itself (default), or
+        # h3d_geo_features + fused field kernel (H3D_FUSE_GEO=0 / .fuse_geo = False)
+        self.fuse_geo = os.environ.get("H3D_FUSE_GEO", "1") != "0"
         for flag in ("2d_semantic_input", "2d_label_input", "2d_latent_input"):
             if k.get(flag, False):
                 raise NotImplementedError(f"{flag}=True is not used by any shipped config and has no HIP path")
@@ -402,17 +406,31 @@ class Map3DGenerator(nn.Module):
         if noise is None:
             drawn = torch.randn((B, R, S, 1), device=dev)                          # volume_rendering.py:24
             noise = drawn * nerf_noise if nerf_noise != 0 else None
+        can_fuse = fused and not differentiable and self.neural_field.fused_supported(S)
+        # A4 inside the fused render (round 4): only the nearest-vertex search runs as its own kernel, the features are built in
+        # the field kernel's prologue -- the [B, N, 31] tensor is never written (H3D_FUSE_GEO=0: the two-kernel path)
+        geo_in = can_fuse and self.fuse_geo and self.neural_field.render_geo_supported(S)
         with stage(self, "geo_features"):
-            geo = self.get_geo_features(pts, c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"],
-                                        c["lbs_weights"])
+            if geo_in:
+                vik = smpl.vertex_inverse_transforms(c["fk_matrices"], c["lbs_weights"])
+                nn_index = smpl.nearest_vertex(pts, c["vertices"])
+                geo = None
+            else:
+                geo = self.get_geo_features(pts, c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"],
+                                            c["lbs_weights"])
         dirs = None
         if not lock_view_dependence:
             dirs = vr.ray_directions_world(focals, c["cam2world_matrices"], (render_width, render_height), S)
         scaler = 2.0 / self.side_length
         clamp_mode = kwargs["clamp_mode"]
         last_back, white_back = kwargs.get("last_back", False), kwargs.get("white_back", False)
-        can_fuse = fused and not differentiable and self.neural_field.fused_supported(S)
-        if differentiable:
+        if geo_in:
+            with stage(self, "render_fused"):
+                feats, depths, weights = self.neural_field.render_geo(
+                    pts, freq, phase, nn_index, c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], vik, dirs, z_vals, S,
+                    legacy_mode=self.legacy_mode, input_scaler=scaler, noise=noise, clamp_mode=clamp_mode,
+                    last_back=last_back, white_back=white_back)
+        elif differentiable:
             with stage(self, "neural_field"):
                 field = field_forward(self.neural_field, pts, freq, phase, geo, dirs, input_scaler=scaler)
             with stage(self, "ray_integrate"):

@@ -204,3 +204,48 @@ class COORDCONCATSIREN(nn.Module):
                                           int(bool(last_back)), int(bool(white_back)), *self._engine()[5], _lib.stream_handle())
         _lib.check(rc, "h3d_render_fused")
         return feats, depth, weights
+
+    # engines whose fused kernel can build the geometry features itself (A4 inside the render, csrc/field_x3.hip GEOIN)
+    _GEO_ENGINES = {"f16x2": "h3d_render_fused_x2_geo", "f16x3": "h3d_render_fused_x3_geo"}
+
+    def render_geo_supported(self, num_steps):
+        return self.precision in self._GEO_ENGINES and self.fused_supported(num_steps)
+
+    @torch.no_grad()
+    def render_geo(self, input, frequencies, phase_shifts, nn_index, skeletons, vertices, tpose_vertices, vertex_ik,
+                   ray_directions, z_vals, num_steps, legacy_mode=False, input_scaler=1., noise=None, clamp_mode="relu",
+                   last_back=False, white_back=False):
+        """`render` with the geometry features built inside the kernel (reference: get_geo_features,
+        lib/components/smpl.py:210-249, then COORDCONCATSIREN.forward and ray_integration): instead of geo_feature [B,N,31] it
+        takes nn_index [B,N] int32 (smpl.nearest_vertex), skeletons [B,24,3], vertices / tpose_vertices [B,V,3] and
+        vertex_ik [B,V,16] (smpl.vertex_inverse_transforms).  -> (features [B,R,F+3], depth [B,R,1], weights [B,R,S,1])."""
+        _lib.need_cuda(input, frequencies, phase_shifts, nn_index, skeletons, vertices, tpose_vertices, vertex_ik,
+                       ray_directions, z_vals, noise)
+        B, N, _ = input.shape
+        S = int(num_steps)
+        R = N // S
+        H, F = self.hidden_dim, self.feature_dim
+        pts = input.contiguous().float()
+        idx = nn_index.contiguous()
+        if idx.dtype != torch.int32 or tuple(idx.shape) != (B, N):
+            raise ValueError("nn_index must be int32 [B, N]")
+        sk, vt = skeletons.contiguous().float(), vertices.contiguous().float()
+        tv, vik = tpose_vertices.contiguous().float(), vertex_ik.contiguous().float()
+        if sk.shape[1:] != (24, 3) or vik.shape[1:] != (vt.shape[1], 16) or tv.shape != vt.shape:
+            raise ValueError("skeletons [B,24,3], vertices / tpose_vertices [B,V,3], vertex_ik [B,V,16] expected")
+        dirs = None if ray_directions is None else ray_directions.contiguous().float()
+        fr, ph = frequencies.contiguous().float(), phase_shifts.contiguous().float()
+        z = z_vals.reshape(B, R, S).contiguous().float()
+        nz = None if noise is None else noise.reshape(B, R, S).contiguous().float()
+        feats = torch.empty((B, R, F + 3), device=pts.device, dtype=torch.float32)
+        depth = torch.empty((B, R, 1), device=pts.device, dtype=torch.float32)
+        weights = torch.empty((B, R, S, 1), device=pts.device, dtype=torch.float32)
+        blob = self.packed_weights(pts.device)
+        mode = {"relu": 0, "softplus": 1}[clamp_mode]
+        fn = getattr(_lib.load(), self._GEO_ENGINES[self.precision])
+        rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vik),
+                vt.shape[1], int(bool(legacy_mode)), _lib.ptr(dirs), _lib.ptr(fr), _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz),
+                _lib.ptr(feats), _lib.ptr(depth), _lib.ptr(weights), B, R, S, H, F, float(input_scaler), mode,
+                int(bool(last_back)), int(bool(white_back)), _lib.stream_handle())
+        _lib.check(rc, "h3d_render_fused_geo")
+        return feats, depth, weights

@@ -90,6 +90,12 @@ int h3d_geo_features(const float* points, const float* joints, const float* vert
                      float* geo, int32_t* nn_index,
                      int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream);
 
+/* The K = 1 nearest-vertex search of h3d_geo_features alone (same filter + exact refine, the same arg-min bit for bit; replaces
+ * pytorch3d.ops.knn_points at lib/components/smpl.py:220): nn_index [B, N] int32 is the only output.  With it the fused field
+ * kernels build the 31 features themselves (h3d_render_fused_x2_geo / _x3_geo below): the [B, N, 31] tensor is never written. */
+int h3d_nearest_vertex(const float* points, const float* vertices, int32_t* nn_index, int B, int64_t N, int V,
+                       h3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A5  pose-conditioned FiLM-SIREN == lib/implicit_funcitions/modulated.py:41-75 (COORDCONCATSIREN.forward)
  *
@@ -219,6 +225,24 @@ int h3d_render_fused_x2(const void* packed, const float* points, const float* ge
                         float* feats, float* depth, float* weights,
                         int B, int R, int S, int Hd, int F, int geo_stride, float input_scaler,
                         int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
+
+/* h3d_render_fused_x2 / _x3 with A4 inside (round 4): instead of the feature tensor `geo` the kernel takes every sample's
+ * nearest-vertex index (h3d_nearest_vertex) and the pose tables -- joints [B,24,3], vertices / tpose_vertices [B,V,3],
+ * vertex_ik [B,V,16] (the blended inverse bone transforms, smpl.py:217-218; 16-byte aligned) -- and builds the sample's geometry
+ * features (lib/components/smpl.py:210-249: canonical coordinates, 24 joint distances, nearest T-pose vertex, distance) in the
+ * prologue of its 32-sample step, as the B fragments of the K = 31 input GEMM.  Everything else as h3d_render_fused_x2 / _x3. */
+int h3d_render_fused_x2_geo(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                            const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                            int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                            const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                            int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                            int white_back, h3d_stream_t stream);
+int h3d_render_fused_x3_geo(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                            const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                            int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                            const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                            int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                            int white_back, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A5 / A5+A6, split-operand arithmetic as the _x3 entry points, for hidden widths up to 448 ("x3t": the activations of
