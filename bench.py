@@ -276,10 +276,15 @@ def kernel_rooflines(G, cfg, batch, stage_ms):
                                                reference_formulation_frac=reference_form / ms / 1e9 / MFMA_F16_PEAK_TF))
     if "geo_features" in stage_ms:
         ms = stage_ms["geo_features"][0]
-        by = pts * (3 + 31) * 4.0 + batch * 6890 * (3 + 3 + 16) * 4.0            # points in, features out, mesh once
-        out["h3d_geo_features"] = dict(bound="valu+mfma (6890 point-vertex pairs per sample); HBM figures for reference",
-                                       ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3, bytes=by,
-                                       hbm_achieved_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS)
+        fused_geo = bool(getattr(G, "fuse_geo", False)) and G.neural_field.render_geo_supported(S)
+        if fused_geo:       # A4 inside the render: this stage is the search alone (points in, one int32 index out, mesh once)
+            by, name = pts * (3 + 1) * 4.0 + batch * 6890 * 3 * 4.0, "h3d_nearest_vertex"
+        else:               # points in, features out, mesh + transforms once
+            by, name = pts * (3 + 31) * 4.0 + batch * 6890 * (3 + 3 + 16) * 4.0, "h3d_geo_features"
+        out[name] = dict(bound="valu+mfma (6890 point-vertex pairs per sample); HBM figures for reference",
+                         ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3, bytes=by,
+                         hbm_achieved_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS,
+                         note="stage time includes the [V,24]x[24,16] blended-transform GEMM of the pose (library, per batch)")
     return out
 
 
@@ -401,6 +406,31 @@ def cpu_baseline_cfg1(runs=3):
                 sample=f"MAP3DBN 256x128, 64x32 rays x 32, batch 1, full size: 1 warm-up + {runs} timed runs")
 
 
+def cpu_baseline_cfg2(batch=8, shrink=2, runs=2):
+    """BASELINE config 2 on the host cores ("cfg 2 (B=8)"): MAP3DBN (hidden 384), batch 8 of the reference-native
+    256x128 image from 64x32 rays x 32 samples, at 1/shrink linear size to bound the time (work is linear in rays and pixels):
+    1 warm-up + `runs` timed oracle forwards of the whole batch, images/s = batch / (median * shrink^2)."""
+    configs = importlib.import_module("3dhumangan_amd.configs")
+    gens = importlib.import_module("3dhumangan_amd.lib.generators")
+    impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+    cfg = {k: v for k, v in configs.MAP3DBN.items() if isinstance(k, str)}
+    cfg.update(dataset_length=4, nerf_noise=0, last_back=cfg["eval_last_back"])
+    torch.manual_seed(1234)
+    G = gens.Map3DGenerator(**dict(cfg, neural_field_cls=impl.COORDCONCATSIREN)).eval()
+    sd = {k: v.detach() for k, v in G.state_dict().items()}
+    cfg.pop("neural_field_cls", None)
+    for k in ("gen_height", "gen_width", "render_height", "render_width"):
+        cfg[k] = max(1, cfg[k] // shrink)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    times = sorted(_oracle_run(cfg, sd, batch, 1234, runs))
+    med = times[len(times) // 2]
+    return dict(value=batch / (med * shrink * shrink), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                runs=[round(t, 2) for t in times], batch=batch,
+                sample=f"MAP3DBN batch {batch} at 1/{shrink} linear size ({cfg['gen_height']}x{cfg['gen_width']} px, "
+                       f"{cfg['render_height']}x{cfg['render_width']} rays x 32): 1 warm-up + {runs} timed runs of the whole batch, "
+                       f"median {med:.1f} s -> {med * shrink * shrink:.0f} s per full-size batch")
+
+
 def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
     """Correctness of what was timed: one more forward of the SAME batch, compared with the CPU oracle restricted to a
     subset of pixels / rays (oracle/h3d_oracle.py: generator_forward_subset) for a few batch items."""
@@ -415,19 +445,24 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
     cells = [(0, 0), (Hr - 1, Wr - 1), (Hr // 2, Wr // 2)] + list(zip(torch.randint(0, Hr, (n_cells,), generator=g).tolist(),
                                                                       torch.randint(0, Wr, (n_cells,), generator=g).tolist()))
     pix = O.pixels_of_cells(cells, (cfg["gen_height"], cfg["gen_width"]), (Hr, Wr))
-    worst, worst_r, rays = 0.0, 0.0, 0
+    worst, worst_r, rays, per_item = 0.0, 0.0, 0, []
     zc, jc = z.cpu(), jitter.cpu()
     for i in items:
+        w_i = 0.0
         ci = {k: v[i:i + 1].cpu() for k, v in cond.items()}
         ref = O.generator_forward_subset(sd, ocfg, zc[i:i + 1], ci, jc[i:i + 1], pix)
         got = rgb[i:i + 1].flatten(2)[:, :, pix]
         got_r = ren[i:i + 1].flatten(2)[:, :, ref["ray_subset"]]
         for c in range(3):
-            worst = max(worst, float((got[:, c] - ref["rgbs"][:, c]).abs().max() / ref["rgbs"][:, c].abs().max()))
+            w_i = max(w_i, float((got[:, c] - ref["rgbs"][:, c]).abs().max() / ref["rgbs"][:, c].abs().max()))
             worst_r = max(worst_r, float((got_r[:, c] - ref["rgbs_render"][:, c]).abs().max() / ref["rgbs_render"][:, c].abs().max()))
         rays = len(ref["ray_subset"])
+        per_item.append(w_i)
+        worst = max(worst, w_i)
+    plan = G.synthesis_plan(z.device)
     return dict(max_rel_err=worst, max_rel_err_render=worst_r, tolerance=1e-3, ok=bool(worst < 1e-3 and worst_r < 1e-3),
-                batch_items=list(items), pixels=int(len(pix)), rays=int(rays),
+                batch_items=list(items), pixels=int(len(pix)), rays=int(rays), per_item_max_rel_err=[round(e, 7) for e in per_item],
+                synthesis_engine=plan.engine, x2_range_guard_fell_back=bool(plan.x2_fell_back()) if plan.engine == "f16x2" else None,
                 against="CPU oracle on a pixel/ray subset (per-channel max-norm); oracle pinned to the reference's vectors")
 
 
@@ -620,12 +655,14 @@ def main():
         "telemetry": tel.report() if tel is not None else None,
         "extra": extra,
     }
-    out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, sorted({0, a.batch - 1}))
+    # every item of the timed batch (round 3 checked items 0 and B - 1 only), 8 + 3 cells each
+    out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, list(range(a.batch)), n_cells=8)
     if world == 1 and not a.no_cpu:
         sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(cfg, sd)
         if not a.no_extra:
             out["extra"]["cpu_baseline_cfg1"] = cpu_baseline_cfg1()
+            out["extra"]["cpu_baseline_cfg2_b8"] = cpu_baseline_cfg2()
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
