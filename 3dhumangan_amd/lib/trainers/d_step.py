@@ -5,13 +5,20 @@ The fake images come from the HIP generator under no_grad (the reference also ge
 discriminator runs through torch autograd.  Multi-GPU: every rank holds a batch shard; the ONLY data-path collectives are
   * the all-gather of the R1 statistics (parallel.r1_allgather, RCCL over xGMI) so that every rank applies the same
     global penalty, and
-  * the all-reduce of the discriminator gradients (parallel.allreduce_gradients), the exchange DDP does implicitly in the
-    reference.
+  * the all-reduce of the discriminator gradients, bucketed and launched from autograd hooks while backward is still
+    running (parallel.GradReducer), the exchange DDP does implicitly in the reference.
 """
 import torch
 
 from ... import parallel
 from . import losses
+
+
+def _stepped_since_update(scaler, optimizer):
+    """True when `optimizer` was unscaled / stepped through `scaler` and scaler.update() has not run since (GradScaler keeps
+    that per optimizer; update() clears it)."""
+    st = getattr(scaler, "_per_optimizer_states", {}).get(id(optimizer))
+    return st is not None and getattr(st.get("stage"), "name", "READY") != "READY"
 
 
 def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta, do_r1=True, r1_mode="reference",
@@ -27,7 +34,12 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
     ``amp_dtype`` / ``scaler``: the reference's AMP mode (autocast around the discriminator forwards; the R1 gradient is taken
     of the SCALED prediction sum and unscaled afterwards, phase_trainer.py:270-283).  The reference shares ONE GradScaler
     between both steps and updates it once per iteration, in train_generator (phase_trainer.py:335-338); its D step only
-    calls scaler.step -- so ``update_scaler`` is off by default here."""
+    calls scaler.step -- so ``update_scaler`` is off by default here.  (Changed in round 3: the defaults used to be
+    r1_mode="per_sample" and an update per D step.)  A caller that runs D steps ALONE, or several per G step, never reaches
+    that update: the step notices that this optimizer was already stepped since the scaler's last update (GradScaler would
+    raise on the second unscale_) and updates the scale itself first."""
+    if scaler is not None and _stepped_since_update(scaler, optimizer):
+        scaler.update()
     amp = dict(device_type="cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None)
     gan_lambda, seg_lambda = meta["gan_lambda"], meta["segmentation_lambda"]
     optimizer.zero_grad(set_to_none=True)
@@ -48,7 +60,9 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
         grad = losses.r1_gradient(real, out_real, gan_lambda, scale=scale)
         stat = losses.r1_statistic(grad, r1_mode)
         if distributed:
-            stat = parallel.r1_allgather(stat)           # all ranks' statistics; only this rank's slice carries a graph
+            # all ranks' statistics; only this rank's slice carries a graph.  The "reference" statistic is C values on every
+            # rank: one collective, no length exchange, no host synchronisation
+            stat = parallel.r1_allgather(stat, equal=(r1_mode == "reference") or bool(meta.get("equal_shards", False)))
             # the mean over the gathered values already divides this rank's share by the world size; the gradient all-reduce
             # below AVERAGES over the ranks (right for the per-shard means gan / seg), so the R1 term is pre-multiplied by it
             r1_scale = float(torch.distributed.get_world_size())
@@ -62,9 +76,14 @@ def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta
         seg = (s_real + s_gen) * seg_lambda
     loss = gan + 4 * penalty + seg                       # lazy regularisation factor of the reference (:392)
     total = gan + 4 * r1_scale * penalty + seg
+    # the gradient all-reduce runs inside backward, bucket by bucket (parallel.GradReducer: the exchange DDP overlaps for the
+    # reference, lib/trainers/base_trainer.py:102-104)
+    reducer = parallel.reducer_of(D) if distributed else None
+    if reducer is not None:
+        reducer.prepare()
     (scaler.scale(total) if scaler is not None else total).backward()
-    if distributed:
-        parallel.allreduce_gradients(D.parameters(), average=True)
+    if reducer is not None:
+        reducer.finish()
     if scaler is not None:
         scaler.unscale_(optimizer)
     if grad_clip is not None:

@@ -83,9 +83,13 @@ def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=N
                 seg = d_out["segments"].sum() * 0
         latent = d_out["latents"].sum() * 0 if "latents" in d_out else 0.0
         loss = gan + seg + latent
+    # gradient all-reduce overlapped with backward, rank-invariant set (parallel.GradReducer)
+    reducer = parallel.reducer_of(G) if distributed else None
+    if reducer is not None:
+        reducer.prepare()
     (scaler.scale(loss) if scaler is not None else loss).backward()
-    if distributed:
-        parallel.allreduce_gradients(G.parameters(), average=True)      # rank-invariant set (see parallel.py)
+    if reducer is not None:
+        reducer.finish()
     if scaler is not None:
         scaler.unscale_(optimizer)
     if meta.get("grad_clip") is not None:

@@ -41,7 +41,7 @@ def gather_images(local, total, group=None):
     return torch.cat(parts, dim=0)
 
 
-def r1_allgather(local_stat, group=None):
+def r1_allgather(local_stat, group=None, equal=False):
     """The one data-path collective of the training step that the north_star names ("RCCL all-gather over xGMI for the
     discriminator R1 step only"): all-gather of the R1 statistics of every rank's batch shard -- the per-sample
     ||grad_x D(x_i)||^2 [b_r], or the reference's per-channel norms of the shard's first sample [C] -> one vector with every
@@ -49,8 +49,10 @@ def r1_allgather(local_stat, group=None):
     reference gets a mean over ranks implicitly, through DDP's gradient averaging of per-rank penalties:
     lib/trainers/phase_trainer.py:259-294, 392).  A few floats per rank: latency-bound.
 
-    Shards may be uneven (shard_bounds gives earlier ranks the remainder): the lengths are exchanged first and the values
-    travel padded to the longest shard, as gather_images does.
+    ``equal=True``: every rank contributes the same number of values (always true for the default "reference" statistic --
+    C channel norms -- and for per-sample statistics of an evenly sharded batch): ONE collective, no host synchronisation.
+    Otherwise shards may be uneven (shard_bounds gives earlier ranks the remainder): the lengths are exchanged first (one
+    more small all-gather and a host read) and the values travel padded to the longest shard, as gather_images does.
 
     Autograd: this rank's slice of the result keeps its graph (the double-backward through D), the other ranks' slices are
     constants -- backward of mean(result) therefore yields exactly this rank's share of the global gradient."""
@@ -59,6 +61,11 @@ def r1_allgather(local_stat, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if local_stat.dim() != 1:
         raise ValueError(f"r1_allgather takes a vector of statistics, got shape {tuple(local_stat.shape)}")
+    if equal:
+        parts = [torch.empty_like(local_stat) for _ in range(world)]
+        dist.all_gather(parts, local_stat.detach().contiguous(), group=group)
+        parts[rank] = local_stat
+        return torch.cat(parts, dim=0)
     n = torch.tensor([local_stat.shape[0]], dtype=torch.int64, device=local_stat.device)
     lens = [torch.empty_like(n) for _ in range(world)]
     dist.all_gather(lens, n, group=group)
@@ -71,6 +78,126 @@ def r1_allgather(local_stat, group=None):
     parts = [t[:k] for t, k in zip(parts, lens)]
     parts[rank] = local_stat
     return torch.cat(parts, dim=0)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce that runs WHILE backward is still running (what DDP's reducer does for the reference:
+    lib/trainers/base_trainer.py:102-104).  The parameters are cut into flat buckets of ~`bucket_bytes` in reverse registration
+    order (about the order in which backward produces their gradients); a post-accumulate hook on every parameter copies its
+    fresh gradient into the bucket and, once a bucket is complete, launches its all-reduce asynchronously -- RCCL works on its
+    own stream while autograd keeps computing the earlier layers' gradients.  Buckets are always launched in bucket order, on
+    every rank, whatever order the hooks fire in, so the collective sequence is the same everywhere.
+
+        reducer = GradReducer(D.parameters())          # once
+        reducer.prepare(); loss.backward(); reducer.finish()      # every step
+
+    ``finish`` launches what is left (a bucket with parameters that received no gradient on this rank travels with zeros in
+    their place), waits, divides by the world size (``average``) and writes the reduced gradients back to ``p.grad``.  Which
+    parameters have a gradient on ANY rank rides along in the bucket itself (one flag per parameter, summed): a parameter
+    with no gradient anywhere keeps ``grad = None``, as under DDP; the flags are only read (a host synchronisation) on a rank
+    that is missing a gradient -- never in the steady state where every rank produces every gradient.
+    World size 1 / no process group: prepare / finish do nothing."""
+
+    def __init__(self, parameters, average=True, group=None, bucket_bytes=64 << 20):
+        self.params = [p for p in parameters if p.requires_grad]
+        self.average, self.group, self.bucket_bytes = average, group, bucket_bytes
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1 and bool(self.params)
+        self.buckets, self._armed, self._handles = [], False, []
+        if not self.active:
+            return
+        cur, size = [], 0
+        for p in reversed(self.params):
+            if cur and (p.dtype != cur[0].dtype or p.device != cur[0].device or size >= bucket_bytes):
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += p.numel() * p.element_size()
+        if cur:
+            self._close(cur)
+        self._slot = {}
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b["params"]):
+                self._slot[id(p)] = (bi, pi)
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _close(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n + len(params), dtype=params[0].dtype, device=params[0].device)     # gradients, then one flag each
+        views = [v.view_as(p) for v, p in zip(flat[:n].split([p.numel() for p in params]), params)]
+        self.buckets.append(dict(params=list(params), flat=flat, views=views, flags=flat[n:], ready=0, launched=False,
+                                 have=[False] * len(params)))
+
+    def prepare(self):
+        """Arm the hooks for the backward that follows."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            b["ready"], b["launched"], b["have"] = 0, False, [False] * len(b["params"])
+        self._handles, self._next, self._armed = [], 0, True
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi, pi = self._slot[id(p)]
+        b = self.buckets[bi]
+        if b["launched"]:
+            raise RuntimeError("GradReducer: a gradient arrived after its bucket was reduced (two backward passes between "
+                               "prepare() and finish()?)")
+        b["views"][pi].copy_(p.grad)
+        if not b["have"][pi]:
+            b["have"][pi] = True
+            b["ready"] += 1
+            self._launch_ready()
+
+    def _launch(self, b):
+        if all(b["have"]):
+            b["flags"].fill_(1.0)
+        else:
+            for pi, h in enumerate(b["have"]):
+                if not h:
+                    b["views"][pi].zero_()
+            b["flags"].copy_(torch.tensor([1.0 if h else 0.0 for h in b["have"]], dtype=b["flat"].dtype))
+        self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        b["launched"] = True
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next]["ready"] == len(self.buckets[self._next]["params"]):
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    def finish(self):
+        """After backward: reduce what has not been launched yet, wait, write the reduced gradients to ``p.grad``."""
+        if not self.active:
+            return
+        if not self._armed:
+            raise RuntimeError("GradReducer.finish() without prepare()")
+        self._armed = False
+        for b in self.buckets[self._next:]:
+            for pi, p in enumerate(b["params"]):            # gradients produced outside the hooks' reach (set by hand)
+                if not b["have"][pi] and p.grad is not None:
+                    b["views"][pi].copy_(p.grad)
+                    b["have"][pi] = True
+            self._launch(b)
+        self._next = len(self.buckets)
+        for h in self._handles:
+            h.wait()
+        world = dist.get_world_size(self.group)
+        for b in self.buckets:
+            if self.average:
+                b["flat"][: b["flat"].numel() - len(b["params"])].div_(world)
+            missing = [pi for pi, h in enumerate(b["have"]) if not h]
+            anywhere = None
+            if missing:                                       # rare: read the summed flags to see who else had a gradient
+                anywhere = (b["flags"] > 0).tolist()
+            dst, src = [], []
+            for pi, p in enumerate(b["params"]):
+                if b["have"][pi]:
+                    dst.append(p.grad)
+                    src.append(b["views"][pi])
+                elif anywhere[pi]:
+                    p.grad = b["views"][pi].clone()
+            if dst:
+                torch._foreach_copy_(dst, src)
 
 
 def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=64 << 20):
@@ -127,3 +254,12 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def reducer_of(module, **kw):
+    """The module's GradReducer, created at first use (its hooks stay on the parameters: one reducer per module)."""
+    red = getattr(module, "_h3d_grad_reducer", None)
+    if red is None or (dist.is_initialized() and dist.get_world_size(kw.get("group")) > 1) != red.active:
+        red = GradReducer(module.parameters(), **kw)
+        object.__setattr__(module, "_h3d_grad_reducer", red)
+    return red

@@ -193,18 +193,17 @@ def train_step_bench(a, rank, world, dist_on, dev, emit=True):
     fwd = {k: v for k, v in cfg.items() if isinstance(k, str)}
 
     def step():
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record()
-        with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
-            fake = G(z, cond, jitter=jitter, **fwd)["rgbs"].float()
-        d = trainers.discriminator_step(D, opt_d, real, fake, gt, meta, do_r1=True, distributed=dist_on,
-                                        grad_clip=cfg.get("grad_clip", 10.0), amp_dtype=amp_dtype, scaler=scaler)
-        e[1].record()
-        gs = trainers.generator_step(G, D, opt_g, z, cond, meta, gt_segments=gt, ema=ema, distributed=dist_on,
-                                     generator_kwargs=dict(jitter=jitter), amp_dtype=amp_dtype, scaler=scaler)
-        e[2].record()
-        ev["d"].append((e[0], e[1]))
-        ev["g"].append((e[1], e[2]))
+        e = {}
+
+        def mark(name):
+            e[name] = torch.cuda.Event(enable_timing=True)
+            e[name].record()
+
+        d, gs = trainers.adversarial_iteration(G, D, opt_d, opt_g, z, cond, real, gt, meta, generator_kwargs=dict(jitter=jitter),
+                                               ema=ema, distributed=dist_on, grad_clip=cfg.get("grad_clip", 10.0),
+                                               amp_dtype=amp_dtype, scaler=scaler, on_phase=mark)
+        ev["d"].append((e["d"], e["g"]))
+        ev["g"].append((e["g"], e["end"]))
         last.update({"d_" + k: v for k, v in d.items()})
         last.update({"g_" + k: v for k, v in gs.items()})
 

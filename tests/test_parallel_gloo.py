@@ -284,3 +284,148 @@ def test_bench_distributed_plumbing_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+# ---------------------------------------------------------------- one whole adversarial iteration (bench.py --mode trainstep), world size 2
+
+class _SynthesisOnlyGenerator(torch.nn.Module):
+    """Stand-in for the differentiable generator on CPU: a real Map3DGenerator whose forward skips the (HIP-only) field and
+    feeds its own SPADE synthesis network -- lib/generators/differentiable.synthesis_forward with the plain-torch kernel set,
+    batch-statistics BatchNorm synchronised over `group`, spectral-norm power iterations -- from a linear map of z.  Same
+    parameter set, names and optimiser groups as the product's generator."""
+
+    def __init__(self, cfg, state, group):
+        super().__init__()
+        gens = importlib.import_module("3dhumangan_amd.lib.generators")
+        self.inner = gens.Map3DGenerator(**cfg)
+        self.inner.load_state_dict(state, strict=True)
+        self.inner.train()
+        self.group = group
+        self.rhw = (cfg["render_height"], cfg["render_width"])
+        self.ghw = (cfg["gen_height"], cfg["gen_width"])
+        g = torch.Generator().manual_seed(17)
+        self.fmap_proj = torch.nn.Parameter(torch.randn(cfg["latent_dim"], self.rhw[0] * self.rhw[1] * cfg["feature_dim"], generator=g) * 0.2)
+        self.style_proj = torch.nn.Parameter(torch.randn(cfg["latent_dim"], cfg["feature_dim"], generator=g) * 0.5)
+
+    def forward(self, z, conditions, **kw):
+        from _torch_spade_kernels import TorchKernels
+        diff = importlib.import_module("3dhumangan_amd.lib.generators.differentiable")
+        B = z.shape[0]
+        fmap = (z @ self.fmap_proj).reshape(B, self.rhw[0] * self.rhw[1], -1)
+        styles = (z @ self.style_proj).reshape(B, 1, -1)
+        rgb = diff.synthesis_forward(self.inner, fmap, styles, self.rhw, self.ghw, training=True, group=self.group,
+                                     spade_kernels=TorchKernels())
+        return {"rgbs": rgb}
+
+
+def _iteration_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from conftest import load_golden
+        r, w, local, dist_on = bench.dist_env()
+        bench.init_distributed(local, backend="gloo")
+        impl = importlib.import_module("3dhumangan_amd.lib.implicit_funcitions")
+        disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+        trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+        ema_mod = importlib.import_module("3dhumangan_amd.lib.components.ema")
+        g = load_golden("gen_train_mixed")
+        cfg = dict(g["meta"])
+        cfg["neural_field_cls"] = impl.COORDCONCATSIREN
+        H, W = cfg["gen_height"], cfg["gen_width"]
+        meta = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+        meta.update(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, gen_lr=5e-3, betas=(0.0, 0.9), label_dim=2,
+                    equal_shards=True, grad_clip=10.0)
+        total = 4
+        gen = torch.Generator().manual_seed(11)
+        z = torch.randn(total, cfg["latent_dim"], generator=gen)
+        real = torch.randn(total, 3, H, W, generator=gen).clamp(-1, 1)
+        gt = torch.randint(0, 2, (total, H, W), generator=gen)
+
+        def run(group, lo, hi, distributed):
+            G = _SynthesisOnlyGenerator(cfg, g["state"], group)
+            torch.manual_seed(99)
+            D = disc.UNetDiscriminator(latent_dim=8, gen_height=H, gen_width=W, label_dim=2, discriminator_blocks=2)
+            opt_d = torch.optim.Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.9))
+            opt_g = trainers.make_generator_optimizer(G, meta)
+            ema = ema_mod.ExponentialMovingAverage(G.parameters(), decay=0.5)
+            out = {}
+
+            def step():
+                out["d"], out["g"] = trainers.adversarial_iteration(
+                    G, D, opt_d, opt_g, z[lo:hi], {}, real[lo:hi], gt[lo:hi], meta, ema=ema, distributed=distributed,
+                    grad_clip=10.0, r1_mode="per_sample")
+
+            # through bench.py's own loop: barrier-bracketed, MAX over ranks; two iterations (the second one runs on the
+            # first one's updated weights, running statistics and Adam state)
+            dt = bench.timed_loop(step, steps=2, warmup=0, dist_on=True, device="cpu")
+            assert dt > 0
+            return G, D, ema, out
+
+        G1, D1, ema1, o1 = run(False, 0, total, False)              # single process, whole batch, no collective
+        lo, hi = par.shard_bounds(total, rank, world)
+        G2, D2, ema2, o2 = run(dist.group.WORLD, lo, hi, True)      # this rank's shard
+        assert G2.inner is not None and par.reducer_of(D2).active and par.reducer_of(G2).active
+        assert len(par.reducer_of(D2).buckets) >= 1
+
+        def worst(a_mod, b_mod):
+            """Largest relative difference over the floating-point state.  Parameters whose gradient is mathematically zero (a
+            conv bias in front of a batch-statistics BatchNorm) are left out: their gradient is rounding noise, and Adam turns
+            noise of either sign into a full +-lr step."""
+            w, n = 0.0, 0
+            sa, sb = a_mod.state_dict(), b_mod.state_dict()
+            grads = {k: p.grad for k, p in b_mod.named_parameters()}
+            for k in sb:
+                if not sb[k].dtype.is_floating_point:
+                    continue
+                gk = grads.get(k)
+                if k in grads and (gk is None or float(gk.abs().max()) < 1e-5):
+                    continue
+                w = max(w, float((sa[k] - sb[k]).abs().max() / (1e-6 + sb[k].abs().max())))
+                n += 1
+            return w, n
+
+        wd, nd = worst(D2, D1)          # discriminator weights after two Adam steps on all-reduced gradients
+        wg, ng = worst(G2, G1)          # generator weights, BatchNorm running statistics, spectral-norm vectors
+        assert nd > 20 and wd < 2e-3, (nd, wd)
+        assert ng > 100 and wg < 2e-3, (ng, wg)
+        live = [p for p in G1.parameters() if p.requires_grad]
+        assert len(live) == len(ema1.shadow_params)
+        we = max(float((a - b).abs().max() / (1e-6 + b.abs().max())) for a, b, p in zip(ema2.shadow_params, ema1.shadow_params, live)
+                 if p.grad is not None and float(p.grad.abs().max()) >= 1e-5)
+        assert we < 2e-3, we
+        # the R1 penalty is the global-batch one on every rank; the per-shard loss terms average to the whole-batch ones
+        assert abs(float(o2["d"]["r1"]) - float(o1["d"]["r1"])) < 1e-3 * (1e-6 + abs(float(o1["d"]["r1"])))
+        for part in ("gan", "segmentation"):
+            for step_name in ("d", "g"):
+                mine = torch.tensor([float(o2[step_name][part])], dtype=torch.float64)
+                dist.all_reduce(mine)
+                assert abs(float(mine) / world - float(o1[step_name][part])) < 1e-3 * (1e-6 + abs(float(o1[step_name][part]))), (step_name, part)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_whole_adversarial_iteration_world2_matches_the_single_process_whole_batch():
+    """one whole `bench.py --mode trainstep` iteration pair -- generator forward with synchronised BatchNorm,
+    discriminator step with the R1 all-gather (equal-shard fast path) and the gradient all-reduce overlapped with backward
+    (parallel.GradReducer), generator step with its own overlapped all-reduce, Adam on both, EMA -- on two gloo ranks holding
+    half the batch each, through bench.py's timed loop, against the same two iterations on the whole batch in one process:
+    weights, running statistics, spectral-norm vectors, EMA shadow and losses agree."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_iteration_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
