@@ -163,3 +163,10 @@ def need_cuda(*tensors):
 def stream_handle():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def aligned16(t):
+    """`t` itself when its first element sits on a 16-byte boundary, else a copy (fresh allocations are aligned).  The kernels
+    that read 16 bytes per lane require it (H3D_REQUIRE(aligned16)); a contiguous view at an odd storage offset -- a slice of a
+    bias vector, a row range of a larger buffer -- is contiguous already, so .contiguous() alone does not fix it."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()

@@ -96,7 +96,7 @@ def _run_conv(x, w, bias=None, transposed=False):
     co = w.shape[1] if transposed else w.shape[0]
     stream = pack_stream(w, transposed)
     out = torch.empty((B, co, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-    b = None if bias is None else bias.detach().contiguous()
+    b = None if bias is None else _lib.aligned16(bias.detach().contiguous())      # a slice of a larger bias vector may start anywhere
     rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
                                  _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3")

@@ -40,7 +40,7 @@ class _ResizeCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hw, HW, adjoint):
         ctx.geom = (hw, HW, adjoint)
-        x = x.contiguous().float()
+        x = _lib.aligned16(x.contiguous().float())
         return _cl_adjoint(x, hw, HW) if adjoint else _cl_forward(x, hw, HW)
 
     @staticmethod

@@ -154,3 +154,26 @@ def test_discriminator_uses_the_native_convolutions_and_matches_the_library_path
     assert set(grads["hip"]) == set(grads["torch"])
     worst = max(rel_err(grads["hip"][n], grads["torch"][n]) for n in grads["torch"] if float(grads["torch"][n].abs().max()) > 1e-6)
     assert worst < 5e-3, worst        # both sides carry their own rounding (MIOpen fp32 Winograd vs split bf16)
+
+
+def test_misaligned_views_fall_back_to_a_copy_instead_of_raising():
+    """the native fast paths were gated on dtype and shape only.  A contiguous view at a storage offset that is not
+    a multiple of 16 bytes (a slice of a bias vector, rows of a larger buffer) must be copied, not rejected by the kernel."""
+    import importlib
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    rs = importlib.import_module("3dhumangan_amd.lib.components.resample")
+    torch.manual_seed(0)
+    big = torch.randn(4096 * 64 + 1, device="cuda")
+    x = big[1:].view(4096, 64)                              # contiguous, first element 4 bytes past a 16-byte boundary
+    w = torch.randn(128, 64, device="cuda")
+    bias = torch.randn(129, device="cuda")[1:]
+    assert x.data_ptr() % 16 and bias.data_ptr() % 16
+    with torch.no_grad():
+        y = lin.linear(x, w, bias)
+    ref = torch.nn.functional.linear(x.double(), w.double(), bias.double())
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-3
+    big2 = torch.randn(2 * 12 * 8 + 1, device="cuda")
+    t = big2[1:].view(1, 12, 16)
+    up = rs.bilinear_resize_cl(t, (4, 3), (16, 12))
+    want = torch.nn.functional.interpolate(t.view(1, 4, 3, 16).permute(0, 3, 1, 2), (16, 12), mode="bilinear", align_corners=False)
+    assert float((up.view(1, 16, 12, 16).permute(0, 3, 1, 2) - want).abs().max()) < 1e-5
