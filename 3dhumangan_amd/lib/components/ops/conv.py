@@ -84,7 +84,7 @@ def _rows(x):
     if os.environ.get("H3D_CONV_DEBUG"):
         key = (tuple(x.shape), tuple(x.stride()))
         _copied[key] = _copied.get(key, 0) + 1
-    return x.contiguous(memory_format=torch.channels_last), C
+    return _lib.aligned16(x.contiguous(memory_format=torch.channels_last)), C
 
 
 def _run_conv(x, w, bias=None, transposed=False):

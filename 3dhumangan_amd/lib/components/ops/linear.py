@@ -72,9 +72,9 @@ def wgrad_narrow(wide, narrow):
 def _rows(t):
     """[..., C] -> a [M, C] view with unit column stride and a row stride that is a multiple of 4, or a contiguous copy."""
     t2 = t.reshape(-1, t.shape[-1])
-    if t2.stride(1) != 1 or t2.stride(0) % 4 or t2.stride(0) < t2.shape[1] or t2.data_ptr() % 16:
+    if t2.stride(1) != 1 or t2.stride(0) % 4 or t2.stride(0) < t2.shape[1]:
         t2 = t2.contiguous()
-    return t2
+    return _lib.aligned16(t2)          # a contiguous view at an odd storage offset is copied (.contiguous() would return it as is)
 
 
 class _LinearX3(torch.autograd.Function):
