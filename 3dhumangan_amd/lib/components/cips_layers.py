@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ..generators.synthesis_pack import pack_matrix
-from .ops.recompute import with_recomputed_grad
+from .ops import conv as native_conv
 
 
 def _pad_rows(v, n):
@@ -56,14 +56,21 @@ class StyleModLayer(nn.Module):
         return self._packed[1]
 
     def forward(self, x, style):
-        """x [B,Cin,H,W] | [B,Cin] | [B,N,Cin]; style [B,S]  ->  same layout with Cout channels.  Differentiable (backward by
-        recomputation: ops/recompute.py)."""
+        """x [B,Cin,H,W] | [B,Cin] | [B,N,Cin]; style [B,S]  ->  same layout with Cout channels.
+        Without gradients: one fused kernel (h3d_modconv2d, fp32 matrix cores).  With gradients (round 4): the same function
+        composed of native primitives -- modulate the input, the shared-weight convolution of csrc/conv_x3.hip (split bf16 on the
+        matrix cores; its three autograd primitives are closed under differentiation, lib/components/ops/conv.py), demodulate --
+        so forward, data gradient and weight gradient all run on hand-written kernels and no library convolution appears in
+        the graph (round 3 recomputed a tensor-algebra restatement on library convolutions in backward)."""
         _lib.need_cuda(x, style)
         assert x.shape[0] == style.shape[0]
         if x.dim() not in (2, 3, 4):
             raise Exception("wrong input size")
-        return with_recomputed_grad(self._launch, self._restate, x, style, self.weight, self.bias, self.geo_feature.weight,
-                                    self.geo_feature.bias)
+        tensors = (x, style, self.weight, self.bias, self.geo_feature.weight, self.geo_feature.bias)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            return self._composed(*tensors)
+        with torch.no_grad():
+            return self._launch(x, style)
 
     @staticmethod
     def _to_image(x):
@@ -86,11 +93,17 @@ class StyleModLayer(nn.Module):
             return weight[0]
         return weight[0].t().reshape(self.out_channel, self.in_channel, 1, 1)
 
-    def _restate(self, x, style, weight, bias, gw, gb):
-        """The grouped convolution as tensor algebra: modulate the input, shared-weight convolution, demodulate the output."""
+    def _composed(self, x, style, weight, bias, gw, gb):
+        """The grouped convolution (reference lib/components/cips_layers.py:235-278) as: modulate the input, shared-weight
+        convolution, demodulate the output -- exact algebra, the convolution on the native kernels (k in {1, 3}; any other
+        kernel size goes to the library convolution)."""
         w = self._oikk(weight).float()
         s = torch.nn.functional.linear(style.float(), gw, gb) + 1.0
-        y = torch.nn.functional.conv2d(self._to_image(x).float() * s[:, :, None, None], w, padding=self.padding)
+        xm = self._to_image(x).float() * s[:, :, None, None]
+        if native_conv.supported(xm, w):
+            y = native_conv.conv2d(xm.contiguous(memory_format=torch.channels_last), w)
+        else:
+            y = torch.nn.functional.conv2d(xm, w, padding=self.padding)
         if self.demodulate:
             y = y * torch.rsqrt((s * s) @ (w * w).sum(dim=(2, 3)).t() + self.eps)[:, :, None, None]
         return self._from_image(y + bias.view(1, -1, 1, 1), x.dim())

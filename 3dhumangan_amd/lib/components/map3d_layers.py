@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ..generators.synthesis_pack import pack_matrix
-from .ops.recompute import with_recomputed_grad
+from .ops.linear import linear as native_linear
 
 
 def _pad_vec(v, n):
@@ -49,21 +49,27 @@ class SpatialStyleModLayer(nn.Module):
         return self._packed[1]
 
     def forward(self, x, style):
-        """x [B,P,Cin]; style [B,P,S] or [B,S,H,W]  ->  [B,P,Cout].  Differentiable (backward by recomputation: ops/recompute.py)."""
+        """x [B,P,Cin]; style [B,P,S] or [B,S,H,W]  ->  [B,P,Cout].
+        Without gradients: one fused kernel (h3d_modconv1x1, fp32 matrix cores).  With gradients (round 4): the same function,
+        ((x m) W) d + b with m = affine(style) + 1, d = rsqrt(m^2 W^2 + eps) (reference lib/components/map3d_layers.py:60-80),
+        composed of the package's own dense layers (ops/linear.py: forward / data-gradient GEMMs on h3d_conv_x3 where the
+        widths allow, weight gradients on h3d_wgrad_x3 / h3d_wgrad_narrow) -- recorded by autograd, differentiable to any order."""
         _lib.need_cuda(x, style)
         if style.dim() > 3:
             B, C, H, W = style.shape
             style = style.permute(0, 2, 3, 1).reshape(B, H * W, C)
-        return with_recomputed_grad(self._launch, self._restate, x, style, self.weight, self.bias, self.affine.weight,
-                                    self.affine.bias)
+        tensors = (x, style, self.weight, self.bias, self.affine.weight, self.affine.bias)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            return self._composed(*tensors)
+        with torch.no_grad():
+            return self._launch(x, style)
 
-    def _restate(self, x, style, weight, bias, aw, ab):
-        """The same function as tensor algebra: ((x m) W) d + b with m = affine(style) + 1, d = rsqrt(m^2 W^2 + eps)."""
-        m = torch.nn.functional.linear(style.float(), aw, ab) + 1.0
-        w = weight[0, 0]
-        y = (x.float() * m) @ w
+    def _composed(self, x, style, weight, bias, aw, ab):
+        m = native_linear(style.float(), aw, ab) + 1.0
+        wt = weight[0, 0].t()                                    # [Cout, Cin]: the layout of a dense layer's weight
+        y = native_linear(x.float() * m, wt)
         if self.demodulate:
-            y = y * torch.rsqrt((m * m) @ (w * w) + self.eps)
+            y = y * torch.rsqrt(native_linear(m * m, wt * wt) + self.eps)
         return y + bias[0]
 
     def _launch(self, x, style, *_):

@@ -32,15 +32,20 @@ def _native(ci, co):
     return ci % 64 == 0 and co % 64 == 0 and tiling(ci, co) is not None
 
 
+def _up64(n):
+    return (n + 63) // 64 * 64
+
+
 def supported(x, weight):
     """The native path takes fp32 CUDA tensors, k in {1, 3} (square).  Channel counts that are multiples of 64 run as they are;
-    a side with fewer than 64 channels (the RGB stem, the 1- and label_dim-channel heads) is zero-padded to 64 by conv2d."""
+    any other count (the RGB stem, the 1- and label_dim-channel heads, odd widths of the modulated convolutions) is zero-padded
+    to the next multiple of 64 by conv2d."""
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 4):
         return False
     co, ci, kh, kw = weight.shape
     if not (kh == kw and kh in (1, 3) and x.shape[1] == ci):
         return False
-    return _native(ci if ci >= 64 else 64, co if co >= 64 else 64)
+    return _native(_up64(ci), _up64(co))
 
 
 def pack_stream(w, transposed=False):
@@ -192,20 +197,21 @@ def conv2d(x, weight, bias=None):
     where it happens -- 3 -> 128 at full resolution becomes the work of a 64 -> 128 layer, the heads that of 64 -> 64 1x1."""
     _lib.need_cuda(x, weight, bias)
     co, ci = weight.shape[:2]
-    if ci < 64:
+    cip, cop = _up64(ci), _up64(co)
+    if cip != ci:
         x = x.contiguous(memory_format=torch.channels_last)
-        x = torch.cat([x, x.new_zeros((x.shape[0], 64 - ci) + tuple(x.shape[2:])).contiguous(memory_format=torch.channels_last)], dim=1)
-        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 64 - ci))
-    if co < 64:
-        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 64 - co))
+        x = torch.cat([x, x.new_zeros((x.shape[0], cip - ci) + tuple(x.shape[2:])).contiguous(memory_format=torch.channels_last)], dim=1)
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cip - ci))
+    if cop != co:
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, cop - co))
     if (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)) and torch.is_grad_enabled():
-        if co >= 64:
+        if cop == co:
             return _Conv.apply(x, weight, bias)
         y = _Conv.apply(x, weight)
-    elif co >= 64:
+    elif cop == co:
         return _run_conv(x, weight, bias)
     else:
         y = _run_conv(x, weight)
-    if co < 64:
+    if cop != co:
         y = _NarrowChannels.apply(y, co) if y.requires_grad else y[:, :co]
     return y if bias is None else y + bias.view(1, -1, 1, 1)

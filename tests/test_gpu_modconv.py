@@ -72,7 +72,9 @@ def _grads(out, cot, tensors):
 
 @pytest.mark.parametrize("cin,cout,s,rows,demod", [(64, 96, 48, 65, True), (33, 7, 5, 3, False)])
 def test_modconv1x1_gradients_vs_oracle(cin, cout, s, rows, demod):
-    """Every input and parameter gets the gradient of the oracle's float64 restatement (forward value from the kernel)."""
+    """Every input and parameter gets the gradient of the oracle's float64 restatement.  With gradients the layer is composed of the
+    package's dense-layer primitives (split-bf16 matrix-core GEMMs where the problem is large enough, ~2e-5 per product), so
+    the bounds are those of that arithmetic -- still 10x inside the 1e-3 budget; the no-grad path is the fused fp32 kernel."""
     torch.manual_seed(cin)
     layer = m3.SpatialStyleModLayer(in_channel=cin, out_channel=cout, style_dim=s, demodulate=demod)
     x, st = torch.randn(2, rows, cin), torch.randn(2, rows, s)
@@ -87,14 +89,14 @@ def test_modconv1x1_gradients_vs_oracle(cin, cout, s, rows, demod):
     ps = dict(layer.named_parameters())
     xd, sd = x.to(DEV).requires_grad_(), st.to(DEV).requires_grad_()
     out = layer(xd, sd)
-    assert out.requires_grad and rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    assert out.requires_grad and rel_err(out.detach().cpu(), ref.detach()) < 1e-4
     got = _grads(out, cot.to(DEV), [xd, sd] + [ps[n] for n in names])
     for name, a, b in zip(["x", "style"] + names, got, ref_g):
-        assert rel_err(a.cpu(), b) < 5e-5, name
+        assert rel_err(a.cpu(), b) < 3e-4, name
     # only some inputs need a gradient / none does
     out = layer(x.to(DEV), sd)
     (g_s,) = _grads(out, cot.to(DEV), [sd])
-    assert rel_err(g_s.cpu(), ref_g[1]) < 5e-5
+    assert rel_err(g_s.cpu(), ref_g[1]) < 3e-4
     with torch.no_grad():
         assert not layer(xd, sd).requires_grad
 
@@ -118,7 +120,18 @@ def test_modconv2d_gradients_vs_oracle(cin, cout, k, hw, dim):
     ps = dict(layer.named_parameters())
     xd, sd = x.to(DEV).requires_grad_(), st.to(DEV).requires_grad_()
     out = layer(xd, sd)
-    assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-4        # with gradients: native split-bf16 convolution (~2e-5 per product)
+    with torch.no_grad():
+        assert rel_err(layer(xd, sd).cpu(), ref.detach()) < 2e-5   # without: the fused fp32 kernel
     got = _grads(out, cot.to(DEV), [xd, sd] + [ps[n] for n in names])
     for name, a, b in zip(["x", "style"] + names, got, ref_g):
-        assert rel_err(a.cpu(), b) < 5e-5, name
+        assert rel_err(a.cpu(), b) < 3e-4, name
+    # second order through the same primitives (they are closed under differentiation): d/dx of a gradient norm
+    if dim == 4:
+        out2 = layer(xd, sd)
+        (gx,) = torch.autograd.grad(out2, [xd], cot.to(DEV), create_graph=True)
+        (hx,) = torch.autograd.grad(gx.square().sum(), [ps["weight"]])
+        rout = O.modconv2d_grouped(img, rst, rw, rb, rgw, rgb)
+        (rgx,) = torch.autograd.grad(rout, [rx], cot.double(), create_graph=True)
+        (rhx,) = torch.autograd.grad(rgx.square().sum(), [rw])
+        assert rel_err(hx.cpu(), rhx) < 1e-3
