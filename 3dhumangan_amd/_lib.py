@@ -78,6 +78,7 @@ _SIGNATURES = {
     "h3d_synthesis_x3t_tiles": (C.c_int, [_i]),
     "h3d_synthesis_x3t": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "h3d_synthesis_x3t_tier": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "h3d_synthesis_x3t_tier_guarded": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
     "h3d_modconv1x1": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _f, _p]),
     "h3d_modconv2d": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_synthesis_x3_geometry_ok": (C.c_int, [_i, _i, _i, _i]),

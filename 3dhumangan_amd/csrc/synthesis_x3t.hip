@@ -31,6 +31,8 @@ struct Args {
     const float* ab;              // [B, n_ab, 2, HdP]
     float* rgb;                   // [B, 3, H, W]
     int g_channels, Hr, Wr, n_cst, n_ab, H, W, NT, first_skip;
+    int* ovf;                     // x2 tier: set to 1 when an activation leaves the range of the f16 planes (nullable)
+    const int* run_if;            // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 tier
 };
 
 __device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
@@ -64,6 +66,7 @@ struct Block {
     float *part, *tw;
     int* tap;
     int lane, m, h, wave, b, t, KS, HdP, act_stride;
+    float* gmax;                        // x2: this lane's running maximum of |activation| (range guard)
     Split split;
     X3tRing<NTF + NX>& ring;            // weight fragments in flight (x3t_common.hpp)
 
@@ -80,7 +83,7 @@ struct Block {
     __device__ __forceinline__ int unit_mt(int u) const { return U.mt(u); }
     template <typename F>
     __device__ __forceinline__ void store_unit(const f32x16& v, int nt, int mt, F f) const {
-        if constexpr (X2) x3t_store_unit_x2<true>(v, actT, KS, nt, mt, lane, f);
+        if constexpr (X2) x3t_store_unit_x2<true>(v, actT, KS, nt, mt, lane, f, gmax);
         else x3t_store_unit<LO>(v, actT, KS, nt, mt, lane, split, f);
     }
 
@@ -196,6 +199,7 @@ struct Block {
                 for (int hh = 0; hh < 2; ++hh) {
                     i32x8 rec = x2_record_dyn(__builtin_bit_cast(F16::vec8, ql[hh]), __builtin_bit_cast(F16::vec8, ql[2 + hh]),
                                               __builtin_bit_cast(F16::vec8, qh[hh]), __builtin_bit_cast(F16::vec8, qh[2 + hh]), amax[hh]);
+                    *gmax = vmax(*gmax, amax[hh]);
                     rec[7] = 0;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -308,12 +312,14 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
     int* tap = reinterpret_cast<int*>(cj + 64);                       // [64][4] low-res tap offsets (pixel index)
     float* tw = reinterpret_cast<float*>(tap + 256);                  // [64][2] (ty, tx)
 
+    if (A.run_if && *A.run_if == 0) return;          // guarded fallback: nothing to redo
     const int t = threadIdx.x, lane0 = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane0 & 31, h = lane0 >> 5;
     const int b = blockIdx.y;
     const int64_t HW = (int64_t)A.H * A.W;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
+    float gmax = 0.f;                                // x2 tier: largest |activation| this lane converted (range guard)
     const h3d_synth_desc& D = A.D;
     X3tUnits<NTF, NX> U0;
     U0.init(wave);
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         return Block<NTF, NX, T, P>{A, U, A.wblob + opaque, A.tables + opaque, actT, aT, part, tw, tap,
-                              lane, m, h, wave, b, t, KS, HdP, act_stride, {}, ring};
+                              lane, m, h, wave, b, t, KS, HdP, act_stride, &gmax, {}, ring};
     };
 
     // ================= blocks before the first skip connection (either style) =======================================
@@ -421,6 +427,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         const int64_t p = p0 + pm;
         if (p < HW) A.rgb[((int64_t)b * 3 + c) * HW + p] = rgb_acc;
     }
+    if constexpr (P == 4) {
+        // sticky range flag of the x2 tier: |activation| >= 2^15 (or non-finite) somewhere in this launch
+        if (A.ovf && !(gmax < 32768.f)) atomicOr(A.ovf, 1);
+    }
 }
 
 size_t lds_bytes(int NT) {
@@ -459,9 +469,10 @@ extern "C" int h3d_synthesis_x3t_tiles(int C) {
     return nt + (nt & 1);
 }
 
-extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
-                                      int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
-                                      float* rgb, int B, int H, int W, int dtype, int products, h3d_stream_t stream) {
+static int synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                              int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
+                              float* rgb, int B, int H, int W, int dtype, int products, h3d_stream_t stream, int* ovf,
+                              const int* run_if) {
     H3D_REQUIRE(wblob && tables && desc && rgb, "h3d_synthesis_x3t: null pointer");
     H3D_REQUIRE((dtype == 0 && products == 3) || (dtype == 1 && (products == 1 || products == 2 || products == 4)),
                 "h3d_synthesis_x3t_tier: (dtype, products) must be (0 bf16, 3), (1 f16, 2), (1 f16, 1) or (1 f16, 4 = x2: f16 hi fragments "
@@ -517,12 +528,32 @@ extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, co
     A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr; A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W;
     A.NT = NT;
     A.first_skip = first_skip;
+    A.ovf = ovf; A.run_if = run_if;
     const int64_t tiles = ((int64_t)H * W + 63) / 64;
     H3D_REQUIRE(tiles < (int64_t(1) << 31), "h3d_synthesis_x3t: image too large");
     H3D_REQUIRE(lds_bytes(NT) <= 160 * 1024, "h3d_synthesis_x3t: width %d does not fit the 160 KB LDS", desc->C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == 0) return launch<BF16, 3>(A, B, tiles, st);
     return products == 4 ? launch<F16, 4>(A, B, tiles, st) : products == 2 ? launch<F16, 2>(A, B, tiles, st) : launch<F16, 1>(A, B, tiles, st);
+}
+
+extern "C" int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                                      int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
+                                      float* rgb, int B, int H, int W, int dtype, int products, h3d_stream_t stream) {
+    return synthesis_x3t_tier(wblob, tables, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W, dtype, products, stream,
+                              nullptr, nullptr);
+}
+
+/* Range-guarded pair of the LDS-resident engine (round 4; see h3d_synthesis_x2_guarded): products == 4 (the x2 tier) ORs 1
+ * into *flag when an activation it converted was >= 2^15 in magnitude or non-finite; any other tier (use (0, 3): bf16 planes,
+ * fp32 exponent range) returns at once, leaving rgb untouched, when *flag == 0. */
+extern "C" int h3d_synthesis_x3t_tier_guarded(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                                              int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab,
+                                              int n_ab, float* rgb, int B, int H, int W, int dtype, int products, int* flag,
+                                              h3d_stream_t stream) {
+    H3D_REQUIRE(flag, "h3d_synthesis_x3t_tier_guarded: null flag");
+    return synthesis_x3t_tier(wblob, tables, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W, dtype, products, stream,
+                              products == 4 ? flag : nullptr, products == 4 ? nullptr : flag);
 }
 
 extern "C" int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,

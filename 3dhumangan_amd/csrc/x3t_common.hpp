@@ -336,8 +336,11 @@ __device__ __forceinline__ void x3t_store_unit(const f32x16& v, unsigned char* a
 // x2 epilogue of one unit: f16 hi fragments of k-steps 2*nt, 2*nt+1 into the hi planes, and the K-tile's fp6 record (codes of
 // lo * 2^12 and hi, the lane's block scale in dword 6; x3_common.hpp) split over the two "lo" planes.
 // DYN: per-lane scale from the largest of the 16 values (unbounded activations); otherwise the static scale for |y| <= 1.
+// gmax (DYN): running maximum of |activation| over everything this lane converts -- the x2 range guard (|x| < 2^15 keeps both
+// f16 planes finite; csrc/synthesis_x3.hip: kX2ActLimit)
 template <bool DYN, typename F>
-__device__ __forceinline__ void x3t_store_unit_x2(const f32x16& v, unsigned char* actT, int KS, int nt, int mt, int lane, F f) {
+__device__ __forceinline__ void x3t_store_unit_x2(const f32x16& v, unsigned char* actT, int KS, int nt, int mt, int lane, F f,
+                                                  float* gmax = nullptr) {
     u32x4 hi[2], lo[2];
     float amax = 0.f;
 #pragma unroll
@@ -356,6 +359,7 @@ __device__ __forceinline__ void x3t_store_unit_x2(const f32x16& v, unsigned char
     const F16::vec8 l0v = __builtin_bit_cast(F16::vec8, lo[0]), l1v = __builtin_bit_cast(F16::vec8, lo[1]);
     const F16::vec8 h0v = __builtin_bit_cast(F16::vec8, hi[0]), h1v = __builtin_bit_cast(F16::vec8, hi[1]);
     i32x8 rec = DYN ? x2_record_dyn(l0v, l1v, h0v, h1v, amax) : x2_record(l0v, l1v, h0v, h1v);
+    if (DYN && gmax) *gmax = vmax(*gmax, amax);
     rec[7] = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -530,7 +530,20 @@ class SynthesisPlan:
         rgb = torch.empty(B, 3, H, W, device=fixed_style.device, dtype=torch.float32)
         what = ("h3d_synthesis_x2" if x2 else "h3d_synthesis_x3") if x3 else "h3d_synthesis_x3t" if x3t else "h3d_synthesis"
         with stage(owner, "synthesis"):
-            if x3t:
+            if x3t and tier[2] == 4 and self.x2_guard:
+                # the x2 tier of the LDS-resident engine, range-guarded like the register engine below: the bf16 tier runs
+                # behind it on the same flag and only does work when the x2 launch left its f16 range
+                alt_tier = self.X3T_TIERS["bf16x3t"]
+                alt = self.build_x3t(alt_tier[0], alt_tier[3])
+                if self._x2_flag is None or self._x2_flag.device != fixed_style.device:
+                    self._x2_flag = torch.zeros(1, dtype=torch.int32, device=fixed_style.device)
+                self._x2_flag.zero_()
+                call = lambda blk, tr: _lib.load().h3d_synthesis_x3t_tier_guarded(
+                    _lib.ptr(blk["wblob"]), _lib.ptr(blk["tables"]), ctypes.byref(blk["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr,
+                    _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W, tr[1], tr[2],
+                    _lib.ptr(self._x2_flag), _lib.stream_handle())
+                rc = call(x3t, tier) or call(alt, alt_tier)
+            elif x3t:
                 rc = _lib.load().h3d_synthesis_x3t_tier(_lib.ptr(x3t["wblob"]), _lib.ptr(x3t["tables"]),
                                                       ctypes.byref(x3t["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr,
                                                       _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids),
@@ -582,7 +595,7 @@ class SynthesisPlan:
     def x2_fell_back(self):
         """True when the last run() of the guarded x2 engine left its f16 range and the image came from the bf16 engine
         (reads the device flag: synchronises; for tests and diagnostics)."""
-        return self._x2_flag is not None and bool(int(self._x2_flag.item()))
+        return self._x2_flag is not None and bool(int(self._x2_flag.item()))        # register engine and LDS-resident x2 tier alike
 
     def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):
         return _lib.load().h3d_synthesis(_lib.ptr(self.blob), ctypes.byref(self.desc), _lib.ptr(G), self.g_channels, Hr, Wr,

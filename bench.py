@@ -461,7 +461,7 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
     plan = G.synthesis_plan(z.device)
     return dict(max_rel_err=worst, max_rel_err_render=worst_r, tolerance=1e-3, ok=bool(worst < 1e-3 and worst_r < 1e-3),
                 batch_items=list(items), pixels=int(len(pix)), rays=int(rays), per_item_max_rel_err=[round(e, 7) for e in per_item],
-                synthesis_engine=plan.engine, x2_range_guard_fell_back=bool(plan.x2_fell_back()) if plan.engine == "f16x2" else None,
+                synthesis_engine=plan.engine, x2_range_guard_fell_back=bool(plan.x2_fell_back()) if plan.engine in ("f16x2", "f16x2t") else None,
                 against="CPU oracle on a pixel/ray subset (per-channel max-norm); oracle pinned to the reference's vectors")
 
 

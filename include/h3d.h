@@ -421,6 +421,13 @@ int h3d_synthesis_x3t(const void* wblob, const float* tables, const h3d_synth_de
 int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G, int g_channels,
                            int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H,
                            int W, int dtype, int products, h3d_stream_t stream);
+/* Range-guarded pair of this engine (round 4; as h3d_synthesis_x2_guarded / h3d_synthesis_x3_if): with products == 4 (the x2
+ * tier) the launch ORs 1 into *flag (int32, device memory, zeroed by the caller) when an activation it converted to the f16
+ * planes was >= 2^15 in magnitude or non-finite; with any other tier -- use (dtype 0, products 3): bf16 planes, fp32 exponent
+ * range, `wblob` in that tier's format -- it returns at once, leaving rgb untouched, when *flag == 0. */
+int h3d_synthesis_x3t_tier_guarded(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
+                                   int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
+                                   float* rgb, int B, int H, int W, int dtype, int products, int* flag, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P3a per-pixel modulated 1x1 convolution == SpatialStyleModLayer.forward (lib/components/map3d_layers.py:60-80)

@@ -182,3 +182,25 @@ def test_trained_like_weights_stay_inside_half_the_budget_or_are_declined(width)
           f"running_var in [{float(rv.min()):.2g}, {float(rv.max()):.2g}]")
     assert e3 < 1e-3
     assert fell or e_ch < 5e-4
+
+
+def test_wide_engine_x2_tier_is_guarded_too():
+    """The LDS-resident engine's x2 tier (f16x2t: MAP3DBN 384, MAP3DBN512L 420) carries the same flag: in range it changes
+    nothing, out of range the bf16 tier recomputes the image."""
+    width = 300
+    G, meta, sd = make(width, 40, 24, 9, 5, seed=6, mode="isolated")
+    plan = G.synthesis_plan(DEV)
+    assert plan.engine == "f16x2t"
+    fmap, style = torch.randn(2, 45, width), torch.randn(2, width)
+    out = run(G, meta, fmap, style)
+    assert not plan.x2_fell_back()
+    assert rel_err(out.cpu(), oracle_rgb(sd, meta, fmap, style)) < 1e-3
+    plan.x2_guard = False
+    assert torch.equal(out, run(G, meta, fmap, style))
+    plan.x2_guard = True
+    big = fmap * 6e4
+    ref = oracle_rgb(sd, meta, big, style)
+    assert torch.isfinite(ref).all()
+    out = run(G, meta, big, style)
+    assert plan.x2_fell_back()
+    assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-3
