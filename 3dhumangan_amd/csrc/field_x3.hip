@@ -131,6 +131,7 @@ struct Args {
     int V, legacy_mode;
 };
 
+constexpr int kHeadPad = 64;       // bytes behind every head's fragment rows in LDS (bank staggering)
 constexpr int kJointRows = 40;     // GEOIN: LDS table of 3 + 24 + 13 float4 rows (joints at rows 3..26, zeros around them)
 
 // the oracle's squared distance, (dx*dx + dy*dy) + dz*dz without contraction (geo_features.hip: sqdist_exact)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
     u32x4 hwh, hwl, hws;
     // head A fragment of k-step s: lane (row m, half h) reads head (m & 3), plane hi / lo (/ hi * 2^-12: the x2 lo
     // fragments are pre-multiplied by 2^12): [head][plane][KS][half][16 B]
-    const lds_ptr hbase = lane_base(head_lds, ((((lane & 3) * PL) * KS) * 2 + (lane >> 5)) * 16);
+    const lds_ptr hbase = lane_base(head_lds, (lane & 3) * (PL * KS * 32 + kHeadPad) + (lane >> 5) * 16);
     auto load_head = [&](int s) __attribute__((always_inline)) {
         hwh = lds_ld<u32x4>(hbase + s * 32);
         hwl = lds_ld<u32x4>(hbase + (KS + s) * 32);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     float* scratch = tfeat0 + HdP;                      // [4 waves][64]: compositing weights, background terms
     float* joint0 = scratch + 4 * 64;                   // GEOIN: [kJointRows] float4 (x, y, z, 0): joints at rows 3 .. 26
     unsigned char* head0 = reinterpret_cast<unsigned char*>(joint0 + (GEOIN ? kJointRows * 4 : 0));      // head A-fragment rows
-    unsigned char* ring_lds = head0 + 4 * (X2 ? 3 : 2) * KS * 32;                        // [ring depth][NT*2 KB]
+    unsigned char* ring_lds = head0 + 4 * ((X2 ? 3 : 2) * KS * 32 + kHeadPad);           // [ring depth][NT*2 KB]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -381,7 +382,10 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         }
         const u32x4* hsrc = reinterpret_cast<const u32x4*>(blob + L.head_w);
         u32x4* hdst = reinterpret_cast<u32x4*>(head0);
-        for (int idx = t; idx < 4 * (X2 ? 3 : 2) * KS * 2; idx += 256) hdst[idx] = hsrc[idx];
+        // 64 bytes of padding behind every head: the four heads' rows would otherwise start 1536 (3072) bytes apart -- the same
+        // banks -- and every head-fragment read (lanes of a 16-lane group address all four heads) was a 4-way conflict
+        constexpr int per_head = (X2 ? 3 : 2) * KS * 2;               // 16-byte units per head
+        for (int idx = t; idx < 4 * per_head; idx += 256) hdst[idx + (idx / per_head) * (kHeadPad / 16)] = hsrc[idx];
     }
     __syncthreads();
 
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 
 size_t lds_bytes(const LayoutX3& L, bool geoin = false) {
     return sizeof(float) * ((size_t)ST_COUNT * 2 * L.HdP + L.HdP + 4 * 64 + (geoin ? kJointRows * 4 : 0)) +
-           (size_t)4 * L.head_planes * L.KS * 32 + (L.head_planes == 3 ? kRingX2 : H3D_RING_DEPTH) * (size_t)L.NT * 2048;
+           (size_t)4 * (L.head_planes * L.KS * 32 + kHeadPad) + (L.head_planes == 3 ? kRingX2 : H3D_RING_DEPTH) * (size_t)L.NT * 2048;
 }
 
 template <int NT, bool FUSED, bool X2, bool GEOIN = false>
