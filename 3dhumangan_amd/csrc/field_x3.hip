@@ -391,9 +391,11 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 
     const float* __restrict__ head_inv = reinterpret_cast<const float*>(A.blob + L.head_inv);
     const float* __restrict__ head_b = reinterpret_cast<const float*>(A.blob + L.head_b);
-    const float inv_f = invs[W_FEAT];
-    const float hi0 = head_inv[0], hi1 = head_inv[1], hi2 = head_inv[2], hi3 = head_inv[3];
-    const float hb0 = head_b[0], hb1 = head_b[1], hb2 = head_b[2], hb3 = head_b[3];
+    float inv_f = invs[W_FEAT];
+    float hi0 = head_inv[0], hi1 = head_inv[1], hi2 = head_inv[2], hi3 = head_inv[3];
+    float hb0 = head_b[0], hb1 = head_b[1], hb2 = head_b[2], hb3 = head_b[3];
+    // uniform constants that only ever feed per-lane arithmetic: kept in vector registers (see the pointers below)
+    asm volatile("" : "+v"(inv_f), "+v"(hi0), "+v"(hi1), "+v"(hi2), "+v"(hi3), "+v"(hb0), "+v"(hb1), "+v"(hb2), "+v"(hb3));
     float* wl_lds = scratch + wave * 64;      // [32] weights, [32] background
 
     const int unit = FUSED ? (S > 32 ? S : 32) : 32;          // samples a wave walks per unit (whole rays when fused)
@@ -406,6 +408,20 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
     int n_groups = A.n_groups;
     asm volatile("" : "+s"(n_groups));           // pinned: not re-loaded from the kernarg segment inside the loop
+    // The per-step global pointers live in VECTOR registers (the kernel has ~60 to spare, and every one of them is only ever
+    // used in per-lane address arithmetic): as scalar values they were the bulk of the kernel's 70-85 spilled SGPRs, each
+    // reloaded with v_readlane where it was used.
+    // (address-space-1 pointer types: a laundered generic pointer would turn every access into a FLAT one)
+    typedef const __attribute__((address_space(1))) float* gcf;
+    typedef __attribute__((address_space(1))) float* gf;
+    typedef const __attribute__((address_space(1))) int* gci;
+    gcf a_points = (gcf)A.points, a_geo = (gcf)A.geo, a_dirs = (gcf)A.dirs, a_z = (gcf)A.z_vals, a_noise = (gcf)A.noise;
+    gf a_feats = (gf)A.feats, a_depth = (gf)A.depth, a_weights = (gf)A.weights, a_out = (gf)A.out;
+    gci a_nn = (gci)A.nn_index;
+    gcf a_vik = (gcf)A.vertex_ik, a_tpose = (gcf)A.tpose, a_verts = (gcf)A.vertices;
+    asm volatile("" : "+v"(a_points), "+v"(a_geo), "+v"(a_dirs), "+v"(a_z), "+v"(a_noise), "+v"(a_feats), "+v"(a_depth),
+                      "+v"(a_weights), "+v"(a_out));
+    if constexpr (GEOIN) asm volatile("" : "+v"(a_nn), "+v"(a_vik), "+v"(a_tpose), "+v"(a_verts));
 
     // Persistent workgroups: the sample's tables above are built once, then the workgroup walks the unit groups blockIdx.x,
     // blockIdx.x + gridDim.x, .. with the weight ring running across them (the stream wraps at the end of every step).
@@ -446,13 +462,13 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         // ---- inputs as B fragments: coordinates (K = 3), geometry features (K = 31), view direction (K = 3)
         half8 ch, cl, gh[2], gl[2];
         {
-            const float* __restrict__ p = A.points + gi * 3;
+            gcf p = a_points + gi * 3;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (e < 3 && h == 0 && ok) ? p[e < 3 ? e : 0] * A.input_scaler : 0.f;
             split8(v, kSIn, ch, cl);
             if constexpr (!GEOIN) {
-                const float* __restrict__ g = A.geo + gi * A.geo_stride;
+                gcf g = a_geo + gi * A.geo_stride;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 // of the sample's 31 features, slot q = 8 ks + e <-> feature k = 16 ks + 8 h + e.  Feature order
                 // [cano 3 | joints 24 | T-pose vertex 3 | distance 1] (legacy_mode: joints first, then cano).
                 const float X = p[0], Y = p[1], Z = p[2];
-                const int vi = A.nn_index[gi];
+                const int vi = a_nn[gi];
                 const int64_t vrow = (int64_t)b * A.V + vi;
                 float f[16];
                 // every slot as a joint distance first: row k (+ 3 in legacy order) of the padded joint table, one broadcast
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                     f[q] = __builtin_amdgcn_sqrtf(ax * ax + ay * ay + az * az) * (1.f / 2.4f);
                 }
                 if (h == (A.legacy_mode ? 1 : 0)) {            // canonical coordinates: features 0..2 (legacy: 24..26)
-                    const float4* __restrict__ M = reinterpret_cast<const float4*>(A.vertex_ik + vrow * 16);
+                    const __attribute__((address_space(1))) float4* M = reinterpret_cast<const __attribute__((address_space(1))) float4*>(a_vik + vrow * 16);
                     const float4 r0 = M[0], r1 = M[1], r2 = M[2];
                     const float cx = (r0.x * X + r0.y * Y + r0.z * Z + r0.w) * 0.5f;
                     const float cy = ((r1.x * X + r1.y * Y + r1.z * Z + r1.w) + 0.2f) * 0.5f;
@@ -491,8 +507,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                     else { f[0] = cx; f[1] = cy; f[2] = cz; }
                 }
                 if (h == 1) {                                   // features 27..30 (+ the padding slot 31)
-                    const float* __restrict__ tv = A.tpose + vrow * 3;
-                    const float* __restrict__ vv = A.vertices + vrow * 3;
+                    gcf tv = a_tpose + vrow * 3;
+                    gcf vv = a_verts + vrow * 3;
                     f[11] = tv[0]; f[12] = tv[1]; f[13] = tv[2] * (1.f / 0.2f);
                     f[14] = __builtin_amdgcn_sqrtf(sqdist_exact(X, Y, Z, vv[0], vv[1], vv[2])) * (1.f / 1.3f);
                     f[15] = 0.f;
@@ -540,8 +556,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
             if (h == 0) {
-                if (A.dirs) {
-                    if (ok) { v[0] = A.dirs[gi * 3]; v[1] = A.dirs[gi * 3 + 1]; v[2] = A.dirs[gi * 3 + 2]; }
+                if (a_dirs) {
+                    if (ok) { v[0] = a_dirs[gi * 3]; v[1] = a_dirs[gi * 3 + 1]; v[2] = a_dirs[gi * 3 + 2]; }
                 } else {
                     v[2] = -1.f;                      // lock_view_dependence: (0, 0, -1)
                 }
@@ -555,15 +571,15 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         const float sigma = __shfl(hacc[0], m, 64) * hi0 + hb0;
         float w = 0.f, bg = 0.f;
         if (!FUSED) {
-            if (ok && h == 0) A.out[gi * (F + 4) + F + 3] = sigma;
+            if (ok && h == 0) a_out[gi * (F + 4) + F + 3] = sigma;
         } else {
             // compositing weights of these 32 samples (both lane halves compute identical values)
             const int s_idx = A.log2S < 0 ? si * 32 + m : (int)(n & (S - 1));
             float alpha = 0.f, f = 1.f, z = 0.f;
             if (ok) {
-                z = A.z_vals[gi];
-                const float delta = (s_idx == S - 1) ? 1e9f : A.z_vals[gi + 1] - z;
-                const float sgn = sigma + (A.noise ? A.noise[gi] : 0.f);
+                z = a_z[gi];
+                const float delta = (s_idx == S - 1) ? 1e9f : a_z[gi + 1] - z;
+                const float sgn = sigma + (a_noise ? a_noise[gi] : 0.f);
                 alpha = 1.f - expf(-delta * density(sgn, A.clamp_mode));
                 f = (1.f - alpha) + 1e-12f;
             }
@@ -588,11 +604,11 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             if (last_step) {
                 bg = 1.f - carryW;
                 if (ok && s_idx == S - 1) {
-                    if (h == 0) A.depth[ray_of(n)] = carryD + bg * z_last;
+                    if (h == 0) a_depth[ray_of(n)] = carryD + bg * z_last;
                     if (A.last_back) w += bg;
                 }
             }
-            if (ok && h == 0) A.weights[gi] = w;
+            if (ok && h == 0) a_weights[gi] = w;
             if (h == 0) { wl_lds[m] = w; wl_lds[32 + m] = bg; }
         }
 
@@ -610,9 +626,9 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
         H3D_TRACE(5);
         if (!FUSED) {
             if (ok && h == 0) {
-                A.out[gi * (F + 4) + 0] = rgb[0];
-                A.out[gi * (F + 4) + 1] = rgb[1];
-                A.out[gi * (F + 4) + 2] = rgb[2];
+                a_out[gi * (F + 4) + 0] = rgb[0];
+                a_out[gi * (F + 4) + 1] = rgb[1];
+                a_out[gi * (F + 4) + 2] = rgb[2];
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r >> 2) * 8 + 4 * h + (r & 3);
                     const int64_t pn = n0 + row;
-                    if (pn < N) A.out[((int64_t)b * N + pn) * (F + 4) + 3 + nn] = fmaf(acc[nt][r], inv_f, bias);
+                    if (pn < N) a_out[((int64_t)b * N + pn) * (F + 4) + 3 + nn] = fmaf(acc[nt][r], inv_f, bias);
                 }
             }
         } else {
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                 }
                 if (last_step && h == 0 && sl < 3 && ok) {
                     const int64_t ray = ray_of(n);
-                    A.feats[ray * C + sl] = mine + (A.white_back ? bg : 0.f);
+                    a_feats[ray * C + sl] = mine + (A.white_back ? bg : 0.f);
                 }
             }
             // features: sum over the rows (samples) of each ray held in this lane's accumulator registers
@@ -661,15 +677,15 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             const float back = A.white_back ? wl_lds[32] : 0.f;
             // per-lane output addresses and background terms, once per step: the tile loop below then needs no scalar pointer,
             // ray index or kernel argument (they were spilled SGPRs, reloaded with v_readlane in every tile iteration)
-            float* fout = A.feats + ray_of(n0) * C + 3 + m;                       // S >= 32: one ray per wave step
-            float* frg[4];
+            gf fout = a_feats + ray_of(n0) * C + 3 + m;                       // S >= 32: one ray per wave step
+            gf frg[4];
             float brg[4];
             bool okrg[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {                                      // S < 32: a ray per 8 / 16 rows
                 const int64_t n_first = n0 + rg * 8;
                 okrg[rg] = h == 0 && n_first < N;
-                frg[rg] = A.feats + ray_of(okrg[rg] ? n_first : n0) * C + 3 + m;
+                frg[rg] = a_feats + ray_of(okrg[rg] ? n_first : n0) * C + 3 + m;
                 brg[rg] = A.white_back ? wl_lds[32 + rg * 8] : 0.f;
             }
             const bool store_ray = last_step && h == 0 && n0 < N;
