@@ -49,6 +49,9 @@ _SIGNATURES = {
     "h3d_conv_x3_tiling": (C.c_int, [_i, _i, C.POINTER(C.c_int)]),
     "h3d_conv_x3_pack": (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
     "h3d_conv_x3": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_f16": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_wgrad_x3_f16": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_wgrad_x3_bias_f16": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_slices": (C.c_int, [_i, _i, _i, _i, _i, _i]),
     "h3d_conv_wgrad_x3_fused": (C.c_int, [_i, _i, _i, _i, _i]),
     "h3d_conv_wgrad_x3": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -103,6 +106,10 @@ _SIGNATURES = {
     "h3d_spade_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_spade_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_spade_bwd_apply": (C.c_int, [_p] * 14 + [_i, _l, _i, _i, _f, _p]),
+    "h3d_channel_moments_f16": (C.c_int, [_p, _p, _i, _l, _i, _p]),
+    "h3d_spade_fwd_f16": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
+    "h3d_spade_bwd_reduce_f16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
+    "h3d_spade_bwd_apply_f16": (C.c_int, [_p] * 14 + [_i, _l, _i, _i, _f, _p]),
     "h3d_bias_act": (C.c_int, [_p, _p, _p, _l, _i, _l, _l, _i, _f, _f, _f, _p]),
     "h3d_bias_act_grad": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _l, _l, _i, _i, _f, _f, _f, _p]),
     "h3d_upfirdn2d": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), _i, _i, _i, _i, C.POINTER(_l),

@@ -13,6 +13,7 @@
 // pipe, and splits them into bf16 hi / lo fragments in registers (fp32 exponent range: gradients need no scaling; 16 mantissa
 // bits per operand: ~2e-5 against fp64).  Every product is hi*hi + hi*lo + lo*hi with fp32 accumulation.
 #include "x3_common.hpp"
+#include <type_traits>
 
 using namespace h3d;
 
@@ -21,14 +22,16 @@ namespace {
 constexpr int kDepth = 7;          // ring stages (NT * 2 KiB each)
 
 struct Args {
-    const float* x;                // [P, Cin]
+    const void* x;                 // [P, Cin] fp32, or _Float16 in the HALF instantiations (AMP: activations travel as f16)
     const unsigned char* stream;   // packed weights
     const float* bias;             // [Cout] or null
-    float* out;                    // [P, Cout]
+    void* out;                     // [P, Cout], same element type as x
     int64_t P;                     // B * H * W
     int H, W, Cin, Cout, k, n_chunks, stages_per_oblk;
-    int ldx, ldo;                  // row strides (floats) of x and out: >= Cin / Cout (channel slices of wider tensors)
+    int ldx, ldo;                  // row strides (elements) of x and out: >= Cin / Cout (channel slices of wider tensors)
 };
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 // this lane's 8 consecutive channels (16 ks + 8 h ..) of its shifted pixel for the KSC k-steps of one chunk: 2 float4 per k-step
 template <int KSC>
@@ -38,6 +41,28 @@ __device__ __forceinline__ void load_chunk(float4 (&raw)[2 * KSC], const float* 
         const float4* q = reinterpret_cast<const float4*>(src + 16 * s + 8 * h);
         raw[2 * s] = valid ? q[0] : make_float4(0.f, 0.f, 0.f, 0.f);
         raw[2 * s + 1] = valid ? q[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// f16 activations: the lane's 8 channels of a k-step are ONE 16-byte load
+template <int KSC>
+__device__ __forceinline__ void load_chunk(u32x4 (&raw)[KSC], const _Float16* __restrict__ src, bool valid, int h) {
+#pragma unroll
+    for (int s = 0; s < KSC; ++s)
+        raw[s] = valid ? *reinterpret_cast<const u32x4*>(src + 16 * s + 8 * h) : u32x4{0u, 0u, 0u, 0u};
+}
+// ... split into bf16 hi / lo as the fp32 path does: exact (f16 carries 11 significant bits, the two bf16 halves 16)
+template <int KSC>
+__device__ __forceinline__ void split_chunk(const u32x4 (&raw)[KSC], BF16::vec8 (&xh)[KSC], BF16::vec8 (&xl)[KSC]) {
+#pragma unroll
+    for (int s = 0; s < KSC; ++s) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const h16x2 v = __builtin_bit_cast(h16x2, raw[s][e]);
+            hw[e] = split2_bf16((float)v.x, (float)v.y, lw[e]);
+        }
+        xh[s] = __builtin_bit_cast(BF16::vec8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+        xl[s] = __builtin_bit_cast(BF16::vec8, u32x4{lw[0], lw[1], lw[2], lw[3]});
     }
 }
 
@@ -55,8 +80,9 @@ __device__ __forceinline__ void split_chunk(const float4 (&raw)[2 * KSC], BF16::
     }
 }
 
-template <int NT, int KSC>
+template <int NT, int KSC, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
+    typedef typename std::conditional<HALF, _Float16, float>::type TX;
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_lds[];
     constexpr int L = NT >= 4 ? 2 : 1;
     const int t = threadIdx.x, lane = t & 63;
@@ -76,25 +102,25 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
     ring.init(A.stream + (int64_t)oblk * A.stages_per_oblk * (NT * 2048), ring_lds, A.stages_per_oblk, wave, lane);
 
     f32x16 acc[NT];
-    float4 raw[2 * KSC];
+    typename std::conditional<HALF, u32x4[KSC], float4[2 * KSC]>::type raw;
     BF16::vec8 xh[KSC], xl[KSC];
-    auto source = [&](int it, bool& valid) -> const float* {
+    auto source = [&](int it, bool& valid) -> const TX* {
         const int tap = it / A.n_chunks, chunk = it - tap * A.n_chunks;
         const int ty = tap / A.k - pad, tx = tap - (tap / A.k) * A.k - pad;
         valid = okp && (unsigned)(y + ty) < (unsigned)A.H && (unsigned)(x + tx) < (unsigned)A.W;
         const int64_t q = valid ? pc + (int64_t)ty * A.W + tx : pc;
-        return A.x + q * A.ldx + chunk * (16 * KSC);
+        return static_cast<const TX*>(A.x) + q * A.ldx + chunk * (16 * KSC);
     };
     {
         bool valid;
-        const float* src = source(0, valid);
+        const TX* src = source(0, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
     // first chunk: fresh accumulators
     split_chunk<KSC>(raw, xh, xl);
     if (n_iter > 1) {
         bool valid;
-        const float* src = source(1, valid);
+        const TX* src = source(1, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
     gemm_x3_roll<BF16, NT, KSC, KSC, false, L, 0, true>(acc, xh, xl, ring);
@@ -104,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
         split_chunk<KSC>(raw, xh, xl);
         if (it + 1 < n_iter) {
             bool valid;
-            const float* src = source(it + 1, valid);
+            const TX* src = source(it + 1, valid);
             load_chunk<KSC>(raw, src, valid, h);
         }
         gemm_x3_roll<BF16, NT, KSC, KSC, false, L>(acc, xh, xl, ring);
@@ -112,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
     ring.drain();
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
     if (okp) {
-        float* __restrict__ o = A.out + p * A.ldo + oblk * (NT * 32);
+        TX* __restrict__ o = static_cast<TX*>(A.out) + p * A.ldo + oblk * (NT * 32);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
@@ -124,7 +150,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
                     const float4 b = *reinterpret_cast<const float4*>(A.bias + oblk * (NT * 32) + n);
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 }
-                *reinterpret_cast<float4*>(o + n) = v;
+                if constexpr (HALF) {            // round to f16 once, after the fp32 accumulation and the bias
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const h16x2 a = __builtin_convertvector(f2{v.x, v.y}, h16x2), c = __builtin_convertvector(f2{v.z, v.w}, h16x2);
+                    *reinterpret_cast<uint2*>(o + n) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c));
+                } else {
+                    *reinterpret_cast<float4*>(o + n) = v;
+                }
             }
         }
     }
@@ -149,12 +181,12 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __
     stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = __builtin_bit_cast(unsigned short, lo);
 }
 
-template <int NT, int KSC>
+template <int NT, int KSC, bool HALF>
 int launch(const Args& A, int n_oblk, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC>));
+    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, HALF>));
     const int64_t tiles = (A.P + 127) / 128;
     h3d::pre_launch();
-    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
+    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, HALF>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
     return h3d::launch_status("h3d_conv_x3");
 }
 
@@ -187,8 +219,22 @@ extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin,
     return h3d::launch_status("h3d_conv_x3_pack");
 }
 
+static int conv_x3_any(bool half, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_);
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
+    return conv_x3_any(false, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
+}
+/* h3d_conv_x3 on f16 activations (AMP, round 4): x and out are _Float16 (row strides in elements, multiples of 8), weights and
+ * bias as for h3d_conv_x3 (fp32 bias, the same bf16 hi/lo stream of the fp32 weights: autocast never rounds the weights here);
+ * fp32 accumulation, one rounding to f16 at the store. */
+extern "C" int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+                               int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
+    H3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0, "h3d_conv_x3_f16: row strides must be multiples of 8 halves (ldx=%d ldo=%d)", ldx, ldo);
+    return conv_x3_any(true, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
+}
+static int conv_x3_any(bool half, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
     H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
@@ -207,7 +253,7 @@ extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const int NT = til[0], KSC = til[2];
-#define H3D_CASE(N, K) if (NT == N && KSC == K) return launch<N, K>(A, til[1], st)
+#define H3D_CASE(N, K) if (NT == N && KSC == K) return half ? launch<N, K, true>(A, til[1], st) : launch<N, K, false>(A, til[1], st)
     H3D_CASE(8, 8); H3D_CASE(8, 4); H3D_CASE(4, 8); H3D_CASE(4, 4); H3D_CASE(2, 8); H3D_CASE(2, 4);
 #undef H3D_CASE
     return H3D_EUNSUPPORTED;

@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
                     f[q] = __builtin_amdgcn_sqrtf(ax * ax + ay * ay + az * az) * (1.f / 2.4f);
                 }
                 if (h == (A.legacy_mode ? 1 : 0)) {            // canonical coordinates: features 0..2 (legacy: 24..26)
-                    const __attribute__((address_space(1))) float4* M = reinterpret_cast<const __attribute__((address_space(1))) float4*>(a_vik + vrow * 16);
-                    const float4 r0 = M[0], r1 = M[1], r2 = M[2];
+                    const __attribute__((address_space(1))) f32x4* M = reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(a_vik + vrow * 16);
+                    const f32x4 r0 = M[0], r1 = M[1], r2 = M[2];
                     const float cx = (r0.x * X + r0.y * Y + r0.z * Z + r0.w) * 0.5f;
                     const float cy = ((r1.x * X + r1.y * Y + r1.z * Z + r1.w) + 0.2f) * 0.5f;
                     const float cz = (r2.x * X + r2.y * Y + r2.z * Z + r2.w) * (1.f / 1.3f);

@@ -13,6 +13,7 @@
 // (q = t % QP) of the rows g, g + G, ... (g = t / QP), so per-channel constants stay in registers and consecutive lanes touch
 // consecutive 16 bytes.  Partial sums leave through LDS in a fixed order: the two-stage reductions are deterministic.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -31,6 +32,29 @@ template <int V> __device__ __forceinline__ void st(float* p, const float (&v)[V
     if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     else p[0] = v[0];
 }
+// f16 storage (the AMP tier, round 4): the big tensors -- x, y, dy, dx and the per-pixel gamma / beta and their gradients -- travel as
+// _Float16, 8 bytes per 4 channels; every value is widened on load and the arithmetic stays fp32 in registers, rounded once at the store
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int V> __device__ __forceinline__ void ld(const _Float16* p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        const h16x2 a = __builtin_bit_cast(h16x2, u.x), b = __builtin_bit_cast(h16x2, u.y);
+        v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y;
+    } else {
+        v[0] = (float)p[0];
+    }
+}
+template <int V> __device__ __forceinline__ void st(_Float16* p, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        const h16x2 a = __builtin_convertvector(f32x2{v[0], v[1]}, h16x2), b = __builtin_convertvector(f32x2{v[2], v[3]}, h16x2);
+        *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    } else {
+        p[0] = (_Float16)v[0];
+    }
+}
+// gamma / beta: per-pixel tensors of the activations' type, or per-sample fp32 vectors
+template <bool PIX, typename T> struct Mod { typedef typename std::conditional<PIX, T, float>::type type; };
 
 struct Tile {
     int Q, QP, G, g, b;
@@ -66,8 +90,8 @@ __device__ __forceinline__ void block_sums(float (*red)[kThreads][V], const Tile
     __syncthreads();
 }
 
-template <int V>
-__global__ __launch_bounds__(kThreads) void channel_moments(const float* __restrict__ x, float* __restrict__ partial,
+template <int V, typename TA>
+__global__ __launch_bounds__(kThreads) void channel_moments(const TA* __restrict__ x, float* __restrict__ partial,
                                                             int64_t P, int C) {
     __shared__ float red[2][kThreads][V];
     Tile T;
@@ -90,10 +114,10 @@ __global__ __launch_bounds__(kThreads) void channel_moments(const float* __restr
 }
 
 // scale = rstd * g, shift = b - mean * scale
-template <int V, bool PIX>
-__global__ __launch_bounds__(kThreads) void spade_fwd(const float* __restrict__ x, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ y, int64_t P, int C,
+template <int V, bool PIX, typename TA>
+__global__ __launch_bounds__(kThreads) void spade_fwd(const TA* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const typename Mod<PIX, TA>::type* __restrict__ gamma,
+                                                      const typename Mod<PIX, TA>::type* __restrict__ beta, TA* __restrict__ y, int64_t P, int C,
                                                       float slope) {
     Tile T;
     T.init<V>(P, C);
@@ -123,11 +147,11 @@ __global__ __launch_bounds__(kThreads) void spade_fwd(const float* __restrict__ 
 
 // partial[b][blk][0][c] = sum dh, [1][c] = sum dh * n   with n = (x - mean) * rstd, h = n * g + b, u = h (1 + gamma) + beta,
 // du = dy * lrelu'(u), dh = du * (1 + gamma)
-template <int V, bool PIX>
-__global__ __launch_bounds__(kThreads) void spade_bwd_reduce(const float* __restrict__ x, const float* __restrict__ mean,
+template <int V, bool PIX, typename TA>
+__global__ __launch_bounds__(kThreads) void spade_bwd_reduce(const TA* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gw,
-                                                             const float* __restrict__ gb, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ dy,
+                                                             const float* __restrict__ gb, const typename Mod<PIX, TA>::type* __restrict__ gamma,
+                                                             const typename Mod<PIX, TA>::type* __restrict__ beta, const TA* __restrict__ dy,
                                                              float* __restrict__ partial, int64_t P, int C, float slope) {
     __shared__ float red[2][kThreads][V];
     Tile T;
@@ -170,14 +194,14 @@ __global__ __launch_bounds__(kThreads) void spade_bwd_reduce(const float* __rest
 
 // dx = rstd * g * (dh - c1 - n * c2)   (c1 = sum dh / M, c2 = sum dh n / M for batch statistics; zeros for running statistics)
 // PIX: dgamma = du * h, dbeta = du as tensors.  !PIX: their per-workgroup sums -> partial[b][blk][0|1][c].
-template <int V, bool PIX>
-__global__ __launch_bounds__(kThreads) void spade_bwd_apply(const float* __restrict__ x, const float* __restrict__ mean,
+template <int V, bool PIX, typename TA>
+__global__ __launch_bounds__(kThreads) void spade_bwd_apply(const TA* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gw,
-                                                            const float* __restrict__ gb, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const float* __restrict__ dy,
+                                                            const float* __restrict__ gb, const typename Mod<PIX, TA>::type* __restrict__ gamma,
+                                                            const typename Mod<PIX, TA>::type* __restrict__ beta, const TA* __restrict__ dy,
                                                             const float* __restrict__ c1, const float* __restrict__ c2,
-                                                            float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ partial, int64_t P,
+                                                            TA* __restrict__ dx, TA* __restrict__ dgamma,
+                                                            TA* __restrict__ dbeta, float* __restrict__ partial, int64_t P,
                                                             int C, float slope) {
     __shared__ float red[2][kThreads][V];
     Tile T;
@@ -246,20 +270,22 @@ int check_shape(const char* what, int B, int64_t P, int C) {
 
 extern "C" int h3d_spade_rows(void) { return kRows; }
 
-extern "C" int h3d_channel_moments(const float* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream) {
+template <typename T>
+static int channel_moments_any(const T* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream) {
     if (int rc = check_shape("h3d_channel_moments", B, P, C)) return rc;
     if (B == 0 || P == 0) return H3D_OK;
     H3D_REQUIRE(x && partial, "h3d_channel_moments: null pointer");
     const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     h3d::pre_launch();
-    if (vec_ok(C, {x})) hipLaunchKernelGGL(channel_moments<4>, grid, dim3(kThreads), 0, s, x, partial, P, C);
-    else hipLaunchKernelGGL(channel_moments<1>, grid, dim3(kThreads), 0, s, x, partial, P, C);
+    if (vec_ok(C, {x})) hipLaunchKernelGGL((channel_moments<4, T>), grid, dim3(kThreads), 0, s, x, partial, P, C);
+    else hipLaunchKernelGGL((channel_moments<1, T>), grid, dim3(kThreads), 0, s, x, partial, P, C);
     return h3d::launch_status("h3d_channel_moments");
 }
 
-extern "C" int h3d_spade_fwd(const float* x, const float* scale, const float* shift, const float* gamma, const float* beta,
-                             float* y, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
+template <typename T>
+static int spade_fwd_any(const T* x, const float* scale, const float* shift, const void* gamma, const void* beta,
+                         T* y, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
     if (int rc = check_shape("h3d_spade_fwd", B, P, C)) return rc;
     if (B == 0 || P == 0) return H3D_OK;
     H3D_REQUIRE(x && scale && shift && gamma && beta && y, "h3d_spade_fwd: null pointer");
@@ -267,16 +293,18 @@ extern "C" int h3d_spade_fwd(const float* x, const float* scale, const float* sh
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = vec_ok(C, {x, scale, shift, gamma, beta, y});
     h3d::pre_launch();
-#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_fwd<V, PIX>), grid, dim3(kThreads), 0, s, x, scale, shift, gamma, beta, y, P, C, slope)
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_fwd<V, PIX, T>), grid, dim3(kThreads), 0, s, x, scale, shift, \
+        static_cast<const typename Mod<PIX, T>::type*>(gamma), static_cast<const typename Mod<PIX, T>::type*>(beta), y, P, C, slope)
     if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
     else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
 #undef H3D_GO
     return h3d::launch_status("h3d_spade_fwd");
 }
 
-extern "C" int h3d_spade_bwd_reduce(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
-                                    const float* gamma, const float* beta, const float* dy, float* partial, int B, int64_t P,
-                                    int C, int per_pixel, float slope, h3d_stream_t stream) {
+template <typename T>
+static int spade_bwd_reduce_any(const T* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                const void* gamma, const void* beta, const T* dy, float* partial, int B, int64_t P,
+                                int C, int per_pixel, float slope, h3d_stream_t stream) {
     if (int rc = check_shape("h3d_spade_bwd_reduce", B, P, C)) return rc;
     if (B == 0 || P == 0) return H3D_OK;
     H3D_REQUIRE(x && mean && rstd && g && b && gamma && beta && dy && partial, "h3d_spade_bwd_reduce: null pointer");
@@ -284,17 +312,19 @@ extern "C" int h3d_spade_bwd_reduce(const float* x, const float* mean, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy});
     h3d::pre_launch();
-#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_reduce<V, PIX>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, gamma, beta, dy, partial, P, C, slope)
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_reduce<V, PIX, T>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, \
+        static_cast<const typename Mod<PIX, T>::type*>(gamma), static_cast<const typename Mod<PIX, T>::type*>(beta), dy, partial, P, C, slope)
     if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
     else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
 #undef H3D_GO
     return h3d::launch_status("h3d_spade_bwd_reduce");
 }
 
-extern "C" int h3d_spade_bwd_apply(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
-                                   const float* gamma, const float* beta, const float* dy, const float* c1, const float* c2,
-                                   float* dx, float* dgamma, float* dbeta, float* partial, int B, int64_t P, int C,
-                                   int per_pixel, float slope, h3d_stream_t stream) {
+template <typename T>
+static int spade_bwd_apply_any(const T* x, const float* mean, const float* rstd, const float* g, const float* b,
+                               const void* gamma, const void* beta, const T* dy, const float* c1, const float* c2,
+                               T* dx, T* dgamma, T* dbeta, float* partial, int B, int64_t P, int C,
+                               int per_pixel, float slope, h3d_stream_t stream) {
     if (int rc = check_shape("h3d_spade_bwd_apply", B, P, C)) return rc;
     if (B == 0 || P == 0) return H3D_OK;
     H3D_REQUIRE(x && mean && rstd && g && b && gamma && beta && dy && c1 && c2 && dx, "h3d_spade_bwd_apply: null pointer");
@@ -304,9 +334,53 @@ extern "C" int h3d_spade_bwd_apply(const float* x, const float* mean, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta});
     h3d::pre_launch();
-#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_apply<V, PIX>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta, partial, P, C, slope)
+#define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_apply<V, PIX, T>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, \
+        static_cast<const typename Mod<PIX, T>::type*>(gamma), static_cast<const typename Mod<PIX, T>::type*>(beta), dy, c1, c2, dx, dgamma, dbeta, partial, P, C, slope)
     if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
     else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
 #undef H3D_GO
     return h3d::launch_status("h3d_spade_bwd_apply");
+}
+
+extern "C" int h3d_channel_moments(const float* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream) {
+    return channel_moments_any<float>(x, partial, B, P, C, stream);
+}
+extern "C" int h3d_spade_fwd(const float* x, const float* scale, const float* shift, const float* gamma, const float* beta,
+                             float* y, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_fwd_any<float>(x, scale, shift, gamma, beta, y, B, P, C, per_pixel, slope, stream);
+}
+extern "C" int h3d_spade_bwd_reduce(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                    const float* gamma, const float* beta, const float* dy, float* partial, int B, int64_t P,
+                                    int C, int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_bwd_reduce_any<float>(x, mean, rstd, g, b, gamma, beta, dy, partial, B, P, C, per_pixel, slope, stream);
+}
+extern "C" int h3d_spade_bwd_apply(const float* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                   const float* gamma, const float* beta, const float* dy, const float* c1, const float* c2,
+                                   float* dx, float* dgamma, float* dbeta, float* partial, int B, int64_t P, int C,
+                                   int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_bwd_apply_any<float>(x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta, partial, B, P, C, per_pixel, slope, stream);
+}
+
+/* The same four passes on f16 activations (AMP tier, round 4): x, y, dy, dx and the PER-PIXEL gamma / beta / dgamma / dbeta are
+ * _Float16; per-channel vectors, per-sample gamma / beta and every partial sum stay fp32; arithmetic in fp32 registers. */
+extern "C" int h3d_channel_moments_f16(const void* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream) {
+    return channel_moments_any<_Float16>(static_cast<const _Float16*>(x), partial, B, P, C, stream);
+}
+extern "C" int h3d_spade_fwd_f16(const void* x, const float* scale, const float* shift, const void* gamma, const void* beta,
+                                 void* y, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_fwd_any<_Float16>(static_cast<const _Float16*>(x), scale, shift, gamma, beta, static_cast<_Float16*>(y), B, P, C, per_pixel, slope, stream);
+}
+extern "C" int h3d_spade_bwd_reduce_f16(const void* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                        const void* gamma, const void* beta, const void* dy, float* partial, int B, int64_t P,
+                                        int C, int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_bwd_reduce_any<_Float16>(static_cast<const _Float16*>(x), mean, rstd, g, b, gamma, beta, static_cast<const _Float16*>(dy), partial, B, P, C,
+                                          per_pixel, slope, stream);
+}
+extern "C" int h3d_spade_bwd_apply_f16(const void* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                       const void* gamma, const void* beta, const void* dy, const float* c1, const float* c2,
+                                       void* dx, void* dgamma, void* dbeta, float* partial, int B, int64_t P, int C,
+                                       int per_pixel, float slope, h3d_stream_t stream) {
+    return spade_bwd_apply_any<_Float16>(static_cast<const _Float16*>(x), mean, rstd, g, b, gamma, beta, static_cast<const _Float16*>(dy), c1, c2,
+                                         static_cast<_Float16*>(dx), static_cast<_Float16*>(dgamma), static_cast<_Float16*>(dbeta), partial, B, P, C,
+                                         per_pixel, slope, stream);
 }

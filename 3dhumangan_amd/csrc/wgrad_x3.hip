@@ -24,14 +24,26 @@ constexpr int kThreads = 256;
 constexpr int kKS = 16;                       // rows per k-step
 
 struct Args {
-    const float* dY;
-    const float* X;
+    const void* dY;               // fp32, or f16 when `half` (AMP: activations and their gradients travel as f16; an f16 value's bf16
+    const void* X;                // hi / lo split is exact, so the arithmetic below is unchanged and exact in the operands)
     float* partial;
     int64_t M;
     int Co, Ci, ldy, ldx, rows_per_wg;
     int conv_k, H, W, slices;     // conv_k > 0: weight gradient of a k x k convolution over [B, H, W] pixels (rows of X shifted per tap)
     float* colsum;                // optional [slices][Co]: column sums of dY over the slice's rows (the bias gradient), or null
+    int half;                     // operands are _Float16 (row strides stay in elements)
 };
+
+// four consecutive operand elements as fp32 (wave-uniform `half`: a scalar branch)
+__device__ __forceinline__ float4 ld4(const void* base, int64_t elem, int half) {
+    if (half) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const _Float16*>(base) + elem);
+        const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
+        return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    }
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
+}
 
 // row of X that pairs with row rr of dY for filter tap (ty, tx): the shifted pixel, or -1 outside the image (zero padding)
 __device__ __forceinline__ int64_t shifted_row(int64_t rr, int ty, int tx, int H, int W) {
@@ -43,7 +55,7 @@ __device__ __forceinline__ int64_t shifted_row(int64_t rr, int ty, int tx, int H
 }
 
 template <int NT, bool SHIFT = false>
-__device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restrict__ src, int ld, int64_t row0, int64_t M,
+__device__ __forceinline__ void load_slab(float4 (&r)[NT], const void* __restrict__ src, int half, int ld, int64_t row0, int64_t M,
                                           int col0, int ncols, int t, int ty = 0, int tx = 0, int H = 1, int W = 1) {
     constexpr int W4 = 16 * NT;               // float4 per slab row (slab width 64 NT floats)
 #pragma unroll
@@ -56,7 +68,7 @@ __device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restri
             rr = shifted_row(rr, ty, tx, H, W);
             ok = rr >= 0;
         }
-        r[j] = ok ? *reinterpret_cast<const float4*>(src + rr * ld + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[j] = ok ? ld4(src, rr * ld + col0 + c, half) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -65,7 +77,7 @@ __device__ __forceinline__ void load_slab(float4 (&r)[NT], const float* __restri
 // the band is zero when y + ty leaves the image, its first row is zero when the pixels start an image row (x = 0 has no left
 // neighbour; that band row is only ever read as the tx = -1 neighbour of pixel 0) and its last row when they end one.
 template <int NT>
-__device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const float* __restrict__ src, int ld, int64_t r0, int64_t r_end,
+__device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const void* __restrict__ src, int half, int ld, int64_t r0, int64_t r_end,
                                           int col0, int ncols, int t, int ty, int H, int W) {
     constexpr int W4 = 16 * NT;               // float4 per band row
     constexpr int NJ = NT + (NT + 7) / 8;     // 18 rows = 16 + 2: ceil(18 * W4 / 256) float4 per thread
@@ -82,7 +94,7 @@ __device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const 
         if (row == 17 && x0 + 16 == W) ok = false;
         // pixels of this k-step past the end of the slice contribute nothing through dY (zero rows); their X rows are in range
         const int64_t q = r0 - 1 + row + (int64_t)ty * W;
-        r[j] = ok ? *reinterpret_cast<const float4*>(src + q * ld + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[j] = ok ? ld4(src, q * ld + col0 + c, half) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -147,8 +159,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         for (int j = 0; j < NA; ++j) { cs[j].x += ra[j].x; cs[j].y += ra[j].y; cs[j].z += ra[j].z; cs[j].w += ra[j].w; }
     };
     // rows past r_end must not leak into this slice: the loaders clip at min(M, r_end) through the `M` argument
-    load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
-    load_slab<NB, CONV>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
+    load_slab<NA>(ra, A.dY, A.half, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_slab<NB, CONV>(rb, A.X, A.half, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
     if (do_colsum) add_colsum();
     park_slab<NA>(ra, smem, t);
     park_slab<NB>(rb, smem + kKS * WA, t);
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         float* nxtA = smem + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
-            load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
-            load_slab<NB, CONV>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
+            load_slab<NA>(ra, A.dY, A.half, A.ldy, row0, r_end, co0, A.Co, t);
+            load_slab<NB, CONV>(rb, A.X, A.half, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
             if (do_colsum) add_colsum();
         }
         BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
                 for (int i = 0; i < 16; ++i) acc[x][a][b][i] = 0.f;
 
     float4 ra[NA], rb[NB + (NB + 7) / 8];
-    load_slab<NA>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
-    load_band<NB>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+    load_slab<NA>(ra, A.dY, A.half, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_band<NB>(rb, A.X, A.half, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
     park_slab<NA>(ra, smem, t);
     park_band<NB>(rb, smem + kKS * WA, t);
     __syncthreads();
@@ -251,8 +263,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
         float* nxtA = smem + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
-            load_slab<NA>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
-            load_band<NB>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+            load_slab<NA>(ra, A.dY, A.half, A.ldy, row0, r_end, co0, A.Co, t);
+            load_band<NB>(rb, A.X, A.half, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
         }
         BF16::vec8 ah[NA], al[NA];
 #pragma unroll
@@ -331,8 +343,17 @@ extern "C" int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci) {
     return (int)want;
 }
 
+static int wgrad_x3_any(const void* dY, const void* X, int half, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                        int ldx, int slices, h3d_stream_t stream);
 extern "C" int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
-                                 int ldx, int slices, h3d_stream_t stream);
+                                 int ldx, int slices, h3d_stream_t stream) {
+    return wgrad_x3_any(dY, X, 0, partial, colsum, M, Co, Ci, ldy, ldx, slices, stream);
+}
+/* h3d_wgrad_x3_bias on f16 operands (AMP, round 4): dY, X are _Float16 (row strides in elements), the gradients fp32. */
+extern "C" int h3d_wgrad_x3_bias_f16(const void* dY, const void* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                                     int ldx, int slices, h3d_stream_t stream) {
+    return wgrad_x3_any(dY, X, 1, partial, colsum, M, Co, Ci, ldy, ldx, slices, stream);
+}
 
 extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int Co, int Ci, int ldy, int ldx,
                             int slices, h3d_stream_t stream) {
@@ -341,8 +362,8 @@ extern "C" int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int
 
 // h3d_wgrad_x3 that also writes colsum[slice][Co] = the column sums of dY over the slice's rows (the bias gradient of the same
 // layer; the caller sums the slices): dY is streamed anyway, so the separate reduction pass over it disappears.
-extern "C" int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
-                                 int ldx, int slices, h3d_stream_t stream) {
+static int wgrad_x3_any(const void* dY, const void* X, int half, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                        int ldx, int slices, h3d_stream_t stream) {
     H3D_REQUIRE(dY && X && partial, "h3d_wgrad_x3: null pointer");
     H3D_REQUIRE(M >= 1 && Co >= 1 && Ci >= 1, "h3d_wgrad_x3: bad shape M=%lld Co=%d Ci=%d", (long long)M, Co, Ci);
     H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
@@ -351,7 +372,7 @@ extern "C" int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial
     H3D_REQUIRE(slices >= 1 && slices <= 65535 * 16, "h3d_wgrad_x3: slices=%d out of range", slices);
     Args a{};
     a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx; a.slices = slices;
-    a.colsum = colsum;
+    a.colsum = colsum; a.half = half;
     const int64_t per = (M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -395,8 +416,19 @@ extern "C" int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int
 //   partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co]^T X[p + tap, Ci]      (the caller sums the slices)
 // dY [B*H*W, Co], X [B*H*W, Ci] fp32 with row strides ldy, ldx (channel slices of wider tensors); Co, Ci multiples of 4;
 // slices: any >= 1.
+static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, int B, int H, int W, int Co, int Ci, int k,
+                          int ldy, int ldx, int slices, h3d_stream_t stream);
 extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
                                  int ldy, int ldx, int slices, h3d_stream_t stream) {
+    return conv_wgrad_any(dY, X, 0, partial, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
+}
+/* h3d_conv_wgrad_x3 on f16 operands (AMP, round 4): dY, X are _Float16 (row strides in elements), the gradient fp32. */
+extern "C" int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
+                                     int ldy, int ldx, int slices, h3d_stream_t stream) {
+    return conv_wgrad_any(dY, X, 1, partial, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
+}
+static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, int B, int H, int W, int Co, int Ci, int k,
+                          int ldy, int ldx, int slices, h3d_stream_t stream) {
     H3D_REQUIRE(dY && X && partial, "h3d_conv_wgrad_x3: null pointer");
     H3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Co >= 1 && Ci >= 1 && (k == 1 || k == 3), "h3d_conv_wgrad_x3: bad shape");
     H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
@@ -405,7 +437,7 @@ extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial
     H3D_REQUIRE(slices >= 1 && (int64_t)slices * k * k <= 65535 * 16, "h3d_conv_wgrad_x3: slices=%d out of range", slices);
     Args a{};
     a.dY = dY; a.X = X; a.partial = partial; a.M = (int64_t)B * H * W; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx;
-    a.conv_k = k; a.H = H; a.W = W; a.slices = slices;
+    a.conv_k = k; a.H = H; a.W = W; a.slices = slices; a.half = half;
     const int64_t per = (a.M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);

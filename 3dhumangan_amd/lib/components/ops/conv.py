@@ -40,8 +40,8 @@ def supported(x, weight):
     """The native path takes fp32 CUDA tensors, k in {1, 3} (square).  Channel counts that are multiples of 64 run as they are;
     any other count (the RGB stem, the 1- and label_dim-channel heads, odd widths of the modulated convolutions) is zero-padded
     to the next multiple of 64 by conv2d."""
-    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 4):
-        return False
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.float16) and weight.dtype == torch.float32 and weight.dim() == 4):
+        return False                      # f16 activations: the AMP tier (h3d_conv_x3_f16); weights stay fp32
     co, ci, kh, kw = weight.shape
     if not (kh == kw and kh in (1, 3) and x.shape[1] == ci):
         return False
@@ -83,8 +83,8 @@ def _rows(x):
     B, C, H, W = x.shape
     sb, sc, sh, sw = x.stride()
     ld = sw
-    if (sc == 1 and ld >= C and ld % 4 == 0 and sh == W * ld and (sb == H * W * ld or B == 1)
-            and (x.storage_offset() * 4 + x.untyped_storage().data_ptr()) % 16 == 0):
+    gran = 4 if x.dtype == torch.float32 else 8           # 16-byte accesses: 4 floats or 8 halves
+    if (sc == 1 and ld >= C and ld % gran == 0 and sh == W * ld and (sb == H * W * ld or B == 1) and x.data_ptr() % 16 == 0):
         return x, ld
     if os.environ.get("H3D_CONV_DEBUG"):
         key = (tuple(x.shape), tuple(x.stride()))
@@ -99,24 +99,30 @@ def _run_conv(x, w, bias=None, transposed=False):
     B, ci, H, W = x.shape
     k = w.shape[2]
     co = w.shape[1] if transposed else w.shape[0]
-    stream = pack_stream(w, transposed)
-    out = torch.empty((B, co, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-    b = None if bias is None else _lib.aligned16(bias.detach().contiguous())      # a slice of a larger bias vector may start anywhere
-    rc = _lib.load().h3d_conv_x3(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
+    stream = pack_stream(w.float(), transposed)
+    out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
+    lib = _lib.load()
+    entry = lib.h3d_conv_x3 if x.dtype == torch.float32 else lib.h3d_conv_x3_f16          # f16 in -> f16 out (AMP)
+    rc = entry(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
                                  _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3")
     return out
 
 
 def _run_wgrad(x, g, k):
-    """x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k]; no autograd."""
+    """x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k] fp32; no autograd.  f16 operands (AMP) go to the _f16 entry point: both
+    then travel as f16 (a mixed pair is brought to f16 first)."""
+    if x.dtype != g.dtype:
+        x, g = x.half(), g.half()
     (x, ldx), (g, ldg) = _rows(x), _rows(g)
     B, ci, H, W = x.shape
     co = g.shape[1]
     lib = _lib.load()
     slices = max(1, lib.h3d_conv_wgrad_x3_slices(B, H, W, co, ci, k))
     partial = torch.empty((k * k, slices, co, ci), device=x.device, dtype=torch.float32)
-    rc = lib.h3d_conv_wgrad_x3(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
+    entry = lib.h3d_conv_wgrad_x3 if x.dtype == torch.float32 else lib.h3d_conv_wgrad_x3_f16
+    rc = entry(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_wgrad_x3")
     return partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
 
@@ -136,9 +142,10 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        g = g.to(x.dtype)                   # the cotangent of an f16 output is f16; the weight / bias gradients come out fp32
         gx = _ConvT.apply(g, w) if ctx.needs_input_grad[0] else None
         gw = _ConvW.apply(x, g, w.shape[2]) if ctx.needs_input_grad[1] else None
-        gb = g.sum(dim=(0, 2, 3)) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
+        gb = g.sum(dim=(0, 2, 3), dtype=torch.float32) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 
@@ -153,6 +160,7 @@ class _ConvT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, h):
         g, w = ctx.saved_tensors
+        h = h.to(g.dtype)
         gg = _Conv.apply(h, w) if ctx.needs_input_grad[0] else None
         gw = _ConvW.apply(h, g, w.shape[2]) if ctx.needs_input_grad[1] else None
         return gg, gw
@@ -169,6 +177,7 @@ class _ConvW(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v):
         x, g = ctx.saved_tensors
+        v = v.float()
         gx = _ConvT.apply(g, v) if ctx.needs_input_grad[0] else None
         gg = _Conv.apply(x, v) if ctx.needs_input_grad[1] else None
         return gx, gg, None
@@ -202,6 +211,7 @@ def conv2d(x, weight, bias=None):
         x = x.contiguous(memory_format=torch.channels_last)
         x = torch.cat([x, x.new_zeros((x.shape[0], cip - ci) + tuple(x.shape[2:])).contiguous(memory_format=torch.channels_last)], dim=1)
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cip - ci))
+    weight = weight.float()                 # parameters stay fp32 under autocast: the kernels split them to bf16 hi / lo themselves
     if cop != co:
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, cop - co))
     if (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)) and torch.is_grad_enabled():
@@ -214,4 +224,4 @@ def conv2d(x, weight, bias=None):
         y = _run_conv(x, weight)
     if cop != co:
         y = _NarrowChannels.apply(y, co) if y.requires_grad else y[:, :co]
-    return y if bias is None else y + bias.view(1, -1, 1, 1)
+    return y if bias is None else y + bias.view(1, -1, 1, 1).to(y.dtype)

@@ -39,16 +39,19 @@ def _native_ok(Co, Ci):
 
 
 def wgrad_x3(dy, x, with_bias=False):
-    """dy [M, Co], x [M, Ci] fp32 row-major (row stride >= width, multiple of 4) -> dy^T x [Co, Ci] fp32; with_bias: also the
-    column sums of dy [Co] (the bias gradient of the same layer, from the same pass over dy) -> (dw, db)."""
+    """dy [M, Co], x [M, Ci] row-major (row stride >= width, multiple of 4), both fp32 or (AMP tier) both f16 -> dy^T x [Co, Ci]
+    fp32; with_bias: also the column sums of dy [Co] (the bias gradient of the same layer, from the same pass over dy) -> (dw, db)."""
     _lib.need_cuda(dy, x)
+    if dy.dtype != x.dtype:
+        dy, x = dy.half(), x.half()
     M, Co = dy.shape
     Ci = x.shape[1]
     lib = _lib.load()
     slices = lib.h3d_wgrad_x3_slices(M, Co, Ci)
     partial = torch.empty((slices, Co, Ci), device=dy.device, dtype=torch.float32)
     colsum = torch.empty((slices, Co), device=dy.device, dtype=torch.float32) if with_bias else None
-    rc = lib.h3d_wgrad_x3_bias(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), _lib.ptr(colsum), M, Co, Ci, dy.stride(0), x.stride(0),
+    entry = lib.h3d_wgrad_x3_bias if dy.dtype == torch.float32 else lib.h3d_wgrad_x3_bias_f16
+    rc = entry(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), _lib.ptr(colsum), M, Co, Ci, dy.stride(0), x.stride(0),
                                slices, _lib.stream_handle())
     _lib.check(rc, "h3d_wgrad_x3")
     dw = partial.sum(dim=0) if slices > 1 else partial[0]
@@ -72,7 +75,7 @@ def wgrad_narrow(wide, narrow):
 def _rows(t):
     """[..., C] -> a [M, C] view with unit column stride and a row stride that is a multiple of 4, or a contiguous copy."""
     t2 = t.reshape(-1, t.shape[-1])
-    if t2.stride(1) != 1 or t2.stride(0) % 4 or t2.stride(0) < t2.shape[1]:
+    if t2.stride(1) != 1 or t2.stride(0) % (4 if t2.dtype == torch.float32 else 8) or t2.stride(0) < t2.shape[1]:
         t2 = t2.contiguous()
     return _lib.aligned16(t2)          # a contiguous view at an odd storage offset is copied (.contiguous() would return it as is)
 
@@ -109,10 +112,45 @@ class _LinearX3(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearAmp(torch.autograd.Function):
+    """The dense layer under float16 autocast (AMP tier, round 4; reference: nn.Linear / 1x1 convs inside torch.cuda.amp.autocast):
+    forward and data gradient are the library's f16 GEMMs on f16 activations, the weight gradient (tall-skinny TN: the shape the
+    library is slow at) is h3d_wgrad_x3 on the f16 operands as they are -- fp32 result, no casts; the weight stays fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xh = x.half()
+        ctx.save_for_backward(xh, w)
+        ctx.has_bias = b is not None
+        return F.linear(xh, w.half(), None if b is None else b.half())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        xh, w = ctx.saved_tensors
+        dyh = dy.half()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dyh @ w.half()
+        dy2, x2 = _rows(dyh), _rows(xh)
+        if ctx.needs_input_grad[1]:
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dw, db = wgrad_x3(dy2, x2, with_bias=True)
+            else:
+                dw = wgrad_x3(dy2, x2)
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(dim=0, dtype=torch.float32)
+        return dx, dw, db
+
+
 def linear(x, w, b=None):
     """F.linear(x, w, b); the weight gradient goes to the HIP kernel when the problem is one it is built for."""
     Co, Ci = w.shape
     rows = x.numel() // max(Ci, 1)
+    if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
+            and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.float32 and rows >= MIN_ROWS
+            and Co % 8 == 0 and Ci % 8 == 0 and Co >= 32 and Ci >= 32):
+        return _LinearAmp.apply(x, w, b)
     if (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and torch.is_grad_enabled()
             and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS
             and ((Co % 4 == 0 and Ci % 4 == 0 and Co >= 32 and Ci >= 32)           # h3d_wgrad_x3

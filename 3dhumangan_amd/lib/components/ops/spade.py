@@ -19,7 +19,12 @@ SLOPE = 0.2
 
 
 class HipKernels:
-    """x [B,P,C] fp32 contiguous; gamma / beta [B,P,C] (per pixel) or [B,C] (per sample); per-channel vectors [C] fp32."""
+    """x [B,P,C] contiguous, fp32 or (AMP tier) f16; gamma / beta [B,P,C] (per pixel, same type as x) or [B,C] (per sample, fp32);
+    per-channel vectors [C] fp32.  f16 tensors go to the _f16 entry points: same passes, fp32 arithmetic in registers."""
+
+    @staticmethod
+    def _fn(name, x):
+        return getattr(_lib.load(), name + ("_f16" if x.dtype == torch.float16 else ""))
 
     @staticmethod
     def _nblk(P):
@@ -30,14 +35,14 @@ class HipKernels:
         """-> [2, C] float64: sum x, sum x^2 over all rows."""
         B, P, C = x.shape
         partial = torch.empty((B, self._nblk(P), 2, C), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().h3d_channel_moments(_lib.ptr(x), _lib.ptr(partial), B, P, C, _lib.stream_handle()),
+        _lib.check(self._fn("h3d_channel_moments", x)(_lib.ptr(x), _lib.ptr(partial), B, P, C, _lib.stream_handle()),
                    "h3d_channel_moments")
         return partial.double().sum(dim=(0, 1))
 
     def forward(self, x, scale, shift, gamma, beta):
         B, P, C = x.shape
         y = torch.empty_like(x)
-        _lib.check(_lib.load().h3d_spade_fwd(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(gamma), _lib.ptr(beta),
+        _lib.check(self._fn("h3d_spade_fwd", x)(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(gamma), _lib.ptr(beta),
                                              _lib.ptr(y), B, P, C, int(gamma.dim() == 3), SLOPE, _lib.stream_handle()),
                    "h3d_spade_fwd")
         return y
@@ -46,7 +51,7 @@ class HipKernels:
         """-> [2, C] float64: sum dh, sum dh * n."""
         B, P, C = x.shape
         partial = torch.empty((B, self._nblk(P), 2, C), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().h3d_spade_bwd_reduce(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
+        _lib.check(self._fn("h3d_spade_bwd_reduce", x)(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
                                                     _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(partial), B, P, C,
                                                     int(gamma.dim() == 3), SLOPE, _lib.stream_handle()),
                    "h3d_spade_bwd_reduce")
@@ -60,7 +65,7 @@ class HipKernels:
         dgamma = torch.empty_like(x) if pix else None
         dbeta = torch.empty_like(x) if pix else None
         partial = None if pix else torch.empty((B, self._nblk(P), 2, C), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().h3d_spade_bwd_apply(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
+        _lib.check(self._fn("h3d_spade_bwd_apply", x)(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
                                                    _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(c1), _lib.ptr(c2),
                                                    _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(partial), B, P, C,
                                                    int(pix), SLOPE, _lib.stream_handle()), "h3d_spade_bwd_apply")
@@ -93,7 +98,7 @@ class _SpadeNormAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, g, b, gamma, beta, mean, rstd, count = ctx.saved_tensors
         k = ctx.kernels
-        dy = dy.contiguous()
+        dy = dy.contiguous().to(x.dtype)
         sums = k.backward_sums(x, mean, rstd, g, b, gamma, beta, dy)              # local: they are d_b, d_g
         d_b, d_g = sums[0].float(), sums[1].float()
         if count is not None:
@@ -117,10 +122,15 @@ def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentu
     if k is _HIP:
         _lib.need_cuda(x, gamma, beta)
     B, P, C = x.shape
-    x = x.contiguous().float()
+    # AMP tier: f16 activations stay f16 through the kernels (the per-pixel gamma / beta travel in the same type); anything else
+    # (bf16 autocast, float64) is brought to fp32
+    dt = torch.float16 if (x.dtype == torch.float16 and k is _HIP) else torch.float32
+    x = x.contiguous().to(dt)
     if gamma.shape[1] == 1 and P != 1:
-        gamma, beta = gamma.reshape(B, C), beta.reshape(B, C)
-    gamma, beta = gamma.contiguous().float(), beta.contiguous().float()
+        gamma, beta = gamma.reshape(B, C).float(), beta.reshape(B, C).float()
+    else:
+        gamma, beta = gamma.to(dt), beta.to(dt)
+    gamma, beta = gamma.contiguous(), beta.contiguous()
     count = None
     if training:
         with torch.no_grad():

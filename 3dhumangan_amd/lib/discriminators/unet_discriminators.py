@@ -39,9 +39,17 @@ class Conv2d(nn.Conv2d):
     state_dict, works under nn.utils.spectral_norm (the hook sets `weight` before forward)."""
 
     def forward(self, x):
-        if (os.environ.get("H3D_DISC_CONV", "hip") != "torch" and not torch.is_autocast_enabled()
-                and conv_ops.supported(x, self.weight)):
-            return conv_ops.conv2d(x, self.weight, self.bias)
+        if os.environ.get("H3D_DISC_CONV", "hip") != "torch":
+            if torch.is_autocast_enabled() and x.is_cuda:
+                # AMP tier (round 4): under float16 autocast the layer stays on the native kernels -- activations and their
+                # gradients travel as f16 (h3d_conv_x3_f16 / h3d_conv_wgrad_x3_f16), the weights stay fp32; any other autocast
+                # type goes to the library
+                if torch.get_autocast_dtype("cuda") == torch.float16:
+                    xh = x.half()
+                    if conv_ops.supported(xh, self.weight):
+                        return conv_ops.conv2d(xh, self.weight, self.bias)
+            elif conv_ops.supported(x, self.weight):
+                return conv_ops.conv2d(x, self.weight, self.bias)
         return super().forward(x)
 
 

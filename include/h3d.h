@@ -196,6 +196,18 @@ int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be 
                 h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
                       int ldy, int ldx, int slices, h3d_stream_t stream_handle);
+
+/* AMP tier (round 4; reference: torch.cuda.amp.autocast around both networks, lib/trainers/base_trainer.py:50-51): the same three
+ * kernels on f16 activations / gradients.  x, out, dY, X are _Float16 (row strides in ELEMENTS, multiples of 8 for h3d_conv_x3_f16);
+ * weights, bias and the weight gradients stay fp32 -- the weight stream is the bf16 hi/lo split of the fp32 weights, so autocast
+ * never rounds a weight here -- accumulation is fp32 and an f16 operand's bf16 hi/lo split is exact: the arithmetic is that of the
+ * fp32 entry points on exactly representable inputs, with one rounding to f16 at h3d_conv_x3_f16's store. */
+int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                    int k, int ldx, int ldo, h3d_stream_t stream_handle);
+int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int ldy,
+                          int ldx, int slices, h3d_stream_t stream);
+int h3d_wgrad_x3_bias_f16(const void* dY, const void* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
+                          int ldx, int slices, h3d_stream_t stream);
 /* K-slices to ask for (HOST helper), and whether a 3x3 problem runs on the kernel that fuses the three taps of a filter row
  * (three passes over dY and X instead of nine; image rows must be multiples of 16 pixels). */
 int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int k);
@@ -518,6 +530,19 @@ int h3d_spade_bwd_apply(const float* x, const float* mean, const float* rstd, co
                         const float* gamma, const float* beta, const float* dy, const float* c1, const float* c2, float* dx,
                         float* dgamma, float* dbeta, float* partial, int B, int64_t P, int C, int per_pixel, float slope,
                         h3d_stream_t stream);
+
+/* AMP tier (round 4): the same four passes on f16 activations -- x, y, dy, dx and the PER-PIXEL gamma / beta / dgamma / dbeta are
+ * _Float16; per-channel vectors, per-sample gamma / beta and every partial sum stay fp32; arithmetic in fp32 registers, one
+ * rounding at each store (reference: the SPADE chain under torch.cuda.amp.autocast, lib/trainers/base_trainer.py:50-51). */
+int h3d_channel_moments_f16(const void* x, float* partial, int B, int64_t P, int C, h3d_stream_t stream);
+int h3d_spade_fwd_f16(const void* x, const float* scale, const float* shift, const void* gamma, const void* beta, void* y, int B,
+                      int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream);
+int h3d_spade_bwd_reduce_f16(const void* x, const float* mean, const float* rstd, const float* g, const float* b, const void* gamma,
+                             const void* beta, const void* dy, float* partial, int B, int64_t P, int C, int per_pixel, float slope,
+                             h3d_stream_t stream);
+int h3d_spade_bwd_apply_f16(const void* x, const float* mean, const float* rstd, const float* g, const float* b, const void* gamma,
+                            const void* beta, const void* dy, const float* c1, const float* c2, void* dx, void* dgamma, void* dbeta,
+                            float* partial, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)

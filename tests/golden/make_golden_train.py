@@ -3,6 +3,8 @@
 BUILD CONTAINER ONLY (imports /root/reference through _ref_import.py).  Stores data only:
   disc_tiny.npz         UNetDiscriminator (2 blocks) weights (fp16-exact), images, eval-mode outputs, the reference's
                         logistic GAN loss, balanced segmentation loss and R1 penalty on those outputs
+  disc_tiny_amp.npz     the same module and inputs under float16 autocast (the reference's AMP mode): outputs, losses, the
+                        weight gradient of the D loss
   ema_tiny.npz          ExponentialMovingAverage: parameters before / after three updates, shadow parameters
   ref_ckpt_tiny_*.pth   the files BaseTrainer.save_model writes (pickled generator module, pickled EMA object, optimizer
                         state dict) for a tiny generator -- to pin the checkpoint loader
@@ -10,6 +12,7 @@ BUILD CONTAINER ONLY (imports /root/reference through _ref_import.py).  Stores d
   gstep_tiny.npz/.json  PhaseTrainer.init_optimizer's five Adam groups for a tiny Map3DGenerator (names per group, learning
                         rates) and PhaseTrainer._train_generator run on stand-in generator / discriminator modules: the z it
                         drew, loss, top-k count and the gradients it left on the generator -- pins the G step's loss algebra
+  gen_train_mixed_amp.npz   the same train-mode forward + backward under float16 autocast: outputs and gradients only
   gen_train_*.npz       TRAIN-mode generator forward + backward: weights, conditions, every random tensor, the
                         outputs, the gradient of a fixed random projection of the outputs w.r.t. every parameter and z, and
                         the buffers the train-mode forward overwrote (BatchNorm running statistics, spectral-norm u / v)
@@ -92,6 +95,27 @@ def disc_fixture():
                    prob_real=prob_real.detach(), prob_gen=prob_gen.detach(), total=loss.detach()),
          grad={gkey: dict(D.named_parameters())[gkey].grad})
     json.dump(dict(kwargs=kw, meta=meta, grad_key=gkey), open(os.path.join(HERE, "disc_tiny.json"), "w"))
+    # ---- the same module, inputs and losses under float16 autocast (the reference's AMP mode, lib/trainers/base_trainer.py:50-51:
+    # torch.cuda.amp.autocast around the network forwards; CPU autocast stands in for it here -- same casting policy, the
+    # convolutions run in f16 with f16 outputs): disc_tiny_amp.npz holds ONLY the outputs, losses and the weight gradient;
+    # weights and inputs are disc_tiny's.  No random number is drawn below, so disc_tiny.npz is bit-identical with or without it.
+    D.zero_grad()
+    real_a = real.detach().clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.float16):
+        a_real = D(real_a, None, 1.0)
+        a_fake = D(fake, None, 1.0)
+    assert a_real["prediction"].dtype == torch.float16
+    a_real32 = {k: v.float() for k, v in a_real.items()}
+    a_fake32 = {k: v.float() for k, v in a_fake.items()}
+    r1_a = pt.PhaseTrainer._calculate_r1_regularization(me, real_a, a_real32, {"name": "p"}, meta)
+    seg_real_a, acc_a, _ = pt.PhaseTrainer._calculate_segmentation_loss(me, a_real32["segments"], gt, meta)
+    seg_gen_a, _, _ = pt.PhaseTrainer._calculate_segmentation_loss(me, a_fake32["segments"], torch.zeros_like(gt), meta)
+    gan_a = torch.nn.functional.softplus(a_fake32["prediction"]).mean() + torch.nn.functional.softplus(-a_real32["prediction"]).mean()
+    loss_a = gan_a + 4 * r1_a + (seg_real_a + seg_gen_a)
+    loss_a.backward()
+    save("disc_tiny_amp", out_real={k: v.detach() for k, v in a_real32.items()}, out_fake={k: v.detach() for k, v in a_fake32.items()},
+         loss=dict(r1=r1_a.detach(), gan=gan_a.detach(), seg_real=seg_real_a.detach(), seg_gen=seg_gen_a.detach(), total=loss_a.detach()),
+         grad={gkey: dict(D.named_parameters())[gkey].grad})
 
 
 def ema_and_checkpoint_fixture():
@@ -176,7 +200,7 @@ def param_order_fixture():
     print("param_order.json", {k: len(v) for k, v in out.items()})
 
 
-def generator_train_fixture(name, seed, batch=3, nerf_noise=0.3, use_pool=False, **over):
+def generator_train_fixture(name, seed, batch=3, nerf_noise=0.3, use_pool=False, amp=False, **over):
     cfg = tiny_cfg(**over)
     torch.manual_seed(seed)
     G = ref_gen.Map3DGenerator(**cfg)
@@ -220,6 +244,20 @@ def generator_train_fixture(name, seed, batch=3, nerf_noise=0.3, use_pool=False,
          meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
          out=dict(rgbs=out["rgbs"], rgbs_render=out["rgbs_render"], loss=loss), grad=grads, buffers_after=changed, **extra)
     print("   parameters with gradient:", len(grads), "of", len(list(G.named_parameters())), "| buffers changed:", len(changed))
+    if not amp:
+        return
+    # ---- the same module, inputs and random tensors under float16 autocast (the reference's AMP mode; CPU autocast stands in for
+    # torch.cuda.amp.autocast: same casting policy).  <name>_amp.npz holds only outputs and gradients; everything else is <name>'s.
+    G.load_state_dict(state0)
+    G.zero_grad()
+    z2 = z.detach().clone().requires_grad_(True)
+    torch.manual_seed(rs)
+    with torch.autocast("cpu", dtype=torch.float16):
+        out2 = G.forward(z2, cond, latent_indices=idx, **run)
+        loss2 = (out2["rgbs"].float() * p_rgb).sum() + (out2["rgbs_render"].float() * p_render).sum()
+    loss2.backward()
+    grads2 = {n: p.grad.float() for n, p in G.named_parameters() if p.grad is not None}
+    save(name + "_amp", out=dict(rgbs=out2["rgbs"].float(), rgbs_render=out2["rgbs_render"].float(), loss=loss2), grad=grads2)
 
 
 def gstep_fixture():
@@ -296,7 +334,13 @@ if __name__ == "__main__":
         generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
                                 white_back=True, last_back=True, clamp_mode="softplus")
         sys.exit(0)
-    generator_train_fixture("gen_train_mixed", 31)
+    if len(sys.argv) > 1 and sys.argv[1] == "disc":
+        disc_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gen_amp":
+        generator_train_fixture("gen_train_mixed", 31, amp=True)
+        sys.exit(0)
+    generator_train_fixture("gen_train_mixed", 31, amp=True)
     generator_train_fixture("gen_train_isolated_legacy_pool", 37, use_pool=True, legacy_mode=True, map3d_mode="isolated",
                             white_back=True, last_back=True, clamp_mode="softplus")
     gstep_fixture()

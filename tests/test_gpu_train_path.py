@@ -427,26 +427,37 @@ def test_train_step_at_real_width_vs_oracle():
 
 @pytest.mark.parametrize("amp", [torch.float16])
 def test_train_step_under_autocast(amp):
-    """The reference's AMP mode (base_trainer.py:50-51, fp16): under autocast the library GEMMs run in half precision and the
-    HIP kernels in fp32.  Tolerance of this tier: outputs within 3e-2 of the fp32 path, gradient direction cos > 0.99.
+    """The reference's AMP mode (base_trainer.py:50-51, fp16) against THE REFERENCE UNDER AUTOCAST (round 4:
+    tests/golden/gen_train_mixed_amp.npz -- the reference module's train-mode forward + backward under float16 autocast, same
+    weights, inputs and random tensors as gen_train_mixed.npz), not against this build's own fp32 run: outputs within 3e-2 of the
+    reference's AMP outputs, gradient direction cos > 0.99 against the reference's AMP gradients, and no further from the fp32
+    truth than the reference's own AMP run is (x 2).
     (bf16 autocast is NOT a usable tier for this network: the sine layers multiply their input by 30 and bf16's 8-bit mantissa
     then misses the 3e-2 bound on the image -- measured on MI355X.)"""
     g = load_golden("gen_train_mixed")
+    a_ref = load_golden("gen_train_mixed_amp")
     cond = {k: v.to(DEV) for k, v in g["cond"].items()}
-    runs = {}
-    for mode in ("fp32", "amp"):
-        G, cfg = _build(g["meta"], g["state"])
-        z = g["z"].to(DEV)
-        with torch.autocast("cuda", dtype=amp, enabled=mode == "amp"):
-            out = G(z, cond, jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV), **cfg)
-            loss = (out["rgbs"].float() * g["p_rgb"].to(DEV)).sum() + (out["rgbs_render"].float() * g["p_render"].to(DEV)).sum()
-        loss.backward()
-        runs[mode] = (out, {n: p.grad.float() for n, p in G.named_parameters() if p.grad is not None})
+    G, cfg = _build(g["meta"], g["state"])
+    z = g["z"].to(DEV)
+    with torch.autocast("cuda", dtype=amp):
+        out = G(z, cond, jitter=g["jitter"].to(DEV), noise=g["noise"].to(DEV), **cfg)
+        loss = (out["rgbs"].float() * g["p_rgb"].to(DEV)).sum() + (out["rgbs_render"].float() * g["p_render"].to(DEV)).sum()
+    loss.backward()
+    grads = {n: p.grad.float().cpu() for n, p in G.named_parameters() if p.grad is not None}
     for k in ("rgbs", "rgbs_render"):
-        assert rel_err(runs["amp"][0][k].float().detach(), runs["fp32"][0][k].detach()) < 3e-2, k
-    names = [n for n in runs["fp32"][1] if float(runs["fp32"][1][n].abs().max()) > 1e-3]
-    a = torch.cat([runs["amp"][1][n].flatten() for n in names]).double()
-    b = torch.cat([runs["fp32"][1][n].flatten() for n in names]).double()
-    assert torch.isfinite(a).all()
-    cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-    assert cos > 0.99, cos
+        mine = out[k].float().detach().cpu()
+        e_amp = rel_err(mine, a_ref["out"][k])
+        e_ref32 = rel_err(a_ref["out"][k], g["out"][k])
+        e_own32 = rel_err(mine, g["out"][k])
+        print(f"{k}: vs reference-under-autocast {e_amp:.2e}; reference AMP vs fp32 {e_ref32:.2e}; ours AMP vs fp32 {e_own32:.2e}")
+        assert e_amp < 3e-2, k
+        assert e_own32 < max(2.0 * e_ref32, 1e-2), k
+    for ref_grads, label in ((a_ref["grad"], "reference AMP"), ({k: v for k, v in g["grad"].items() if k != "__z__"}, "reference fp32")):
+        names = [n for n in ref_grads if n in grads and float(ref_grads[n].abs().max()) > 1e-3]
+        assert len(names) > 100
+        a = torch.cat([grads[n].flatten() for n in names]).double()
+        b = torch.cat([ref_grads[n].flatten().float() for n in names]).double()
+        assert torch.isfinite(a).all()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        print(f"gradient cosine vs {label}: {cos:.5f}")
+        assert cos > 0.99, (label, cos)
