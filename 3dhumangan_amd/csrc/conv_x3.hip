@@ -58,7 +58,8 @@ __device__ __forceinline__ void split_chunk(const u32x4 (&raw)[KSC], BF16::vec8 
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const h16x2 v = __builtin_bit_cast(h16x2, raw[s][e]);
+            const unsigned word = raw[s][e];           // a copy first: __builtin_bit_cast of a vector-element lvalue reads element 0
+            const h16x2 v = __builtin_bit_cast(h16x2, word);
             hw[e] = split2_bf16((float)v.x, (float)v.y, lw[e]);
         }
         xh[s] = __builtin_bit_cast(BF16::vec8, u32x4{hw[0], hw[1], hw[2], hw[3]});
