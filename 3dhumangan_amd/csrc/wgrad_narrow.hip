@@ -10,8 +10,9 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRows = 256;                    // 2048 workgroups for 0.5 M rows: enough loads in flight to stream at HBM rate
 
-template <int V>
-__global__ __launch_bounds__(kThreads) void wgrad_narrow_kernel(const float* __restrict__ wide, const float* __restrict__ narrow,
+// T = float (V = 4 or 1) or _Float16 (AMP tier, V = 8 or 1): both operands in T, products and sums in fp32
+template <typename T, int V>
+__global__ __launch_bounds__(kThreads) void wgrad_narrow_kernel(const T* __restrict__ wide, const T* __restrict__ narrow,
                                                                 float* __restrict__ partial, int64_t M, int C, int ldw, int nn) {
     __shared__ float red[4][kThreads][V];
     const int Q = C / V, QP = Q < kThreads ? Q : kThreads, G = kThreads / QP;
@@ -30,15 +31,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_narrow_kernel(const float* __r
 #pragma unroll 4
             for (int64_t r = r0 + g; r < r1; r += G) {
                 float v[V];
-                if constexpr (V == 4) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(wide + r * ldw + q * 4);
-                    v[0] = w4.x; v[1] = w4.y; v[2] = w4.z; v[3] = w4.w;
-                } else {
-                    v[0] = wide[r * ldw + q];
+                if constexpr (V == 1) {
+                    v[0] = (float)wide[r * ldw + q];
+                } else {                    // one 16-byte load: four floats or eight halves
+                    typedef T vecT __attribute__((ext_vector_type(V)));
+                    const vecT w = *reinterpret_cast<const vecT*>(wide + r * ldw + q * V);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v[k] = (float)w[k];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float nj = j < nn ? narrow[r * nn + j] : 0.f;
+                    const float nj = j < nn ? (float)narrow[r * nn + j] : 0.f;
 #pragma unroll
                     for (int k = 0; k < V; ++k) acc[j][k] = fmaf(nj, v[k], acc[j][k]);
                 }
@@ -76,8 +79,28 @@ extern "C" int h3d_wgrad_narrow(const float* wide, const float* narrow, float* p
     hipStream_t st = static_cast<hipStream_t>(stream);
     h3d::pre_launch();
     if (C % 4 == 0 && ldw % 4 == 0 && h3d::aligned16(wide))
-        hipLaunchKernelGGL(wgrad_narrow_kernel<4>, dim3((unsigned)nblk), dim3(kThreads), 0, st, wide, narrow, partial, M, C, ldw, nn);
+        hipLaunchKernelGGL((wgrad_narrow_kernel<float, 4>), dim3((unsigned)nblk), dim3(kThreads), 0, st, wide, narrow, partial, M, C, ldw, nn);
     else
-        hipLaunchKernelGGL(wgrad_narrow_kernel<1>, dim3((unsigned)nblk), dim3(kThreads), 0, st, wide, narrow, partial, M, C, ldw, nn);
+        hipLaunchKernelGGL((wgrad_narrow_kernel<float, 1>), dim3((unsigned)nblk), dim3(kThreads), 0, st, wide, narrow, partial, M, C, ldw, nn);
     return h3d::launch_status("h3d_wgrad_narrow");
+}
+
+// The same with both operands in f16 (AMP tier: the ToRGB / head / coordinate layers under float16 autocast -- the library's f16
+// GEMM takes 4 ms for a 3 x 256 result from 0.5 M rows); fp32 products, sums and result.
+extern "C" int h3d_wgrad_narrow_f16(const void* wide, const void* narrow, float* partial, int64_t M, int C, int ldw, int nn,
+                                    h3d_stream_t stream) {
+    H3D_REQUIRE(wide && narrow && partial, "h3d_wgrad_narrow_f16: null pointer");
+    H3D_REQUIRE(M >= 1 && C >= 1 && ldw >= C, "h3d_wgrad_narrow_f16: bad shape M=%lld C=%d ldw=%d", (long long)M, C, ldw);
+    H3D_REQUIRE(nn >= 1 && nn <= 4, "h3d_wgrad_narrow_f16: the narrow side must have 1..4 columns (got %d)", nn);
+    const int64_t nblk = (M + kRows - 1) / kRows;
+    H3D_REQUIRE(nblk < (int64_t(1) << 31), "h3d_wgrad_narrow_f16: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const _Float16* w = static_cast<const _Float16*>(wide);
+    const _Float16* n = static_cast<const _Float16*>(narrow);
+    h3d::pre_launch();
+    if (C % 8 == 0 && ldw % 8 == 0 && h3d::aligned16(wide))
+        hipLaunchKernelGGL((wgrad_narrow_kernel<_Float16, 8>), dim3((unsigned)nblk), dim3(kThreads), 0, st, w, n, partial, M, C, ldw, nn);
+    else
+        hipLaunchKernelGGL((wgrad_narrow_kernel<_Float16, 1>), dim3((unsigned)nblk), dim3(kThreads), 0, st, w, n, partial, M, C, ldw, nn);
+    return h3d::launch_status("h3d_wgrad_narrow_f16");
 }

@@ -31,19 +31,34 @@ struct Args {
     int Co, Ci, ldy, ldx, rows_per_wg;
     int conv_k, H, W, slices;     // conv_k > 0: weight gradient of a k x k convolution over [B, H, W] pixels (rows of X shifted per tap)
     float* colsum;                // optional [slices][Co]: column sums of dY over the slice's rows (the bias gradient), or null
-    int half;                     // operands are _Float16 (row strides stay in elements)
+    int half;                     // operands are _Float16 (row strides stay in elements): picks the HALF instantiation
 };
 
-// four consecutive operand elements as fp32 (wave-uniform `half`: a scalar branch)
-__device__ __forceinline__ float4 ld4(const void* base, int64_t elem, int half) {
-    if (half) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const _Float16*>(base) + elem);
-        const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
-        return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+// Four consecutive operand elements, as loaded: a float4 (fp32) or two words of packed f16 (AMP tier).  The prefetch keeps them
+// in this form; they become fp32 only when parked in LDS, AFTER the step's MFMAs -- a conversion next to the load would make
+// every load wait for its own data (eight serial HBM round trips per k-step; measured: the f16 kernels ran 2 x slower than fp32).
+template <bool HALF> struct Raw4;
+template <> struct Raw4<false> {
+    typedef float4 type;
+    static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ type load(const void* base, int64_t elem) {
+        return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
     }
-    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
-}
+    static __device__ __forceinline__ float4 widen(const type& r) { return r; }
+};
+template <> struct Raw4<true> {
+    typedef unsigned type __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ type zero() { return type{0u, 0u}; }
+    static __device__ __forceinline__ type load(const void* base, int64_t elem) {
+        return *reinterpret_cast<const type*>(static_cast<const _Float16*>(base) + elem);
+    }
+    static __device__ __forceinline__ float4 widen(const type& r) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned w0 = r[0], w1 = r[1];          // copies first: bit_cast of a vector-element lvalue reads element 0
+        const h2 a = __builtin_bit_cast(h2, w0), b = __builtin_bit_cast(h2, w1);
+        return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+    }
+};
 
 // row of X that pairs with row rr of dY for filter tap (ty, tx): the shifted pixel, or -1 outside the image (zero padding)
 __device__ __forceinline__ int64_t shifted_row(int64_t rr, int ty, int tx, int H, int W) {
@@ -54,8 +69,8 @@ __device__ __forceinline__ int64_t shifted_row(int64_t rr, int ty, int tx, int H
     return rr + (int64_t)ty * W + tx;
 }
 
-template <int NT, bool SHIFT = false>
-__device__ __forceinline__ void load_slab(float4 (&r)[NT], const void* __restrict__ src, int half, int ld, int64_t row0, int64_t M,
+template <int NT, bool HALF, bool SHIFT = false>
+__device__ __forceinline__ void load_slab(typename Raw4<HALF>::type (&r)[NT], const void* __restrict__ src, int ld, int64_t row0, int64_t M,
                                           int col0, int ncols, int t, int ty = 0, int tx = 0, int H = 1, int W = 1) {
     constexpr int W4 = 16 * NT;               // float4 per slab row (slab width 64 NT floats)
 #pragma unroll
@@ -68,7 +83,7 @@ __device__ __forceinline__ void load_slab(float4 (&r)[NT], const void* __restric
             rr = shifted_row(rr, ty, tx, H, W);
             ok = rr >= 0;
         }
-        r[j] = ok ? ld4(src, rr * ld + col0 + c, half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[j] = ok ? Raw4<HALF>::load(src, rr * ld + col0 + c) : Raw4<HALF>::zero();
     }
 }
 
@@ -76,8 +91,8 @@ __device__ __forceinline__ void load_slab(float4 (&r)[NT], const void* __restric
 // (tx = -1, 0, +1 read rows e, e + 1, e + 2 of it).  W % 16 == 0 and r0 % 16 == 0, so the 16 pixels lie in one image row y:
 // the band is zero when y + ty leaves the image, its first row is zero when the pixels start an image row (x = 0 has no left
 // neighbour; that band row is only ever read as the tx = -1 neighbour of pixel 0) and its last row when they end one.
-template <int NT>
-__device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const void* __restrict__ src, int half, int ld, int64_t r0, int64_t r_end,
+template <int NT, bool HALF>
+__device__ __forceinline__ void load_band(typename Raw4<HALF>::type (&r)[NT + (NT + 7) / 8], const void* __restrict__ src, int ld, int64_t r0, int64_t r_end,
                                           int col0, int ncols, int t, int ty, int H, int W) {
     constexpr int W4 = 16 * NT;               // float4 per band row
     constexpr int NJ = NT + (NT + 7) / 8;     // 18 rows = 16 + 2: ceil(18 * W4 / 256) float4 per thread
@@ -94,24 +109,24 @@ __device__ __forceinline__ void load_band(float4 (&r)[NT + (NT + 7) / 8], const 
         if (row == 17 && x0 + 16 == W) ok = false;
         // pixels of this k-step past the end of the slice contribute nothing through dY (zero rows); their X rows are in range
         const int64_t q = r0 - 1 + row + (int64_t)ty * W;
-        r[j] = ok ? ld4(src, q * ld + col0 + c, half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[j] = ok ? Raw4<HALF>::load(src, q * ld + col0 + c) : Raw4<HALF>::zero();
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void park_band(const float4 (&r)[NT + (NT + 7) / 8], float* lds, int t) {
+template <int NT, bool HALF>
+__device__ __forceinline__ void park_band(const typename Raw4<HALF>::type (&r)[NT + (NT + 7) / 8], float* lds, int t) {
     constexpr int W4 = 16 * NT, NJ = NT + (NT + 7) / 8;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int idx = j * kThreads + t;
-        if (idx < 18 * W4) *reinterpret_cast<float4*>(lds + idx * 4) = r[j];
+        if (idx < 18 * W4) *reinterpret_cast<float4*>(lds + idx * 4) = Raw4<HALF>::widen(r[j]);
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void park_slab(const float4 (&r)[NT], float* lds, int t) {
+template <int NT, bool HALF>
+__device__ __forceinline__ void park_slab(const typename Raw4<HALF>::type (&r)[NT], float* lds, int t) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(lds + (j * kThreads + t) * 4) = r[j];
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(lds + (j * kThreads + t) * 4) = Raw4<HALF>::widen(r[j]);
 }
 
 // bf16 hi / lo fragments of column `col` of an LDS slab of width W: element e <-> row 8 * (lane >> 5) + e
@@ -125,8 +140,9 @@ __device__ __forceinline__ void read_frag(const float* lds, int col, int lane, B
     lo = __builtin_bit_cast(BF16::vec8, h3d::u32x4{l[0], l[1], l[2], l[3]});
 }
 
-template <int NA, int NB, bool CONV = false>
+template <int NA, int NB, bool CONV, bool HALF>
 __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
+    typedef typename Raw4<HALF>::type raw_t;
     constexpr int WA = 64 * NA, WB = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kBuf = kKS * (WA + WB);        // floats per buffer: the dY slab, then the X slab
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    float4 ra[NA], rb[NB];
+    raw_t ra[NA], rb[NB];
     // bias gradient riding along (first column block of X, first tap only): a thread's slab positions (row, 4 columns) are the
     // same in every k-step, so it keeps NA running float4 sums; the 16 rows are folded through LDS at the end
     const bool do_colsum = A.colsum != nullptr && blockIdx.z == 0 && tap == 0;
@@ -156,14 +172,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
     for (int j = 0; j < NA; ++j) cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto add_colsum = [&]() {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) { cs[j].x += ra[j].x; cs[j].y += ra[j].y; cs[j].z += ra[j].z; cs[j].w += ra[j].w; }
-    };
+        for (int j = 0; j < NA; ++j) {
+            const float4 v = Raw4<HALF>::widen(ra[j]);
+            cs[j].x += v.x; cs[j].y += v.y; cs[j].z += v.z; cs[j].w += v.w;
+        }
+    };      // called where the slab is parked (its loads have landed by then), never next to the loads
     // rows past r_end must not leak into this slice: the loaders clip at min(M, r_end) through the `M` argument
-    load_slab<NA>(ra, A.dY, A.half, A.ldy, r_begin, r_end, co0, A.Co, t);
-    load_slab<NB, CONV>(rb, A.X, A.half, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
+    load_slab<NA, HALF>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_slab<NB, HALF, CONV>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
     if (do_colsum) add_colsum();
-    park_slab<NA>(ra, smem, t);
-    park_slab<NB>(rb, smem + kKS * WA, t);
+    park_slab<NA, HALF>(ra, smem, t);
+    park_slab<NB, HALF>(rb, smem + kKS * WA, t);
     __syncthreads();
 
     for (int s = 0; s < n_steps; ++s) {
@@ -172,9 +191,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
         float* nxtA = smem + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
-            load_slab<NA>(ra, A.dY, A.half, A.ldy, row0, r_end, co0, A.Co, t);
-            load_slab<NB, CONV>(rb, A.X, A.half, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
-            if (do_colsum) add_colsum();
+            load_slab<NA, HALF>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
+            load_slab<NB, HALF, CONV>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
         }
         BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
 #pragma unroll
@@ -190,8 +208,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
                 acc[a][b] = BF16::mfma(ah[a], bh[b], acc[a][b]);
             }
         if (s + 1 < n_steps) {
-            park_slab<NA>(ra, nxtA, t);
-            park_slab<NB>(rb, nxtA + kKS * WA, t);
+            if (do_colsum) add_colsum();
+            park_slab<NA, HALF>(ra, nxtA, t);
+            park_slab<NB, HALF>(rb, nxtA + kKS * WA, t);
         }
         __syncthreads();
     }
@@ -226,8 +245,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
 // 3x3 convolution weight gradient with the three taps of a filter row fused: a workgroup owns a K-slice of pixels, one filter
 // row ty and a [64 NA x 64 NB] block of dW for tx = -1, 0, +1 (3 NA NB accumulator tiles per wave, NA, NB <= 2), so dY and X are
 // read three times (once per ty) instead of nine.  partial[3 ty + tx][slice][Co][Ci].
-template <int NA, int NB>
+template <int NA, int NB, bool HALF>
 __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
+    typedef typename Raw4<HALF>::type raw_t;
     constexpr int WA = 64 * NA, WB = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int kBuf = kKS * WA + 18 * WB;     // floats per buffer: the dY slab (16 rows), then the X band (18 rows)
@@ -250,11 +270,11 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[x][a][b][i] = 0.f;
 
-    float4 ra[NA], rb[NB + (NB + 7) / 8];
-    load_slab<NA>(ra, A.dY, A.half, A.ldy, r_begin, r_end, co0, A.Co, t);
-    load_band<NB>(rb, A.X, A.half, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
-    park_slab<NA>(ra, smem, t);
-    park_band<NB>(rb, smem + kKS * WA, t);
+    raw_t ra[NA], rb[NB + (NB + 7) / 8];
+    load_slab<NA, HALF>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
+    load_band<NB, HALF>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+    park_slab<NA, HALF>(ra, smem, t);
+    park_band<NB, HALF>(rb, smem + kKS * WA, t);
     __syncthreads();
 
     for (int s = 0; s < n_steps; ++s) {
@@ -263,8 +283,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
         float* nxtA = smem + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
-            load_slab<NA>(ra, A.dY, A.half, A.ldy, row0, r_end, co0, A.Co, t);
-            load_band<NB>(rb, A.X, A.half, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+            load_slab<NA, HALF>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
+            load_band<NB, HALF>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
         }
         BF16::vec8 ah[NA], al[NA];
 #pragma unroll
@@ -284,8 +304,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
                 }
         }
         if (s + 1 < n_steps) {
-            park_slab<NA>(ra, nxtA, t);
-            park_band<NB>(rb, nxtA + kKS * WA, t);
+            park_slab<NA, HALF>(ra, nxtA, t);
+            park_band<NB, HALF>(rb, nxtA + kKS * WA, t);
         }
         __syncthreads();
     }
@@ -311,7 +331,8 @@ int launch_conv3(const Args& a, hipStream_t st) {
     constexpr size_t lds = 2 * (kKS * 64 * NA + 18 * 64 * NB) * sizeof(float);
     const dim3 grid((unsigned)(a.slices * 3), (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
     h3d::pre_launch();
-    hipLaunchKernelGGL((wgrad_conv3_kernel<NA, NB>), grid, dim3(kThreads), lds, st, a);
+    if (a.half) hipLaunchKernelGGL((wgrad_conv3_kernel<NA, NB, true>), grid, dim3(kThreads), lds, st, a);
+    else hipLaunchKernelGGL((wgrad_conv3_kernel<NA, NB, false>), grid, dim3(kThreads), lds, st, a);
     return h3d::launch_status("h3d_conv_wgrad_x3");
 }
 
@@ -323,8 +344,13 @@ int launch(const Args& a, int slices, hipStream_t st) {
     const int taps = a.conv_k > 0 ? a.conv_k * a.conv_k : 1;
     const dim3 grid((unsigned)(slices * taps), (unsigned)((a.Co + 64 * NA - 1) / (64 * NA)), (unsigned)((a.Ci + 64 * NB - 1) / (64 * NB)));
     h3d::pre_launch();
-    if (a.conv_k > 0) hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, true>), grid, dim3(kThreads), lds, st, a);
-    else hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, false>), grid, dim3(kThreads), lds, st, a);
+    if (a.conv_k > 0) {
+        if (a.half) hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, true, true>), grid, dim3(kThreads), lds, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, true, false>), grid, dim3(kThreads), lds, st, a);
+    } else {
+        if (a.half) hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, false, true>), grid, dim3(kThreads), lds, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<NA, NB, false, false>), grid, dim3(kThreads), lds, st, a);
+    }
     return h3d::launch_status(a.conv_k > 0 ? "h3d_conv_wgrad_x3" : "h3d_wgrad_x3");
 }
 

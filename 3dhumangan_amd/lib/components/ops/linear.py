@@ -17,6 +17,7 @@ from .... import _lib
 MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this the library GEMM is as good
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
+AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
 
 
 def _as_image(t2):
@@ -59,15 +60,19 @@ def wgrad_x3(dy, x, with_bias=False):
 
 
 def wgrad_narrow(wide, narrow):
-    """wide [M, C], narrow [M, n] (n <= 4) fp32 -> narrow^T wide [n, C] (streams `wide` once; csrc/wgrad_narrow.hip)."""
+    """wide [M, C], narrow [M, n] (n <= 4), both fp32 or (AMP tier) both f16 -> narrow^T wide [n, C] fp32 (streams `wide` once;
+    csrc/wgrad_narrow.hip)."""
     _lib.need_cuda(wide, narrow)
+    if wide.dtype != narrow.dtype:
+        wide, narrow = wide.half(), narrow.half()
     M, C = wide.shape
     n = narrow.shape[1]
     narrow = narrow.contiguous()
     lib = _lib.load()
     nblk = (M + lib.h3d_wgrad_narrow_rows() - 1) // lib.h3d_wgrad_narrow_rows()
     partial = torch.empty((nblk, n, C), device=wide.device, dtype=torch.float32)
-    rc = lib.h3d_wgrad_narrow(_lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(partial), M, C, wide.stride(0), n, _lib.stream_handle())
+    entry = lib.h3d_wgrad_narrow if wide.dtype == torch.float32 else lib.h3d_wgrad_narrow_f16
+    rc = entry(_lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(partial), M, C, wide.stride(0), n, _lib.stream_handle())
     _lib.check(rc, "h3d_wgrad_narrow")
     return partial.sum(dim=0)
 
@@ -114,14 +119,18 @@ class _LinearX3(torch.autograd.Function):
 
 class _LinearAmp(torch.autograd.Function):
     """The dense layer under float16 autocast (AMP tier, round 4; reference: nn.Linear / 1x1 convs inside torch.cuda.amp.autocast):
-    forward and data gradient are the library's f16 GEMMs on f16 activations, the weight gradient (tall-skinny TN: the shape the
-    library is slow at) is h3d_wgrad_x3 on the f16 operands as they are -- fp32 result, no casts; the weight stays fp32."""
+    forward and data gradient are the library's f16 GEMMs on f16 activations (HBM-bound there: 126 us for 0.5 M x 256 x 256), or
+    h3d_conv_x3_f16 with H3D_AMP_LINEAR=x3; the weight gradient (tall-skinny TN, the shape the library is slow at: 4 ms for a
+    3 x 256 result) is h3d_wgrad_x3 / h3d_wgrad_narrow on the f16 operands as they are -- fp32 result, no casts; the weight
+    stays fp32."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         xh = x.half()
         ctx.save_for_backward(xh, w)
         ctx.has_bias = b is not None
+        if AMP_NATIVE_GEMM and _native_ok(*w.shape):
+            return gemm_x3(_rows(xh), w, b).view(*x.shape[:-1], w.shape[0])
         return F.linear(xh, w.half(), None if b is None else b.half())
 
     @staticmethod
@@ -130,11 +139,19 @@ class _LinearAmp(torch.autograd.Function):
         xh, w = ctx.saved_tensors
         dyh = dy.half()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = dyh @ w.half()
         dy2, x2 = _rows(dyh), _rows(xh)
+        if ctx.needs_input_grad[0]:
+            if AMP_NATIVE_GEMM and _native_ok(*w.shape):
+                dx = gemm_x3(dy2, w, transposed=True).view(*dy.shape[:-1], w.shape[1])
+            else:
+                dx = dyh @ w.half()
         if ctx.needs_input_grad[1]:
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            Co, Ci = w.shape
+            if Co <= 4:
+                dw = wgrad_narrow(x2, dy2)                           # [Co, Ci]
+            elif Ci <= 4:
+                dw = wgrad_narrow(dy2, x2).t()                       # [Ci, Co] -> [Co, Ci]
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
                 dw, db = wgrad_x3(dy2, x2, with_bias=True)
             else:
                 dw = wgrad_x3(dy2, x2)
@@ -149,7 +166,7 @@ def linear(x, w, b=None):
     rows = x.numel() // max(Ci, 1)
     if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
             and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.float32 and rows >= MIN_ROWS
-            and Co % 8 == 0 and Ci % 8 == 0 and Co >= 32 and Ci >= 32):
+            and ((Co % 8 == 0 and Ci % 8 == 0 and Co >= 32 and Ci >= 32) or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):
         return _LinearAmp.apply(x, w, b)
     if (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and torch.is_grad_enabled()
             and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS

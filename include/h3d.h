@@ -505,6 +505,11 @@ int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* co
 int h3d_wgrad_narrow_rows(void);
 int h3d_wgrad_narrow(const float* wide, const float* narrow, float* partial, int64_t M, int C, int ldw, int nn,
                      h3d_stream_t stream);
+/* AMP tier: the same with both operands in f16 (fp32 products, sums and result); replaces the f16 library GEMM torch autocast
+ * would run for these layers' weight gradients (reference: nn.Linear / 1x1 Conv2d backward inside torch.cuda.amp.autocast,
+ * lib/trainers/base_trainer.py:50-51). */
+int h3d_wgrad_narrow_f16(const void* wide, const void* narrow, float* partial, int64_t M, int C, int ldw, int nn,
+                         h3d_stream_t stream);
 
 /* Training-side SPADE (backward of A9): BatchNorm + SPADE modulation + LeakyReLU of one SPADEBlock half
  *     y = lrelu_slope( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )
