@@ -90,8 +90,10 @@ def _resize_channels_last(t, render_hw, gen_hw):
     """Bilinear (align_corners=False) resize of a channels-last map [B, Hr*Wr, C] -> [B, H*W, C] without leaving the
     channels-last layout (F.interpolate on the NCHW *view* of the same memory)."""
     B, _, C = t.shape
-    if t.is_cuda and t.dtype == torch.float32 and C % 4 == 0 and not torch.is_autocast_enabled() and B * gen_hw[0] < 65536:
-        return bilinear_resize_cl(t, render_hw, gen_hw)        # own kernels: the backward reads the gradient once, no atomics
+    if t.is_cuda and t.dtype in (torch.float32, torch.float16) and C % 4 == 0 and B * gen_hw[0] < 65536:
+        # own kernels: the backward reads the gradient once, no atomics.  Under autocast too (F.interpolate's channels-last
+        # kernels take 3.4 ms forward + 4.9 ms backward here, these 0.5 + 0.3 ms): computed in fp32, returned in the input's type
+        return bilinear_resize_cl(t.float(), render_hw, gen_hw).to(t.dtype)
     nchw = t.reshape(B, render_hw[0], render_hw[1], C).permute(0, 3, 1, 2)
     up = F.interpolate(nchw, gen_hw, mode="bilinear", align_corners=False)
     return up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)

@@ -216,7 +216,9 @@ def train_step_bench(a, rank, world, dist_on, dev, emit=True):
             "metric": "adversarial training iterations: images/sec at 512x256 (D step + G step)", "value": a.batch * world * a.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp32" if a.amp == "none" else f"AMP {a.amp} autocast (GEMMs / convolutions in {a.amp}, HIP kernels fp32)") +
+            "dtype": ("fp32" if a.amp == "none" else
+                      f"AMP {a.amp} autocast + GradScaler (the reference's AMP mode): activations and their gradients travel as {a.amp} "
+                      "through the hand-written convolution / weight-gradient / SPADE / sine kernels, weights and accumulation fp32") +
                      " (generator: split-bf16 matrix-core GEMMs / weight gradients + HIP activation / integration / SPADE kernels; discriminator: "
                      "hand-written split-bf16 convolution kernels, forward / backward-data / weight gradient / R1 double backward)",
             "data": "synthetic",
@@ -630,8 +632,17 @@ def main():
                                               generator_step_ms=t4["stage_ms"]["generator_step"], peak_memory_GB=t4["peak_memory_GB"],
                                               batch=4, steps=3, warmup=2, dtype=t4["dtype"], workload=t4["config"]["workload"])
             torch.cuda.empty_cache()
+            # the same iteration in the reference's AMP mode (float16 autocast + one GradScaler)
+            torch.cuda.reset_peak_memory_stats()
+            t4h = train_step_bench(argparse.Namespace(config=a.config, batch=4, steps=3, warmup=6, amp="fp16"), 0, 1, False, dev, emit=False)
+            extra["cfg4_trainstep_b4_amp_fp16"] = dict(images_per_s=t4h["value"], ms_per_iteration=t4h["ms_per_step"],
+                                                       discriminator_step_ms=t4h["stage_ms"]["discriminator_step"],
+                                                       generator_step_ms=t4h["stage_ms"]["generator_step"],
+                                                       peak_memory_GB=t4h["peak_memory_GB"], batch=4, steps=3, warmup=6)
+            torch.cuda.empty_cache()
         except Exception as e:                                  # noqa: BLE001 -- a side workload must not lose the headline
-            extra["cfg4_trainstep_b4"] = dict(error=repr(e)[:300])
+            extra.setdefault("cfg4_trainstep_b4", dict(error=repr(e)[:300]))
+            extra["cfg4_trainstep_error"] = repr(e)[:300]
 
     out = {
         "metric": "generator images/sec at 512^2", "value": value, "unit": "images/s", "n_gpus": world,

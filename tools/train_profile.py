@@ -71,3 +71,10 @@ if shapes:
     srows.sort(key=lambda r: -r[2])
     for k, shp, ms, n in srows[:40]:
         print(f"{ms:9.2f} ms  x{n:<4d} {k:28s} {shp}")
+    print("# type conversions / copies by input shape")
+    crow = [(e.key, str(e.input_shapes), e.device_time_total / N / 1e3, e.count // N)
+            for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::_to_copy", "aten::copy_", "aten::contiguous", "aten::clone")
+            and e.device_time_total > 0]
+    crow.sort(key=lambda r: -r[2])
+    for k, shp, ms, n in crow[:40]:
+        print(f"{ms:9.2f} ms  x{n:<4d} {k:28s} {shp}")
