@@ -99,6 +99,7 @@ _SIGNATURES = {
     "h3d_wgrad_narrow_rows": (C.c_int, []),
     "h3d_wgrad_narrow": (C.c_int, [_p, _p, _p, _l, _i, _i, _i, _p]),
     "h3d_wgrad_narrow_f16": (C.c_int, [_p, _p, _p, _l, _i, _i, _i, _p]),
+    "h3d_wgrad_narrow_sums": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_x3_slices": (C.c_int, [_l, _i, _i]),
     "h3d_wgrad_x3": (C.c_int, [_p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_x3_bias": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),

@@ -59,9 +59,10 @@ def wgrad_x3(dy, x, with_bias=False):
     return (dw, colsum.sum(dim=0)) if with_bias else dw
 
 
-def wgrad_narrow(wide, narrow):
+def wgrad_narrow(wide, narrow, wide_sum=False, narrow_sum=False):
     """wide [M, C], narrow [M, n] (n <= 4), both fp32 or (AMP tier) both f16 -> narrow^T wide [n, C] fp32 (streams `wide` once;
-    csrc/wgrad_narrow.hip)."""
+    csrc/wgrad_narrow.hip).  wide_sum (n <= 3): also the column sums of `wide` [C]; narrow_sum: also those of `narrow` [n] -- the
+    bias gradient of the layer, from the same pass.  -> dw, or (dw, sum)."""
     _lib.need_cuda(wide, narrow)
     if wide.dtype != narrow.dtype:
         wide, narrow = wide.half(), narrow.half()
@@ -69,12 +70,19 @@ def wgrad_narrow(wide, narrow):
     n = narrow.shape[1]
     narrow = narrow.contiguous()
     lib = _lib.load()
+    ones = int(bool(wide_sum))
     nblk = (M + lib.h3d_wgrad_narrow_rows() - 1) // lib.h3d_wgrad_narrow_rows()
-    partial = torch.empty((nblk, n, C), device=wide.device, dtype=torch.float32)
-    entry = lib.h3d_wgrad_narrow if wide.dtype == torch.float32 else lib.h3d_wgrad_narrow_f16
-    rc = entry(_lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(partial), M, C, wide.stride(0), n, _lib.stream_handle())
+    partial = torch.empty((nblk, n + ones, C), device=wide.device, dtype=torch.float32)
+    colsum = torch.empty((nblk, 4), device=wide.device, dtype=torch.float32) if narrow_sum else None
+    rc = lib.h3d_wgrad_narrow_sums(_lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(partial), _lib.ptr(colsum), M, C, wide.stride(0), n,
+                                   ones, int(wide.dtype == torch.float16), _lib.stream_handle())
     _lib.check(rc, "h3d_wgrad_narrow")
-    return partial.sum(dim=0)
+    out = partial.sum(dim=0)
+    if wide_sum:
+        return out[:n], out[n]
+    if narrow_sum:
+        return out, colsum.sum(dim=0)[:n]
+    return out
 
 
 def _rows(t):
@@ -104,8 +112,14 @@ class _LinearX3(torch.autograd.Function):
             dx = gemm_x3(dy2, w, transposed=True).view(*dy.shape[:-1], w.shape[1]) if _native_ok(*w.shape) else dy @ w
         if ctx.needs_input_grad[1]:
             Co, Ci = w.shape
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if Co <= 4:
-                dw = wgrad_narrow(_rows(x), dy2)                     # [Co, Ci]
+                dw = wgrad_narrow(_rows(x), dy2, narrow_sum=want_db)   # [Co, Ci] (, column sums of dy: the bias gradient)
+                if want_db:
+                    dw, db = dw
+            elif Ci <= 3 and want_db:
+                dw, db = wgrad_narrow(dy2, _rows(x), wide_sum=True)  # [Ci, Co], column sums of dy
+                dw = dw.t()
             elif Ci <= 4:
                 dw = wgrad_narrow(dy2, _rows(x)).t()                 # [Ci, Co] -> [Co, Ci]
             elif ctx.has_bias and ctx.needs_input_grad[2]:
@@ -147,8 +161,14 @@ class _LinearAmp(torch.autograd.Function):
                 dx = dyh @ w.half()
         if ctx.needs_input_grad[1]:
             Co, Ci = w.shape
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if Co <= 4:
-                dw = wgrad_narrow(x2, dy2)                           # [Co, Ci]
+                dw = wgrad_narrow(x2, dy2, narrow_sum=want_db)       # [Co, Ci] (, column sums of dy: the bias gradient)
+                if want_db:
+                    dw, db = dw
+            elif Ci <= 3 and want_db:
+                dw, db = wgrad_narrow(dy2, x2, wide_sum=True)        # [Ci, Co], column sums of dy
+                dw = dw.t()
             elif Ci <= 4:
                 dw = wgrad_narrow(dy2, x2).t()                       # [Ci, Co] -> [Co, Ci]
             elif ctx.has_bias and ctx.needs_input_grad[2]:

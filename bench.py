@@ -512,7 +512,37 @@ def op_rooflines():
     y = rs.bilinear_resize(x, (512, 512))
     out["h3d_bilinear_resize"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: rs.bilinear_resize(x, (512, 512))),
                                        "[4,256,96,96] -> [4,256,512,512] f32")
+    out["conv_x3_by_shape"] = conv_rooflines(timeit)
     return out
+
+
+def conv_rooflines(timeit):
+    """Per-shape table of the discriminator's / dense layers' matrix-core kernels (the conv_x3 roofline must be
+    recomputable): algorithmic flops 2 B H W Ci Co k^2 and bytes (input + output once, weights negligible) against measured time,
+    for fp32 activations and for the AMP tier's f16 activations.  Each algorithmic product is three bf16 MFMA products (x3), so
+    `mfma_pipe_util` = 3 x frac; `hbm_frac` = bytes / time / 8 TB/s.  Times include the per-call weight packing launch."""
+    conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+    rows = []
+    shapes = [(4, 512, 256, 128, 128, 3), (4, 256, 128, 128, 256, 3), (4, 256, 128, 256, 256, 3), (4, 128, 64, 256, 512, 3),
+              (4, 128, 64, 512, 512, 3), (4, 64, 32, 512, 512, 3), (4, 512, 256, 256, 128, 3), (4, 512, 256, 128, 128, 1),
+              (1, 1, 524288, 256, 256, 1)]
+    for B, H, W, ci, co, k in shapes:
+        w = torch.randn(co, ci, k, k, device="cuda") / (ci * k * k) ** 0.5
+        for dt in (torch.float32, torch.float16):
+            x = torch.randn(B, ci, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+            g = torch.randn(B, co, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+            flop = 2.0 * B * H * W * ci * co * k * k
+            esz = 4 if dt == torch.float32 else 2
+            for name, fn, by in (("forward", lambda: conv._run_conv(x, w), B * H * W * (ci + co) * esz),
+                                 ("weight_gradient", lambda: conv._run_wgrad(x, g, k), B * H * W * (ci + co) * esz)):
+                ms = timeit(fn, iters=5)
+                ach = flop / ms / 1e9
+                rows.append(dict(kernel="h3d_conv_x3" if name == "forward" else "h3d_conv_wgrad_x3", pass_=name,
+                                 shape=f"B{B} {H}x{W} {ci}->{co} k{k}", activations="f32" if dt == torch.float32 else "f16",
+                                 ms=ms, flop=flop, bytes=by, achieved_TFLOPs=ach, frac=ach / MFMA_F16_PEAK_TF,
+                                 mfma_pipe_util=3.0 * ach / MFMA_F16_PEAK_TF, hbm_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS))
+            del x, g
+    return rows
 
 
 def main():

@@ -510,6 +510,14 @@ int h3d_wgrad_narrow(const float* wide, const float* narrow, float* partial, int
  * lib/trainers/base_trainer.py:50-51). */
 int h3d_wgrad_narrow_f16(const void* wide, const void* narrow, float* partial, int64_t M, int C, int ldw, int nn,
                          h3d_stream_t stream);
+/* The general form of the two above: operands fp32 (half = 0) or f16 (half = 1); ones = 1 appends the column sums of `wide` as
+ * output row nn (partial is then [nblk, nn + 1, C], nn <= 3) -- the bias gradient when `wide` is dY (coordinate layers); colsum
+ * (or NULL) receives [nblk, 4] per-block column sums of `narrow` -- the bias gradient when `narrow` is dY (ToRGB, heads).  Both
+ * ride along the one pass over the operands (torch's column sum of a [0.5 M, 3] tensor alone takes 0.24 ms).
+ * Reference: the bias gradients of nn.Linear / 1x1 Conv2d backward (lib/components/cips_layers.py:199-233 ToRGB, the heads of
+ * lib/implicit_funcitions/modulated.py). */
+int h3d_wgrad_narrow_sums(const void* wide, const void* narrow, float* partial, float* colsum, int64_t M, int C, int ldw, int nn,
+                          int ones, int half, h3d_stream_t stream);
 
 /* Training-side SPADE (backward of A9): BatchNorm + SPADE modulation + LeakyReLU of one SPADEBlock half
  *     y = lrelu_slope( ((x - mean) * rstd * g + b) * (1 + gamma) + beta )

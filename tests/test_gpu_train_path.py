@@ -184,6 +184,18 @@ def test_wgrad_narrow_vs_fp64(M, C, n):
     got = lin.wgrad_narrow(wide.to(DEV), narrow.to(DEV))
     ref = narrow.double().t() @ wide.double()
     assert got.shape == (n, C) and rel_err(got.cpu(), ref) < 2e-5
+    # the bias gradients riding along: column sums of the narrow side, and (n <= 3) of the wide side as one more output row
+    got2, nsum = lin.wgrad_narrow(wide.to(DEV), narrow.to(DEV), narrow_sum=True)
+    assert torch.equal(got2, got) and nsum.shape == (n,)
+    assert float((nsum.cpu().double() - narrow.double().sum(dim=0)).abs().max()) < 1e-5 * M
+    if n <= 3:
+        got3, wsum = lin.wgrad_narrow(wide.to(DEV), narrow.to(DEV), wide_sum=True)
+        assert torch.equal(got3, got) and wsum.shape == (C,)
+        assert float(((wsum.cpu().double() - wide.double().sum(dim=0)).abs() / wide.double().abs().sum(dim=0)).max()) < 1e-5
+    # f16 operands (AMP tier): exact products of the f16 values, fp32 sums
+    wh, nh = wide.half(), narrow.half()
+    goth = lin.wgrad_narrow(wh.to(DEV), nh.to(DEV))
+    assert rel_err(goth.cpu(), nh.double().t() @ wh.double()) < 2e-5
 
 
 @pytest.mark.parametrize("Co,Ci", [(3, 64), (1, 96), (64, 3)])

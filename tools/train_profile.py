@@ -78,3 +78,11 @@ if shapes:
     crow.sort(key=lambda r: -r[2])
     for k, shp, ms, n in crow[:40]:
         print(f"{ms:9.2f} ms  x{n:<4d} {k:28s} {shp}")
+    print("# element-wise / reduction / resampling operators by input shape (self device time)")
+    skip = set(lib_ops) | {"aten::_to_copy", "aten::copy_", "aten::contiguous", "aten::clone"}
+    erow = [(e.key, str(e.input_shapes)[:110], e.self_device_time_total / N / 1e3, e.count // N)
+            for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.key not in skip
+            and e.self_device_time_total > 0]
+    erow.sort(key=lambda r: -r[2])
+    for k, shp, ms, n in erow[:70]:
+        print(f"{ms:9.2f} ms  x{n:<4d} {k:34s} {shp}")
