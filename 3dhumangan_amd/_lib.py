@@ -33,6 +33,10 @@ _SIGNATURES = {
     "h3d_ray_setup": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "h3d_geo_features": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _p]),
     "h3d_nearest_vertex": (C.c_int, [_p, _p, _p, _i, _l, _i, _p]),
+    "h3d_mesh_sort_bytes": (C.c_int64, [_i, _i]),
+    "h3d_mesh_sort": (C.c_int, [_p, _p, _i, _i, _p]),
+    "h3d_geo_features_sorted": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _p]),
+    "h3d_nearest_vertex_sorted": (C.c_int, [_p, _p, _p, _i, _l, _i, _p]),
     "h3d_render_fused_x2_geo": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "h3d_render_fused_x3_geo": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "h3d_field_pack_size": (C.c_int64, [_i, _i]),

@@ -23,6 +23,18 @@
 // refined in scan order; a point that overflows the list (pathological ties) is refined over the whole mesh.
 // The per-point tail gathers the blended inverse bone transform of the winner (64 B), canonicalises the point,
 // gathers the T-pose vertex and evaluates the 24 joint distances.
+//
+// Round 4: chunk pruning on a spatially sorted mesh (SORTED instantiations, h3d_mesh_sort + h3d_*_sorted).  h3d_mesh_sort puts the
+// pose's vertices in Morton order (one workgroup per pose, bitonic sort in LDS; key = 30-bit code << 32 | original index, so the
+// order is a deterministic function of the mesh) and records a bounding sphere per chunk of 64.  A wave skips a chunk when, for
+// every one of its 256 points, the sphere lies outside the point's current search radius:
+//     |p - c| > r (1 + 1e-5) + s,    s^2 >= run + 3 tol + |p|^2      (run = the point's running filter minimum)
+// so that every vertex of the chunk has a = |p - v|^2 - |p|^2 > run + 2 tol, hence a filter value > run + tol: the chunk
+// would not have been a candidate and would not have lowered `run` -- the candidate lists, and with them the result, are those
+// of the full scan of the same vertex order, bit for bit.  Exact ties are broken by the ORIGINAL vertex index (carried as a
+// fourth LDS plane), which is what "first index wins" means for the unsorted mesh.  The chunk nearest to the wave's centroid is
+// scanned first, so `run` is tight from the start: measured on the bench workload a wave scans ~22 % of the chunks
+// (tests/test_nn_pruning_cpu.py models the rule; the GPU tests compare indices with the oracle's brute force).
 #include "common.hpp"
 
 namespace {
@@ -31,12 +43,13 @@ constexpr int kThreads = 512;
 constexpr int kPts = 4;
 constexpr int kJoints = 24;
 constexpr int kChunk = 64;                 // vertices per filter chunk
-constexpr int kCand = 8;                   // remembered candidate chunks per point
+constexpr int kCand = 6;                   // remembered candidate chunks per point (8 until round 4: the sorted kernels need the registers)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
@@ -52,25 +65,47 @@ __device__ __forceinline__ float sqdist_exact(float px, float py, float pz, floa
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// exact scan of vertices [v4_begin*4, v4_end*4) in ascending order, strict "<": first index among exact minima
-__device__ __forceinline__ void refine(const f4* vx4, const f4* vy4, const f4* vz4, int v4_begin, int v4_end, float px,
-                                       float py, float pz, float& best, int& bi) {
+// exact scan of vertices [v4_begin*4, v4_end*4): the smallest distance, and among exact minima the smallest vertex index.
+// Unsorted mesh (ids == null): position = index, ascending scan, strict "<".  Sorted mesh: ids holds the original index of
+// every position and the tie rule is explicit (the scan order is no longer the index order).
+template <bool SORTED>
+__device__ __forceinline__ void refine(const f4* vx4, const f4* vy4, const f4* vz4, const i4* ids4, int v4_begin, int v4_end,
+                                       float px, float py, float pz, float& best, int& bi) {
+#pragma clang loop unroll(disable)
     for (int v4 = v4_begin; v4 < v4_end; ++v4) {
         const f4 X = vx4[v4], Y = vy4[v4], Z = vz4[v4];
         const float d0 = sqdist_exact(px, py, pz, X.x, Y.x, Z.x);
         const float d1 = sqdist_exact(px, py, pz, X.y, Y.y, Z.y);
         const float d2 = sqdist_exact(px, py, pz, X.z, Y.z, Z.z);
         const float d3 = sqdist_exact(px, py, pz, X.w, Y.w, Z.w);
-        if (d0 < best) { best = d0; bi = v4 * 4 + 0; }
-        if (d1 < best) { best = d1; bi = v4 * 4 + 1; }
-        if (d2 < best) { best = d2; bi = v4 * 4 + 2; }
-        if (d3 < best) { best = d3; bi = v4 * 4 + 3; }
+        if constexpr (SORTED) {
+            // one 64-bit key per vertex: distance bits (non-negative floats order like their bit patterns) above the original index
+            const i4 I = ids4[v4];
+            unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi;
+            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)I.x;
+            const unsigned long long k1 = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)I.y;
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)I.z;
+            const unsigned long long k3 = ((unsigned long long)__float_as_uint(d3) << 32) | (unsigned)I.w;
+            key = k0 < key ? k0 : key;
+            key = k1 < key ? k1 : key;
+            key = k2 < key ? k2 : key;
+            key = k3 < key ? k3 : key;
+            best = __uint_as_float((unsigned)(key >> 32));
+            bi = (int)(unsigned)key;
+        } else {
+            if (d0 < best) { best = d0; bi = v4 * 4 + 0; }
+            if (d1 < best) { best = d1; bi = v4 * 4 + 1; }
+            if (d2 < best) { best = d2; bi = v4 * 4 + 2; }
+            if (d3 < best) { best = d3; bi = v4 * 4 + 3; }
+        }
     }
 }
 
 // FEATURES = false: the search only -- nn_index is the whole output (h3d_nearest_vertex; the features are then built in the field
 // kernel's prologue, csrc/field_x3.hip GEOIN).
-template <bool FEATURES>
+// SORTED: `vertices` is the workspace of h3d_mesh_sort for this batch: per pose Vpad float4 (x, y, z, original index as bits; the
+// padding positions at 3e18) followed by Vpad / 64 float4 chunk spheres (centre, inflated radius).
+template <bool FEATURES, bool SORTED>
 __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     const float* __restrict__ points, const float* __restrict__ joints, const float* __restrict__ vertices,
     const float* __restrict__ tpose, const float* __restrict__ vertex_ik, float* __restrict__ geo,
@@ -79,20 +114,30 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     float* vx = smem;
     float* vy = smem + Vpad;
     float* vz = smem + 2 * Vpad;
-    float* jl = smem + 3 * Vpad;   // 24*3 joints
+    int* vid = reinterpret_cast<int*>(smem + 3 * Vpad);          // SORTED only
+    float* jl = smem + (SORTED ? 4 : 3) * Vpad;   // 24*3 joints
     unsigned* v2max_bits = reinterpret_cast<unsigned*>(jl + kJoints * 3);
     const int b = blockIdx.y;
     const int t = threadIdx.x;
     const float* __restrict__ vb = vertices + (int64_t)b * V * 3;
+    const f4* __restrict__ ws = reinterpret_cast<const f4*>(vertices) + (int64_t)b * (Vpad + Vpad / kChunk);
+    const f4* __restrict__ bounds = ws + Vpad;
     if (t == 0) *v2max_bits = 0u;
     __syncthreads();
     float v2 = 0.f;
     for (int i = t; i < Vpad; i += kThreads) {
-        const bool ok = i < V;
-        // padding vertices sit at +inf distance for the exact scan and can never win (the filter masks them itself)
-        const float x = ok ? vb[i * 3 + 0] : 3.0e18f, y = ok ? vb[i * 3 + 1] : 3.0e18f, z = ok ? vb[i * 3 + 2] : 3.0e18f;
+        const bool ok = SORTED ? true : i < V;
+        float x, y, z;
+        if constexpr (SORTED) {
+            const f4 q = ws[i];
+            x = q.x; y = q.y; z = q.z;
+            vid[i] = __float_as_int(q.w);
+        } else {
+            // padding vertices sit at +inf distance for the exact scan and can never win (the filter masks them itself)
+            x = ok ? vb[i * 3 + 0] : 3.0e18f; y = ok ? vb[i * 3 + 1] : 3.0e18f; z = ok ? vb[i * 3 + 2] : 3.0e18f;
+        }
         vx[i] = x; vy[i] = y; vz[i] = z;
-        if (ok) v2 = fmaxf(v2, x * x + y * y + z * z);
+        if (x < 1.0e18f) v2 = fmaxf(v2, x * x + y * y + z * z);
     }
     atomicMax(v2max_bits, __float_as_uint(v2));      // non-negative floats order like their bit patterns
     if (FEATURES && t < kJoints * 3) jl[t] = joints[(int64_t)b * kJoints * 3 + t];
@@ -116,6 +161,7 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     const f4* vx4 = reinterpret_cast<const f4*>(vx);
     const f4* vy4 = reinterpret_cast<const f4*>(vy);
     const f4* vz4 = reinterpret_cast<const f4*>(vz);
+    const i4* vid4 = reinterpret_cast<const i4*>(vid);
 
     // ---- filter operands: B fragments of the 8 point sets.  Lane (m, hh) holds k-slots 8*hh .. 8*hh+7 of column m:
     //      hh = 0: [B_hi | B_lo], hh = 1: [B_hi | 0]  against  A: hh = 0: [A_hi | A_hi], hh = 1: [A_lo | 0].
@@ -131,21 +177,66 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
         bfrag[j] = __builtin_bit_cast(half8, u4{hi01, hi23, hh ? 0u : lo01, hh ? 0u : lo23});
     }
     float run[kPts], tol[kPts], cval[kPts][kCand];
+    float sk[kPts], sb[kPts];                 // SORTED: search radius of the skip test; 3 tol + |p|^2
     unsigned long long cid[kPts];
     int ncand[kPts];
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        const float S = px[k] * px[k] + py[k] * py[k] + pz[k] * pz[k] + v2max;
+        const float p2 = px[k] * px[k] + py[k] * py[k] + pz[k] * pz[k];
+        const float S = p2 + v2max;
         // beyond the range the f16 operands cover comfortably every chunk becomes a candidate (-> exact whole-mesh scan)
         tol[k] = (S < 1.0e4f) ? 3.0517578e-5f * S : 3.0e38f;
+        sb[k] = 3.f * tol[k] + p2;
         run[k] = 3.0e38f;
+        sk[k] = 3.0e18f;                      // nothing is skipped before the first candidate
         cid[k] = 0ull;
         ncand[k] = 0;
 #pragma unroll
         for (int q = 0; q < kCand; ++q) cval[k][q] = 3.4e38f;
     }
     const int n_chunks = Vpad / kChunk;
-    for (int c = 0; c < n_chunks; ++c) {
+    // SORTED: the chunk whose sphere centre is nearest to the centroid of the wave's 256 points is scanned first
+    int seed = -1;
+    if constexpr (SORTED) {
+        float sx = (px[0] + px[1]) + (px[2] + px[3]), sy = (py[0] + py[1]) + (py[2] + py[3]), sz = (pz[0] + pz[1]) + (pz[2] + pz[3]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            sx += __shfl_xor(sx, d, 64); sy += __shfl_xor(sy, d, 64); sz += __shfl_xor(sz, d, 64);
+        }
+        sx *= 1.f / 256.f; sy *= 1.f / 256.f; sz *= 1.f / 256.f;
+        float bd = 3.4e38f;
+        int bc = 0;
+        for (int c0 = lane; c0 < n_chunks; c0 += 64) {
+            const f4 cb = bounds[c0];
+            const float dx = sx - cb.x, dy = sy - cb.y, dz = sz - cb.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < bd) { bd = d2; bc = c0; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float od = __shfl_xor(bd, d, 64);
+            const int oc = __shfl_xor(bc, d, 64);
+            if (od < bd || (od == bd && oc < bc)) { bd = od; bc = oc; }
+        }
+        seed = __builtin_amdgcn_readfirstlane(bc);
+    }
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < n_chunks; ++it) {
+        // scan order: the seed chunk first, then the others in position order
+        const int c = !SORTED ? it : it == 0 ? seed : (it <= seed ? it - 1 : it);
+        if constexpr (SORTED) {
+            // skip test (see the header): every point's search sphere misses the chunk's bounding sphere
+            const f4 cb = bounds[c];                        // wave-uniform address: scalar loads
+            bool need = false;
+#pragma unroll
+            for (int k = 0; k < kPts; ++k) {
+                const float dx = px[k] - cb.x, dy = py[k] - cb.y, dz = pz[k] - cb.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float reach = cb.w + sk[k];
+                need |= d2 <= reach * reach;
+            }
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+        }
         float cmv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) cmv[j] = 3.4e38f;
@@ -184,6 +275,8 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
                 cid[k] = (cid[k] << 8) | (unsigned long long)(c & 0xff);
                 ++ncand[k];
                 run[k] = fminf(run[k], cm[k]);
+                if constexpr (SORTED)           // s^2 >= run + 3 tol + |p|^2, rounded up (tol = 3e38 -> inf: never skip)
+                    sk[k] = __builtin_sqrtf(fmaxf(run[k] + sb[k], 0.f)) * 1.00001f;
             }
         }
     }
@@ -196,13 +289,13 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
         // nothing relevant was dropped; otherwise (eight near-ties in a row) scan the whole mesh exactly.
         const bool overflow = ncand[k] > kCand && cval[k][0] <= run[k] + 2.f * tol[k];
         if (overflow) {
-            refine(vx4, vy4, vz4, 0, Vpad / 4, px[k], py[k], pz[k], best[k], bi[k]);
+            refine<SORTED>(vx4, vy4, vz4, vid4, 0, Vpad / 4, px[k], py[k], pz[k], best[k], bi[k]);
         } else {
 #pragma unroll
             for (int q = 0; q < kCand; ++q) {
                 if (cval[k][q] <= run[k] + tol[k]) {
                     const int c = (int)((cid[k] >> (8 * (kCand - 1 - q))) & 0xffull);
-                    refine(vx4, vy4, vz4, c * (kChunk / 4), (c + 1) * (kChunk / 4), px[k], py[k], pz[k], best[k], bi[k]);
+                    refine<SORTED>(vx4, vy4, vz4, vid4, c * (kChunk / 4), (c + 1) * (kChunk / 4), px[k], py[k], pz[k], best[k], bi[k]);
                 }
             }
         }
@@ -239,32 +332,162 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     }
 }
 
+// ---- h3d_mesh_sort: Morton order of a pose's vertices + bounding spheres of the chunks of 64 (one workgroup per pose)
+constexpr int kSortThreads = 1024;
+
+__device__ __forceinline__ unsigned spread3(unsigned q) {        // 10 bits -> every third bit
+    q &= 0x3ffu;
+    q = (q | (q << 16)) & 0x030000ffu;
+    q = (q | (q << 8)) & 0x0300f00fu;
+    q = (q | (q << 4)) & 0x030c30c3u;
+    q = (q | (q << 2)) & 0x09249249u;
+    return q;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kSortThreads) void mesh_sort_kernel(const float* __restrict__ vertices, f4* __restrict__ ws, int V, int Vpad,
+                                                                 int NP2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];        // NP2 keys
+    __shared__ float box[6][kSortThreads / 64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* __restrict__ vb = vertices + (int64_t)b * V * 3;
+    f4* __restrict__ out = ws + (int64_t)b * (Vpad + Vpad / kChunk);
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = t; i < V; i += kSortThreads)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = vb[i * 3 + a];
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]);
+        if (lane == 0) { box[a][wave] = lo[a]; box[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    float inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = box[a][0], h = box[3 + a][0];
+        for (int w = 1; w < kSortThreads / 64; ++w) { l = fminf(l, box[a][w]); h = fmaxf(h, box[3 + a][w]); }
+        lo[a] = l;
+        inv[a] = h > l ? 1023.f / (h - l) : 0.f;
+    }
+    for (int i = t; i < NP2; i += kSortThreads) {
+        unsigned long long key = ~0ull;                                  // padding sorts last
+        if (i < V) {
+            unsigned code = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float q = fminf(fmaxf((vb[i * 3 + a] - lo[a]) * inv[a], 0.f), 1023.f);
+                code |= spread3((unsigned)q) << a;
+            }
+            key = ((unsigned long long)code << 32) | (unsigned)i;       // distinct keys: the order is a function of the mesh
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < NP2; i += kSortThreads) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const unsigned long long a = keys[i], c = keys[o];
+                    if ((a > c) == ((i & k) == 0)) { keys[i] = c; keys[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < Vpad; i += kSortThreads) {
+        if (i < V) {
+            const int idx = (int)(unsigned)(keys[i] & 0xffffffffull);
+            out[i] = f4{vb[idx * 3 + 0], vb[idx * 3 + 1], vb[idx * 3 + 2], __int_as_float(idx)};
+        } else {
+            out[i] = f4{3.0e18f, 3.0e18f, 3.0e18f, __int_as_float(0x7fffffff)};       // never nearest, never wins a tie
+        }
+    }
+    for (int c = wave; c < Vpad / kChunk; c += kSortThreads / 64) {     // every chunk holds at least one real vertex
+        const int i = c * kChunk + lane;
+        const bool real = i < V;
+        const int idx = real ? (int)(unsigned)(keys[i] & 0xffffffffull) : 0;
+        const float x = vb[idx * 3 + 0], y = vb[idx * 3 + 1], z = vb[idx * 3 + 2];
+        const float cx = 0.5f * (wave_min(real ? x : 3.0e38f) + wave_max(real ? x : -3.0e38f));
+        const float cy = 0.5f * (wave_min(real ? y : 3.0e38f) + wave_max(real ? y : -3.0e38f));
+        const float cz = 0.5f * (wave_min(real ? z : 3.0e38f) + wave_max(real ? z : -3.0e38f));
+        const float dx = x - cx, dy = y - cy, dz = z - cz;
+        const float r2 = wave_max(real ? dx * dx + dy * dy + dz * dz : 0.f);
+        if (lane == 0) out[Vpad + c] = f4{cx, cy, cz, __builtin_sqrtf(r2) * 1.00001f + 1.0e-7f};      // rounded up
+    }
+}
+
+int next_pow2(int v) {
+    int p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
 }  // namespace
 
-static int geo_launch(bool features, const float* points, const float* joints, const float* vertices,
+static int geo_launch(bool features, bool sorted, const float* points, const float* joints, const float* vertices,
                       const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
                       int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
     H3D_REQUIRE(B >= 0 && B <= 65535 && N >= 0, "h3d_geo_features / h3d_nearest_vertex: bad B=%d N=%lld", B, (long long)N);
     H3D_REQUIRE(V >= 1, "h3d_geo_features / h3d_nearest_vertex: V=%d", V);
     if (B == 0 || N == 0) return H3D_OK;
     const int Vpad = (V + kChunk - 1) / kChunk * kChunk;
-    const size_t lds = sizeof(float) * (3 * (size_t)Vpad + kJoints * 3 + 4);
+    const size_t lds = sizeof(float) * ((sorted ? 4 : 3) * (size_t)Vpad + kJoints * 3 + 4);
     H3D_REQUIRE(lds <= 160 * 1024, "h3d_geo_features: mesh with V=%d vertices does not fit the 160 KB LDS", V);
-    H3D_ALLOW_MAX_LDS(geo_features_kernel<true>);
-    H3D_ALLOW_MAX_LDS(geo_features_kernel<false>);
+    H3D_REQUIRE(!sorted || Vpad / kChunk <= 256, "h3d_geo_features: V=%d has more than 256 chunks", V);
+    H3D_ALLOW_MAX_LDS((geo_features_kernel<true, false>));
+    H3D_ALLOW_MAX_LDS((geo_features_kernel<false, false>));
+    H3D_ALLOW_MAX_LDS((geo_features_kernel<true, true>));
+    H3D_ALLOW_MAX_LDS((geo_features_kernel<false, true>));
     const int64_t per_block = (int64_t)kThreads * kPts;
     const int64_t gx = (N + per_block - 1) / per_block;
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_geo_features: N too large");
     h3d::pre_launch();
-    if (features)
-        hipLaunchKernelGGL(geo_features_kernel<true>, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
-                           points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
-                           legacy_mode);
-    else
-        hipLaunchKernelGGL(geo_features_kernel<false>, dim3((unsigned)gx, B), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
-                           points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, N, V, Vpad, geo_stride,
-                           legacy_mode);
+    const dim3 grid((unsigned)gx, B), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define H3D_GEO_LAUNCH(F, S)                                                                                                    \
+    hipLaunchKernelGGL((geo_features_kernel<F, S>), grid, block, lds, st, points, joints, vertices, tpose_vertices, vertex_ik, geo, \
+                       nn_index, N, V, Vpad, geo_stride, legacy_mode)
+    if (features && sorted) H3D_GEO_LAUNCH(true, true);
+    else if (features) H3D_GEO_LAUNCH(true, false);
+    else if (sorted) H3D_GEO_LAUNCH(false, true);
+    else H3D_GEO_LAUNCH(false, false);
+#undef H3D_GEO_LAUNCH
     return h3d::launch_status(features ? "h3d_geo_features" : "h3d_nearest_vertex");
+}
+
+// Workspace of h3d_mesh_sort for B poses of V vertices, in bytes.
+extern "C" int64_t h3d_mesh_sort_bytes(int B, int V) {
+    if (B < 0 || V < 1) return -1;
+    const int64_t Vpad = (V + kChunk - 1) / kChunk * kChunk;
+    return (int64_t)B * (Vpad + Vpad / kChunk) * 16;
+}
+
+extern "C" int h3d_mesh_sort(const float* vertices, void* workspace, int B, int V, h3d_stream_t stream) {
+    H3D_REQUIRE(vertices && workspace, "h3d_mesh_sort: null pointer");
+    H3D_REQUIRE(B >= 0 && B <= 65535 && V >= 1, "h3d_mesh_sort: bad B=%d V=%d", B, V);
+    H3D_REQUIRE(h3d::aligned16(workspace), "h3d_mesh_sort: the workspace must be 16-byte aligned");
+    if (B == 0) return H3D_OK;
+    const int Vpad = (V + kChunk - 1) / kChunk * kChunk, NP2 = next_pow2(V);
+    H3D_REQUIRE((size_t)NP2 * 8 <= 128 * 1024, "h3d_mesh_sort: V=%d does not fit the LDS sort (max 16384)", V);
+    H3D_ALLOW_MAX_LDS(mesh_sort_kernel);
+    h3d::pre_launch();
+    hipLaunchKernelGGL(mesh_sort_kernel, dim3(B), dim3(kSortThreads), (size_t)NP2 * 8, static_cast<hipStream_t>(stream), vertices,
+                       static_cast<f4*>(workspace), V, Vpad, NP2);
+    return h3d::launch_status("h3d_mesh_sort");
 }
 
 extern "C" int h3d_geo_features(const float* points, const float* joints, const float* vertices,
@@ -273,7 +496,7 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
     H3D_REQUIRE(points && joints && vertices && tpose_vertices && vertex_ik && geo, "h3d_geo_features: null pointer");
     H3D_REQUIRE(geo_stride >= 31, "h3d_geo_features: geo_stride=%d must be >= 31", geo_stride);
     H3D_REQUIRE(h3d::aligned16(vertex_ik), "h3d_geo_features: vertex_ik must be 16-byte aligned");
-    return geo_launch(true, points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, B, N, V, geo_stride, legacy_mode, stream);
+    return geo_launch(true, false, points, joints, vertices, tpose_vertices, vertex_ik, geo, nn_index, B, N, V, geo_stride, legacy_mode, stream);
 }
 
 /* The K = 1 nearest-vertex search of h3d_geo_features alone (same filter + exact refine, same arg-min bit for bit):
@@ -282,5 +505,26 @@ extern "C" int h3d_geo_features(const float* points, const float* joints, const 
 extern "C" int h3d_nearest_vertex(const float* points, const float* vertices, int32_t* nn_index, int B, int64_t N, int V,
                                   h3d_stream_t stream) {
     H3D_REQUIRE(points && vertices && nn_index, "h3d_nearest_vertex: null pointer");
-    return geo_launch(false, points, nullptr, vertices, nullptr, nullptr, nullptr, nn_index, B, N, V, 31, 0, stream);
+    return geo_launch(false, false, points, nullptr, vertices, nullptr, nullptr, nullptr, nn_index, B, N, V, 31, 0, stream);
+}
+
+/* The same two on a mesh prepared by h3d_mesh_sort (`sorted_mesh` = its workspace): chunks of 64 vertices whose bounding sphere
+ * lies outside every search sphere of a wave's 256 points are skipped -- the same indices and features bit for bit (header of
+ * this file), about a fifth of the chunks scanned. */
+extern "C" int h3d_geo_features_sorted(const float* points, const float* joints, const void* sorted_mesh,
+                                       const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
+                                       int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
+    H3D_REQUIRE(points && joints && sorted_mesh && tpose_vertices && vertex_ik && geo, "h3d_geo_features_sorted: null pointer");
+    H3D_REQUIRE(geo_stride >= 31, "h3d_geo_features_sorted: geo_stride=%d must be >= 31", geo_stride);
+    H3D_REQUIRE(h3d::aligned16(vertex_ik) && h3d::aligned16(sorted_mesh), "h3d_geo_features_sorted: vertex_ik / sorted_mesh must be 16-byte aligned");
+    return geo_launch(true, true, points, joints, static_cast<const float*>(sorted_mesh), tpose_vertices, vertex_ik, geo, nn_index, B, N, V,
+                      geo_stride, legacy_mode, stream);
+}
+
+extern "C" int h3d_nearest_vertex_sorted(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int64_t N, int V,
+                                         h3d_stream_t stream) {
+    H3D_REQUIRE(points && sorted_mesh && nn_index, "h3d_nearest_vertex_sorted: null pointer");
+    H3D_REQUIRE(h3d::aligned16(sorted_mesh), "h3d_nearest_vertex_sorted: sorted_mesh must be 16-byte aligned");
+    return geo_launch(false, true, points, nullptr, static_cast<const float*>(sorted_mesh), nullptr, nullptr, nullptr, nn_index, B, N, V, 31, 0,
+                      stream);
 }

@@ -1,9 +1,29 @@
 """SMPL-conditioned geometry features (reference: lib/components/smpl.py:210-249), HIP-backed."""
 import torch
 
+import os
+
 from ... import _lib
 
 GEO_DIM = 31
+# H3D_NN_PRUNE=0: the full scan of the unsorted mesh (h3d_geo_features / h3d_nearest_vertex) instead of the pruned scan of the
+# Morton-sorted one (h3d_mesh_sort + h3d_*_sorted): the same indices bit for bit, for A/B measurements
+PRUNE = os.environ.get("H3D_NN_PRUNE", "1") != "0"
+
+
+def sort_mesh(vertices):
+    """vertices [B,V,3] fp32 (device) -> the workspace of h3d_mesh_sort: per pose the vertices in Morton order with their original
+    indices, and the bounding spheres of the chunks of 64.  One launch, one workgroup per pose; None when the mesh is too large
+    for the LDS sort (the callers then take the unsorted path)."""
+    B, V, _ = vertices.shape
+    lib = _lib.load()
+    nbytes = lib.h3d_mesh_sort_bytes(B, V)
+    if nbytes <= 0 or V > 16384 or (V + 63) // 64 > 256:
+        return None
+    ws = torch.empty(nbytes // 4, device=vertices.device, dtype=torch.float32)
+    rc = lib.h3d_mesh_sort(_lib.ptr(vertices), _lib.ptr(ws), B, V, _lib.stream_handle())
+    _lib.check(rc, "h3d_mesh_sort")
+    return ws
 
 
 def vertex_inverse_transforms(fk_matrices, lbs_weights):
@@ -35,9 +55,15 @@ def get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, l
     if out_stride > GEO_DIM:
         geo[..., GEO_DIM:].zero_()
     idx = torch.empty((B, N), device=pts.device, dtype=torch.int32) if return_index else None
-    rc = _lib.load().h3d_geo_features(_lib.ptr(pts), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vertex_ik),
-                                      _lib.ptr(geo), _lib.ptr(idx), B, N, V, out_stride, int(bool(legacy_mode)),
-                                      _lib.stream_handle())
+    ws = sort_mesh(vt) if PRUNE and B > 0 and N > 0 else None
+    if ws is not None:
+        rc = _lib.load().h3d_geo_features_sorted(_lib.ptr(pts), _lib.ptr(sk), _lib.ptr(ws), _lib.ptr(tv), _lib.ptr(vertex_ik),
+                                                 _lib.ptr(geo), _lib.ptr(idx), B, N, V, out_stride, int(bool(legacy_mode)),
+                                                 _lib.stream_handle())
+    else:
+        rc = _lib.load().h3d_geo_features(_lib.ptr(pts), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vertex_ik),
+                                          _lib.ptr(geo), _lib.ptr(idx), B, N, V, out_stride, int(bool(legacy_mode)),
+                                          _lib.stream_handle())
     _lib.check(rc, "h3d_geo_features")
     return (geo, idx) if return_index else geo
 
@@ -51,6 +77,10 @@ def nearest_vertex(points, vertices):
     pts = points.contiguous().float()
     vt = vertices.contiguous().float()
     idx = torch.empty((B, N), device=pts.device, dtype=torch.int32)
-    rc = _lib.load().h3d_nearest_vertex(_lib.ptr(pts), _lib.ptr(vt), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())
+    ws = sort_mesh(vt) if PRUNE and B > 0 and N > 0 else None
+    if ws is not None:
+        rc = _lib.load().h3d_nearest_vertex_sorted(_lib.ptr(pts), _lib.ptr(ws), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())
+    else:
+        rc = _lib.load().h3d_nearest_vertex(_lib.ptr(pts), _lib.ptr(vt), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())
     _lib.check(rc, "h3d_nearest_vertex")
     return idx

@@ -96,6 +96,21 @@ int h3d_geo_features(const float* points, const float* joints, const float* vert
 int h3d_nearest_vertex(const float* points, const float* vertices, int32_t* nn_index, int B, int64_t N, int V,
                        h3d_stream_t stream);
 
+/* Round 4: the same search with chunk pruning on a spatially sorted mesh (same indices and features, bit for bit; ~4/5 of the
+ * point-vertex work skipped).  h3d_mesh_sort writes, per pose, the vertices in Morton order with their original indices
+ * ([Vpad] float4: x, y, z, index bits; Vpad = V rounded up to 64) followed by the bounding spheres of the chunks of 64
+ * ([Vpad / 64] float4: centre, radius rounded up) into `workspace` (h3d_mesh_sort_bytes(B, V) bytes, 16-byte aligned; one
+ * workgroup per pose, bitonic sort in LDS, V <= 16384).  The _sorted entry points take that workspace in place of `vertices`;
+ * ties between equidistant vertices still go to the smallest ORIGINAL index (pytorch3d.ops.knn_points contract,
+ * lib/components/smpl.py:220).  The unsorted entry points above stay for meshes outside these limits. */
+int64_t h3d_mesh_sort_bytes(int B, int V);
+int h3d_mesh_sort(const float* vertices, void* workspace, int B, int V, h3d_stream_t stream);
+int h3d_geo_features_sorted(const float* points, const float* joints, const void* sorted_mesh,
+                            const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
+                            int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream);
+int h3d_nearest_vertex_sorted(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int64_t N, int V,
+                              h3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A5  pose-conditioned FiLM-SIREN == lib/implicit_funcitions/modulated.py:41-75 (COORDCONCATSIREN.forward)
  *

@@ -104,3 +104,57 @@ def test_generator_uses_the_fused_geometry_path_by_default():
     for k in ("rgbs", "rgbs_render"):
         assert rel_err(out[k].cpu(), g["out"][k]) < TOL
         assert rel_err(out[k].cpu(), two[k].cpu()) < 1e-4
+
+
+def test_pruned_search_on_the_sorted_mesh_equals_the_full_scan_at_render_scale(monkeypatch):
+    """Round 4: h3d_mesh_sort + h3d_nearest_vertex_sorted (chunks of the Morton-sorted mesh skipped by bounding sphere) against
+    the full scan of the unsorted mesh on the renderer's own points (4 x 96 x 96 rays x 64 jittered samples: 2.4 M points per
+    pose, where exact distance ties DO occur), a mirror-symmetric mesh with duplicated vertices (ties by construction), and the
+    oracle's brute force on a subset.  Indices are integers: torch.equal."""
+    vr = importlib.import_module("3dhumangan_amd.lib.generators.volume_rendering")
+    cond = synthetic.make_conditions(2, n_vertices=6890, seed=11)
+    v = cond["vertices"]
+    v[1, :3000, 0] = v[1, :3000, 0].abs() + 0.01                    # pose 1: vertices 3000..5999 mirror 0..2999 in x = 0,
+    v[1, 3000:6000] = v[1, :3000] * torch.tensor([-1.0, 1.0, 1.0])  # 6000.. duplicate some of them
+    v[1, 6000:] = v[1, 100:990]
+    jit = torch.rand(2, 96 * 96, 64, 1, generator=torch.Generator().manual_seed(3))
+    c = dev_dict(cond)
+    pts, _ = vr.sample_rays(c["intrinsics"][:, 0, 0], c["scales"], c["cam2world_matrices"], 64, (96, 96), -0.5, 0.55, jitter=jit.to(DEV))
+    pts = pts.reshape(2, -1, 3).clone()
+    pts[1, ::7, 0] = 0.0                                            # on the symmetry plane: every nearest vertex is tied
+    monkeypatch.setattr(smpl, "PRUNE", True)
+    pruned = smpl.nearest_vertex(pts, c["vertices"])
+    monkeypatch.setattr(smpl, "PRUNE", False)
+    full = smpl.nearest_vertex(pts, c["vertices"])
+    assert torch.equal(pruned, full)
+    sub = torch.randperm(pts.shape[1], generator=torch.Generator().manual_seed(1))[:6000]
+    sub = torch.cat([sub, torch.arange(0, 7 * 300, 7)])             # some of the tied ones too
+    _, ridx = O.nearest_vertex(pts[:, sub].cpu().float(), cond["vertices"].float())
+    assert torch.equal(pruned[:, sub].cpu().long(), ridx)
+    # the feature kernel on the sorted mesh: same index, same features as on the unsorted one
+    monkeypatch.setattr(smpl, "PRUNE", True)
+    args = (pts[:, :70000], c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"], c["lbs_weights"], False)
+    g1, i1 = smpl.get_geo_features(*args, return_index=True)
+    monkeypatch.setattr(smpl, "PRUNE", False)
+    g2, i2 = smpl.get_geo_features(*args, return_index=True)
+    assert torch.equal(i1, i2) and torch.equal(i1, pruned[:, :70000]) and torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("V", [1, 63, 64, 65, 700, 6890, 10000])
+def test_mesh_sort_is_a_permutation_with_valid_spheres(V):
+    """h3d_mesh_sort: the workspace holds every vertex exactly once with its original index, padding at 3e18, and every chunk's
+    sphere contains its vertices."""
+    g = torch.Generator().manual_seed(V)
+    verts = torch.randn(3, V, 3, generator=g).to(DEV)
+    verts[2] = verts[2, :1]                                           # a degenerate pose: all vertices identical
+    ws = smpl.sort_mesh(verts)
+    Vpad = (V + 63) // 64 * 64
+    ws = ws.view(3, Vpad + Vpad // 64, 4)
+    ids = ws[:, :V, 3].contiguous().view(torch.int32).long()
+    assert torch.equal(ids.sort(dim=1).values, torch.arange(V, device=DEV).expand(3, V))
+    assert torch.equal(ws[:, :V, :3], torch.gather(verts, 1, ids[..., None].expand(3, V, 3)))
+    assert bool((ws[:, V:Vpad, :3] > 1e18).all())
+    for c in range(Vpad // 64):
+        vv = ws[:, c * 64:min((c + 1) * 64, V), :3]
+        cen, rad = ws[:, Vpad + c, :3], ws[:, Vpad + c, 3]
+        assert bool(((vv - cen[:, None]).double().norm(dim=-1) <= rad[:, None].double()).all())
