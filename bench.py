@@ -280,11 +280,11 @@ def kernel_rooflines(G, cfg, batch, stage_ms):
         fused_geo = bool(getattr(G, "fuse_geo", False)) and G.neural_field.render_geo_supported(S)
         if fused_geo:       # A4 inside the render: this stage is the search alone (points in, one int32 index out, mesh once)
             by, name = pts * (3 + 1) * 4.0 + batch * 6890 * 3 * 4.0, "h3d_nearest_vertex"
-            if os.environ.get("H3D_NN_PRUNE", "1") != "0":
-                name = "h3d_mesh_sort + h3d_nearest_vertex_sorted"
         else:               # points in, features out, mesh + transforms once
             by, name = pts * (3 + 31) * 4.0 + batch * 6890 * (3 + 3 + 16) * 4.0, "h3d_geo_features"
+        pruned = os.environ.get("H3D_NN_PRUNE", "1") != "0"
         out[name] = dict(bound="valu+mfma (6890 point-vertex pairs per sample); HBM figures for reference",
+                         entry_points=("h3d_mesh_sort + " + name + "_sorted (chunk pruning on the Morton-sorted mesh)") if pruned else name,
                          ms=ms, point_vertex_pairs_per_s=pts * 6890 / ms * 1e3, bytes=by,
                          hbm_achieved_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS,
                          note="stage time includes the [V,24]x[24,16] blended-transform GEMM of the pose (library, per batch) and the "

@@ -8,7 +8,7 @@ import re
 import sys
 
 NAMES = {"synthesis_x3_kernel": "h3d_synthesis", "field_x3_kernel": "h3d_render_fused", "synthesis_x3t_kernel": "h3d_synthesis",
-         "field_x3t_kernel": "h3d_render_fused", "geo_features_kernel<true>": "h3d_geo_features", "geo_features_kernel<false>": "h3d_nearest_vertex", "ray_integrate": "h3d_ray_integrate"}
+         "field_x3t_kernel": "h3d_render_fused", "geo_features_kernel<true": "h3d_geo_features", "geo_features_kernel<false": "h3d_nearest_vertex", "mesh_sort_kernel": "h3d_mesh_sort", "ray_integrate": "h3d_ray_integrate"}
 
 
 def parse(path):
