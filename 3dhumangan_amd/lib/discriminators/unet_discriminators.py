@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..components.ops import conv as conv_ops
+from ..components.ops import pool_up
 
 
 class _Slot(nn.Module):
@@ -80,23 +81,37 @@ class ResBlock(nn.Module):
         return x
 
     def forward(self, x):
-        # shortcut: the first block pools BEFORE its 1x1 conv, later down blocks after it; up blocks upsample first
-        s = x
-        if self.first or self.up_or_down > 0:
-            s = self._resample(s)
-        if self.conv_s is not None:
-            s = self.conv_s(s)
-        if not self.first and self.up_or_down < 0:
-            s = self._resample(s)
-        # residual branch
+        """Same function as the reference's ResBlock.forward (unet_discriminators.py:48-72), evaluated in an order that does less
+        work (round 4); every rewrite is exact algebra on the reference's graph:
+          * up blocks: a 1x1 convolution commutes with nearest-neighbour upsampling (each output pixel is a function of one input
+            pixel), so the shortcut is up(conv_s(x)) instead of conv_s(up(x)): a quarter of the convolution, fout instead of fin
+            channels through the resampler -- bit for bit the same values;
+          * down blocks (all but the first): average pooling is linear, so pool(conv_s(x)) + pool(conv2(..)) is one pooling of
+            the sum (differs from the reference's two by fp32 rounding order, ~1e-7).
+        The first block keeps the reference's order (pool BEFORE its 1x1 convolution: already the cheap one).
+        The resampling / activation glue runs on two fused kernels (ops/pool_up.py: up(lrelu(x)) in one pass, up(s) + d,
+        avgpool(s + d) -- each the other's adjoint, so the R1 double backward stays on them); `H3D_DISC_GLUE=torch` keeps
+        F.leaky_relu / F.interpolate / F.avg_pool2d."""
+        fused = x.is_cuda and os.environ.get("H3D_DISC_GLUE", "hip") != "torch" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
         d = x
         if not self.first:
-            d = F.leaky_relu(d, 0.2)
-            if self.up_or_down > 0:
-                d = self._resample(d)
+            if self.up_or_down > 0 and fused and pool_up.supported(d):
+                d = pool_up.lrelu_up2(d, 0.2)
+            else:
+                d = F.leaky_relu(d, 0.2)
+                if self.up_or_down > 0:
+                    d = self._resample(d)
         d = self.conv2(F.leaky_relu(self.conv1(d), 0.2))
+        if self.first:
+            s = pool_up.avgpool2(x) if fused and pool_up.supported(x) else self._resample(x)
+            if self.conv_s is not None:
+                s = self.conv_s(s)
+            return s + (pool_up.avgpool2(d) if fused and pool_up.supported(d) else self._resample(d))
+        s = x if self.conv_s is None else self.conv_s(x)
+        if self.up_or_down > 0:
+            return pool_up.up2_add(s, d) if fused and pool_up.supported(s, d) else self._resample(s) + d
         if self.up_or_down < 0:
-            d = self._resample(d)
+            return pool_up.avgpool2_sum(s, d) if fused and pool_up.supported(s, d) else self._resample(s + d)
         return s + d
 
 

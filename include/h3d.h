@@ -607,6 +607,20 @@ int h3d_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                   int upx, int upy, int downx, int downy, int padx0, int pady0, int flip, float gain,
                   h3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * The discriminator's resampling / activation glue, fused (round 4).  Reference: lib/discriminators/unet_discriminators.py:8-72 --
+ * nn.Sequential(LeakyReLU(0.2), nn.Upsample(scale_factor=2), conv) in the up blocks (:24-27), nn.AvgPool2d(2) (:44) and the
+ * residual sum of forward() (:48-56).  Channels-last activations [B, H, W, C] of fp32 (half = 0) or f16 (half = 1, AMP tier).
+ *   h3d_up2_mask:   out[b, 2y+i, 2x+j, c] = scale * m(mask[b,y,x,c]) * x[b,y,x,c] (+ addend[b, 2y+i, 2x+j, c]);  H, W = INPUT size
+ *   h3d_pool2_mask: out[b, y, x, c] = scale * m(mask[b,y,x,c]) * sum_{i,j} (x (+ x2))[b, 2y+i, 2x+j, c];        Ho, Wo = OUTPUT size
+ * m(t) = 1 for t > 0, else `slope` (LeakyReLU's derivative); mask / addend / x2 may be NULL (m = 1, nothing added).  For a fixed
+ * mask the two are adjoint, each the other's backward: up(lrelu(x)) = up2_mask(x, mask = x), avgpool(s + d) = pool2_mask(s, d,
+ * scale = 1/4). */
+int h3d_up2_mask(const void* x, const void* mask, const void* addend, void* out, int B, int H, int W, int C, float slope, float scale,
+                 int half, h3d_stream_t stream);
+int h3d_pool2_mask(const void* x, const void* x2, const void* mask, void* out, int B, int Ho, int Wo, int C, float slope, float scale,
+                   int half, h3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

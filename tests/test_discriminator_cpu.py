@@ -32,7 +32,8 @@ def test_state_dict_schema_and_forward(fx):
         assert set(out) == set(g[name])
         for k, v in out.items():
             assert v.shape == g[name][k].shape
-            assert rel_err(v.detach(), g[name][k]) < 1e-6, (name, k)
+            # fp32 rounding order only: round 4 pools the SUM of the two branches of a down block once (ResBlock.forward)
+            assert rel_err(v.detach(), g[name][k]) < 3e-6, (name, k)
 
 
 def test_losses_match_the_reference(fx):
