@@ -100,6 +100,9 @@ _SIGNATURES = {
     "h3d_film_sin": (C.c_int, [_p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_film_sin_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_ray_integrate_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "h3d_spectral_norm_scratch": (C.c_int64, [_i, _i]),
+    "h3d_spectral_norm": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "h3d_spectral_norm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "h3d_up2_mask": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
     "h3d_pool2_mask": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p]),
     "h3d_wgrad_narrow_rows": (C.c_int, []),

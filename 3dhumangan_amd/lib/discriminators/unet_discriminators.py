@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from ..components.ops import conv as conv_ops
 from ..components.ops import pool_up
+from ..components.ops import spectral as spectral_ops
 
 
 class _Slot(nn.Module):
@@ -40,6 +41,15 @@ class Conv2d(nn.Conv2d):
     state_dict, works under nn.utils.spectral_norm (the hook sets `weight` before forward)."""
 
     def forward(self, x):
+        hook = getattr(self, "_sn_hook", None)
+        if hook is not None:
+            # spectral normalisation (round 4): torch's forward pre-hook was taken off the module by _conv(); the same arithmetic
+            # runs here -- on the fused kernels (ops/spectral.py) in the case the trainer is in, through torch's own
+            # SpectralNorm.compute_weight otherwise (eval mode, CPU, H3D_DISC_SN=torch)
+            if os.environ.get("H3D_DISC_SN", "hip") != "torch" and spectral_ops.supported(self, hook):
+                setattr(self, hook.name, spectral_ops.spectral_weight(self, hook))
+            else:
+                hook(self, None)
         if os.environ.get("H3D_DISC_CONV", "hip") != "torch":
             if torch.is_autocast_enabled() and x.is_cuda:
                 # AMP tier (round 4): under float16 autocast the layer stays on the native kernels -- activations and their
@@ -56,7 +66,16 @@ class Conv2d(nn.Conv2d):
 
 def _conv(cin, cout, k, spectral):
     conv = Conv2d(cin, cout, k, 1, k // 2)
-    return nn.utils.spectral_norm(conv) if spectral else conv
+    if not spectral:
+        return conv
+    conv = nn.utils.spectral_norm(conv)           # parameters weight_orig, buffers weight_u / weight_v, state_dict hooks: torch's
+    # ... but its forward pre-hook (13 small launches per layer and pass) is called from Conv2d.forward instead, which can then
+    # run the fused kernels; the state_dict layout and the load / save hooks stay torch's
+    for key, fn in list(conv._forward_pre_hooks.items()):
+        if type(fn).__name__ == "SpectralNorm":
+            del conv._forward_pre_hooks[key]
+            conv._sn_hook = fn
+    return conv
 
 
 class ResBlock(nn.Module):

@@ -621,6 +621,19 @@ int h3d_up2_mask(const void* x, const void* mask, const void* addend, void* out,
 int h3d_pool2_mask(const void* x, const void* x2, const void* mask, void* out, int B, int Ho, int Wo, int C, float slope, float scale,
                    int half, h3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Spectral normalisation of a weight with one power iteration (round 4).  Reference: torch.nn.utils.spectral_norm as applied to
+ * every convolution of the discriminator (lib/discriminators/unet_discriminators.py:17); arithmetic of SpectralNorm.compute_weight:
+ *     v' = normalize(W^T u, eps),  u' = normalize(W v', eps),  sigma = u' . (W v'),  W_sn = W / sigma         W [R, K] row-major fp32
+ * u', v' are written twice: to *_out (this call's copies, kept for the backward) and to *_buf (the module's buffers, updated in
+ * place as torch does).  scratch: h3d_spectral_norm_scratch(R, K) floats.  Three launches; deterministic two-stage reductions.
+ * Backward (u', v' constants, as in torch): dW = (G - sum(G * W_sn) u' v'^T) / sigma; two launches. */
+int64_t h3d_spectral_norm_scratch(int R, int K);
+int h3d_spectral_norm(const float* W, const float* u, float* u_out, float* u_buf, float* v_out, float* v_buf, float* sigma,
+                      float* W_sn, float* scratch, int R, int K, float eps, h3d_stream_t stream);
+int h3d_spectral_norm_bwd(const float* G, const float* W_sn, const float* u, const float* v, const float* sigma, float* dW,
+                          float* scratch, int R, int K, h3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,38 @@ def test_non_channels_last_and_sliced_inputs_are_accepted():
     assert rel_err(pu.lrelu_up2(wide[:, 16:80]).cpu(), F.interpolate(F.leaky_relu(wide[:, 16:80], 0.2), scale_factor=2).cpu()) < 2e-6
     with pytest.raises(ValueError):
         pu.avgpool2(torch.randn(1, 4, 5, 4, device=DEV))
+
+
+@pytest.mark.parametrize("co,ci,k", [(128, 3, 3), (512, 512, 3), (64, 256, 1), (256, 1024, 1), (26, 64, 1)])
+def test_fused_spectral_norm_matches_torchs_hook(co, ci, k):
+    """ops/spectral.py (h3d_spectral_norm / _bwd) against torch.nn.utils.spectral_norm in float64: the normalised weight, the
+    updated u / v buffers over two forwards (the GAN pattern: D(real), D(fake), one backward through both), and the gradient
+    with respect to weight_orig."""
+    disc = importlib.import_module("3dhumangan_amd.lib.discriminators.unet_discriminators")
+    torch.manual_seed(co + ci)
+    m = disc._conv(ci, co, k, True).to(DEV).train()
+    assert hasattr(m, "_sn_hook") and not any(type(h).__name__ == "SpectralNorm" for h in m._forward_pre_hooks.values())
+    ref = torch.nn.utils.spectral_norm(torch.nn.Conv2d(ci, co, k, 1, k // 2)).double()
+    ref.load_state_dict({n: t.detach().cpu().double() for n, t in m.state_dict().items()})
+    ref.train()
+    x = torch.randn(2, ci, 8, 8)
+    cots = [torch.randn(2, co, 8, 8) for _ in range(2)]
+    loss = rloss = 0
+    for c in cots:
+        loss = loss + (torch.nn.functional.conv2d(x.to(DEV), _weight_after_forward(m, x.to(DEV)), m.bias, padding=k // 2) * c.to(DEV)).sum()
+        rloss = rloss + (ref(x.double()) * c.double()).sum()
+        assert rel_err(m.weight.detach().cpu(), ref.weight.detach()) < 2e-6
+        assert rel_err(m.weight_u.cpu(), ref.weight_u) < 2e-6 and rel_err(m.weight_v.cpu(), ref.weight_v) < 2e-6
+    loss.backward()
+    rloss.backward()
+    assert rel_err(m.weight_orig.grad.cpu(), ref.weight_orig.grad) < 1e-5
+    # eval mode goes through torch's own compute_weight (no power iteration): same value as the reference module in eval mode
+    m.eval(), ref.eval()
+    _weight_after_forward(m, x.to(DEV))
+    ref(x.double())
+    assert rel_err(m.weight.detach().cpu(), ref.weight.detach()) < 2e-6
+
+
+def _weight_after_forward(m, x):
+    m(x)                          # Conv2d.forward sets m.weight (fused spectral normalisation) before convolving
+    return m.weight
