@@ -5,8 +5,8 @@
 // and its backward  dW = (G - c u' v'^T) / sigma,  c = sum(G * W_sn)  (sigma = u'^T W v' with u', v' constants).
 // torch spends ~13 launches per layer and forward on this (two mv, two norms, clamps, divisions, clones, mv, dot, a division of
 // the whole weight) and ~8 on its backward; the discriminator has 25 such layers and runs three times per iteration -- ~16 ms of
-// 220 in tiny kernels.  Here: three launches forward, two backward, every reduction two-stage in a fixed order (deterministic).
-//   h3d_spectral_norm      sn_wtu (t = W^T u, partial |t|^2) -> sn_wv (v' out, s = W v', partial |s|^2) -> sn_scale (u', sigma, W_sn)
+// 220 in tiny kernels.  Here: four launches forward, two backward, every reduction two-stage in a fixed order (deterministic).
+//   h3d_spectral_norm      sn_wtu (partial W^T u per 16 rows) -> sn_treduce (t, partial |t|^2) -> sn_wv (v' out, s = W v', partial |s|^2) -> sn_scale (u', sigma, W_sn)
 //   h3d_spectral_norm_bwd  sn_dot (partial sum(G * W_sn)) -> sn_bwd (dW)
 #include "common.hpp"
 
@@ -39,17 +39,34 @@ __device__ __forceinline__ float sum_parts(const float* __restrict__ parts, int 
     return block_sum(v, red);
 }
 
-// t[j] = sum_i W[i, j] u[i]: a thread per column, rows in order; parts[block] = sum of t^2 over the block's columns
-__global__ __launch_bounds__(kThreads) void sn_wtu(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t,
-                                                   float* __restrict__ parts, int R, int K) {
+// tp[p][j] = sum over the p-th group of kRowsPer rows of W[i, j] u[i]: a thread per column, a block per (256 columns, row group):
+// R / 16 x K / 256 workgroups (a single workgroup per 256 columns walking all R rows is latency-bound: 100 us for 512 x 4608)
+constexpr int kRowsPer = 16;
+__global__ __launch_bounds__(kThreads) void sn_wtu(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ tp,
+                                                   int R, int K) {
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    const int i0 = blockIdx.y * kRowsPer;
+    if (j >= K) return;
+    float w[kRowsPer];
+#pragma unroll
+    for (int r = 0; r < kRowsPer; ++r) w[r] = i0 + r < R ? W[(int64_t)(i0 + r) * K + j] : 0.f;      // all loads in flight
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < kRowsPer; ++r) acc = fmaf(w[r], i0 + r < R ? u[i0 + r] : 0.f, acc);
+    tp[(int64_t)blockIdx.y * K + j] = acc;
+}
+
+// t[j] = sum_p tp[p][j] (fixed order); parts[block] = sum of t^2 over the block's columns
+__global__ __launch_bounds__(kThreads) void sn_treduce(const float* __restrict__ tp, int P, float* __restrict__ t, float* __restrict__ parts,
+                                                       int K) {
     __shared__ float red[kThreads / 64];
     const int j = blockIdx.x * kThreads + threadIdx.x;
     float acc = 0.f;
     if (j < K)
-        for (int i = 0; i < R; ++i) acc = fmaf(W[(int64_t)i * K + j], u[i], acc);
+        for (int p = 0; p < P; ++p) acc += tp[(int64_t)p * K + j];
     if (j < K) t[j] = acc;
-    const float p = block_sum(j < K ? acc * acc : 0.f, red);
-    if (threadIdx.x == 0) parts[blockIdx.x] = p;
+    const float q = block_sum(j < K ? acc * acc : 0.f, red);
+    if (threadIdx.x == 0) parts[blockIdx.x] = q;
 }
 
 // v' = t / max(|t|, eps) (written by block 0 into both destinations); s[i] = W[i, :] . v': a wave per row;
@@ -142,7 +159,8 @@ int grid_for(int64_t n, int per_thread) {
 // Scratch floats h3d_spectral_norm needs for an [R, K] weight: t [K], s [R], two partial arrays.
 extern "C" int64_t h3d_spectral_norm_scratch(int R, int K) {
     if (R < 1 || K < 1) return -1;
-    return (int64_t)K + R + 2 * kMaxParts;
+    const int64_t P = (R + kRowsPer - 1) / kRowsPer;
+    return (int64_t)K * (P + 1) + R + 2 * kMaxParts;
 }
 
 extern "C" int h3d_spectral_norm(const float* W, const float* u, float* u_out, float* u_buf, float* v_out, float* v_buf, float* sigma,
@@ -152,11 +170,13 @@ extern "C" int h3d_spectral_norm(const float* W, const float* u, float* u_out, f
     H3D_REQUIRE(h3d::aligned16(W) && h3d::aligned16(W_sn), "h3d_spectral_norm: W / W_sn must be 16-byte aligned");
     const int nb1 = (K + kThreads - 1) / kThreads, nb2 = (R + kThreads / 64 - 1) / (kThreads / 64);
     H3D_REQUIRE(nb1 <= kMaxParts && nb2 <= kMaxParts, "h3d_spectral_norm: weight too large (R=%d, K=%d)", R, K);
-    float *t = scratch, *s = scratch + K, *p1 = s + R, *p2 = p1 + kMaxParts;
+    const int P = (R + kRowsPer - 1) / kRowsPer;
+    float *t = scratch, *s = scratch + K, *p1 = s + R, *p2 = p1 + kMaxParts, *tp = p2 + kMaxParts;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)R * K;
     h3d::pre_launch();
-    hipLaunchKernelGGL(sn_wtu, dim3(nb1), dim3(kThreads), 0, st, W, u, t, p1, R, K);
+    hipLaunchKernelGGL(sn_wtu, dim3(nb1, P), dim3(kThreads), 0, st, W, u, tp, R, K);
+    hipLaunchKernelGGL(sn_treduce, dim3(nb1), dim3(kThreads), 0, st, tp, P, t, p1, K);
     hipLaunchKernelGGL(sn_wv, dim3(nb2), dim3(kThreads), 0, st, W, t, p1, nb1, eps, v_out, v_buf, s, p2, R, K);
     hipLaunchKernelGGL(sn_scale, dim3(grid_for(n, 4)), dim3(kThreads), 0, st, W, s, p2, nb2, eps, u_out, u_buf, sigma, W_sn, R, n);
     return h3d::launch_status("h3d_spectral_norm");
