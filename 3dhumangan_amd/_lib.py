@@ -55,6 +55,7 @@ _SIGNATURES = {
     "h3d_conv_x3": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_x3_f16": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_f16": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_wgrad_x3_bias": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_x3_bias_f16": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_slices": (C.c_int, [_i, _i, _i, _i, _i, _i]),
     "h3d_conv_wgrad_x3_fused": (C.c_int, [_i, _i, _i, _i, _i]),

@@ -271,8 +271,21 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
                 for (int i = 0; i < 16; ++i) acc[x][a][b][i] = 0.f;
 
     raw_t ra[NA], rb[NB + (NB + 7) / 8];
+    // the convolution's bias gradient (column sums of dY) rides along, as in wgrad_x3_kernel: first filter row, first X block only
+    const bool do_colsum = A.colsum != nullptr && blockIdx.z == 0 && tyi == 0;
+    float4 cs[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_colsum = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const float4 v = Raw4<HALF>::widen(ra[j]);
+            cs[j].x += v.x; cs[j].y += v.y; cs[j].z += v.z; cs[j].w += v.w;
+        }
+    };
     load_slab<NA, HALF>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
     load_band<NB, HALF>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
+    if (do_colsum) add_colsum();
     park_slab<NA, HALF>(ra, smem, t);
     park_band<NB, HALF>(rb, smem + kKS * WA, t);
     __syncthreads();
@@ -304,10 +317,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
                 }
         }
         if (s + 1 < n_steps) {
+            if (do_colsum) add_colsum();
             park_slab<NA, HALF>(ra, nxtA, t);
             park_band<NB, HALF>(rb, nxtA + kKS * WA, t);
         }
         __syncthreads();
+    }
+    if (do_colsum) {            // fold the 16 slab rows through LDS (the buffers are free now)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<float4*>(smem + (j * kThreads + t) * 4) = cs[j];
+        __syncthreads();
+        if (t < WA && co0 + t < A.Co) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < kKS; ++r) v += smem[r * WA + t];
+            A.colsum[(int64_t)slice * A.Co + co0 + t] = v;
+        }
     }
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
@@ -442,19 +467,26 @@ extern "C" int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int
 //   partial[tap][slice][Co][Ci] = sum_{p in slice} dY[p, Co]^T X[p + tap, Ci]      (the caller sums the slices)
 // dY [B*H*W, Co], X [B*H*W, Ci] fp32 with row strides ldy, ldx (channel slices of wider tensors); Co, Ci multiples of 4;
 // slices: any >= 1.
-static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, int B, int H, int W, int Co, int Ci, int k,
-                          int ldy, int ldx, int slices, h3d_stream_t stream);
+static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, float* colsum, int B, int H, int W, int Co, int Ci,
+                          int k, int ldy, int ldx, int slices, h3d_stream_t stream);
+/* ... with the bias gradient: colsum [slices][Co] receives the column sums of dY over each slice's pixels (the caller sums the
+ * slices), from the pass that streams dY anyway; half = 1: f16 operands. */
+extern "C" int h3d_conv_wgrad_x3_bias(const void* dY, const void* X, float* partial, float* colsum, int B, int H, int W, int Co, int Ci,
+                                      int k, int ldy, int ldx, int slices, int half, h3d_stream_t stream) {
+    H3D_REQUIRE(colsum, "h3d_conv_wgrad_x3_bias: null colsum");
+    return conv_wgrad_any(dY, X, half, partial, colsum, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
+}
 extern "C" int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
                                  int ldy, int ldx, int slices, h3d_stream_t stream) {
-    return conv_wgrad_any(dY, X, 0, partial, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
+    return conv_wgrad_any(dY, X, 0, partial, nullptr, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
 }
 /* h3d_conv_wgrad_x3 on f16 operands (AMP, round 4): dY, X are _Float16 (row strides in elements), the gradient fp32. */
 extern "C" int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k,
                                      int ldy, int ldx, int slices, h3d_stream_t stream) {
-    return conv_wgrad_any(dY, X, 1, partial, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
+    return conv_wgrad_any(dY, X, 1, partial, nullptr, B, H, W, Co, Ci, k, ldy, ldx, slices, stream);
 }
-static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, int B, int H, int W, int Co, int Ci, int k,
-                          int ldy, int ldx, int slices, h3d_stream_t stream) {
+static int conv_wgrad_any(const void* dY, const void* X, int half, float* partial, float* colsum, int B, int H, int W, int Co, int Ci,
+                          int k, int ldy, int ldx, int slices, h3d_stream_t stream) {
     H3D_REQUIRE(dY && X && partial, "h3d_conv_wgrad_x3: null pointer");
     H3D_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Co >= 1 && Ci >= 1 && (k == 1 || k == 3), "h3d_conv_wgrad_x3: bad shape");
     H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldy >= Co && ldx >= Ci,
@@ -463,7 +495,7 @@ static int conv_wgrad_any(const void* dY, const void* X, int half, float* partia
     H3D_REQUIRE(slices >= 1 && (int64_t)slices * k * k <= 65535 * 16, "h3d_conv_wgrad_x3: slices=%d out of range", slices);
     Args a{};
     a.dY = dY; a.X = X; a.partial = partial; a.M = (int64_t)B * H * W; a.Co = Co; a.Ci = Ci; a.ldy = ldy; a.ldx = ldx;
-    a.conv_k = k; a.H = H; a.W = W; a.slices = slices; a.half = half;
+    a.conv_k = k; a.H = H; a.W = W; a.slices = slices; a.half = half; a.colsum = colsum;
     const int64_t per = (a.M + slices - 1) / slices;
     a.rows_per_wg = (int)(((per + kKS - 1) / kKS) * kKS);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -110,9 +110,10 @@ def _run_conv(x, w, bias=None, transposed=False):
     return out
 
 
-def _run_wgrad(x, g, k):
+def _run_wgrad(x, g, k, with_bias=False):
     """x [B, Ci, H, W], g [B, Co, H, W] -> [Co, Ci, k, k] fp32; no autograd.  f16 operands (AMP) go to the _f16 entry point: both
-    then travel as f16 (a mixed pair is brought to f16 first)."""
+    then travel as f16 (a mixed pair is brought to f16 first).  with_bias: also the bias gradient g.sum((0, 2, 3)) [Co] fp32, from
+    the same pass over g (h3d_conv_wgrad_x3_bias) -> (dw, db)."""
     if x.dtype != g.dtype:
         x, g = x.half(), g.half()
     (x, ldx), (g, ldg) = _rows(x), _rows(g)
@@ -121,10 +122,16 @@ def _run_wgrad(x, g, k):
     lib = _lib.load()
     slices = max(1, lib.h3d_conv_wgrad_x3_slices(B, H, W, co, ci, k))
     partial = torch.empty((k * k, slices, co, ci), device=x.device, dtype=torch.float32)
-    entry = lib.h3d_conv_wgrad_x3 if x.dtype == torch.float32 else lib.h3d_conv_wgrad_x3_f16
-    rc = entry(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
+    if with_bias:
+        colsum = torch.empty((slices, co), device=x.device, dtype=torch.float32)
+        rc = lib.h3d_conv_wgrad_x3_bias(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), _lib.ptr(colsum), B, H, W, co, ci, k, ldg, ldx,
+                                        slices, int(x.dtype == torch.float16), _lib.stream_handle())
+    else:
+        entry = lib.h3d_conv_wgrad_x3 if x.dtype == torch.float32 else lib.h3d_conv_wgrad_x3_f16
+        rc = entry(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_wgrad_x3")
-    return partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
+    dw = partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
+    return (dw, colsum.sum(dim=0)) if with_bias else dw
 
 
 def _transposed(w):
@@ -144,8 +151,14 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.to(x.dtype)                   # the cotangent of an f16 output is f16; the weight / bias gradients come out fp32
         gx = _ConvT.apply(g, w) if ctx.needs_input_grad[0] else None
-        gw = _ConvW.apply(x, g, w.shape[2]) if ctx.needs_input_grad[1] else None
-        gb = g.sum(dim=(0, 2, 3), dtype=torch.float32) if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None
+        want_b = len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
+        gw = gb = None
+        if ctx.needs_input_grad[1] and want_b:
+            gw, gb = _ConvWB.apply(x, g, w.shape[2])          # the bias gradient rides along the weight-gradient pass over g
+        elif ctx.needs_input_grad[1]:
+            gw = _ConvW.apply(x, g, w.shape[2])
+        elif want_b:
+            gb = g.sum(dim=(0, 2, 3), dtype=torch.float32)
         return gx, gw, gb
 
 
@@ -183,6 +196,25 @@ class _ConvW(torch.autograd.Function):
         return gx, gg, None
 
 
+class _ConvWB(torch.autograd.Function):
+    """_ConvW together with the bias gradient g.sum((0, 2, 3)): x, g -> ([Co, Ci, k, k], [Co]), one pass over g."""
+
+    @staticmethod
+    def forward(ctx, x, g, k):
+        ctx.save_for_backward(x, g)
+        return _run_wgrad(x, g, k, with_bias=True)
+
+    @staticmethod
+    def backward(ctx, v, vb):
+        x, g = ctx.saved_tensors
+        v = v.float()
+        gx = _ConvT.apply(g, v) if ctx.needs_input_grad[0] else None
+        gg = _Conv.apply(x, v) if ctx.needs_input_grad[1] else None
+        if gg is not None and vb is not None:
+            gg = gg + vb.to(gg.dtype).view(1, -1, 1, 1)          # d(sum over pixels of g) / dg
+        return gx, gg, None
+
+
 class _NarrowChannels(torch.autograd.Function):
     """y[:, :co] whose gradient stays channels-last (torch's slice backward builds an NCHW-contiguous zero-padded tensor, which the
     next convolution would have to copy); differentiable again (a concatenation)."""
@@ -217,11 +249,11 @@ def conv2d(x, weight, bias=None):
     if (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)) and torch.is_grad_enabled():
         if cop == co:
             return _Conv.apply(x, weight, bias)
-        y = _Conv.apply(x, weight)
+        # padded output channels: the bias travels zero-padded through the kernel's epilogue (and its gradient comes back from
+        # the weight-gradient pass) instead of a broadcast add and a reduction over the sliced output
+        y = _Conv.apply(x, weight, None if bias is None else torch.nn.functional.pad(bias.float(), (0, cop - co)))
     elif cop == co:
         return _run_conv(x, weight, bias)
     else:
-        y = _run_conv(x, weight)
-    if cop != co:
-        y = _NarrowChannels.apply(y, co) if y.requires_grad else y[:, :co]
-    return y if bias is None else y + bias.view(1, -1, 1, 1).to(y.dtype)
+        y = _run_conv(x, weight, None if bias is None else torch.nn.functional.pad(bias.float(), (0, cop - co)))
+    return _NarrowChannels.apply(y, co) if y.requires_grad else y[:, :co]

@@ -221,6 +221,11 @@ int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* 
                     int k, int ldx, int ldo, h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int ldy,
                           int ldx, int slices, h3d_stream_t stream);
+/* ... with the convolution's bias gradient riding along (round 4): colsum [slices][Co] fp32 = column sums of dY over each slice's
+ * pixels (the caller sums the slices, as for `partial`); half = 1: f16 operands.  Replaces the separate dY.sum((0, 2, 3)) pass of
+ * nn.Conv2d's backward (reference: the biased convolutions of lib/discriminators/unet_discriminators.py:8-72). */
+int h3d_conv_wgrad_x3_bias(const void* dY, const void* X, float* partial, float* colsum, int B, int H, int W, int Co, int Ci, int k,
+                           int ldy, int ldx, int slices, int half, h3d_stream_t stream);
 int h3d_wgrad_x3_bias_f16(const void* dY, const void* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
                           int ldx, int slices, h3d_stream_t stream);
 /* K-slices to ask for (HOST helper), and whether a 3x3 problem runs on the kernel that fuses the three taps of a filter row
