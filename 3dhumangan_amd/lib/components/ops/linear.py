@@ -8,6 +8,7 @@ contracts over the M rows and produces a tiny output -- the library runs it at ~
 (HBM-bound) and returns the bias gradient from the same pass.  Used by lib/generators/differentiable.py for every layer with enough
 rows; anything else (few rows, half-precision autocast inputs, odd widths, CPU tensors) is F.linear."""
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -18,6 +19,26 @@ MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this th
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
+
+
+_half_cache = {}
+
+
+def _half_cached(t):
+    """t.half() for a parameter, cast once per parameter VERSION (the optimiser's in-place update bumps it) instead of once per
+    call: a dense layer's weight is used by the D step's generator forward, the G step's forward and its data gradient -- three
+    casts and three tiny launches per layer and iteration otherwise (torch's autocast keeps the same kind of cache)."""
+    if t is None or t.dtype == torch.float16:
+        return t
+    e = _half_cache.get(id(t))
+    if e is not None and e[0] == t._version and e[1]() is t:
+        return e[2]
+    h = t.detach().half()
+    if len(_half_cache) > 1024:                       # temporaries (a scaled weight built per call) leave dead entries behind
+        for k in [k for k, v in _half_cache.items() if v[1]() is None]:
+            del _half_cache[k]
+    _half_cache[id(t)] = (t._version, weakref.ref(t), h)
+    return h
 
 
 def _as_image(t2):
@@ -145,7 +166,7 @@ class _LinearAmp(torch.autograd.Function):
         ctx.has_bias = b is not None
         if AMP_NATIVE_GEMM and _native_ok(*w.shape):
             return gemm_x3(_rows(xh), w, b).view(*x.shape[:-1], w.shape[0])
-        return F.linear(xh, w.half(), None if b is None else b.half())
+        return F.linear(xh, _half_cached(w), _half_cached(b))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -158,7 +179,7 @@ class _LinearAmp(torch.autograd.Function):
             if AMP_NATIVE_GEMM and _native_ok(*w.shape):
                 dx = gemm_x3(dy2, w, transposed=True).view(*dy.shape[:-1], w.shape[1])
             else:
-                dx = dyh @ w.half()
+                dx = dyh @ _half_cached(w)
         if ctx.needs_input_grad[1]:
             Co, Ci = w.shape
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
