@@ -6,7 +6,7 @@ R=${1:-r3}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 REPO=$PWD
-KERN='x3_kernel|x3t_kernel|geo_features|ray_integrate|conv_x3|wgrad'
+KERN='x3_kernel|x3t_kernel|geo_features|mesh_sort|ray_integrate|conv_x3|wgrad'
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err        # the driver's protocol
 python bench.py --steps 200 --warmup 5 --no-extra --no-cpu --no-check > $OUT/bench_200steps.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
@@ -33,5 +33,11 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_train -o k -- python $REPO/bench.py --mode trainstep --batch 4 --steps 3 --warmup 2 > $OUT/trainstep_bench_under_rocprof.json 2>> $OUT/trainstep.err
 cd $REPO
 python tools/rocprof_summary.py $(find $OUT/stats_train -name '*.db' | head -1) $OUT/trainstep_kernel_stats.csv
+# the same iteration in the reference's AMP mode: bench line + kernel table
+python bench.py --mode trainstep --batch 4 --steps 5 --warmup 6 --amp fp16 > $OUT/trainstep_1gpu_amp_fp16.json 2>> $OUT/trainstep.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_train_amp -o k -- python $REPO/bench.py --mode trainstep --batch 4 --steps 3 --warmup 6 --amp fp16 > /dev/null 2>> $OUT/trainstep.err
+cd $REPO
+python tools/rocprof_summary.py $(find $OUT/stats_train_amp -name '*.db' | head -1) $OUT/trainstep_amp_fp16_kernel_stats.csv
 find $OUT -name '*.db' -delete
 tail -c 400 $OUT/bench.json
