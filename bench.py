@@ -373,7 +373,7 @@ def _oracle_run(cfg, sd, batch, seed, runs):
     return times
 
 
-def cpu_baseline(cfg, sd, seed=1234, shrink=2, runs=3):
+def cpu_baseline(cfg, sd, seed=1234, shrink=2, runs=2):
     """The CPU oracle (a port of the reference path, pinned to the reference by tests/golden) on the host cores.
     Bounded sample of the SAME workload: one image at 1/shrink of the height and width (output pixels, rays) with the
     same samples per ray, widths and weights -- per-ray and per-pixel work is identical and the total is linear in
@@ -393,7 +393,7 @@ def cpu_baseline(cfg, sd, seed=1234, shrink=2, runs=3):
                        "linear in rays and pixels); pure-PyTorch CPU oracle, brute-force nearest-vertex search")
 
 
-def cpu_baseline_cfg1(runs=3):
+def cpu_baseline_cfg1(runs=1):
     """BASELINE config 1 on the host cores, FULL size: MAP3DBN (hidden 384), one 256x128 image from 64x32 rays x 32
     samples (the reference-native '256^2'); 1 warm-up + `runs` timed runs of the oracle, images/s = 1 / median."""
     configs = importlib.import_module("3dhumangan_amd.configs")
@@ -412,7 +412,7 @@ def cpu_baseline_cfg1(runs=3):
                 sample=f"MAP3DBN 256x128, 64x32 rays x 32, batch 1, full size: 1 warm-up + {runs} timed runs")
 
 
-def cpu_baseline_cfg2(batch=8, shrink=2, runs=2):
+def cpu_baseline_cfg2(batch=8, shrink=2, runs=1):
     """BASELINE config 2 on the host cores ("cfg 2 (B=8)"): MAP3DBN (hidden 384), batch 8 of the reference-native
     256x128 image from 64x32 rays x 32 samples, at 1/shrink linear size to bound the time (work is linear in rays and pixels):
     1 warm-up + `runs` timed oracle forwards of the whole batch, images/s = batch / (median * shrink^2)."""
