@@ -387,7 +387,9 @@ extern "C" int h3d_wgrad_x3_slices(int64_t M, int Co, int Ci) {
     if (M <= 0 || Co <= 0 || Ci <= 0) return 0;
     const int na = tiles_for(Co), nb = tiles_for(Ci);
     const int64_t blocks = (int64_t)((Co + 64 * na - 1) / (64 * na)) * ((Ci + 64 * nb - 1) / (64 * nb));
-    int64_t want = ((int64_t)h3d::compute_units() + blocks - 1) / blocks;
+    // FLOOR: one workgroup per compute unit at a time (392 registers per lane), so slices x blocks must not EXCEED the unit count --
+    // rounding up (round 3) gave e.g. 86 x 3 = 258 workgroups on 256 units: a second round for two stragglers
+    int64_t want = (int64_t)h3d::compute_units() / blocks;
     const int64_t most = (M + 255) / 256;
     if (want > most) want = most;
     if (want < 1) want = 1;
@@ -456,7 +458,9 @@ extern "C" int h3d_conv_wgrad_x3_slices(int B, int H, int W, int Co, int Ci, int
         const int na = tiles_for(Co), nb = tiles_for(Ci);
         per_slice_wgs = (int64_t)k * k * ((Co + 64 * na - 1) / (64 * na)) * ((Ci + 64 * nb - 1) / (64 * nb));
     }
-    int64_t want = (2 * (int64_t)h3d::compute_units() + per_slice_wgs - 1) / per_slice_wgs;
+    // FLOOR, for the same reason as in h3d_wgrad_x3_slices: 171 slices x 3 filter rows = 513 workgroups ran as THREE rounds on 256
+    // units (one workgroup per unit at a time) instead of two -- a third of every fused 3x3 weight gradient's time
+    int64_t want = 2 * (int64_t)h3d::compute_units() / per_slice_wgs;
     const int64_t most = (M + 255) / 256;
     if (want > most) want = most;
     if (want < 1) want = 1;
