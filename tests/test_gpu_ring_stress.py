@@ -13,7 +13,6 @@ import importlib
 import pytest
 import torch
 
-from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 gens = importlib.import_module("3dhumangan_amd.lib.generators")
@@ -59,9 +58,26 @@ def test_x3_kernels_are_bit_reproducible_over_200_launches(thrash, engines):
         bad += int(not torch.equal(out["rgbs"], ref_rgb)) + int(not torch.equal(out["rgbs_render"], ref_ren))
     torch.cuda.synchronize()
     assert bad == 0, f"{bad} of 400 outputs differ from the first launch"
-    # and the ring-less fp32-MFMA engines agree with it to rounding
+    # and the ring-less fp32-MFMA engines agree with it to rounding -- except on rays whose LAST sample has a density within
+    # rounding of zero: the reference gives that sample delta = 1e9 (lib/generators/volume_rendering.py:21), so its alpha is 0 or 1 by the SIGN
+    # of the density, and with white_back the background term 1 - sum(w) flips between "all of the remaining transmittance" and
+    # 0 -- the same shift in every channel.  With this random-initialised field (densities centred on zero) that happens on about
+    # one ray in 20 000 (round 4: 1 of 18 432 once the fused render builds its own geometry features, which differ from
+    # h3d_geo_features' in the last bit).  Such rays are identified by that signature, counted, and left out of the tolerance.
     G.neural_field.precision = "f32"
     G.synthesis_plan(DEV).engine = "f32"
     strict = G.forward(z, cond, jitter=jit, **cfg)
-    assert rel_err(ref_rgb.cpu(), strict["rgbs"].cpu()) < (2e-4 if engines[1] == "bf16x3" else 1e-3)
-    assert rel_err(ref_ren.cpu(), strict["rgbs_render"].cpu()) < 2e-4
+    d = (ref_ren - strict["rgbs_render"]).cpu()                        # [B, 3, Hr, Wr]
+    flipped = d.abs().amax(1) > 1e-2
+    assert float(flipped.float().mean()) < 5e-4, f"{int(flipped.sum())} rays differ by more than 1e-2"
+    if flipped.any():
+        spread = (d.amax(1) - d.amin(1))[flipped]
+        assert float(spread.max()) < 1e-3, "a ray differs by more than the background term of the last-sample discontinuity"
+    keep = ~flipped
+    ren_err = float((d.abs().amax(1) * keep).max() / strict["rgbs_render"].abs().max())
+    assert ren_err < 2e-4, ren_err
+    # the image: leave out the footprint of those rays (the feature map is resized bilinearly: a flipped ray reaches 2 rays far)
+    far = torch.nn.functional.max_pool2d(flipped.float()[:, None], 5, 1, 2)
+    keep_px = torch.nn.functional.interpolate(1.0 - far, size=ref_rgb.shape[-2:], mode="nearest")
+    img_err = float(((ref_rgb - strict["rgbs"]).cpu().abs() * keep_px).max() / strict["rgbs"].abs().max())
+    assert img_err < (2e-4 if engines[1] == "bf16x3" else 1e-3), img_err
