@@ -14,6 +14,7 @@ channels-last fp32 (torch.channels_last memory format of the logical NCHW tensor
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -48,16 +49,29 @@ def supported(x, weight):
     return _native(_up64(ci), _up64(co))
 
 
+_stream_cache = {}
+
+
 def pack_stream(w, transposed=False):
     """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
     kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
-    taps flipped) instead."""
-    w = w.detach().contiguous()
-    co, ci, k, _ = w.shape
-    out = torch.empty(2 * w.numel(), device=w.device, dtype=torch.int16)
-    rc = _lib.load().h3d_conv_x3_pack(_lib.ptr(w), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
+    taps flipped) instead.  Cached per tensor OBJECT and version: the same (spectrally normalised) weight is convolved with in the
+    forward, again in the R1 double backward, and its transposed stream in both backward passes -- one pack each instead of one
+    per call (a weight rebuilt per call, e.g. a zero-padded one, simply misses)."""
+    key = (id(w), bool(transposed))
+    e = _stream_cache.get(key)
+    if e is not None and e[0] == w._version and e[1]() is w:
+        return e[2]
+    wd = w.detach().contiguous()
+    co, ci, k, _ = wd.shape
+    out = torch.empty(2 * wd.numel(), device=wd.device, dtype=torch.int16)
+    rc = _lib.load().h3d_conv_x3_pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
                                       _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_pack")
+    if len(_stream_cache) > 512:
+        for kk in [kk for kk, v in _stream_cache.items() if v[1]() is None]:
+            del _stream_cache[kk]
+    _stream_cache[key] = (w._version, weakref.ref(w), out)
     return out
 
 
