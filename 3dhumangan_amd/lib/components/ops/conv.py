@@ -68,7 +68,7 @@ def pack_stream(w, transposed=False):
     rc = _lib.load().h3d_conv_x3_pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
                                       _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_pack")
-    if len(_stream_cache) > 512:
+    if len(_stream_cache) > 96:            # dead entries (their tensors are gone) hold device memory: drop them early
         for kk in [kk for kk, v in _stream_cache.items() if v[1]() is None]:
             del _stream_cache[kk]
     _stream_cache[key] = (w._version, weakref.ref(w), out)
