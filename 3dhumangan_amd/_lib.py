@@ -52,6 +52,7 @@ _SIGNATURES = {
                                       _i, _i, _p]),
     "h3d_conv_x3_tiling": (C.c_int, [_i, _i, C.POINTER(C.c_int)]),
     "h3d_conv_x3_pack": (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_pack_f16": (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
     "h3d_conv_x3": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_x3_f16": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_f16": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -12,6 +12,9 @@
 // channels of its (shifted) pixel -- 32 contiguous bytes, channels-last -- one chunk (<= 128 channels) ahead of the matrix
 // pipe, and splits them into bf16 hi / lo fragments in registers (fp32 exponent range: gradients need no scaling; 16 mantissa
 // bits per operand: ~2e-5 against fp64).  Every product is hi*hi + hi*lo + lo*hi with fp32 accumulation.
+// AMP tier (HALF instantiations): the activations ARE f16 -- one exact plane -- so the loaded words are the B fragments as they
+// are (no conversion, no split) on the F16 matrix instruction, the weights travel as f16 hi + f16 lo (22 significant bits;
+// h3d_conv_x3_pack_f16), and a product is W_hi x + W_lo x: two matrix instructions instead of three, no vector work per element.
 #include "x3_common.hpp"
 #include <type_traits>
 
@@ -50,23 +53,6 @@ __device__ __forceinline__ void load_chunk(u32x4 (&raw)[KSC], const _Float16* __
     for (int s = 0; s < KSC; ++s)
         raw[s] = valid ? *reinterpret_cast<const u32x4*>(src + 16 * s + 8 * h) : u32x4{0u, 0u, 0u, 0u};
 }
-// ... split into bf16 hi / lo as the fp32 path does: exact (f16 carries 11 significant bits, the two bf16 halves 16)
-template <int KSC>
-__device__ __forceinline__ void split_chunk(const u32x4 (&raw)[KSC], BF16::vec8 (&xh)[KSC], BF16::vec8 (&xl)[KSC]) {
-#pragma unroll
-    for (int s = 0; s < KSC; ++s) {
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned word = raw[s][e];           // a copy first: __builtin_bit_cast of a vector-element lvalue reads element 0
-            const h16x2 v = __builtin_bit_cast(h16x2, word);
-            hw[e] = split2_bf16((float)v.x, (float)v.y, lw[e]);
-        }
-        xh[s] = __builtin_bit_cast(BF16::vec8, u32x4{hw[0], hw[1], hw[2], hw[3]});
-        xl[s] = __builtin_bit_cast(BF16::vec8, u32x4{lw[0], lw[1], lw[2], lw[3]});
-    }
-}
-
 template <int KSC>
 __device__ __forceinline__ void split_chunk(const float4 (&raw)[2 * KSC], BF16::vec8 (&xh)[KSC], BF16::vec8 (&xl)[KSC]) {
 #pragma unroll
@@ -104,7 +90,16 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
 
     f32x16 acc[NT];
     typename std::conditional<HALF, u32x4[KSC], float4[2 * KSC]>::type raw;
-    BF16::vec8 xh[KSC], xl[KSC];
+    typedef typename std::conditional<HALF, F16, BF16>::type TE;          // the engine's element type
+    typename TE::vec8 xh[KSC], xl[KSC];
+    auto fragments = [&]() {
+        if constexpr (HALF) {
+#pragma unroll
+            for (int s = 0; s < KSC; ++s) xh[s] = __builtin_bit_cast(F16::vec8, raw[s]);      // the f16 words as loaded
+        } else {
+            split_chunk<KSC>(raw, xh, xl);
+        }
+    };
     auto source = [&](int it, bool& valid) -> const TX* {
         const int tap = it / A.n_chunks, chunk = it - tap * A.n_chunks;
         const int ty = tap / A.k - pad, tx = tap - (tap / A.k) * A.k - pad;
@@ -118,23 +113,23 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
         load_chunk<KSC>(raw, src, valid, h);
     }
     // first chunk: fresh accumulators
-    split_chunk<KSC>(raw, xh, xl);
+    fragments();
     if (n_iter > 1) {
         bool valid;
         const TX* src = source(1, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
-    gemm_x3_roll<BF16, NT, KSC, KSC, false, L, 0, true>(acc, xh, xl, ring);
+    gemm_x3_roll<TE, NT, KSC, KSC, false, L, 0, true, !HALF>(acc, xh, xl, ring);
 #pragma unroll 1
     for (int it = 1; it < n_iter; ++it) {
         pin_agpr<NT>(acc);
-        split_chunk<KSC>(raw, xh, xl);
+        fragments();
         if (it + 1 < n_iter) {
             bool valid;
             const TX* src = source(it + 1, valid);
             load_chunk<KSC>(raw, src, valid, h);
         }
-        gemm_x3_roll<BF16, NT, KSC, KSC, false, L>(acc, xh, xl, ring);
+        gemm_x3_roll<TE, NT, KSC, KSC, false, L, 0, false, !HALF>(acc, xh, xl, ring);
     }
     ring.drain();
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
@@ -166,20 +161,28 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
 // Weight stream of h3d_conv_x3 from OIHW fp32 weights, one launch: thread <-> (o, i, tap) of the convolution that will RUN
 // (transposed: the backward-data convolution of w, W'[o][i][tap] = w[i][o][k*k - 1 - tap]).
 __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ stream, int Cout, int Cin, int kk, int NT,
-                                 int KSC, int n_chunks, int transposed, int64_t total) {
+                                 int KSC, int n_chunks, int transposed, int64_t total, int f16) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int tap = (int)(idx % kk);
     const int i = (int)((idx / kk) % Cin), o = (int)(idx / ((int64_t)kk * Cin));
     const float v = transposed ? w[((int64_t)i * Cout + o) * kk + (kk - 1 - tap)] : w[((int64_t)o * Cin + i) * kk + tap];
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
+    unsigned short hb, lb;
+    if (f16) {              // the AMP tier's stream: f16 hi + f16 lo (22 significant bits) for the F16 matrix instruction
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        hb = __builtin_bit_cast(unsigned short, hi); lb = __builtin_bit_cast(unsigned short, lo);
+    } else {
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        hb = __builtin_bit_cast(unsigned short, hi); lb = __builtin_bit_cast(unsigned short, lo);
+    }
     const int ob = o / (32 * NT), nt = (o / 32) % NT, j = o & 31;
     const int chunk = i / (16 * KSC), ks = (i / 16) % KSC, h = (i >> 3) & 1, e = i & 7;
     // [ob][tap][chunk][ks][nt][hi|lo][64 lanes = 32 h + j][8]
     const int64_t base = (((((int64_t)ob * kk + tap) * n_chunks + chunk) * KSC + ks) * NT + nt) * 2;
-    stream[(base * 64 + 32 * h + j) * 8 + e] = __builtin_bit_cast(unsigned short, hi);
-    stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = __builtin_bit_cast(unsigned short, lo);
+    stream[(base * 64 + 32 * h + j) * 8 + e] = hb;
+    stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = lb;
 }
 
 template <int NT, int KSC, bool HALF>
@@ -206,7 +209,7 @@ extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
 // Pack OIHW fp32 weights `w` (device) into the stream h3d_conv_x3 reads (2 * Cout * Cin * k * k bf16, device).  transposed = 0:
 // w is [Cout, Cin, k, k], the forward convolution; transposed = 1: w is [Cin, Cout, k, k] and the stream is that of its
 // backward-data convolution (Cout <- Cin channels, flipped taps).
-extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
+static int conv_pack_any(const float* w, void* stream, int Cout, int Cin, int k, int transposed, int f16, h3d_stream_t stream_) {
     H3D_REQUIRE(w && stream && (k == 1 || k == 3), "h3d_conv_x3_pack: null pointer / kernel size");
     int til[4];
     if (h3d_conv_x3_tiling(Cin, Cout, til)) {
@@ -216,8 +219,16 @@ extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin,
     const int64_t total = (int64_t)Cout * Cin * k * k;
     h3d::pre_launch();
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w,
-                       static_cast<unsigned short*>(stream), Cout, Cin, k * k, til[0], til[2], til[3], transposed, total);
+                       static_cast<unsigned short*>(stream), Cout, Cin, k * k, til[0], til[2], til[3], transposed, total, f16);
     return h3d::launch_status("h3d_conv_x3_pack");
+}
+extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
+    return conv_pack_any(w, stream, Cout, Cin, k, transposed, 0, stream_);
+}
+// The stream h3d_conv_x3_f16 reads: the same layout with f16 hi + f16 lo planes (for the F16 matrix instruction; weights must lie
+// in the f16 range, |w| < 65504: a convolution weight does).
+extern "C" int h3d_conv_x3_pack_f16(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
+    return conv_pack_any(w, stream, Cout, Cin, k, transposed, 1, stream_);
 }
 
 static int conv_x3_any(bool half, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
@@ -226,9 +237,10 @@ extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     return conv_x3_any(false, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
 }
-/* h3d_conv_x3 on f16 activations (AMP, round 4): x and out are _Float16 (row strides in elements, multiples of 8), weights and
- * bias as for h3d_conv_x3 (fp32 bias, the same bf16 hi/lo stream of the fp32 weights: autocast never rounds the weights here);
- * fp32 accumulation, one rounding to f16 at the store. */
+/* h3d_conv_x3 on f16 activations (AMP, round 4): x and out are _Float16 (row strides in elements, multiples of 8), fp32 bias, the
+ * weight stream of h3d_conv_x3_pack_f16 (f16 hi + lo planes of the fp32 weights, 22 significant bits: autocast never rounds the
+ * weights to 11 here); two F16 matrix products per weight (the activation is exact in one plane), fp32 accumulation, one rounding
+ * to f16 at the store. */
 extern "C" int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                                int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     H3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0, "h3d_conv_x3_f16: row strides must be multiples of 8 halves (ldx=%d ldo=%d)", ldx, ldo);

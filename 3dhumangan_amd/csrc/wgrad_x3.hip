@@ -113,20 +113,32 @@ __device__ __forceinline__ void load_band(typename Raw4<HALF>::type (&r)[NT + (N
     }
 }
 
+// LDS slabs hold the operands as they will be multiplied: fp32 (split into bf16 hi / lo by the consumer) or, in the HALF
+// instantiations, the f16 values themselves -- an f16 operand is exact in one plane, so the AMP tier's weight gradient is ONE
+// v_mfma_f32_32x32x16_f16 per tile and k-step instead of three bf16 products, with no conversion anywhere (round 4).
+template <bool HALF> struct SlabElem { typedef float type; };
+template <> struct SlabElem<true> { typedef _Float16 type; };
+
+template <bool HALF>
+__device__ __forceinline__ void park4(typename SlabElem<HALF>::type* dst, const typename Raw4<HALF>::type& r) {
+    if constexpr (HALF) *reinterpret_cast<typename Raw4<true>::type*>(dst) = r;          // four halves: one 8-byte store
+    else *reinterpret_cast<float4*>(dst) = r;
+}
+
 template <int NT, bool HALF>
-__device__ __forceinline__ void park_band(const typename Raw4<HALF>::type (&r)[NT + (NT + 7) / 8], float* lds, int t) {
+__device__ __forceinline__ void park_band(const typename Raw4<HALF>::type (&r)[NT + (NT + 7) / 8], typename SlabElem<HALF>::type* lds, int t) {
     constexpr int W4 = 16 * NT, NJ = NT + (NT + 7) / 8;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int idx = j * kThreads + t;
-        if (idx < 18 * W4) *reinterpret_cast<float4*>(lds + idx * 4) = Raw4<HALF>::widen(r[j]);
+        if (idx < 18 * W4) park4<HALF>(lds + idx * 4, r[j]);
     }
 }
 
 template <int NT, bool HALF>
-__device__ __forceinline__ void park_slab(const typename Raw4<HALF>::type (&r)[NT], float* lds, int t) {
+__device__ __forceinline__ void park_slab(const typename Raw4<HALF>::type (&r)[NT], typename SlabElem<HALF>::type* lds, int t) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(lds + (j * kThreads + t) * 4) = Raw4<HALF>::widen(r[j]);
+    for (int j = 0; j < NT; ++j) park4<HALF>(lds + (j * kThreads + t) * 4, r[j]);
 }
 
 // bf16 hi / lo fragments of column `col` of an LDS slab of width W: element e <-> row 8 * (lane >> 5) + e
@@ -139,6 +151,29 @@ __device__ __forceinline__ void read_frag(const float* lds, int col, int lane, B
     hi = __builtin_bit_cast(BF16::vec8, h3d::u32x4{h[0], h[1], h[2], h[3]});
     lo = __builtin_bit_cast(BF16::vec8, h3d::u32x4{l[0], l[1], l[2], l[3]});
 }
+// the f16 fragment of the same column: eight 16-bit LDS reads, no arithmetic
+template <int W>
+__device__ __forceinline__ void read_frag(const _Float16* lds, int col, int lane, h3d::F16::vec8& v, int row0 = 0) {
+    const _Float16* p = lds + (row0 + 8 * (lane >> 5)) * W + col;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[e * W];
+}
+
+// one k-step of a tile: three split-bf16 products, or the one exact f16 product
+template <bool HALF> struct Frag {
+    BF16::vec8 h, l;
+    template <int W> __device__ __forceinline__ void read(const float* lds, int col, int lane, int row0 = 0) { read_frag<W>(lds, col, lane, h, l, row0); }
+    static __device__ __forceinline__ f32x16 mul(const Frag& a, const Frag& b, f32x16 acc) {
+        acc = BF16::mfma(a.l, b.h, acc);
+        acc = BF16::mfma(a.h, b.l, acc);
+        return BF16::mfma(a.h, b.h, acc);
+    }
+};
+template <> struct Frag<true> {
+    h3d::F16::vec8 v;
+    template <int W> __device__ __forceinline__ void read(const _Float16* lds, int col, int lane, int row0 = 0) { read_frag<W>(lds, col, lane, v, row0); }
+    static __device__ __forceinline__ f32x16 mul(const Frag& a, const Frag& b, f32x16 acc) { return h3d::F16::mfma(a.v, b.v, acc); }
+};
 
 template <int NA, int NB, bool CONV, bool HALF>
 __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
@@ -181,32 +216,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
     load_slab<NA, HALF>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
     load_slab<NB, HALF, CONV>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
     if (do_colsum) add_colsum();
-    park_slab<NA, HALF>(ra, smem, t);
-    park_slab<NB, HALF>(rb, smem + kKS * WA, t);
+    typedef typename SlabElem<HALF>::type slab_t;
+    slab_t* slab = reinterpret_cast<slab_t*>(smem);
+    park_slab<NA, HALF>(ra, slab, t);
+    park_slab<NB, HALF>(rb, slab + kKS * WA, t);
     __syncthreads();
 
     for (int s = 0; s < n_steps; ++s) {
-        const float* curA = smem + (s & 1) * kBuf;
-        const float* curB = curA + kKS * WA;
-        float* nxtA = smem + ((s + 1) & 1) * kBuf;
+        const slab_t* curA = slab + (s & 1) * kBuf;
+        const slab_t* curB = curA + kKS * WA;
+        slab_t* nxtA = slab + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
             load_slab<NA, HALF>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
             load_slab<NB, HALF, CONV>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, tx, A.H, A.W);
         }
-        BF16::vec8 ah[NA], al[NA], bh[NB], bl[NB];
+        Frag<HALF> fa[NA], fb[NB];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) read_frag<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane, ah[a], al[a]);
+        for (int a = 0; a < NA; ++a) fa[a].template read<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) read_frag<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane, bh[b], bl[b]);
+        for (int b = 0; b < NB; ++b) fb[b].template read<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane);
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                acc[a][b] = BF16::mfma(al[a], bh[b], acc[a][b]);
-                acc[a][b] = BF16::mfma(ah[a], bl[b], acc[a][b]);
-                acc[a][b] = BF16::mfma(ah[a], bh[b], acc[a][b]);
-            }
+            for (int b = 0; b < NB; ++b) acc[a][b] = Frag<HALF>::mul(fa[a], fb[b], acc[a][b]);
         if (s + 1 < n_steps) {
             if (do_colsum) add_colsum();
             park_slab<NA, HALF>(ra, nxtA, t);
@@ -286,35 +319,33 @@ __global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
     load_slab<NA, HALF>(ra, A.dY, A.ldy, r_begin, r_end, co0, A.Co, t);
     load_band<NB, HALF>(rb, A.X, A.ldx, r_begin, r_end, ci0, A.Ci, t, ty, A.H, A.W);
     if (do_colsum) add_colsum();
-    park_slab<NA, HALF>(ra, smem, t);
-    park_band<NB, HALF>(rb, smem + kKS * WA, t);
+    typedef typename SlabElem<HALF>::type slab_t;
+    slab_t* slab = reinterpret_cast<slab_t*>(smem);
+    park_slab<NA, HALF>(ra, slab, t);
+    park_band<NB, HALF>(rb, slab + kKS * WA, t);
     __syncthreads();
 
     for (int s = 0; s < n_steps; ++s) {
-        const float* curA = smem + (s & 1) * kBuf;
-        const float* curB = curA + kKS * WA;
-        float* nxtA = smem + ((s + 1) & 1) * kBuf;
+        const slab_t* curA = slab + (s & 1) * kBuf;
+        const slab_t* curB = curA + kKS * WA;
+        slab_t* nxtA = slab + ((s + 1) & 1) * kBuf;
         if (s + 1 < n_steps) {
             const int64_t row0 = r_begin + (int64_t)(s + 1) * kKS;
             load_slab<NA, HALF>(ra, A.dY, A.ldy, row0, r_end, co0, A.Co, t);
             load_band<NB, HALF>(rb, A.X, A.ldx, row0, r_end, ci0, A.Ci, t, ty, A.H, A.W);
         }
-        BF16::vec8 ah[NA], al[NA];
+        Frag<HALF> fa[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) read_frag<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane, ah[a], al[a]);
+        for (int a = 0; a < NA; ++a) fa[a].template read<WA>(curA, (wy * NA + a) * 32 + (lane & 31), lane);
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            BF16::vec8 bh[NB], bl[NB];
+            Frag<HALF> fb[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) read_frag<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane, bh[b], bl[b], x);
+            for (int b = 0; b < NB; ++b) fb[b].template read<WB>(curB, (wx * NB + b) * 32 + (lane & 31), lane, x);
 #pragma unroll
             for (int a = 0; a < NA; ++a)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc[x][a][b] = BF16::mfma(al[a], bh[b], acc[x][a][b]);
-                    acc[x][a][b] = BF16::mfma(ah[a], bl[b], acc[x][a][b]);
-                    acc[x][a][b] = BF16::mfma(ah[a], bh[b], acc[x][a][b]);
-                }
+                for (int b = 0; b < NB; ++b) acc[x][a][b] = Frag<HALF>::mul(fa[a], fb[b], acc[x][a][b]);
         }
         if (s + 1 < n_steps) {
             if (do_colsum) add_colsum();

@@ -290,7 +290,10 @@ struct NoHook {
 // called as hook(IC<g>{}) once per tile-pair section g = ks * NT/2 + p, in program order before the section's six
 // MFMAs; VALU_PER_MFMA > 0 asks the scheduler to slot that many VALU instructions behind each MFMA of the section.
 // Every index is a compile-time constant (static_for), so fragment / accumulator arrays stay in registers.
-template <typename T, int NT, int KS, int KSA, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
+// XLO = false: the activation operand is exact in ONE plane (f16 inputs on the F16 engine, the AMP tier): two products, W_hi x +
+// W_lo x, and xl is not read.
+template <typename T, int NT, int KS, int KSA, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, bool XLO = true, typename RING,
+          typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA],
                                              const typename T::vec8 (&xl)[KSA], RING& ring, HOOK hook = HOOK()) {
     constexpr int P = NT / 2, G = KS * P, NB = L + 1;
@@ -342,8 +345,10 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
             acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
         }
 #if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 2      // timing experiments only (wrong results)
-        acc[n0] = mm<T, SWAP>(b.h[0], xl[s], acc[n0]);
-        acc[n1] = mm<T, SWAP>(b.h[1], xl[s], acc[n1]);
+        if constexpr (XLO) {
+            acc[n0] = mm<T, SWAP>(b.h[0], xl[s], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.h[1], xl[s], acc[n1]);
+        }
 #endif
 #if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 3
         acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);

@@ -52,21 +52,21 @@ def supported(x, weight):
 _stream_cache = {}
 
 
-def pack_stream(w, transposed=False):
+def pack_stream(w, transposed=False, half=False):
     """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
     kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
     taps flipped) instead.  Cached per tensor OBJECT and version: the same (spectrally normalised) weight is convolved with in the
     forward, again in the R1 double backward, and its transposed stream in both backward passes -- one pack each instead of one
-    per call (a weight rebuilt per call, e.g. a zero-padded one, simply misses)."""
-    key = (id(w), bool(transposed))
+    per call (a weight rebuilt per call, e.g. a zero-padded one, simply misses).  half: the f16 hi/lo stream of h3d_conv_x3_f16."""
+    key = (id(w), bool(transposed), bool(half))
     e = _stream_cache.get(key)
     if e is not None and e[0] == w._version and e[1]() is w:
         return e[2]
     wd = w.detach().contiguous()
     co, ci, k, _ = wd.shape
     out = torch.empty(2 * wd.numel(), device=wd.device, dtype=torch.int16)
-    rc = _lib.load().h3d_conv_x3_pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
-                                      _lib.stream_handle())
+    pack = _lib.load().h3d_conv_x3_pack_f16 if half else _lib.load().h3d_conv_x3_pack
+    rc = pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed), _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_pack")
     if len(_stream_cache) > 96:            # dead entries (their tensors are gone) hold device memory: drop them early
         for kk in [kk for kk, v in _stream_cache.items() if v[1]() is None]:
@@ -113,7 +113,7 @@ def _run_conv(x, w, bias=None, transposed=False):
     B, ci, H, W = x.shape
     k = w.shape[2]
     co = w.shape[1] if transposed else w.shape[0]
-    stream = pack_stream(w.float(), transposed)
+    stream = pack_stream(w.float(), transposed, half=x.dtype == torch.float16)
     out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
     lib = _lib.load()

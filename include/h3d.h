@@ -206,6 +206,8 @@ int h3d_conv_x3_tiling(int Cin, int Cout, int* out /* [4]: NT, blocks, KSC, chun
 /* Device-side packer of that stream (one launch): w OIHW fp32 [Cout, Cin, k, k] -> stream (2 * Cout * Cin * k * k bf16);
  * transposed = 1: w is [Cin, Cout, k, k] and the stream is the one of its backward-data convolution. */
 int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_handle);
+/* ... for h3d_conv_x3_f16 (AMP tier): the same stream layout with f16 hi + f16 lo planes (|w| < 65504). */
+int h3d_conv_x3_pack_f16(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_handle);
 int h3d_conv_x3(const float* x, const void* stream, const float* bias /* may be NULL */, float* out, int B, int H, int W,
                 int Cin, int Cout, int k, int ldx, int ldo /* row strides in floats: channel slices of wider tensors */,
                 h3d_stream_t stream_handle);

@@ -45,6 +45,29 @@ def test_conv_f16_forward_and_gradients_vs_float64(B, H, W, ci, co, k):
     assert rel_err(hb.cpu(), gb) < 1e-5
 
 
+def test_f16_matrix_products_keep_subnormal_operands():
+    """The AMP convolution / weight-gradient kernels multiply the f16 values themselves on v_mfma_f32_32x32x16_f16 (round 4: one exact
+    plane, no bf16 split).  f16 subnormals (|x| < 6.1e-5: small activations, unscaled gradients) must take part in the products
+    like any other value -- operands entirely in the subnormal range against float64."""
+    torch.manual_seed(3)
+    B, H, W, ci, co = 2, 16, 16, 128, 128
+    x = (torch.randn(B, ci, H, W) * 2e-5).half()                   # every element subnormal or nearly so
+    assert float((x.abs() < 6.1e-5).float().mean()) > 0.95
+    w = torch.randn(co, ci, 3, 3) / (ci * 9) ** 0.5
+    cot = (torch.randn(B, co, H, W) * 2e-5).half()
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv2d(xd, wd, padding=1)
+    gx, gw = torch.autograd.grad(ref, [xd, wd], cot.double())
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wg = w.to(DEV).requires_grad_()
+    out = conv.conv2d(xg, wg)
+    hx, hw = torch.autograd.grad(out, [xg, wg], cot.to(DEV))
+    # the outputs are themselves subnormal f16 (spacing 6e-8): compare in units of the reference's range
+    assert rel_err(out.detach().float().cpu(), ref.detach()) < 2e-2
+    assert rel_err(hw.cpu(), gw) < 1e-4                            # fp32 result of exact products: the subnormals were not flushed
+    assert rel_err(hx.float().cpu(), gx) < 5e-2
+
+
 def test_spade_kernels_f16_vs_the_fp32_kernels():
     from _torch_spade_kernels import TorchKernels
     torch.manual_seed(0)
