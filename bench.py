@@ -533,8 +533,10 @@ def op_rooflines():
 def conv_rooflines(timeit):
     """Per-shape table of the discriminator's / dense layers' matrix-core kernels (the conv_x3 roofline must be
     recomputable): algorithmic flops 2 B H W Ci Co k^2 and bytes (input + output once, weights negligible) against measured time,
-    for fp32 activations and for the AMP tier's f16 activations.  Each algorithmic product is three bf16 MFMA products (x3), so
-    `mfma_pipe_util` = 3 x frac; `hbm_frac` = bytes / time / 8 TB/s.  Times include the per-call weight packing launch."""
+    for fp32 activations and for the AMP tier's f16 activations.  `mfma_pipe_util` = matrix instructions issued per algorithmic
+    product x frac: three bf16 products for fp32 operands (x3); for f16 operands two F16 products in the convolution (the
+    activation is exact in one plane, the weights travel as f16 hi + lo) and ONE in the weight gradient (both operands exact).
+    `hbm_frac` = bytes / time / 8 TB/s.  Times include the per-call weight packing launch (cached per weight version)."""
     conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
     rows = []
     shapes = [(4, 512, 256, 128, 128, 3), (4, 256, 128, 128, 256, 3), (4, 256, 128, 256, 256, 3), (4, 128, 64, 256, 512, 3),
@@ -551,10 +553,12 @@ def conv_rooflines(timeit):
                                  ("weight_gradient", lambda: conv._run_wgrad(x, g, k), B * H * W * (ci + co) * esz)):
                 ms = timeit(fn, iters=5)
                 ach = flop / ms / 1e9
+                issue = 3.0 if dt == torch.float32 else 2.0 if name == "forward" else 1.0
                 rows.append(dict(kernel="h3d_conv_x3" if name == "forward" else "h3d_conv_wgrad_x3", pass_=name,
                                  shape=f"B{B} {H}x{W} {ci}->{co} k{k}", activations="f32" if dt == torch.float32 else "f16",
                                  ms=ms, flop=flop, bytes=by, achieved_TFLOPs=ach, frac=ach / MFMA_F16_PEAK_TF,
-                                 mfma_pipe_util=3.0 * ach / MFMA_F16_PEAK_TF, hbm_GBs=by / ms / 1e6, hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS))
+                                 mfma_issue_factor=issue, mfma_pipe_util=issue * ach / MFMA_F16_PEAK_TF, hbm_GBs=by / ms / 1e6,
+                                 hbm_frac=by / ms / 1e6 / HBM_PEAK_GBS))
             del x, g
     return rows
 
