@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kThreads) void sn_scale(const float* __restrict__ W
         }
         if (threadIdx.x == 0) *sigma_out = sigma;
     }
-    const float r = 1.f / sigma;
     for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4; e < n; e += (int64_t)gridDim.x * kThreads * 4) {
         if (e + 3 < n) {
             const float4 w = *reinterpret_cast<const float4*>(W + e);
@@ -125,7 +124,6 @@ __global__ __launch_bounds__(kThreads) void sn_scale(const float* __restrict__ W
             for (int64_t q = e; q < n; ++q) Wsn[q] = W[q] / sigma;
         }
     }
-    (void)r;
 }
 
 __global__ __launch_bounds__(kThreads) void sn_dot(const float* __restrict__ G, const float* __restrict__ Wsn, float* __restrict__ parts,

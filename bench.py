@@ -464,7 +464,7 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
         # term flips by the whole remaining transmittance -- the same shift in all three channels).  Identified by that signature,
         # counted, and left out of the tolerance together with the item's pixels (the resized feature map spreads such a ray).
         dr = got_r - ref["rgbs_render"]
-        flip = (dr.abs().amax(1) > 1e-2) & ((dr.amax(1) - dr.amin(1)) < 1e-3)
+        flip = discontinuity_rays(dr)
         flipped_rays += int(flip.sum())
         for c in range(3):
             if not bool(flip.any()):
@@ -479,6 +479,14 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
                 rays_on_the_last_sample_discontinuity=flipped_rays,
                 synthesis_engine=plan.engine, x2_range_guard_fell_back=bool(plan.x2_fell_back()) if plan.engine in ("f16x2", "f16x2t") else None,
                 against="CPU oracle on a pixel/ray subset (per-channel max-norm); oracle pinned to the reference's vectors")
+
+
+def discontinuity_rays(dr):
+    """dr [B, 3, R] = rendered colour minus reference -> bool [B, R]: rays whose difference is the signature of the reference's
+    last-sample discontinuity: far above the tolerance and THE SAME in all three channels (the background
+    term 1 - sum(w), which flips by the remaining transmittance when the sign of a last-sample density within rounding of zero
+    flips).  A genuine error of the field or of the compositing does not shift every channel by one amount."""
+    return (dr.abs().amax(1) > 1e-2) & ((dr.amax(1) - dr.amin(1)) < 1e-3)
 
 
 def op_rooflines():
