@@ -18,7 +18,9 @@ def sort_mesh(vertices):
     B, V, _ = vertices.shape
     lib = _lib.load()
     nbytes = lib.h3d_mesh_sort_bytes(B, V)
-    if nbytes <= 0 or V > 16384 or (V + 63) // 64 > 256:
+    vpad = (V + 63) // 64 * 64
+    # the sorted search keeps FOUR planes of the mesh in LDS (x, y, z, original index): larger meshes take the full scan (three)
+    if nbytes <= 0 or V > 16384 or vpad // 64 > 256 or 4 * (4 * vpad + 24 * 3 + 4) > 160 * 1024:
         return None
     ws = torch.empty(nbytes // 4, device=vertices.device, dtype=torch.float32)
     rc = lib.h3d_mesh_sort(_lib.ptr(vertices), _lib.ptr(ws), B, V, _lib.stream_handle())
