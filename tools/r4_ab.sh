@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 development call: targeted parity tests of the reworked register engines, then a same-lease A/B of the bench
-# (this tree vs the round-3 tree kept in _r3_baseline/).  Everything lands in gpurun_out/.
+# (this tree vs the round-3 tree: recreate it with `git worktree add _r3_baseline 943f8f6 && (cd _r3_baseline && python -c "import __graft_entry__ as g; g.build()")`).  Everything lands in gpurun_out/.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
