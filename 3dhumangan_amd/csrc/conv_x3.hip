@@ -13,7 +13,7 @@
 // pipe, and splits them into bf16 hi / lo fragments in registers (fp32 exponent range: gradients need no scaling; 16 mantissa
 // bits per operand: ~2e-5 against fp64).  Every product is hi*hi + hi*lo + lo*hi with fp32 accumulation.
 // AMP tier (HALF instantiations): the activations ARE f16 -- one exact plane -- so the loaded words are the B fragments as they
-// are (no conversion, no split) on the F16 matrix instruction, the weights travel as f16 hi + f16 lo (22 significant bits;
+// are (no conversion, no split) on the F16 matrix instruction, the weights travel as f16 hi + f16 lo (to max(2^-22 |W|, 2^-25);
 // h3d_conv_x3_pack_f16), and a product is W_hi x + W_lo x: two matrix instructions instead of three, no vector work per element.
 #include "x3_common.hpp"
 #include <type_traits>
@@ -168,7 +168,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __
     const int i = (int)((idx / kk) % Cin), o = (int)(idx / ((int64_t)kk * Cin));
     const float v = transposed ? w[((int64_t)i * Cout + o) * kk + (kk - 1 - tap)] : w[((int64_t)o * Cin + i) * kk + tap];
     unsigned short hb, lb;
-    if (f16) {              // the AMP tier's stream: f16 hi + f16 lo (22 significant bits) for the F16 matrix instruction
+    if (f16) {              // the AMP tier's stream: f16 hi + f16 lo (the weight to max(2^-22 |W|, 2^-25)) for the F16 matrix instruction
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         hb = __builtin_bit_cast(unsigned short, hi); lb = __builtin_bit_cast(unsigned short, lo);
@@ -238,8 +238,8 @@ extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias
     return conv_x3_any(false, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
 }
 /* h3d_conv_x3 on f16 activations (AMP, round 4): x and out are _Float16 (row strides in elements, multiples of 8), fp32 bias, the
- * weight stream of h3d_conv_x3_pack_f16 (f16 hi + lo planes of the fp32 weights, 22 significant bits: autocast never rounds the
- * weights to 11 here); two F16 matrix products per weight (the activation is exact in one plane), fp32 accumulation, one rounding
+ * weight stream of h3d_conv_x3_pack_f16 (f16 hi + lo planes of the fp32 weights: the weight to max(2^-22 |W|, 2^-25), where autocast
+ * rounds it to 11 bits); two F16 matrix products per weight (the activation is exact in one plane), fp32 accumulation, one rounding
  * to f16 at the store. */
 extern "C" int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                                int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
