@@ -579,7 +579,8 @@ def generator_forward_subset(state, cfg, z, cond, jitter, pixel_subset, noise=No
     this is the full computation on the rays / pixels the subset touches -- nothing is approximated; it exists so that
     BASELINE-size workloads (B=16, 512^2, 96x96 rays x 64 samples ...) can be checked in seconds.  jitter / noise are the
     FULL-size tensors.  -> dict(rgbs [B,3,P], rgbs_render [B,3,Rs], ray_subset [Rs] (sorted ray indices the pixels
-    need), raw_depth [B,Rs,1], weights [B,Rs,S,1], feature_maps [B,F,Rs])."""
+    need), raw_depth [B,Rs,1], weights [B,Rs,S,1], feature_maps [B,F,Rs], sigma [B,Rs,S] (densities as integrated: noise
+    added, before the clamp), taps [4,P] (positions in ray_subset of each pixel's four bilinear taps))."""
     B = z.shape[0]
     H, W = cfg["gen_height"], cfg["gen_width"]
     Hr, Wr = cfg["render_height"], cfg["render_width"]
@@ -598,7 +599,10 @@ def generator_forward_subset(state, cfg, z, cond, jitter, pixel_subset, noise=No
         freq = af + psi * (freq - af)
         phase = ap + psi * (phase - ap)
         styles = ast + psi * (styles - ast)
-    rgb_render, fmap, depth, w, _ = render(state, cfg, freq, phase, cond, jitter, noise, ray_subset=rays)
+    rgb_render, fmap, depth, w, internal = render(state, cfg, freq, phase, cond, jitter, noise, ray_subset=rays)
+    sigma = internal["field"][..., -1]                                                                        # [B,Rs,S]
+    if noise is not None:
+        sigma = sigma + noise[:, rays, :, 0]
     fm = fmap[:, :, 0, :]                                                                                     # [B,F,Rs]
     txp, typ = tx[X], ty[Y]
     top = fm[:, :, pos[0]] * (1 - txp) + fm[:, :, pos[1]] * txp
@@ -613,7 +617,7 @@ def generator_forward_subset(state, cfg, z, cond, jitter, pixel_subset, noise=No
     syn = synthesis_network(state, x0in, fmap_up, styles, cfg.get("map3d_mode", "isolated"),
                             tuple(cfg["mod_blocks"]), cfg["synthesis_blocks"])
     return dict(rgbs=syn["final"][..., 0], rgbs_render=rgb_render[:, :, 0, :], ray_subset=rays, raw_depth=depth,
-                weights=w, feature_maps=fm, styles=styles, freq=freq, phase=phase)
+                weights=w, feature_maps=fm, styles=styles, freq=freq, phase=phase, sigma=sigma, taps=pos)
 
 
 # --------------------------------------------------------------------------
