@@ -356,7 +356,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         wil = __builtin_bit_cast(bf8, u32x4{lw[0], lw[1], lw[2], lw[3]});
     }
     // texel row of this half-wave (k = 8h + e) and the per-column offsets (wave-uniform)
-    const float* trow = Gb + ((int64_t)min(ya + h, A.Hr - 1) * A.Wr) * A.g_channels + m;
+    // explicitly a GLOBAL pointer: laundered through the asm above the address space is unknown to the compiler, and a generic
+    // pointer makes these FLAT loads -- while a FLAT access is pending the waitcnt pass turns every later LDS wait into lgkmcnt(0)
+    typedef const __attribute__((address_space(1))) float* gptr;
+    const gptr trow = (gptr)(Gb + ((int64_t)min(ya + h, A.Hr - 1) * A.Wr) * A.g_channels + m);
     f32x16 x[NT];
     frag8 xh[KS], xl[KS];
     i32x8 b6[NT];
@@ -615,7 +618,10 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = rgb_acc[c] + __shfl_xor(rgb_acc[c], 32, 64);
-        if (okp && h == 0) rgb_out[((int64_t)b * 3 + c) * HW + p] = v;
+        // a GLOBAL store (see trow above): as a generic pointer this is a FLAT store, and a FLAT access that is never waited for
+        // (stores are not) keeps "pending flat" alive around the persistent tile loop: EVERY LDS wait of the kernel then became
+        // s_waitcnt lgkmcnt(0) -- the weight-fragment look-ahead was drained at every table read (round 5, found in the ISA)
+        if (okp && h == 0) ((__attribute__((address_space(1))) float*)rgb_out)[((int64_t)b * 3 + c) * HW + p] = v;
     }
     }   // tiles
     if constexpr (X2) {

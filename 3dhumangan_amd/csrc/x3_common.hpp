@@ -134,6 +134,8 @@ struct WeightRing {
     unsigned read_at, rd_begin, rd_end;     // LDS address of the buffer acquired next / of the ring / past it
     int vslot;                              // vector: this lane's 16 bytes inside a stage = (wave * kChunks) KiB + lane * 16
     int lane;
+    int wave;                               // scalar: this wave's index in the workgroup (staggered refills)
+    bool primed = false;                    // experiments only
 
     __device__ __forceinline__ void init(const unsigned char* stream, unsigned char* lds, int total_stages, int w, int l) {
 #ifdef H3D_EXPERIMENT_SMALL_STREAM
@@ -147,9 +149,23 @@ struct WeightRing {
         m0_end = m0_begin + kRingBytes;
         vslot = w * kChunks * 1024 + l * 16;
         lane = l;
+        wave = w;
         asm volatile("" : "+s"(fill_g), "+s"(fill_m0), "+s"(read_at));
 #pragma unroll
         for (int i = 0; i < kBuf - 1 - LAG; ++i) issue();
+        primed = true;
+    }
+    // Staggered refill (H3D_RING_STAGGER): the kChunks pieces a wave owes per stage are issued in ONE section of the k-step,
+    // a different one for each wave (section c <-> wave c), instead of one piece per section by all four waves at once: the
+    // waves of a workgroup run in lockstep between barriers, so their pieces otherwise arrive at the CU's vector-memory path
+    // together and queue behind each other (issue cost of a piece: ~60 cycles alone, 100-185 in a crowd, MI355X_MICROARCH.md).
+    template <int C>
+    __device__ __forceinline__ void issue_slot() {
+#ifdef H3D_RING_STAGGER
+        if ((wave % kChunks) == C) issue();
+#else
+        issue_chunk<C>();
+#endif
     }
     // One 1 KB piece of the stage being filled.  Issued through inline asm on purpose: hipcc models
     // global_load_lds as a FLAT access that touches both LDS and memory and, while one is pending, degrades EVERY
@@ -162,6 +178,9 @@ struct WeightRing {
     // every write of M0 in it is one of these).
     template <int C>
     __device__ __forceinline__ void issue_chunk() {           // C = 0 .. kChunks-1, in order
+#ifdef H3D_EXPERIMENT_NO_DMA                                  // timing experiment (wrong results): the refills are never issued
+        if (primed) return;
+#endif
 #ifndef H3D_RING_M0_PER_PIECE
         if (C == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0" : : "s"(fill_m0), "v"(vslot), "s"(fill_g) : "m0");
         else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(vslot), "s"(fill_g), "n"(C * 1024));
@@ -357,7 +376,7 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
         // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
         // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()
         constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
-        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_chunk<since % P>();
+        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
         if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -565,7 +584,7 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
             }
         }
         constexpr int since = g - (P - L);
-        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_chunk<since % P>();
+        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
         if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < n_mfma; ++i) {

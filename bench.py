@@ -737,6 +737,7 @@ def main():
     ap.add_argument("--no-telemetry", action="store_true", help="do not sample clocks / power around the timed region")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle-subset self-check of the timed workload")
+    ap.add_argument("--check-items", type=int, default=0, help="self-check only the first N items of the batch (0: all; development)")
     a = ap.parse_args()
     respawn_under_torchrun(a, sys.argv[1:])
 
@@ -883,7 +884,7 @@ def main():
     except (KeyError, TypeError):
         pass
     # every item of the timed batch (round 3 checked items 0 and B - 1 only), 8 + 3 cells each
-    out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, list(range(a.batch)), n_cells=8)
+    out["checked"] = None if a.no_check else self_check(G, cfg, z, cond, jitter, list(range(a.check_items or a.batch)), n_cells=8)
     if world == 1 and not a.no_cpu:
         sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(cfg, sd)
