@@ -53,7 +53,10 @@ class SpatialStyleModLayer(nn.Module):
         Without gradients: one fused kernel (h3d_modconv1x1, fp32 matrix cores).  With gradients (round 4): the same function,
         ((x m) W) d + b with m = affine(style) + 1, d = rsqrt(m^2 W^2 + eps) (reference lib/components/map3d_layers.py:60-80),
         composed of the package's own dense layers (ops/linear.py: forward / data-gradient GEMMs on h3d_conv_x3 where the
-        widths allow, weight gradients on h3d_wgrad_x3 / h3d_wgrad_narrow) -- recorded by autograd, differentiable to any order."""
+        widths allow, weight gradients on h3d_wgrad_x3 / h3d_wgrad_narrow) -- recorded by autograd.  FIRST order only: the dense
+        layers' backward functions (ops/linear.py: _LinearX3, _LinearAmp) are once_differentiable, so a double backward through this
+        layer raises; the k x k StyleModLayer (cips_layers.py) goes through ops/conv.py's three mutually recursive primitives and is
+        differentiable to any order."""
         _lib.need_cuda(x, style)
         if style.dim() > 3:
             B, C, H, W = style.shape

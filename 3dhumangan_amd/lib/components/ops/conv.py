@@ -52,26 +52,34 @@ def supported(x, weight):
 _stream_cache = {}
 
 
-def pack_stream(w, transposed=False, half=False):
+def pack_stream(w, transposed=False, half=False, owner=None):
     """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
     kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
     taps flipped) instead.  Cached per tensor OBJECT and version: the same (spectrally normalised) weight is convolved with in the
     forward, again in the R1 double backward, and its transposed stream in both backward passes -- one pack each instead of one
-    per call (a weight rebuilt per call, e.g. a zero-padded one, simply misses).  half: the f16 hi/lo stream of h3d_conv_x3_f16."""
-    key = (id(w), bool(transposed), bool(half))
-    e = _stream_cache.get(key)
-    if e is not None and e[0] == w._version and e[1]() is w:
-        return e[2]
+    per call.  `owner`: the long-lived tensor `w` is a per-call view / reshape of (the dense layers hand in
+    ``weight.detach()[:, :, None, None]``, a new object every call): the cache is keyed on the owner's identity and version, so
+    those calls hit too.  Inference tensors (torch.inference_mode) have no version counter: they are packed every call.
+    half: the f16 hi/lo stream of h3d_conv_x3_f16."""
+    ref = w if owner is None else owner
+    cacheable = not ref.is_inference()
+    key = (id(ref), bool(transposed), bool(half), tuple(w.shape))
+    if cacheable:
+        e = _stream_cache.get(key)
+        if e is not None and e[0] == ref._version and e[1]() is ref:
+            return e[2]
     wd = w.detach().contiguous()
     co, ci, k, _ = wd.shape
     out = torch.empty(2 * wd.numel(), device=wd.device, dtype=torch.int16)
     pack = _lib.load().h3d_conv_x3_pack_f16 if half else _lib.load().h3d_conv_x3_pack
     rc = pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed), _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_pack")
-    if len(_stream_cache) > 96:            # dead entries (their tensors are gone) hold device memory: drop them early
+    if not cacheable:
+        return out
+    if len(_stream_cache) > 32:            # dead entries (their tensors are gone) hold device memory: drop them early
         for kk in [kk for kk, v in _stream_cache.items() if v[1]() is None]:
             del _stream_cache[kk]
-    _stream_cache[key] = (w._version, weakref.ref(w), out)
+    _stream_cache[key] = (ref._version, weakref.ref(ref), out)
     return out
 
 
@@ -106,14 +114,15 @@ def _rows(x):
     return _lib.aligned16(x.contiguous(memory_format=torch.channels_last)), C
 
 
-def _run_conv(x, w, bias=None, transposed=False):
+def _run_conv(x, w, bias=None, transposed=False, owner=None):
     """x [B, Ci, H, W] (any layout), w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd.  transposed: w is
     [Ci, Co, k, k] and the backward-data convolution of w runs instead (x has w's OUTPUT channel count)."""
     x, ldx = _rows(x)
     B, ci, H, W = x.shape
     k = w.shape[2]
     co = w.shape[1] if transposed else w.shape[0]
-    stream = pack_stream(w.float(), transposed, half=x.dtype == torch.float16)
+    wf = w.float()                         # fp32 weights come back as the same object: the cache key survives
+    stream = pack_stream(wf, transposed, half=x.dtype == torch.float16, owner=owner if (owner is not None and wf is w) else None)
     out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
     lib = _lib.load()

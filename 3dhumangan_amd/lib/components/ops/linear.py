@@ -51,7 +51,9 @@ def _as_image(t2):
 def gemm_x3(x2, w, bias=None, transposed=False):
     """x2 [M, Ci] @ w[Co, Ci]^T (+ bias) -> [M, Co]; transposed: x2 [M, Co] @ w[Co, Ci] -> [M, Ci].  Split-bf16 matrix-core kernel."""
     from . import conv
-    y = conv._run_conv(_as_image(x2), w.detach()[:, :, None, None], bias, transposed=transposed)
+    # owner=w: the packed weight stream is cached on the caller's (long-lived) weight, not on this per-call view of it
+    y = conv._run_conv(_as_image(x2), w.detach()[:, :, None, None], bias, transposed=transposed,
+                       owner=w if w.dtype == torch.float32 else None)
     return y.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
 
 

@@ -112,6 +112,8 @@ class ResBlock(nn.Module):
         avgpool(s + d) -- each the other's adjoint, so the R1 double backward stays on them); `H3D_DISC_GLUE=torch` keeps
         F.leaky_relu / F.interpolate / F.avg_pool2d."""
         fused = x.is_cuda and os.environ.get("H3D_DISC_GLUE", "hip") != "torch" and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+        if self.first and self.up_or_down >= 0:
+            fused = False       # the fused first-block glue IS the average pooling: a first block that does not go down keeps _resample
         d = x
         if not self.first:
             if self.up_or_down > 0 and fused and pool_up.supported(d):

@@ -15,10 +15,22 @@ from . import losses
 
 
 def _stepped_since_update(scaler, optimizer):
-    """True when `optimizer` was unscaled / stepped through `scaler` and scaler.update() has not run since (GradScaler keeps
-    that per optimizer; update() clears it)."""
-    st = getattr(scaler, "_per_optimizer_states", {}).get(id(optimizer))
-    return st is not None and getattr(st.get("stage"), "name", "READY") != "READY"
+    """True when `optimizer` was unscaled / stepped through `scaler` and scaler.update() has not run since.  GradScaler keeps
+    that per optimizer in ``_per_optimizer_states[id(optimizer)]["stage"]`` (READY / UNSCALED / STEPPED; update() resets it) --
+    private state, so its shape is CHECKED: if a torch release moves it, this raises instead of silently answering False (the
+    second D-alone step would then die inside unscale_ with a message about something else);
+    tests/test_scaler_state_cpu.py pins it."""
+    states = getattr(scaler, "_per_optimizer_states", None)
+    if states is None or not hasattr(states, "get"):
+        raise RuntimeError("GradScaler no longer exposes _per_optimizer_states: discriminator_step cannot tell whether the "
+                           "scale must be updated before this step; call scaler.update() yourself after every step")
+    st = states.get(id(optimizer))
+    if st is None:
+        return False
+    stage = st.get("stage") if hasattr(st, "get") else None
+    if stage is None or not hasattr(stage, "name"):
+        raise RuntimeError("GradScaler's per-optimizer state has no 'stage': see _stepped_since_update")
+    return stage.name != "READY"
 
 
 def discriminator_step(D, optimizer, real_images, fake_images, gt_segments, meta, do_r1=True, r1_mode="reference",

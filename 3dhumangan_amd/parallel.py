@@ -80,45 +80,74 @@ def r1_allgather(local_stat, group=None, equal=False):
     return torch.cat(parts, dim=0)
 
 
+DDP_BUCKET_BYTES = 25 << 20        # the reference's DDP default (bucket_cap_mb = 25: lib/trainers/base_trainer.py:102-104)
+
+
 class GradReducer:
     """Bucketed gradient all-reduce that runs WHILE backward is still running (what DDP's reducer does for the reference:
-    lib/trainers/base_trainer.py:102-104).  The parameters are cut into flat buckets of ~`bucket_bytes` in reverse registration
-    order (about the order in which backward produces their gradients); a post-accumulate hook on every parameter copies its
-    fresh gradient into the bucket and, once a bucket is complete, launches its all-reduce asynchronously -- RCCL works on its
-    own stream while autograd keeps computing the earlier layers' gradients.  Buckets are always launched in bucket order, on
-    every rank, whatever order the hooks fire in, so the collective sequence is the same everywhere.
+    lib/trainers/base_trainer.py:102-104).  The parameters are cut into flat buckets of ~`bucket_bytes` (25 MB, DDP's default: a
+    95-122 MB discriminator gives 4-5 buckets, the 39 MB generator 2, so the first all-reduce starts a quarter into backward);
+    a post-accumulate hook on every parameter marks it ready and, once a bucket is complete, packs the bucket with ONE
+    multi-tensor copy and launches its all-reduce asynchronously -- RCCL works on its own stream while autograd keeps computing
+    the earlier layers' gradients.  Buckets are always launched in bucket order, on every rank, whatever order the hooks fire
+    in, so the collective sequence is the same everywhere.
 
         reducer = GradReducer(D.parameters())          # once
         reducer.prepare(); loss.backward(); reducer.finish()      # every step
+
+    Bucket order: the first step uses reverse registration order (about the order in which backward produces gradients); at
+    the end of that step the buckets are REBUILT in the order in which the gradients actually arrived on rank 0 (broadcast, so
+    every rank cuts the same buckets; DDP does the same after its first iteration), with the parameters that produced no
+    gradient in a last bucket of their own -- a head the loss does not touch then no longer holds bucket 0 back until finish().
 
     ``finish`` launches what is left (a bucket with parameters that received no gradient on this rank travels with zeros in
     their place), waits, divides by the world size (``average``) and writes the reduced gradients back to ``p.grad``.  Which
     parameters have a gradient on ANY rank rides along in the bucket itself (one flag per parameter, summed): a parameter
     with no gradient anywhere keeps ``grad = None``, as under DDP; the flags are only read (a host synchronisation) on a rank
     that is missing a gradient -- never in the steady state where every rank produces every gradient.
-    World size 1 / no process group: prepare / finish do nothing."""
+    A gradient that arrives after its bucket was reduced (a second backward between prepare() and finish()) raises instead of
+    leaving a stale reduction behind.  World size 1 / no process group: prepare / finish do nothing."""
 
-    def __init__(self, parameters, average=True, group=None, bucket_bytes=64 << 20):
+    def __init__(self, parameters, average=True, group=None, bucket_bytes=DDP_BUCKET_BYTES, rebuild=True):
         self.params = [p for p in parameters if p.requires_grad]
         self.average, self.group, self.bucket_bytes = average, group, bucket_bytes
         self.active = dist.is_initialized() and dist.get_world_size(group) > 1 and bool(self.params)
-        self.buckets, self._armed, self._handles = [], False, []
+        self.buckets, self._armed, self._handles, self._hooks = [], False, [], []
+        self._rebuild_pending, self._arrival = bool(rebuild), []
         if not self.active:
             return
-        cur, size = [], 0
-        for p in reversed(self.params):
-            if cur and (p.dtype != cur[0].dtype or p.device != cur[0].device or size >= bucket_bytes):
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._cut(list(reversed(self.params)))
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def signature(self):
+        """What a cached reducer was built for: the identity of the parameters that require gradients."""
+        return tuple(id(p) for p in self.params)
+
+    def close(self):
+        """Remove the hooks (a reducer that is being replaced must not keep firing)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.active, self._armed = [], False, False
+
+    def _cut(self, ordered, tail=()):
+        """Buckets over `ordered` (then `tail`, never merged into a bucket of `ordered`)."""
+        self.buckets = []
+        for group_ in (ordered, list(tail)):
+            cur, size = [], 0
+            for p in group_:
+                if cur and (p.dtype != cur[0].dtype or p.device != cur[0].device or size >= self.bucket_bytes):
+                    self._close(cur)
+                    cur, size = [], 0
+                cur.append(p)
+                size += p.numel() * p.element_size()
+            if cur:
                 self._close(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += p.numel() * p.element_size()
-        if cur:
-            self._close(cur)
         self._slot = {}
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b["params"]):
                 self._slot[id(p)] = (bi, pi)
-                p.register_post_accumulate_grad_hook(self._hook)
 
     def _close(self, params):
         n = sum(p.numel() for p in params)
@@ -133,7 +162,7 @@ class GradReducer:
             return
         for b in self.buckets:
             b["ready"], b["launched"], b["have"] = 0, False, [False] * len(b["params"])
-        self._handles, self._next, self._armed = [], 0, True
+        self._handles, self._next, self._armed, self._arrival = [], 0, True, []
 
     def _hook(self, p):
         if not self._armed:
@@ -143,14 +172,18 @@ class GradReducer:
         if b["launched"]:
             raise RuntimeError("GradReducer: a gradient arrived after its bucket was reduced (two backward passes between "
                                "prepare() and finish()?)")
-        b["views"][pi].copy_(p.grad)
-        if not b["have"][pi]:
+        if not b["have"][pi]:                   # the gradient itself stays in p.grad until the bucket is packed (_launch)
             b["have"][pi] = True
             b["ready"] += 1
+            if self._rebuild_pending:
+                self._arrival.append(self._index[id(p)])
             self._launch_ready()
 
     def _launch(self, b):
-        if all(b["have"]):
+        have = [pi for pi, h in enumerate(b["have"]) if h]
+        if have:                                # ONE multi-tensor copy per bucket, not one launch per parameter
+            torch._foreach_copy_([b["views"][pi] for pi in have], [b["params"][pi].grad for pi in have])
+        if len(have) == len(b["have"]):
             b["flags"].fill_(1.0)
         else:
             for pi, h in enumerate(b["have"]):
@@ -175,7 +208,6 @@ class GradReducer:
         for b in self.buckets[self._next:]:
             for pi, p in enumerate(b["params"]):            # gradients produced outside the hooks' reach (set by hand)
                 if not b["have"][pi] and p.grad is not None:
-                    b["views"][pi].copy_(p.grad)
                     b["have"][pi] = True
             self._launch(b)
         self._next = len(self.buckets)
@@ -198,11 +230,27 @@ class GradReducer:
                     p.grad = b["views"][pi].clone()
             if dst:
                 torch._foreach_copy_(dst, src)
+        if self._rebuild_pending:
+            self._rebuild()
+
+    def _rebuild(self):
+        """Once, after the first step: buckets in rank 0's gradient-arrival order, the parameters without a gradient last."""
+        self._rebuild_pending = False
+        n = len(self.params)
+        seen = set(self._arrival)
+        order = self._arrival + [i for i in range(n) if i not in seen]
+        t = torch.tensor(order + [len(self._arrival)], dtype=torch.int64, device=self.params[0].device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        got = t.tolist()
+        order, n_arrived = got[:-1], got[-1]
+        if sorted(order) != list(range(n)):
+            raise RuntimeError("GradReducer: rank 0 broadcast an inconsistent bucket order")
+        self._cut([self.params[i] for i in order[:n_arrived]], [self.params[i] for i in order[n_arrived:]])
 
 
-def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=64 << 20):
+def allreduce_gradients(parameters, average=True, group=None, bucket_bytes=DDP_BUCKET_BYTES):
     """Sum (or average) the .grad of `parameters` over the ranks with a few large flat all-reduces (RCCL ring all-reduce is
-    per-link bound on xGMI: fewer, larger messages -- 64 MB buckets -- instead of one collective per tensor).
+    per-link bound on xGMI: fewer, larger messages -- 25 MB buckets, DDP's default -- instead of one collective per tensor).
 
     The set of tensors that travel is the same on every rank by construction: every ``requires_grad`` parameter that has a
     gradient on ANY rank (one small MAX all-reduce of the has-gradient flags first); a rank that lacks one of them
@@ -257,9 +305,15 @@ def max_over_ranks(seconds, device=None):
 
 
 def reducer_of(module, **kw):
-    """The module's GradReducer, created at first use (its hooks stay on the parameters: one reducer per module)."""
+    """The module's GradReducer, created at first use (its hooks stay on the parameters: one reducer per module).  Rebuilt --
+    the old one's hooks removed first -- when the process group appears / disappears or when the set of parameters that
+    require gradients changes (a frozen sub-network, a new training phase)."""
     red = getattr(module, "_h3d_grad_reducer", None)
-    if red is None or (dist.is_initialized() and dist.get_world_size(kw.get("group")) > 1) != red.active:
+    want_active = dist.is_initialized() and dist.get_world_size(kw.get("group")) > 1
+    sig = tuple(id(p) for p in module.parameters() if p.requires_grad)
+    if red is None or want_active != red.active or sig != red.signature():
+        if red is not None:
+            red.close()
         red = GradReducer(module.parameters(), **kw)
         object.__setattr__(module, "_h3d_grad_reducer", red)
     return red

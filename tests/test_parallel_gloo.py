@@ -429,3 +429,120 @@ def test_whole_adversarial_iteration_world2_matches_the_single_process_whole_bat
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GradReducer on its own (round 5): 25 MB-style bucketing, one multi-tensor copy per bucket, the arrival-order rebuild with
+# the never-used parameters last, hooks removed on replacement, and the documented error for a second backward.
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.manual_seed(3)
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.unused_head = torch.nn.Linear(8, 8)           # registered FIRST -> reversed order puts it in the LAST bucket
+                self.a = torch.nn.Linear(16, 32)
+                self.b = torch.nn.Linear(32, 32)
+                self.c = torch.nn.Linear(32, 4)
+                self.unused_tail = torch.nn.Linear(4, 4)           # registered LAST -> bucket 0 of the first step: never ready
+
+            def forward(self, x):
+                return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+        net = Net()
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        x_all = torch.randn(8, 16, generator=torch.Generator().manual_seed(5))
+        lo, hi = par.shard_bounds(8, rank, world)
+        red = par.GradReducer(net.parameters(), bucket_bytes=2048)          # tiny buckets: several of them
+        assert red.active and len(red.buckets) >= 3
+        first_cut = [[id(p) for p in b["params"]] for b in red.buckets]
+        assert id(net.unused_tail.bias) in first_cut[0]                     # the never-ready parameter leads the first step
+        launches = []
+        orig = red._launch
+        red._launch = lambda b: (launches.append(([id(x) for x in red.buckets].index(id(b)), red._armed)), orig(b))[1]
+
+        def step(model, xs, reducer=None):
+            model.zero_grad(set_to_none=True)
+            if reducer:
+                reducer.prepare()
+            (model(xs) ** 2).mean().backward()
+            if reducer:
+                reducer.finish()
+
+        step(ref, x_all)                                                    # whole batch, one process
+        step(net, x_all[lo:hi], red)                                        # this rank's shard
+        for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+            if "unused" in n:
+                assert p.grad is None, n                                    # no gradient on any rank: stays None, as under DDP
+            else:
+                assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
+        assert all(not armed for _, armed in launches), "first step: bucket 0 never completes, everything waits for finish()"
+        # rebuilt: arrival order, the unused parameters in a tail of their own
+        cut = [[id(p) for p in b["params"]] for b in red.buckets]
+        unused = {id(p) for n, p in net.named_parameters() if "unused" in n}
+        assert cut != first_cut and set(cut[-1]) <= unused and not (set(sum(cut[:-1], [])) & unused)
+        assert id(net.c.bias) in cut[0] or id(net.c.weight) in cut[0]       # the last layer's gradients arrive first
+        order = torch.tensor([red._index[i] for b in cut for i in b])
+        ranks = [torch.empty_like(order) for _ in range(world)]
+        dist.all_gather(ranks, order)
+        assert all(torch.equal(ranks[0], t) for t in ranks), "every rank cuts the same buckets"
+        # second step: buckets are reduced from inside backward now
+        launches.clear()
+        step(ref, x_all)
+        step(net, x_all[lo:hi], red)
+        assert sum(1 for _, armed in launches if armed) >= len(red.buckets) - 1, launches
+        for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+            if "unused" not in n:
+                assert torch.allclose(p.grad, r.grad, rtol=1e-5, atol=1e-7), n
+        # two backward passes between prepare() and finish(): the second one's gradients would miss the reduction -> error
+        net.zero_grad(set_to_none=True)
+        red.prepare()
+        (net(x_all[lo:hi]) ** 2).mean().backward()
+        try:
+            (net(x_all[lo:hi]) ** 2).mean().backward()
+            raise AssertionError("a gradient arriving after its bucket was reduced must raise")
+        except RuntimeError as e:
+            assert "after its bucket was reduced" in str(e)
+        red.finish()                                                        # the collectives already launched are matched on every rank
+        # reducer_of: cached per module, replaced (old hooks removed) when the requires_grad set changes
+        r1 = par.reducer_of(net, bucket_bytes=2048)
+        assert par.reducer_of(net) is r1
+        for p in net.a.parameters():
+            p.requires_grad_(False)
+        r2 = par.reducer_of(net, bucket_bytes=2048)
+        assert r2 is not r1 and not r1.active and not r1._hooks
+        assert all(id(p) not in r2._slot for p in net.a.parameters())
+        step(net, x_all[lo:hi], r2)
+        assert net.a.weight.grad is None and net.b.weight.grad is not None
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_grad_reducer_buckets_rebuild_and_double_backward_error_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in got:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_ddp_bucket_size_is_the_reference_default():
+    assert par.DDP_BUCKET_BYTES == 25 << 20
+    assert par.GradReducer.__init__.__defaults__[2] == par.DDP_BUCKET_BYTES
