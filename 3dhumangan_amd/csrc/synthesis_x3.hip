@@ -58,6 +58,7 @@ struct Args {
     float* state;          // [wave tiles][NT*4 + 1][64 lanes] float4: activations (+ rgb partial sums) between segments
     int load_state, store_state;
     int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
+    int n_walk, tile_first, tile_step;   // the tiles a launch covers: tile_first + i * tile_step, i < n_walk (all of them: 0, 1, n_tiles)
     int* ovf;              // x2: set to 1 when an activation leaves the range the f16 planes carry (nullable)
     const int* run_if;     // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 engine
 };
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     typedef typename std::conditional<X2, F16, BF16>::type T;
     typedef typename T::vec8 frag8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int HdP = A.HdP, C = A.C;
+    const int HdP = A.HdP;
     float* tab0 = smem;                                      // [table_floats] static tables (descriptor offsets)
     float* ab0 = tab0 + ((A.table_floats + 3) & ~3);         // [n_ab][2][HdP] this sample's constant-style affines
     float* cst0 = ab0 + A.n_ab * 2 * HdP;                    // [n_cst][128]   this sample's shared-MLP constants
@@ -313,13 +314,15 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     // kernel arguments used late in the kernel, pinned in scalar registers now (the compiler would otherwise re-load them from the
     // kernarg segment where they are used -- see above)
     int first_skip = A.first_skip, n_pixel_blocks = A.n_pixel_blocks, n_tiles = A.n_tiles;
+    // the tiles of this workgroup: tile_first + (blockIdx.x + i * gridDim.x) * tile_step < n_tiles, as ONE running index
+    int tile_stride = (int)gridDim.x * A.tile_step;
     float* rgb_out = A.rgb;
-    asm volatile("" : "+s"(first_skip), "+s"(n_pixel_blocks), "+s"(rgb_out), "+s"(n_tiles));
+    asm volatile("" : "+s"(first_skip), "+s"(n_pixel_blocks), "+s"(rgb_out), "+s"(n_tiles), "+s"(tile_stride));
     // Persistent workgroups: a workgroup walks the 128-pixel tiles blockIdx.x, blockIdx.x + gridDim.x, .. of its sample with the
     // tables above staged once and the weight ring running across tile boundaries (the stream wraps exactly at the end of the
     // network, so the first stages of the next tile are prefetched under the last layers of this one).
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = A.tile_first + (int)blockIdx.x * A.tile_step; tile < n_tiles; tile += tile_stride) {
     const int64_t p_tile = ((int64_t)tile * 4 + wave) * 32;
     int64_t p = p_tile + m;
     const bool okp = p < HW;
@@ -642,6 +645,10 @@ template <int NT, int DEPTH, bool SEG, bool X2>
 int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
     H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2>));
     A.n_tiles = (int)groups;
+    if (A.tile_step <= 0) { A.tile_first = 0; A.tile_step = 1; }
+    A.n_walk = A.tile_first < A.n_tiles ? (A.n_tiles - A.tile_first + A.tile_step - 1) / A.tile_step : 0;
+    if (A.n_walk == 0) return H3D_OK;
+    groups = A.n_walk;
     // persistent workgroups (one per CU at a time: registers and LDS): about four per CU in total, so that the tables are staged
     // once per ~n_tiles * B / (4 CUs) tiles while the tail of the launch stays short; segmented runs keep one tile per workgroup
     static int cus = 0;
@@ -676,7 +683,7 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
                        const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                        const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                        float* state, int load_state, int store_state, h3d_stream_t stream_, int* ovf = nullptr,
-                       const int* run_if = nullptr) {
+                       const int* run_if = nullptr, int tile_first = 0, int tile_step = 1) {
     H3D_REQUIRE(stream && tables && desc && rgb, "h3d_synthesis_x3: null pointer");
     H3D_REQUIRE(h3d::aligned16(stream) && h3d::aligned16(tables), "h3d_synthesis_x3: stream/tables must be 16-byte aligned");
     H3D_REQUIRE(desc->n_blocks >= 1 && desc->n_blocks <= H3D_MAX_BLOCKS, "h3d_synthesis_x3: n_blocks=%d", desc->n_blocks);
@@ -743,6 +750,8 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     Args A{};
     A.state = state; A.load_state = load_state; A.store_state = store_state;
     A.ovf = ovf; A.run_if = run_if;
+    H3D_REQUIRE(tile_first >= 0 && tile_step >= 1, "h3d_synthesis_x3: tile subset (%d, %d)", tile_first, tile_step);
+    A.tile_first = tile_first; A.tile_step = tile_step;
     A.stream = static_cast<const unsigned char*>(stream);
     A.tables = tables; A.D = *desc; A.G = G; A.cst = cst; A.ab = ab; A.rgb = rgb;
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
@@ -805,6 +814,77 @@ extern "C" int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, con
     return synthesis_x(false, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
                        nullptr, 0, 0, stream_, nullptr, run_if);
 }
+/* Sampled error monitor of the x2 engine (round 5).  h3d_synthesis_x3_tiles is h3d_synthesis_x3 restricted to the 128-pixel
+ * tiles tile_first, tile_first + tile_step, .. of every sample: it writes those pixels of `rgb` (a scratch image of the full
+ * shape) and nothing else.  h3d_synthesis_check compares an image with such a scratch image on exactly those tiles. */
+extern "C" int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                                      int tile_first, int tile_step, h3d_stream_t stream_) {
+    return synthesis_x(false, stream, total_stages, tables, table_floats, desc, G, g_channels, Hr, Wr, cst, n_cst, ab, n_ab, rgb, B, H, W,
+                       nullptr, 0, 0, stream_, nullptr, nullptr, tile_first, tile_step);
+}
+
+namespace {
+// one workgroup per sample: per-channel max |ref| and max |img - ref| over the sampled tiles -> err = max_c (diff_c / ref_c)
+__global__ __launch_bounds__(256) void synthesis_check_kernel(const float* __restrict__ img, const float* __restrict__ ref, int64_t HW,
+                                                              int n_tiles, int tile_first, int tile_step, float tol, int* flag,
+                                                              float* err_out) {
+    __shared__ float red[2][3][4];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float mr[3] = {0.f, 0.f, 0.f}, md[3] = {0.f, 0.f, 0.f};
+    bool bad = false;
+    for (int tile = tile_first; tile < n_tiles; tile += tile_step) {
+        for (int i = t; i < 128; i += 256) {
+            const int64_t p = (int64_t)tile * 128 + i;
+            if (p >= HW) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r = ref[((int64_t)b * 3 + c) * HW + p], v = img[((int64_t)b * 3 + c) * HW + p];
+                const float d = fabsf(v - r);
+                bad = bad || !(d <= 3.0e38f) || !(fabsf(r) <= 3.0e38f);       // NaN / inf anywhere in the sample
+                mr[c] = fmaxf(mr[c], fabsf(r));
+                md[c] = fmaxf(md[c], d);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mr[c] = fmaxf(mr[c], __shfl_xor(mr[c], o, 64));
+            md[c] = fmaxf(md[c], __shfl_xor(md[c], o, 64));
+        }
+        if (lane == 0) { red[0][c][wave] = mr[c]; red[1][c][wave] = md[c]; }
+    }
+    const bool any_bad = __syncthreads_or(bad);
+    if (t == 0) {
+        float err = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float r = fmaxf(fmaxf(red[0][c][0], red[0][c][1]), fmaxf(red[0][c][2], red[0][c][3]));
+            const float d = fmaxf(fmaxf(red[1][c][0], red[1][c][1]), fmaxf(red[1][c][2], red[1][c][3]));
+            err = fmaxf(err, d / fmaxf(r, 1e-30f));
+        }
+        if (any_bad) err = __builtin_inff();
+        if (err_out) err_out[b] = err;
+        if (!(err <= tol)) atomicOr(flag, 1);
+    }
+}
+}  // namespace
+
+extern "C" int h3d_synthesis_check(const float* rgb, const float* rgb_ref, int B, int H, int W, int tile_first, int tile_step,
+                                   float tol, int* flag, float* err_out, h3d_stream_t stream_) {
+    H3D_REQUIRE(rgb && rgb_ref && flag, "h3d_synthesis_check: null pointer");
+    H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && tile_first >= 0 && tile_step >= 1 && tol >= 0.f, "h3d_synthesis_check: bad arguments");
+    if (B == 0) return H3D_OK;
+    const int64_t HW = (int64_t)H * W;
+    const int n_tiles = (int)((HW + 127) / 128);
+    h3d::pre_launch();
+    hipLaunchKernelGGL(synthesis_check_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream_), rgb, rgb_ref, HW,
+                       n_tiles, tile_first, tile_step, tol, flag, err_out);
+    return h3d::launch_status("h3d_synthesis_check");
+}
+
 /* HOST helper: LDS bytes of the x3 (x2 = 0) / x2 (x2 = 1) kernel at its minimum ring depth for a network of width C with
  * `table_floats` static table floats, n_ab constant-style and n_cst per-pixel SPADEs -- the planner's fit test (<= 160 KiB). */
 extern "C" int64_t h3d_synthesis_x3_lds_bytes(int table_floats, int n_ab, int n_cst, int C, int x2) {

@@ -196,7 +196,9 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         }
     };
     auto mfmas = [&](const AF& a, const BF& b) __attribute__((always_inline)) {      // short (GUARD) phases: never x2
-        static_for<0, P * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, IC<0>{}, a, b, a, b); });
+        // (a non-generic lambda's body is instantiated with the enclosing template even where `if constexpr (GUARD)` never calls
+        // it: without this guard the x2 instantiations indexed acc[] with j up to P * NU - 1 -- dead code, but out-of-bounds code)
+        if constexpr (!X2) static_for<0, P * NU>([&](auto jc) __attribute__((always_inline)) { mfma1(jc, IC<0>{}, a, b, a, b); });
     };
     // One k-step with its memory traffic in the shadow of the matrix pipe (one wave per SIMD: whatever is issued between
     // two MFMAs is free, whatever is issued before the first one leaves the pipe idle): after MFMA j comes weight load j

@@ -161,6 +161,15 @@ class SynthesisPlan:
                    else ("f16x2t" if self.x2_weights_in_range() else "bf16x3t") if self.x3t_supported() else "f32")
         self._x2_flag = None          # int32 [1] on the device: the x2 engine's range flag of the LAST run (see run())
         self.x2_guard = os.environ.get("H3D_SYNTH_GUARD", "1") != "0"
+        # Sampled error monitor of the x2 register engine (round 5): every forward re-evaluates ~16 of its 128-pixel tiles per
+        # image on the fp32-class engine and raises the same device flag as the range guard when a sampled pixel differs by more
+        # than `x2_monitor_tol` of the sample's channel maximum -- the bf16 engine behind it then redoes the batch.  The x2
+        # arithmetic uses up most of the 1e-3 parity budget (up to 9.5e-4 over 64 images, profiles/r5_x2_fullimage_error.txt):
+        # a pose / checkpoint that pushes it over is caught here instead of shipping.  H3D_SYNTH_MONITOR=0 switches it off.
+        self.x2_monitor = os.environ.get("H3D_SYNTH_MONITOR", "1") != "0"
+        self.x2_monitor_tol = float(os.environ.get("H3D_SYNTH_MONITOR_TOL", "1e-3"))
+        self.x2_monitor_tiles = 16
+        self._x2_monitor_buf = None   # (scratch image [B,3,H,W], per-item sampled error [B]) of the last run
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
@@ -575,6 +584,17 @@ class SynthesisPlan:
                                          len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
                                          _lib.ptr(self._x2_flag), _lib.stream_handle())
                     rc = lib.h3d_synthesis_x2_guarded(*common(seg))
+                    if not rc and self.x2_monitor:
+                        what = "h3d_synthesis_x3_tiles / h3d_synthesis_check"
+                        first, step = self.monitor_tiles(H, W)
+                        buf = self._x2_monitor_buf
+                        if buf is None or buf[0].shape != rgb.shape or buf[0].device != rgb.device:
+                            buf = (torch.empty_like(rgb), torch.zeros(B, device=rgb.device, dtype=torch.float32))
+                            self._x2_monitor_buf = buf
+                        rc = lib.h3d_synthesis_x3_tiles(*common(alt)[:13], _lib.ptr(buf[0]), B, H, W, first, step, _lib.stream_handle())
+                        rc = rc or lib.h3d_synthesis_check(_lib.ptr(rgb), _lib.ptr(buf[0]), B, H, W, first, step,
+                                                           self.x2_monitor_tol, _lib.ptr(self._x2_flag), _lib.ptr(buf[1]),
+                                                           _lib.stream_handle())
                     if not rc:
                         what = "h3d_synthesis_x3_if"
                         rc = lib.h3d_synthesis_x3_if(*common(alt))
@@ -591,6 +611,17 @@ class SynthesisPlan:
                 rc = self._launch(G, cst, ab, rgb, B, Hr, Wr, H, W)
         _lib.check(rc, what)
         return rgb
+
+    def monitor_tiles(self, H, W):
+        """(first, step) of the 128-pixel tiles the x2 monitor samples: ~x2_monitor_tiles of them, an odd step so that the
+        samples walk through the columns of the image as well as down its rows."""
+        n_tiles = (H * W + 127) // 128
+        step = max(1, n_tiles // max(1, self.x2_monitor_tiles)) | 1
+        return min(step // 2, n_tiles - 1), step
+
+    def x2_monitor_errors(self):
+        """Per-item sampled error of the LAST guarded x2 run (device tensor [B]; reading it synchronises), or None."""
+        return None if self._x2_monitor_buf is None else self._x2_monitor_buf[1]
 
     def x2_fell_back(self):
         """True when the last run() of the guarded x2 engine left its f16 range and the image came from the bf16 engine

@@ -487,6 +487,10 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
                 batch_items=list(items), pixels=int(len(pix)), rays=int(rays), per_item_max_rel_err=[round(e, 7) for e in per_item],
                 rays_excluded_as_ill_conditioned_in_the_oracle=excluded, max_excluded=max_excluded, rays_checked=n_rays,
                 synthesis_engine=plan.engine, x2_range_guard_fell_back=bool(plan.x2_fell_back()) if plan.engine in ("f16x2", "f16x2t") else None,
+                x2_monitor=(dict(tolerance=plan.x2_monitor_tol, max_sampled_err=float(plan.x2_monitor_errors().max()),
+                                 tiles_per_image=len(range(*((lambda fs: (fs[0], (cfg["gen_height"] * cfg["gen_width"] + 127) // 128, fs[1]))
+                                                              (plan.monitor_tiles(cfg["gen_height"], cfg["gen_width"]))))))
+                            if plan.engine == "f16x2" and plan.x2_monitor and plan.x2_monitor_errors() is not None else None),
                 against="CPU oracle on a pixel/ray subset (per-channel max-norm); oracle pinned to the reference's vectors")
 
 
@@ -507,11 +511,13 @@ def discontinuity_rays(dr):
 
 
 def op_rooflines():
-    """HBM rooflines of the stand-alone HBM-bound ops: algorithmic bytes (inputs + outputs once) / time."""
+    """HBM rooflines of the stand-alone HBM-bound ops: algorithmic bytes (inputs + outputs once) / time.  The kernels
+    are called straight through the C ABI on PREALLOCATED outputs (as ray_integrate_roofline does): the HIP events bracket kernel
+    launches only, no allocation, no Python wrapper."""
+    import ctypes
     L = importlib.import_module("3dhumangan_amd._lib")
-    ba = importlib.import_module("3dhumangan_amd.lib.components.ops.bias_act")
     uf = importlib.import_module("3dhumangan_amd.lib.components.ops.upfirdn2d")
-    rs = importlib.import_module("3dhumangan_amd.lib.components.resample")
+    lib, st = L.load(), L.stream_handle()
 
     def timeit(fn, iters=10):
         for _ in range(2):
@@ -527,7 +533,7 @@ def op_rooflines():
 
     def entry(by, ms, shape):
         return dict(bound="hbm", achieved=by / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / ms / 1e6 / HBM_PEAK_GBS,
-                    ms=ms, bytes=by, shape=shape, note="time includes the wrapper's output allocation")
+                    ms=ms, bytes=by, shape=shape, note="C ABI on preallocated outputs: kernel time only")
 
     out = {}
     x = torch.empty(8, 64, 512, 512, device="cuda")
@@ -537,20 +543,41 @@ def op_rooflines():
                                            note="a plain fill of a 537 MB tensor: what a write-only stream reaches on this box (context for "
                                                 "the write-dominated resampling kernels below; the 8 TB/s peak is read + write)")
     del x
+    # P1 bias_act: lrelu (activation index 3, alpha 0.2, gain sqrt 2, no clamp), bias along dim 1 of [8,256,512,256] f32
     x = torch.randn(8, 256, 512, 256, device="cuda")
-    b = torch.randn(256, device="cuda")
-    out["h3d_bias_act"] = entry(2.0 * x.numel() * 4, timeit(lambda: ba.bias_act(x, b, act="lrelu")), "lrelu [8,256,512,256] f32")
-    del x
-    x = torch.randn(8, 64, 256, 256, device="cuda")
-    f = uf.setup_filter([1, 3, 3, 1], device="cuda", separable=False)          # 4x4 taps: one pass
-    y = uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)
-    out["h3d_upfirdn2d"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)),
-                                 "2x up, 4x4 [1,3,3,1] filter, [8,64,256,256] -> [8,64,512,512] f32")
+    bvec = torch.randn(256, device="cuda")
+    y = torch.empty_like(x)
+
+    def run_bias_act():
+        L.check(lib.h3d_bias_act(L.ptr(x), L.ptr(bvec), L.ptr(y), x.numel(), 0, 256, x.stride(1), 3, 0.2, 2.0 ** 0.5, -1.0, st),
+                "h3d_bias_act")
+
+    out["h3d_bias_act"] = entry(2.0 * x.numel() * 4, timeit(run_bias_act), "lrelu [8,256,512,256] f32")
     del x, y
+    # P2 upfirdn2d: 2x up with the 4x4 [1,3,3,1] filter (one pass), padding (2,1,2,1), gain 4
+    x = torch.randn(8, 64, 256, 256, device="cuda")
+    f = uf.setup_filter([1, 3, 3, 1], device="cuda", separable=False).contiguous()
+    y = torch.empty(8, 64, 512, 512, device="cuda")
+    xs, ys = (ctypes.c_int64 * 4)(*x.stride()), (ctypes.c_int64 * 4)(*y.stride())
+
+    def run_upfirdn():
+        L.check(lib.h3d_upfirdn2d(L.ptr(x), L.ptr(f), L.ptr(y), 0, 8, 64, 256, 256, xs, 4, 4, 512, 512, ys, 2, 2, 1, 1, 2, 2, 0, 4.0, st),
+                "h3d_upfirdn2d")
+
+    out["h3d_upfirdn2d"] = entry((x.numel() + y.numel()) * 4.0, timeit(run_upfirdn),
+                                 "2x up, 4x4 [1,3,3,1] filter, [8,64,256,256] -> [8,64,512,512] f32")
+    ref = uf.upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4)                  # the wrapper's result: same launch parameters
+    out["h3d_upfirdn2d"]["matches_wrapper"] = bool(torch.equal(ref, y))
+    del x, y, ref
+    # A7 bilinear resize [4,256,96,96] -> [4,256,512,512]
     x = torch.randn(4, 256, 96, 96, device="cuda")
-    y = rs.bilinear_resize(x, (512, 512))
-    out["h3d_bilinear_resize"] = entry((x.numel() + y.numel()) * 4.0, timeit(lambda: rs.bilinear_resize(x, (512, 512))),
-                                       "[4,256,96,96] -> [4,256,512,512] f32")
+    y = torch.empty(4, 256, 512, 512, device="cuda")
+
+    def run_bilinear():
+        L.check(lib.h3d_bilinear_resize(L.ptr(x), L.ptr(y), 4, 256, 96, 96, 512, 512, st), "h3d_bilinear_resize")
+
+    out["h3d_bilinear_resize"] = entry((x.numel() + y.numel()) * 4.0, timeit(run_bilinear), "[4,256,96,96] -> [4,256,512,512] f32")
+    del x, y
     out["conv_x3_by_shape"] = conv_rooflines(timeit)
     return out
 
@@ -653,7 +680,9 @@ def compact_line(out):
                          "sample": cpu["sample"][:200]} if cpu else None,
         "checked": {"max_rel_err": _r(chk["max_rel_err"], 7), "max_rel_err_render": _r(chk["max_rel_err_render"], 7),
                     "ok": chk["ok"], "tolerance": chk["tolerance"], "items": len(chk["batch_items"]),
-                    "rays_excluded": chk["rays_excluded_as_ill_conditioned_in_the_oracle"]} if chk else None,
+                    "rays_excluded": chk["rays_excluded_as_ill_conditioned_in_the_oracle"],
+                    "x2_monitor_err": _r((chk.get("x2_monitor") or {}).get("max_sampled_err"), 7),
+                    "x2_fell_back": chk.get("x2_range_guard_fell_back")} if chk else None,
         "stage_ms": {k: _r(v, 3) for k, v in list((out.get("stage_ms") or {}).items())[:8]},
         "extra": {k: v for k, v in extra.items() if v is not None},
         "detail": "bench_detail.json",

@@ -433,6 +433,25 @@ int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* t
                         const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                         const int* run_if, h3d_stream_t stream_handle);
 
+/* Sampled error monitor of the x2 engine (round 5; replaces nothing in the reference -- its fp32 convolutions,
+ * lib/components/map3d_layers.py:176-238, have no reduced-precision tier to watch).  The x2 arithmetic sits inside the 1e-3
+ * parity budget with little room (measured over 64 images: up to 9.5e-4 of the channel maximum), so every forward checks a
+ * sample of its own output against the fp32-class engine:
+ *   h3d_synthesis_x3_tiles  h3d_synthesis_x3 (single launch, `stream` in the x3 format) restricted to the 128-pixel tiles
+ *                           tile_first, tile_first + tile_step, .. of every sample; writes those pixels of `rgb` (a scratch
+ *                           image of the full [B,3,H,W] shape) and nothing else;
+ *   h3d_synthesis_check     per sample, over exactly those tiles: err = max over channels of max|rgb - rgb_ref| / max|rgb_ref|
+ *                           (written to err_out[b] when err_out != NULL); ORs 1 into *flag (int32, device memory) when
+ *                           err > tol or anything in the sample is not finite.
+ * Launched behind h3d_synthesis_x2_guarded and in front of h3d_synthesis_x3_if with the same flag this is "x2, redone on x3
+ * when a sampled pixel leaves the budget", without a host synchronisation (SynthesisPlan.run).  tile_step >= 1. */
+int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, const float* tables, int table_floats,
+                           const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
+                           const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
+                           int tile_first, int tile_step, h3d_stream_t stream_handle);
+int h3d_synthesis_check(const float* rgb, const float* rgb_ref, int B, int H, int W, int tile_first, int tile_step,
+                        float tol, int* flag, float* err_out, h3d_stream_t stream_handle);
+
 /* Same network, split-bf16 arithmetic as h3d_synthesis_x3, for widths up to 448 ("x3t": the activations of a 64-pixel
  * tile live in LDS as ready-made MFMA fragments, the channels are split over the four waves; csrc/x3t_common.hpp).
  * tiles = h3d_synthesis_x3t_tiles(C) (even, >= 4; -1 when C > 448), HdP = 32*tiles.

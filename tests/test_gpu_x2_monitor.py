@@ -1,0 +1,106 @@
+"""The x2 synthesis engine's sampled error monitor (round 5): every guarded x2 forward re-evaluates ~16 of its 128-pixel tiles per
+image on the bf16 x3 engine (h3d_synthesis_x3_tiles), compares (h3d_synthesis_check) and raises the range guard's device flag when
+a sampled pixel leaves the tolerance -- the x3 engine behind it then redoes the batch.  The x2 arithmetic sits inside the 1e-3
+parity budget with little room; the monitor is what keeps a pose / checkpoint that pushes it over from shipping.  Reference
+semantics: lib/components/map3d_layers.py:176-238 (fp32 convolutions, nothing to monitor)."""
+import ctypes
+import importlib
+
+import pytest
+import torch
+
+from conftest import rel_err
+from test_gpu_x2_guard import make, oracle_rgb, run
+
+pytestmark = pytest.mark.gpu
+_lib = importlib.import_module("3dhumangan_amd._lib")
+DEV = "cuda"
+
+
+def test_monitor_is_quiet_on_the_default_arithmetic_and_reports_the_sampled_error():
+    G, meta, sd = make(256, 128, 128, 24, 24, seed=1)
+    plan = G.synthesis_plan(DEV)
+    assert plan.engine == "f16x2" and plan.x2_guard and plan.x2_monitor and plan.x2_monitor_tol == 1e-3
+    B = 3
+    fmap, style = torch.randn(B, 576, 256), torch.randn(B, 256)
+    out = run(G, meta, fmap, style)
+    assert not plan.x2_fell_back()
+    err = plan.x2_monitor_errors().cpu()
+    assert err.shape == (B,) and float(err.max()) < 1e-3 and float(err.min()) > 1e-6      # a real, non-trivial measurement
+    # the same numbers from the two full images
+    plan.engine = "bf16x3"
+    ref = run(G, meta, fmap, style)
+    plan.engine = "f16x2"
+    first, step = plan.monitor_tiles(128, 128)
+    tiles = torch.arange(first, 128 * 128 // 128, step)
+    assert 12 <= len(tiles) <= 20 and step % 2 == 1
+    px = (tiles[:, None] * 128 + torch.arange(128)[None, :]).flatten().to(DEV)
+    a, b = out.flatten(2)[:, :, px], ref.flatten(2)[:, :, px]
+    want = ((a - b).abs().amax(2) / b.abs().amax(2)).amax(1).cpu()
+    assert torch.allclose(err, want, rtol=1e-5, atol=0)
+    # switching the monitor off changes nothing in the image
+    plan.x2_monitor = False
+    assert torch.equal(run(G, meta, fmap, style), out)
+
+
+def test_a_sampled_pixel_outside_the_tolerance_redoes_the_batch_on_x3():
+    G, meta, sd = make(256, 128, 128, 24, 24, seed=2)
+    plan = G.synthesis_plan(DEV)
+    fmap, style = torch.randn(2, 576, 256), torch.randn(2, 256)
+    x2 = run(G, meta, fmap, style)
+    assert not plan.x2_fell_back()
+    plan.engine = "bf16x3"
+    x3 = run(G, meta, fmap, style)
+    plan.engine = "f16x2"
+    assert not torch.equal(x2, x3)
+    plan.x2_monitor_tol = 1e-7                    # tighter than the x2 arithmetic can be: every forward must fall back
+    out = run(G, meta, fmap, style)
+    assert plan.x2_fell_back()
+    assert torch.equal(out, x3)                   # the image IS the x3 engine's
+    assert rel_err(out.cpu(), oracle_rgb(sd, meta, fmap, style)) < 1e-4
+
+
+def test_tile_subset_launch_writes_the_sampled_tiles_only():
+    G, meta, sd = make(128, 64, 128, 12, 24, seed=3)
+    plan = G.synthesis_plan(DEV)
+    B, H, W, Hr, Wr = 2, 64, 128, 12, 24
+    fmap, style = torch.randn(B, Hr * Wr, 128).to(DEV), torch.randn(B, 128).to(DEV)
+    plan.engine = "bf16x3"
+    full = plan.run(fmap, style, (Hr, Wr), (H, W))
+    seg = plan.build_x3(False)["segments"][0]
+    Gt, cst, ab = plan.x3_forward_tables(fmap.float(), style.float(), False)
+    scratch = torch.full_like(full, -7.0)
+    first, step = 3, 5
+    rc = _lib.load().h3d_synthesis_x3_tiles(_lib.ptr(seg["stream"]), seg["stages"], _lib.ptr(seg["tables"]), seg["tables"].numel(),
+                                            ctypes.byref(seg["desc"]), _lib.ptr(Gt), plan.g_channels, Hr, Wr, _lib.ptr(cst),
+                                            len(plan.pixel_ids), _lib.ptr(ab), len(plan.const_ids), _lib.ptr(scratch), B, H, W,
+                                            first, step, _lib.stream_handle())
+    _lib.check(rc, "h3d_synthesis_x3_tiles")
+    n_tiles = H * W // 128
+    sampled = torch.zeros(n_tiles, dtype=torch.bool)
+    sampled[first::step] = True
+    mask = sampled[:, None].expand(n_tiles, 128).reshape(H * W).to(DEV)
+    s, f = scratch.flatten(2), full.flatten(2)
+    assert torch.equal(s[:, :, mask], f[:, :, mask])                     # same kernel, same arithmetic: bit-identical pixels
+    assert bool((s[:, :, ~mask] == -7.0).all())                          # nothing else touched
+    # the check kernel: identical images -> 0, no flag; one perturbed sampled pixel -> that error, flag; non-finite -> flag
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    err = torch.zeros(B, device=DEV)
+    chk = lambda img, tol: _lib.check(_lib.load().h3d_synthesis_check(_lib.ptr(img), _lib.ptr(scratch), B, H, W, first, step, tol,
+                                                                      _lib.ptr(flag), _lib.ptr(err), _lib.stream_handle()), "check")
+    chk(full, 1e-3)
+    assert int(flag.item()) == 0 and float(err.max()) == 0.0
+    bad = full.clone()
+    p = first * 128 + 17
+    bad.flatten(2)[1, 2, p] += 0.5
+    chk(bad, 1e-3)
+    want = 0.5 / float(f[1, 2][mask].abs().max())
+    assert int(flag.item()) == 1 and abs(float(err[1]) - want) < 1e-5 * want and float(err[0]) == 0.0
+    flag.zero_()
+    bad.flatten(2)[1, 2, p + 128] += 0.5                                 # a pixel OUTSIDE the sample: not seen (that is what sampling means)
+    bad.flatten(2)[1, 2, p] = full.flatten(2)[1, 2, p]
+    chk(bad, 1e-3)
+    assert int(flag.item()) == 0
+    bad.flatten(2)[0, 0, p] = float("nan")
+    chk(bad, 1e-3)
+    assert int(flag.item()) == 1 and not torch.isfinite(err[0])

@@ -1,0 +1,37 @@
+"""GPU: full-image error of the default (x2) engines against the x3 engines (fp32-class, ~1e-5) on bench.py's workload, every
+pixel of every item -- bench.py's `checked` and the parity tests look at pixel subsets against the CPU oracle; this looks at all
+262 144 pixels per item, with the x3 engines standing in for the oracle.  Per item: per-channel max |d| / max |ref|, and the
+fraction of pixels above 5e-4 / 1e-3 of the channel maximum.  usage: python tools/x2_fullimage_error.py [seeds=1234,1,2,3]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+seeds = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1234,1,2,3").split(",")]
+dev = torch.device("cuda", 0)
+G, cfg = bench.build_generator("MAP3DBN512", (512, 512), (96, 96), 64, dev)
+rows, worst = [], 0.0
+for seed in seeds:
+    z, cond, jitter = bench.make_inputs(cfg, 16, dev, seed=seed)
+    outs = {}
+    for name, (f, s) in (("x2", ("f16x2", "f16x2")), ("x3", ("f16x3", "bf16x3")), ("x2field_x3synth", ("f16x2", "bf16x3"))):
+        G.neural_field.precision = f
+        G.synthesis_plan(dev).engine = s
+        outs[name] = G.forward(z, cond, jitter=jitter, **cfg)["rgbs"].double()
+    ref = outs["x3"]
+    den = ref.abs().amax(dim=(2, 3), keepdim=True)
+    for name in ("x2", "x2field_x3synth"):
+        d = (outs[name] - ref).abs() / den                              # [16, 3, H, W]
+        per_item = d.amax(dim=(1, 2, 3))
+        rows.append(dict(seed=seed, engines=name, max=float(per_item.max()), per_item=[round(float(v), 6) for v in per_item],
+                         frac_above_5e4=float((d.amax(1) > 5e-4).double().mean()), frac_above_1e3=float((d.amax(1) > 1e-3).double().mean()),
+                         rms=float((d ** 2).mean().sqrt())))
+        if name == "x2":
+            worst = max(worst, float(per_item.max()))
+        print(json.dumps(rows[-1]), flush=True)
+print(json.dumps(dict(worst_x2_full_image=worst, seeds=seeds, items_per_seed=16)))
