@@ -55,6 +55,8 @@ _SIGNATURES = {
     "h3d_conv_x3_pack_f16": (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
     "h3d_conv_x3": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_x3_f16": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_pack_f16x1": (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_f16x1": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_f16": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_conv_wgrad_x3_bias": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_x3_bias_f16": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),

@@ -67,8 +67,13 @@ __device__ __forceinline__ void split_chunk(const float4 (&raw)[2 * KSC], BF16::
     }
 }
 
-template <int NT, int KSC, bool HALF = false>
+// MODE 0: fp32 activations, split-bf16 x3.  MODE 1: f16 activations, weights as f16 hi + lo (two products per weight).  MODE 2: f16
+// activations, weights rounded to f16 ONCE -- the reference's autocast semantics (lib/trainers/base_trainer.py:50-51: autocast
+// rounds the weight to 11 bits) -- one product per weight, a ring stage carries two k-steps (gemm_x3_roll PAIRK), half the stream.
+template <int NT, int KSC, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
+    constexpr bool HALF = MODE != 0, ONE = MODE == 2;
+    constexpr int KST = ONE ? KSC / 2 : KSC;          // ring stages per chunk
     typedef typename std::conditional<HALF, _Float16, float>::type TX;
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_lds[];
     constexpr int L = NT >= 4 ? 2 : 1;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
         const TX* src = source(1, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
-    gemm_x3_roll<TE, NT, KSC, KSC, false, L, 0, true, !HALF>(acc, xh, xl, ring);
+    gemm_x3_roll<TE, NT, KST, KSC, false, L, 0, true, !HALF, ONE>(acc, xh, xl, ring);
 #pragma unroll 1
     for (int it = 1; it < n_iter; ++it) {
         pin_agpr<NT>(acc);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
             const TX* src = source(it + 1, valid);
             load_chunk<KSC>(raw, src, valid, h);
         }
-        gemm_x3_roll<TE, NT, KSC, KSC, false, L, 0, false, !HALF>(acc, xh, xl, ring);
+        gemm_x3_roll<TE, NT, KST, KSC, false, L, 0, false, !HALF, ONE>(acc, xh, xl, ring);
     }
     ring.drain();
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
@@ -168,7 +173,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __
     const int i = (int)((idx / kk) % Cin), o = (int)(idx / ((int64_t)kk * Cin));
     const float v = transposed ? w[((int64_t)i * Cout + o) * kk + (kk - 1 - tap)] : w[((int64_t)o * Cin + i) * kk + tap];
     unsigned short hb, lb;
-    if (f16) {              // the AMP tier's stream: f16 hi + f16 lo (the weight to max(2^-22 |W|, 2^-25)) for the F16 matrix instruction
+    if (f16) {              // the AMP tier's streams: f16 hi + f16 lo (the weight to max(2^-22 |W|, 2^-25)) for the F16 matrix instruction
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         hb = __builtin_bit_cast(unsigned short, hi); lb = __builtin_bit_cast(unsigned short, lo);
@@ -179,18 +184,23 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __
     }
     const int ob = o / (32 * NT), nt = (o / 32) % NT, j = o & 31;
     const int chunk = i / (16 * KSC), ks = (i / 16) % KSC, h = (i >> 3) & 1, e = i & 7;
+    if (f16 == 2) {         // one plane: [ob][tap][chunk][ks / 2][nt][ks % 2][64 lanes][8] -- a stage holds two k-steps
+        const int64_t base = (((((int64_t)ob * kk + tap) * n_chunks + chunk) * (KSC / 2) + ks / 2) * NT + nt) * 2 + (ks & 1);
+        stream[(base * 64 + 32 * h + j) * 8 + e] = hb;
+        return;
+    }
     // [ob][tap][chunk][ks][nt][hi|lo][64 lanes = 32 h + j][8]
     const int64_t base = (((((int64_t)ob * kk + tap) * n_chunks + chunk) * KSC + ks) * NT + nt) * 2;
     stream[(base * 64 + 32 * h + j) * 8 + e] = hb;
     stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = lb;
 }
 
-template <int NT, int KSC, bool HALF>
+template <int NT, int KSC, int MODE>
 int launch(const Args& A, int n_oblk, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, HALF>));
+    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, MODE>));
     const int64_t tiles = (A.P + 127) / 128;
     h3d::pre_launch();
-    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, HALF>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
+    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, MODE>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
     return h3d::launch_status("h3d_conv_x3");
 }
 
@@ -230,12 +240,16 @@ extern "C" int h3d_conv_x3_pack(const float* w, void* stream, int Cout, int Cin,
 extern "C" int h3d_conv_x3_pack_f16(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
     return conv_pack_any(w, stream, Cout, Cin, k, transposed, 1, stream_);
 }
+// The stream h3d_conv_x3_f16x1 reads: ONE f16 plane (Cout * Cin * k * k halves), the weight rounded to f16 as autocast rounds it.
+extern "C" int h3d_conv_x3_pack_f16x1(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
+    return conv_pack_any(w, stream, Cout, Cin, k, transposed, 2, stream_);
+}
 
-static int conv_x3_any(bool half, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                        int Cout, int k, int ldx, int ldo, h3d_stream_t stream_);
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
-    return conv_x3_any(false, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
+    return conv_x3_any(0, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
 }
 /* h3d_conv_x3 on f16 activations (AMP, round 4): x and out are _Float16 (row strides in elements, multiples of 8), fp32 bias, the
  * weight stream of h3d_conv_x3_pack_f16 (f16 hi + lo planes of the fp32 weights: the weight to max(2^-22 |W|, 2^-25), where autocast
@@ -244,9 +258,17 @@ extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias
 extern "C" int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                                int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     H3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0, "h3d_conv_x3_f16: row strides must be multiples of 8 halves (ldx=%d ldo=%d)", ldx, ldo);
-    return conv_x3_any(true, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
+    return conv_x3_any(1, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
 }
-static int conv_x3_any(bool half, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+/* h3d_conv_x3_f16 with the weights in ONE f16 plane (stream of h3d_conv_x3_pack_f16x1): one F16 matrix product per weight, exactly
+ * what the reference computes under float16 autocast (weight and activation rounded to f16, fp32 accumulation); half the weight
+ * stream and half the matrix instructions of the two-plane tier. */
+extern "C" int h3d_conv_x3_f16x1(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+                                 int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
+    H3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0, "h3d_conv_x3_f16x1: row strides must be multiples of 8 halves (ldx=%d ldo=%d)", ldx, ldo);
+    return conv_x3_any(2, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
+}
+static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                        int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
@@ -262,11 +284,11 @@ static int conv_x3_any(bool half, const void* x, const void* stream, const float
     Args A{};
     A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out;
     A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
-    A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * til[2]; A.ldx = ldx; A.ldo = ldo;
+    A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * (mode == 2 ? til[2] / 2 : til[2]); A.ldx = ldx; A.ldo = ldo;
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const int NT = til[0], KSC = til[2];
-#define H3D_CASE(N, K) if (NT == N && KSC == K) return half ? launch<N, K, true>(A, til[1], st) : launch<N, K, false>(A, til[1], st)
+#define H3D_CASE(N, K) if (NT == N && KSC == K) return mode == 2 ? launch<N, K, 2>(A, til[1], st) : mode == 1 ? launch<N, K, 1>(A, til[1], st) : launch<N, K, 0>(A, til[1], st)
     H3D_CASE(8, 8); H3D_CASE(8, 4); H3D_CASE(4, 8); H3D_CASE(4, 4); H3D_CASE(2, 8); H3D_CASE(2, 4);
 #undef H3D_CASE
     return H3D_EUNSUPPORTED;

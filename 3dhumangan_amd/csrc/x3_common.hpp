@@ -311,12 +311,16 @@ struct NoHook {
 // Every index is a compile-time constant (static_for), so fragment / accumulator arrays stay in registers.
 // XLO = false: the activation operand is exact in ONE plane (f16 inputs on the F16 engine, the AMP tier): two products, W_hi x +
 // W_lo x, and xl is not read.
-template <typename T, int NT, int KS, int KSA, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, bool XLO = true, typename RING,
-          typename HOOK = NoHook>
+// PAIRK = true (with XLO = false): BOTH operands are exact in one plane (the AMP tier with the weights rounded to f16 once, which
+// is what autocast does to them): a stage's two planes hold the weight fragments of TWO consecutive k-steps, plane 0 x xh[2s] +
+// plane 1 x xh[2s + 1] -- one product per weight, half the stream of the two-plane format; KS counts stages (= k-steps / 2).
+template <typename T, int NT, int KS, int KSA, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, bool XLO = true, bool PAIRK = false,
+          typename RING, typename HOOK = NoHook>
 __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T::vec8 (&xh)[KSA],
                                              const typename T::vec8 (&xl)[KSA], RING& ring, HOOK hook = HOOK()) {
     constexpr int P = NT / 2, G = KS * P, NB = L + 1;
-    static_assert(NT % 2 == 0 && KS <= KSA && L >= 1 && L <= P, "look-ahead is at most one k-step");
+    static_assert(NT % 2 == 0 && KS * (PAIRK ? 2 : 1) <= KSA && L >= 1 && L <= P, "look-ahead is at most one k-step");
+    static_assert(!PAIRK || !XLO, "paired k-steps: one plane per operand");
     static_assert(RING::kChunks == P, "one DMA chunk per tile pair");
     struct Pair { typename T::vec8 h[2], l[2]; } buf[NB];
     lds_ptr st[2];
@@ -355,13 +359,14 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
 #endif
         const Pair& b = buf[g % NB];
         constexpr int n0 = 2 * p, n1 = 2 * p + 1;
+        constexpr int sx = PAIRK ? 2 * s : s;    // activation fragment of plane 0 (plane 1: the same one, or the next k-step's)
         if constexpr (ZERO && s == 0) {          // fresh accumulators: C = 0 is an inline constant, no init pass
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], zero);
-            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], zero);
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[sx], zero);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[sx], zero);
         } else {
-            acc[n0] = mm<T, SWAP>(b.h[0], xh[s], acc[n0]);
-            acc[n1] = mm<T, SWAP>(b.h[1], xh[s], acc[n1]);
+            acc[n0] = mm<T, SWAP>(b.h[0], xh[sx], acc[n0]);
+            acc[n1] = mm<T, SWAP>(b.h[1], xh[sx], acc[n1]);
         }
 #if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 2      // timing experiments only (wrong results)
         if constexpr (XLO) {
@@ -370,8 +375,8 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
         }
 #endif
 #if !defined(H3D_EXPERIMENT_PRODUCTS) || H3D_EXPERIMENT_PRODUCTS >= 3
-        acc[n0] = mm<T, SWAP>(b.l[0], xh[s], acc[n0]);
-        acc[n1] = mm<T, SWAP>(b.l[1], xh[s], acc[n1]);
+        acc[n0] = mm<T, SWAP>(b.l[0], xh[PAIRK ? sx + 1 : sx], acc[n0]);
+        acc[n1] = mm<T, SWAP>(b.l[1], xh[PAIRK ? sx + 1 : sx], acc[n1]);
 #endif
         // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
         // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()

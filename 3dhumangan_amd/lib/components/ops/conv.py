@@ -50,9 +50,13 @@ def supported(x, weight):
 
 
 _stream_cache = {}
+# AMP tier: f16 weight planes of the convolution kernels.  1 (default, round 5) = the weight rounded to f16 once, as the reference's
+# autocast rounds it: one matrix product per weight, half the weight stream (h3d_conv_x3_f16x1); 2 = f16 hi + lo (the weight to
+# max(2^-22 |W|, 2^-25): more precise than what it is compared with, twice the matrix work) -- the opt-in tier.
+AMP_WEIGHT_PLANES = int(os.environ.get("H3D_AMP_WEIGHT_PLANES", "1"))
 
 
-def pack_stream(w, transposed=False, half=False, owner=None):
+def pack_stream(w, transposed=False, half=False, owner=None, planes=2):
     """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
     kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
     taps flipped) instead.  Cached per tensor OBJECT and version: the same (spectrally normalised) weight is convolved with in the
@@ -63,15 +67,16 @@ def pack_stream(w, transposed=False, half=False, owner=None):
     half: the f16 hi/lo stream of h3d_conv_x3_f16."""
     ref = w if owner is None else owner
     cacheable = not ref.is_inference()
-    key = (id(ref), bool(transposed), bool(half), tuple(w.shape))
+    one = bool(half) and planes == 1
+    key = (id(ref), bool(transposed), bool(half), tuple(w.shape), one)
     if cacheable:
         e = _stream_cache.get(key)
         if e is not None and e[0] == ref._version and e[1]() is ref:
             return e[2]
     wd = w.detach().contiguous()
     co, ci, k, _ = wd.shape
-    out = torch.empty(2 * wd.numel(), device=wd.device, dtype=torch.int16)
-    pack = _lib.load().h3d_conv_x3_pack_f16 if half else _lib.load().h3d_conv_x3_pack
+    out = torch.empty((1 if one else 2) * wd.numel(), device=wd.device, dtype=torch.int16)
+    pack = _lib.load().h3d_conv_x3_pack_f16x1 if one else _lib.load().h3d_conv_x3_pack_f16 if half else _lib.load().h3d_conv_x3_pack
     rc = pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed), _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_pack")
     if not cacheable:
@@ -122,11 +127,12 @@ def _run_conv(x, w, bias=None, transposed=False, owner=None):
     k = w.shape[2]
     co = w.shape[1] if transposed else w.shape[0]
     wf = w.float()                         # fp32 weights come back as the same object: the cache key survives
-    stream = pack_stream(wf, transposed, half=x.dtype == torch.float16, owner=owner if (owner is not None and wf is w) else None)
+    half = x.dtype == torch.float16
+    stream = pack_stream(wf, transposed, half=half, owner=owner if (owner is not None and wf is w) else None, planes=AMP_WEIGHT_PLANES)
     out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
     lib = _lib.load()
-    entry = lib.h3d_conv_x3 if x.dtype == torch.float32 else lib.h3d_conv_x3_f16          # f16 in -> f16 out (AMP)
+    entry = lib.h3d_conv_x3 if not half else (lib.h3d_conv_x3_f16x1 if AMP_WEIGHT_PLANES == 1 else lib.h3d_conv_x3_f16)   # f16 in -> f16 out (AMP)
     rc = entry(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
                                  _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3")

@@ -601,12 +601,19 @@ def conv_rooflines(timeit):
             g = torch.randn(B, co, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
             flop = 2.0 * B * H * W * ci * co * k * k
             esz = 4 if dt == torch.float32 else 2
-            for name, fn, by in (("forward", lambda: conv._run_conv(x, w), B * H * W * (ci + co) * esz),
-                                 ("weight_gradient", lambda: conv._run_wgrad(x, g, k), B * H * W * (ci + co) * esz)):
+            cases = [("forward", lambda: conv._run_conv(x, w), B * H * W * (ci + co) * esz),
+                     ("weight_gradient", lambda: conv._run_wgrad(x, g, k), B * H * W * (ci + co) * esz)]
+            if k == 1:      # the library's GEMM on the same rows (hipBLASLt: what H3D_AMP_LINEAR=library / H3D_LINEAR=library run)
+                x2 = x.permute(0, 2, 3, 1).reshape(-1, ci)
+                w2 = w.reshape(co, ci).to(dt)
+                cases.append(("forward_library_gemm", lambda: torch.nn.functional.linear(x2, w2), B * H * W * (ci + co) * esz))
+            for name, fn, by in cases:
                 ms = timeit(fn, iters=5)
                 ach = flop / ms / 1e9
-                issue = 3.0 if dt == torch.float32 else 2.0 if name == "forward" else 1.0
-                rows.append(dict(kernel="h3d_conv_x3" if name == "forward" else "h3d_conv_wgrad_x3", pass_=name,
+                planes = getattr(conv, "AMP_WEIGHT_PLANES", 2)
+                issue = (1.0 if name == "forward_library_gemm" else 3.0 if dt == torch.float32
+                         else float(planes) if name == "forward" else 1.0)
+                rows.append(dict(kernel="h3d_conv_x3" if name == "forward" else "hipBLASLt" if name == "forward_library_gemm" else "h3d_conv_wgrad_x3", pass_=name,
                                  shape=f"B{B} {H}x{W} {ci}->{co} k{k}", activations="f32" if dt == torch.float32 else "f16",
                                  ms=ms, flop=flop, bytes=by, achieved_TFLOPs=ach, frac=ach / MFMA_F16_PEAK_TF,
                                  mfma_issue_factor=issue, mfma_pipe_util=issue * ach / MFMA_F16_PEAK_TF, hbm_GBs=by / ms / 1e6,

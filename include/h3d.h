@@ -221,6 +221,13 @@ int h3d_conv_wgrad_x3(const float* dY, const float* X, float* partial, int B, in
  * fp32 entry points on exactly representable inputs, with one rounding to f16 at h3d_conv_x3_f16's store. */
 int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
                     int k, int ldx, int ldo, h3d_stream_t stream_handle);
+/* The AMP tier with the weights in ONE f16 plane (round 5) -- the reference's own arithmetic under float16 autocast
+ * (lib/trainers/base_trainer.py:50-51: autocast rounds weight and activation to f16, fp32 accumulation): one F16 matrix product
+ * per weight, half the weight stream of h3d_conv_x3_f16.  h3d_conv_x3_pack_f16x1 writes Cout * Cin * k * k halves: the layout of
+ * h3d_conv_x3_pack with the two planes of a stage holding the fragments of two consecutive k-steps. */
+int h3d_conv_x3_pack_f16x1(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_handle);
+int h3d_conv_x3_f16x1(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
+                      int Cout, int k, int ldx, int ldo, h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int ldy,
                           int ldx, int slices, h3d_stream_t stream);
 /* ... with the convolution's bias gradient riding along (round 4): colsum [slices][Co] fp32 = column sums of dY over each slice's

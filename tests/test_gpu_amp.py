@@ -45,6 +45,35 @@ def test_conv_f16_forward_and_gradients_vs_float64(B, H, W, ci, co, k):
     assert rel_err(hb.cpu(), gb) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,k", [(2, 16, 16, 128, 128, 3), (1, 9, 7, 64, 256, 1), (2, 32, 16, 256, 512, 3), (1, 1, 4099, 256, 256, 1)])
+def test_conv_f16_single_weight_plane_is_the_autocast_arithmetic(B, H, W, ci, co, k, monkeypatch):
+    """Round 5: the AMP tier's default rounds the weight to f16 ONCE (h3d_conv_x3_f16x1: one product per weight, a ring stage carries
+    two k-steps) -- what float16 autocast computes in the reference (lib/trainers/base_trainer.py:50-51).  Against float64 on the
+    f16-ROUNDED weights only the output's own rounding to f16 is left; against the two-plane tier the difference is the weights' 11
+    bits."""
+    torch.manual_seed(ci + co + k)
+    x = torch.randn(B, ci, H, W).half()
+    w = torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5
+    b = torch.randn(co) * 0.1
+    cot = torch.randn(B, co, H, W).half()
+    xd, wd = x.double().requires_grad_(), w.half().double().requires_grad_()
+    ref = F.conv2d(xd, wd, b.double(), padding=k // 2)
+    gx, = torch.autograd.grad(ref, [xd], cot.double())
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wg, bg = w.to(DEV).requires_grad_(), b.to(DEV)
+    outs = {}
+    for planes in (1, 2):
+        monkeypatch.setattr(conv, "AMP_WEIGHT_PLANES", planes)
+        out = conv.conv2d(xg, wg, bg)
+        hx, hw = torch.autograd.grad(out, [xg, wg], cot.to(DEV))
+        outs[planes] = (out.detach().float().cpu(), hx.float().cpu(), hw.cpu())
+    assert conv.pack_stream(wg.detach(), half=True, planes=1).numel() * 2 == conv.pack_stream(wg.detach(), half=True, planes=2).numel()
+    assert rel_err(outs[1][0], ref.detach()) < 6e-4                     # only the f16 rounding of the result (2^-11 of its magnitude)
+    assert rel_err(outs[1][1], gx) < 6e-4                               # backward-data: the same kernel on the transposed stream
+    assert 1e-6 < rel_err(outs[1][0], outs[2][0]) < 1.5e-3              # differs from the two-plane tier by the weights' rounding
+    assert torch.equal(outs[1][2], outs[2][2])                          # the weight gradient never reads the weight stream
+
+
 def test_f16_matrix_products_keep_subnormal_operands():
     """The AMP convolution / weight-gradient kernels multiply the f16 values themselves on v_mfma_f32_32x32x16_f16 (round 4: one exact
     plane, no bf16 split).  f16 subnormals (|x| < 6.1e-5: small activations, unscaled gradients) must take part in the products

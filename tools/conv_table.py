@@ -1,12 +1,18 @@
-"""The per-shape table of the convolution / weight-gradient kernels alone (bench.py's op_rooflines()['conv_x3_by_shape']).
-usage: python tools/conv_table.py [forward|weight_gradient]"""
+"""GPU: the per-shape table of the convolution / weight-gradient kernels (bench.py: conv_rooflines) as text.
+usage: python tools/conv_table.py [weight planes of the AMP tier: 1 | 2]"""
+import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+
+conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+if len(sys.argv) > 1:
+    conv.AMP_WEIGHT_PLANES = int(sys.argv[1])
 
 
 def timeit(fn, iters=10):
@@ -22,7 +28,8 @@ def timeit(fn, iters=10):
     return a.elapsed_time(b) / iters
 
 
-want = sys.argv[1] if len(sys.argv) > 1 else None
+print(f"AMP weight planes = {conv.AMP_WEIGHT_PLANES}")
+print(f"{'kernel':18s} {'pass':22s} {'shape':28s} {'act':4s} {'ms':>8s} {'TFLOP/s':>9s} {'frac':>6s} {'pipe':>6s} {'GB/s':>8s}")
 for r in bench.conv_rooflines(timeit):
-    if want is None or r["pass_"] == want:
-        print(f'{r["shape"]:28s} {r["activations"]} {r["pass_"]:16s} {r["ms"]:7.3f} ms  pipe {r["mfma_pipe_util"]:.3f}  hbm {r["hbm_frac"]:.3f}')
+    print(f"{r['kernel']:18s} {r['pass_']:22s} {r['shape']:28s} {r['activations']:4s} {r['ms']:8.4f} {r['achieved_TFLOPs']:9.1f} "
+          f"{r['frac']:6.3f} {r['mfma_pipe_util']:6.3f} {r['hbm_GBs']:8.0f}")
