@@ -142,6 +142,7 @@ class SynthesisPlan:
         self.con_index = torch.tensor(self.const_ids, dtype=torch.long, device=device)
         # [F, 128 * n_pixel]: low-res shared conv for every per-pixel SPADE in one GEMM
         self.ws_pixel_t = (self.ws_all[pix].reshape(-1, F).t().contiguous() if len(self.pixel_ids) else None)
+        self.ws_pixel = (self.ws_all[pix].reshape(-1, F).contiguous() if len(self.pixel_ids) else None)       # [128 np, F] rows = outputs
         if self.const_ids:
             self.wg_c, self.bg_c = torch.stack(wg_c), torch.stack(bg_c)   # [nc,128,C], [nc,C]
             self.wb_c, self.bb_c = torch.stack(wb_c), torch.stack(bb_c)
@@ -487,7 +488,7 @@ class SynthesisPlan:
         pre_fixed = torch.einsum("bf,skf->bsk", fixed_style, self.ws_all)          # [B, 2nb, 128]
         G = cst = ab = None
         if self.pixel_ids:
-            G = torch.matmul(feature_maps, self.ws_pixel_t).contiguous()           # [B,R,128*np]
+            G = self._shared_first_layer(feature_maps)                              # [B,R,128*np]
             cst = self.bs_all[self.pix_index].unsqueeze(0).expand(B, -1, -1)
             if self.mode in ("all", "mixed"):                                       # style = feature map + fixed style
                 cst = cst + pre_fixed[:, self.pix_index]
@@ -500,6 +501,22 @@ class SynthesisPlan:
             ab[:, :, 0, : self.C] = self.sc_c * gamma1
             ab[:, :, 1, : self.C] = self.sh_c * gamma1 + beta
         return G, cst, ab
+
+    def _shared_first_layer(self, feature_maps):
+        """The SPADEs' shared 1x1 convolution at LOW resolution (it commutes with the bilinear resize): [B,R,F] x [F, 128 np].
+        58 GFLOP at the bench size -- on the package's own split-bf16 matrix-core GEMM (ops/linear.py: gemm_x3, fp32-class, ~1e-6)
+        when the widths are multiples of 64 and the rows are many (round 5: the last library GEMM of the inference path that was not
+        a GEMV); the library's fp32 GEMM otherwise (CPU plans of the host-logic tests, hidden 420)."""
+        B, R, F = feature_maps.shape
+        # (the row threshold sits below one image of every shipped geometry, so a batch and its items alone take the same kernel
+        # and stay bit-identical: the x2 arithmetic behind it turns a 1e-6 difference of its input into 1e-4 of quantisation noise)
+        if feature_maps.is_cuda and os.environ.get("H3D_SHARED_GEMM", "x3") == "x3" and B * R >= 1024:
+            from ..components.ops import linear
+            if linear._native_ok(self.ws_pixel.shape[0], F):
+                # the rendered maps arrive as a channel slice [.., 3:] of the [B,R,F+3] render output (row stride F + 3, 12 bytes
+                # in): _rows makes the aligned [M, F] copy the kernel's 16-byte loads need (151 MB at the bench size, ~0.06 ms)
+                return linear.gemm_x3(linear._rows(feature_maps), self.ws_pixel).view(B, R, -1)
+        return torch.matmul(feature_maps, self.ws_pixel_t).contiguous()
 
     def x3_forward_tables(self, feature_maps, fixed_style, x2=False):
         """per_forward_tables for the x3 engine: the conv biases folded into the constant-style shifts (build_x3) and

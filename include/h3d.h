@@ -447,9 +447,10 @@ int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* t
  *   h3d_synthesis_x3_tiles  h3d_synthesis_x3 (single launch, `stream` in the x3 format) restricted to the 128-pixel tiles
  *                           tile_first, tile_first + tile_step, .. of every sample; writes those pixels of `rgb` (a scratch
  *                           image of the full [B,3,H,W] shape) and nothing else;
- *   h3d_synthesis_check     per sample, over exactly those tiles: err = max over channels of max|rgb - rgb_ref| / max|rgb_ref|
- *                           (written to err_out[b] when err_out != NULL); ORs 1 into *flag (int32, device memory) when
- *                           err > tol or anything in the sample is not finite.
+ *   h3d_synthesis_check     per sample: err = max over channels of (max|rgb - rgb_ref| over exactly those tiles) / (max|rgb|
+ *                           over the WHOLE image: the scale the 1e-3 budget is relative to), written to err_out[b] when
+ *                           err_out != NULL; ORs 1 into *flag (int32, device memory) when err > tol or anything it read is
+ *                           not finite.
  * Launched behind h3d_synthesis_x2_guarded and in front of h3d_synthesis_x3_if with the same flag this is "x2, redone on x3
  * when a sampled pixel leaves the budget", without a host synchronisation (SynthesisPlan.run).  tile_step >= 1. */
 int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, const float* tables, int table_floats,

@@ -54,6 +54,11 @@ def check_workload(cfg_name, gen_hw, render_hw, S, B, oracle_items, n_cells=24, 
     cd = {k: v.to(DEV) for k, v in cond.items()}
     out = G.forward(z.to(DEV), cd, jitter=jit.to(DEV), **cfg)
     rgb, ren = out["rgbs"].cpu(), out["rgbs_render"].cpu()
+    plan = G.synthesis_plan(DEV)
+    batch_fell_back = plan.x2_fell_back()         # range guard / sampled error monitor of the x2 engine: the batch was redone on x3
+    if plan.x2_monitor_errors() is not None:
+        print(f"{cfg_name} {gen_hw} B={B}: x2 monitor sampled errors {[round(float(v), 6) for v in plan.x2_monitor_errors().cpu()]}, "
+              f"fell back: {batch_fell_back}")
     assert rgb.shape == (B, 3) + tuple(gen_hw) and torch.isfinite(rgb).all()
     # ---- oracle on a subset of pixels (and the rays they need) for a few batch items
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
@@ -74,7 +79,10 @@ def check_workload(cfg_name, gen_hw, render_hw, S, B, oracle_items, n_cells=24, 
     for i in sorted(set([0, B - 1] + list(oracle_items))):
         ci = {k: v[i:i + 1].to(DEV) for k, v in cond.items()}
         one = G.forward(z[i:i + 1].to(DEV), ci, jitter=jit[i:i + 1].to(DEV), **cfg)
-        assert rel_err_channels(one["rgbs"].cpu(), rgb[i:i + 1]) < 2e-5
+        # the same engine -> the same image; when the monitor sent only one of the two runs to the x3 engine (the flag is per
+        # launch: one item over the tolerance redoes its whole batch) both images are within the budget of the reference
+        same_engine = plan.x2_fell_back() == batch_fell_back
+        assert rel_err_channels(one["rgbs"].cpu(), rgb[i:i + 1]) < (2e-5 if same_engine else 1e-3)
         assert rel_err_channels(one["rgbs_render"].cpu(), ren[i:i + 1]) < 2e-5
     return G
 
