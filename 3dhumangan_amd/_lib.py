@@ -87,7 +87,7 @@ _SIGNATURES = {
     "h3d_synthesis_x2_guarded": (C.c_int, [_p, _l, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _p]),
     "h3d_synthesis_x3_if": (C.c_int, [_p, _l, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _p]),
     "h3d_synthesis_x3_tiles": (C.c_int, [_p, _l, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
-    "h3d_synthesis_check": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
+    "h3d_synthesis_check": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "h3d_synthesis_x3t_tiles": (C.c_int, [_i]),
     "h3d_synthesis_x3t": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "h3d_synthesis_x3t_tier": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),

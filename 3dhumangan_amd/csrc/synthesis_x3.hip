@@ -826,77 +826,84 @@ extern "C" int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, 
 }
 
 namespace {
-// one workgroup per sample: per channel, max |img| over the WHOLE image (the scale the parity budget is relative to; img and ref
-// agree to ~1e-3, so either serves) and max |img - ref| over the sampled tiles -> err = max_c (diff_c / scale_c)
-__global__ __launch_bounds__(256) void synthesis_check_kernel(const float* __restrict__ img, const float* __restrict__ ref, int64_t HW,
-                                                              int n_tiles, int tile_first, int tile_step, float tol, int* flag,
-                                                              float* err_out) {
-    __shared__ float red[2][3][4];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float mr[3] = {0.f, 0.f, 0.f}, md[3] = {0.f, 0.f, 0.f};
-    bool bad = false;
+// Stage 1, grid (B, kCheckSlices): slice s of sample b takes every kCheckSlices-th float4 of the three channel planes (max |img|:
+// the scale the parity budget is relative to; img and ref agree to ~1e-3, so either serves) and every kCheckSlices-th sampled tile
+// (max |img - ref|); the six maxima are merged with atomicMax on the bit patterns (non-negative floats order like unsigned ints, a
+// NaN pattern sorts above infinity and so survives).  work [B][6] is zeroed by the entry point.
+constexpr int kCheckSlices = 32;
+__global__ __launch_bounds__(256) void synthesis_check_partial(const float* __restrict__ img, const float* __restrict__ ref, int64_t HW,
+                                                               int n_tiles, int tile_first, int tile_step, unsigned* work) {
+    __shared__ float red[6][4];
+    const int b = blockIdx.x, sl = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto fold = [](float a, float v) { return (a != a) ? a : (v != v) ? v : fmaxf(a, v); };   // keep a NaN once seen (fmaxf drops it)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* p = img + ((int64_t)b * 3 + c) * HW;
         const int64_t n4 = (HW % 4 == 0 && (reinterpret_cast<size_t>(p) & 15) == 0) ? HW / 4 : 0;
-        for (int64_t i = t; i < n4; i += 256) {
+        for (int64_t i = (int64_t)sl * 256 + t; i < n4; i += (int64_t)kCheckSlices * 256) {
             const float4 v = reinterpret_cast<const float4*>(p)[i];
-            const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-            bad = bad || !(m <= 3.0e38f);                                   // NaN / inf anywhere in the image
-            mr[c] = fmaxf(mr[c], m);
+            m[c] = fold(fold(fold(fold(m[c], fabsf(v.x)), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
         }
-        for (int64_t i = n4 * 4 + t; i < HW; i += 256) {
-            const float m = fabsf(p[i]);
-            bad = bad || !(m <= 3.0e38f);
-            mr[c] = fmaxf(mr[c], m);
-        }
+        for (int64_t i = n4 * 4 + (int64_t)sl * 256 + t; i < HW; i += (int64_t)kCheckSlices * 256) m[c] = fold(m[c], fabsf(p[i]));
     }
-    for (int tile = tile_first; tile < n_tiles; tile += tile_step) {
+    for (int tile = tile_first + sl * tile_step; tile < n_tiles; tile += kCheckSlices * tile_step) {
         for (int i = t; i < 128; i += 256) {
             const int64_t p = (int64_t)tile * 128 + i;
             if (p >= HW) continue;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float d = fabsf(img[((int64_t)b * 3 + c) * HW + p] - ref[((int64_t)b * 3 + c) * HW + p]);
-                bad = bad || !(d <= 3.0e38f);                               // a non-finite reference sample
-                md[c] = fmaxf(md[c], d);
-            }
+            for (int c = 0; c < 3; ++c)
+                m[3 + c] = fold(m[3 + c], fabsf(img[((int64_t)b * 3 + c) * HW + p] - ref[((int64_t)b * 3 + c) * HW + p]));
         }
     }
 #pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[k] = fold(m[k], __shfl_xor(m[k], o, 64));
+        if (lane == 0) red[k][wave] = m[k];
+    }
+    __syncthreads();
+    if (t < 6) {
+        const float v = fold(fold(red[t][0], red[t][1]), fold(red[t][2], red[t][3]));
+        atomicMax(work + b * 6 + t, __float_as_uint(v));
+    }
+}
+// Stage 2, one thread per sample: err = max_c (diff_c / scale_c); anything not finite -> infinity; flag when err > tol
+__global__ void synthesis_check_final(const unsigned* __restrict__ work, int B, float tol, int* flag, float* err_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float err = 0.f;
+    bool bad = false;
     for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mr[c] = fmaxf(mr[c], __shfl_xor(mr[c], o, 64));
-            md[c] = fmaxf(md[c], __shfl_xor(md[c], o, 64));
-        }
-        if (lane == 0) { red[0][c][wave] = mr[c]; red[1][c][wave] = md[c]; }
+        const float r = __uint_as_float(work[b * 6 + c]), d = __uint_as_float(work[b * 6 + 3 + c]);
+        bad = bad || !(r <= 3.0e38f) || !(d <= 3.0e38f);
+        err = fmaxf(err, d / fmaxf(r, 1e-30f));
     }
-    const bool any_bad = __syncthreads_or(bad);
-    if (t == 0) {
-        float err = 0.f;
-        for (int c = 0; c < 3; ++c) {
-            const float r = fmaxf(fmaxf(red[0][c][0], red[0][c][1]), fmaxf(red[0][c][2], red[0][c][3]));
-            const float d = fmaxf(fmaxf(red[1][c][0], red[1][c][1]), fmaxf(red[1][c][2], red[1][c][3]));
-            err = fmaxf(err, d / fmaxf(r, 1e-30f));
-        }
-        if (any_bad) err = __builtin_inff();
-        if (err_out) err_out[b] = err;
-        if (!(err <= tol)) atomicOr(flag, 1);
-    }
+    if (bad) err = __builtin_inff();
+    if (err_out) err_out[b] = err;
+    if (!(err <= tol)) atomicOr(flag, 1);
 }
 }  // namespace
 
 extern "C" int h3d_synthesis_check(const float* rgb, const float* rgb_ref, int B, int H, int W, int tile_first, int tile_step,
-                                   float tol, int* flag, float* err_out, h3d_stream_t stream_) {
-    H3D_REQUIRE(rgb && rgb_ref && flag, "h3d_synthesis_check: null pointer");
-    H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && tile_first >= 0 && tile_step >= 1 && tol >= 0.f, "h3d_synthesis_check: bad arguments");
+                                   float tol, int* flag, float* err_out, float* work, h3d_stream_t stream_) {
+    H3D_REQUIRE(rgb && rgb_ref && flag && work, "h3d_synthesis_check: null pointer");
+    H3D_REQUIRE(B >= 0 && B <= 65535 && H >= 1 && W >= 1 && tile_first >= 0 && tile_step >= 1 && tol >= 0.f, "h3d_synthesis_check: bad arguments");
     if (B == 0) return H3D_OK;
     const int64_t HW = (int64_t)H * W;
     const int n_tiles = (int)((HW + 127) / 128);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (hipMemsetAsync(work, 0, sizeof(float) * 6 * (size_t)B, st) != hipSuccess) {
+        h3d::set_error("h3d_synthesis_check: hipMemsetAsync failed");
+        return H3D_ELAUNCH;
+    }
     h3d::pre_launch();
-    hipLaunchKernelGGL(synthesis_check_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream_), rgb, rgb_ref, HW,
-                       n_tiles, tile_first, tile_step, tol, flag, err_out);
+    hipLaunchKernelGGL(synthesis_check_partial, dim3((unsigned)B, kCheckSlices), dim3(256), 0, st, rgb, rgb_ref, HW, n_tiles, tile_first,
+                       tile_step, reinterpret_cast<unsigned*>(work));
+    int rc = h3d::launch_status("h3d_synthesis_check");
+    if (rc) return rc;
+    hipLaunchKernelGGL(synthesis_check_final, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, reinterpret_cast<const unsigned*>(work), B, tol,
+                       flag, err_out);
     return h3d::launch_status("h3d_synthesis_check");
 }
 

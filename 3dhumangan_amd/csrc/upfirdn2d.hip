@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T* __restrict__ x, 
 template <int UX_, int UY_, int DX_, int DY_, int FW_, int FH_, int RX_, int RY_, int VY_ = 4>
 struct Poly {
     static constexpr int UX = UX_, UY = UY_, DX = DX_, DY = DY_, FW = FW_, FH = FH_, RX = RX_, RY = RY_;
-    static constexpr int VX = 4, VY = VY_, TW = 64, TH = 16 * VY_;    // patch per thread (4 rows: 0.208 -> 0.190 ms vs 2), tile per WG
+#ifndef H3D_UPFIRDN_TW
+#define H3D_UPFIRDN_TW 64
+#endif
+    // patch per thread (4 rows: 0.208 -> 0.190 ms vs 2), tile per WG: TW outputs wide (TW / 4 threads across), 256 / (TW / 4) thread rows
+    static constexpr int VX = 4, VY = VY_, TW = H3D_UPFIRDN_TW, TXG = TW / VX, TH = (256 / TXG) * VY_;
+    static_assert(TW % VX == 0 && 256 % TXG == 0, "tile width");
     static constexpr int WX = (RX + (VX - 1) * DX + FW - 1) / UX + 1;                 // register window of a thread
     static constexpr int WY = (RY + (VY - 1) * DY + FH - 1) / UY + 1;
     static constexpr int IN_W = (RX + (TW - 1) * DX + FW - 1) / UX + 1;               // LDS tile of a workgroup
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_poly(const T* __restrict__ x, c
         }
     }
     __syncthreads();
-    const int txg = t & 15, ty = t >> 4;
+    const int txg = t % P::TXG, ty = t / P::TXG;
     const int ox = ox0 + P::VX * txg, oy = oy0 + P::VY * ty;
     if (ox >= p.outW || oy >= p.outH) return;
     const float* __restrict__ wp = tile + (P::VY * ty * P::DY / P::UY) * P::LD + P::VX * txg * P::DX / P::UX;

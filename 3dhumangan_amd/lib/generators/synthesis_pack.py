@@ -606,12 +606,13 @@ class SynthesisPlan:
                         first, step = self.monitor_tiles(H, W)
                         buf = self._x2_monitor_buf
                         if buf is None or buf[0].shape != rgb.shape or buf[0].device != rgb.device:
-                            buf = (torch.empty_like(rgb), torch.zeros(B, device=rgb.device, dtype=torch.float32))
+                            buf = (torch.empty_like(rgb), torch.zeros(B, device=rgb.device, dtype=torch.float32),
+                                   torch.zeros(6 * B, device=rgb.device, dtype=torch.float32))
                             self._x2_monitor_buf = buf
                         rc = lib.h3d_synthesis_x3_tiles(*common(alt)[:13], _lib.ptr(buf[0]), B, H, W, first, step, _lib.stream_handle())
                         rc = rc or lib.h3d_synthesis_check(_lib.ptr(rgb), _lib.ptr(buf[0]), B, H, W, first, step,
                                                            self.x2_monitor_tol, _lib.ptr(self._x2_flag), _lib.ptr(buf[1]),
-                                                           _lib.stream_handle())
+                                                           _lib.ptr(buf[2]), _lib.stream_handle())
                     if not rc:
                         what = "h3d_synthesis_x3_if"
                         rc = lib.h3d_synthesis_x3_if(*common(alt))

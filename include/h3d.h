@@ -458,7 +458,8 @@ int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, const float
                            const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
                            int tile_first, int tile_step, h3d_stream_t stream_handle);
 int h3d_synthesis_check(const float* rgb, const float* rgb_ref, int B, int H, int W, int tile_first, int tile_step,
-                        float tol, int* flag, float* err_out, h3d_stream_t stream_handle);
+                        float tol, int* flag, float* err_out, float* work /* [6 B] scratch, zeroed by the call */,
+                        h3d_stream_t stream_handle);
 
 /* Same network, split-bf16 arithmetic as h3d_synthesis_x3, for widths up to 448 ("x3t": the activations of a 64-pixel
  * tile live in LDS as ready-made MFMA fragments, the channels are split over the four waves; csrc/x3t_common.hpp).

@@ -85,9 +85,10 @@ def test_tile_subset_launch_writes_the_sampled_tiles_only():
     assert bool((s[:, :, ~mask] == -7.0).all())                          # nothing else touched
     # the check kernel: identical images -> 0, no flag; one perturbed sampled pixel -> that error, flag; non-finite -> flag
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    err = torch.zeros(B, device=DEV)
+    err, work = torch.zeros(B, device=DEV), torch.full((6 * B,), 9.0, device=DEV)       # the call zeroes its scratch itself
     chk = lambda img, tol: _lib.check(_lib.load().h3d_synthesis_check(_lib.ptr(img), _lib.ptr(scratch), B, H, W, first, step, tol,
-                                                                      _lib.ptr(flag), _lib.ptr(err), _lib.stream_handle()), "check")
+                                                                      _lib.ptr(flag), _lib.ptr(err), _lib.ptr(work),
+                                                                      _lib.stream_handle()), "check")
     chk(full, 1e-3)
     assert int(flag.item()) == 0 and float(err.max()) == 0.0
     bad = full.clone()

@@ -2,13 +2,15 @@
 # Round profile: bench line, rocprofv3 kernel stats of the same command, separate PMC passes for HBM traffic and for the SQ
 # counters, the same for the wide (x3t) workload.  usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r2
 set -u
-R=${1:-r3}
+R=${1:-r5}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 REPO=$PWD
-KERN='x3_kernel|x3t_kernel|geo_features|mesh_sort|ray_integrate|conv_x3|wgrad'
+KERN='x3_kernel|x3t_kernel|geo_features|mesh_sort|ray_integrate|conv_x3|wgrad|synthesis_check'
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err        # the driver's protocol
+cp bench_detail.json $OUT/bench_detail.json                                              # the full record behind the compact line
 python bench.py --steps 200 --warmup 5 --no-extra --no-cpu --no-check > $OUT/bench_200steps.json 2>> $OUT/bench.err
+cp bench_detail.json $OUT/bench_200steps_detail.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu --no-extra --no-check > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
