@@ -38,6 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 using namespace h3d;
 
@@ -207,7 +208,17 @@ struct FilmProducer {
     template <int TILE, int C>
     static constexpr int chan() { return TILE * 32 + (C / 2) * 8 + (C % 2) * 2; }      // + 4 h: in the lane base
     __device__ __forceinline__ void prime() { tv = ldt4(tab, 2 * chan<0, 0>()); }
+    // The table row of chunk C + 1, read at the TOP of the section that runs chunk C (gemm_x2_roll's PRE hook), in front of the
+    // section's burst of weight-fragment reads: one section later the wait for it leaves that burst in flight.  (Read inside
+    // chunk C -- after the burst in program order, or sunk there by instruction selection -- it is the YOUNGEST LDS read at its
+    // use and its wait is s_waitcnt lgkmcnt(0): the look-ahead drained once per section; round 5, seen in the ISA.)
+    f32x4 tn;
     template <int TILE, int C>
+    __device__ __forceinline__ void prefetch() {
+        if constexpr (C < 7) tn = ldt4_pinned(tab, 2 * chan<TILE, C + 1>());
+        else if constexpr (TILE + 1 < NT) tn = ldt4_pinned(tab, 2 * chan<TILE + 1, 0>());
+    }
+    template <int TILE, int C, bool PRE = false>
     __device__ __forceinline__ void chunk() {
         if constexpr (C == 0) pin1(src[TILE]);
         constexpr int rg = C / 2;
@@ -218,8 +229,12 @@ struct FilmProducer {
         const float s0 = sv[(C % 4) * 2], s1 = sv[(C % 4) * 2 + 1];
         const float u0 = fmaf(s0, tv.x, tv.z);
         const float u1 = fmaf(s1, tv.y, tv.w);
-        if constexpr (C < 7) tv = ldt4(tab, 2 * chan<TILE, C + 1>());
-        else if constexpr (TILE + 1 < NT) tv = ldt4(tab, 2 * chan<TILE + 1, 0>());
+        if constexpr (PRE) {
+            tv = tn;                                        // fetched by prefetch<TILE, C>() at the top of this section
+        } else {
+            if constexpr (C < 7) tv = ldt4(tab, 2 * chan<TILE, C + 1>());
+            else if constexpr (TILE + 1 < NT) tv = ldt4(tab, 2 * chan<TILE + 1, 0>());
+        }
         unsigned lo;
         const unsigned hi = X2 ? split2_act_x2(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo)
                                : split2_act(__builtin_amdgcn_sinf(u0), __builtin_amdgcn_sinf(u1), lo);
@@ -233,6 +248,13 @@ struct FilmProducer {
     __device__ __forceinline__ void convert() {
         if constexpr (X2) b6[TILE] = x2_record(xl[2 * TILE], xl[2 * TILE + 1], xh[2 * TILE], xh[2 * TILE + 1]);
     }
+};
+
+struct NoProducer {
+    __device__ __forceinline__ void prime() {}
+    template <int TILE, int C, bool PRE = false> __device__ __forceinline__ void chunk() {}
+    template <int TILE, int C> __device__ __forceinline__ void prefetch() {}
+    template <int TILE> __device__ __forceinline__ void convert() {}
 };
 
 // Tile-0 work of the NEXT layer's producer (its source is this GEMM's destination): tiles 0 and 1 of dst are final after
@@ -272,12 +294,24 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
     };
     if constexpr (HEAD) load_head(0);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef H3D_FIELD_NO_PREFETCH_PIN
+    constexpr bool kPre = false;
+#else
+    constexpr bool kPre = X2 && PER == 1 && !std::is_same<PROD, NoProducer>::value;       // one chunk per section: one prefetch per section
+#endif
+    auto pre = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int t = g / W + 1, j = g % W;
+        if constexpr (kPre && t < NT) prod.template prefetch<t, j * PER>();
+    };
     auto hook = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int t = g / W + 1, j = g % W;
         if constexpr (X2 && j == 0 && t - 1 < NT) prod.template convert<t - 1>();      // first section of k-step 2 * (t - 1)
         if constexpr (t < NT) {
-            static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
+            static_for<0, PER>([&](auto q) __attribute__((always_inline)) {
+                prod.template chunk<t, j * PER + decltype(q)::value, kPre>();
+            });
         }
         next_tile0<P, KSG - 1, g>(next);
         if constexpr (HEAD) {
@@ -299,7 +333,7 @@ __device__ __forceinline__ void layer(f32x16 (&dst)[NT], half8 (&xh)[2 * NT + 1]
     if constexpr (X2) {
         constexpr int KS3 = KSG - KS;
         const half8 tail[1] = {xl[KS]};                 // view direction k-step: assembled from memory, lo unscaled
-        gemm_x2_roll<NT, KS, KS3, 2 * NT + 1, NT, SWAP, kLookF, kValuF2, ZERO>(dst, xh, b6, tail, ring, hook);
+        gemm_x2_roll<NT, KS, KS3, 2 * NT + 1, NT, SWAP, kLookF, kValuF2, ZERO>(dst, xh, b6, tail, ring, hook, pre);
     } else {
         gemm_x3_roll<F16, NT, KSG, 2 * NT + 1, SWAP, kLookF, kValuF, ZERO>(dst, xh, xl, ring, hook);
     }
@@ -314,11 +348,6 @@ __device__ __forceinline__ void input_layer(f32x16 (&dst)[NT], const half8 (&ih)
     });
 }
 
-struct NoProducer {
-    __device__ __forceinline__ void prime() {}
-    template <int TILE, int C> __device__ __forceinline__ void chunk() {}
-    template <int TILE> __device__ __forceinline__ void convert() {}
-};
 
 #ifndef H3D_FIELD_RINGX2
 #define H3D_FIELD_RINGX2 8

@@ -106,6 +106,13 @@ __device__ __forceinline__ lds_ptr lane_base(const void* table, unsigned lane_by
     return reinterpret_cast<lds_ptr>(a);
 }
 __device__ __forceinline__ f32x4 ldt4(lds_ptr base, int float_index) { return lds_ld<f32x4>(base + 4 * float_index); }
+// The same read as a VOLATILE access: it keeps its place in program order against the sections' sched barriers and the ring's asm
+// statements.  For software-prefetched table rows: instruction selection otherwise sinks the (pure) load to its first use, one
+// section later, behind that section's burst of weight-fragment reads -- the wait for it is then s_waitcnt lgkmcnt(0), a drain of
+// the whole look-ahead (seen in the ISA of field_x3_kernel: every FiLM table read was the YOUNGEST read at its use).
+__device__ __forceinline__ f32x4 ldt4_pinned(lds_ptr base, int float_index) {
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) f32x4*>(base + 4 * float_index);
+}
 
 // Workgroup-shared weight ring in LDS, filled by LDS-DMA.  Stage = one k-step of one matrix = NT*2 chunks of 1 KB
 // ([tile][hi/lo][64 lanes][16 B]); the stream is linear in memory and wraps after `total` stages.
@@ -512,9 +519,13 @@ __device__ __forceinline__ i32x8 x2_record_dyn(const F16::vec8& l0, const F16::v
 // acc[nt] (+)= W x X over KS2 x2 k-steps (KS2 even; B operands xh[s] and the K-tile records b6[s / 2]) followed by KS3 x3
 // k-steps (B operands xh[s], xl3[s - KS2]: fragments assembled from memory, lo unscaled).  Same ring protocol, look-ahead
 // and hook convention as gemm_x3_roll; a section carries 2 (even x2 k-step), 4 (odd) or 6 (x3) MFMAs.
-template <int NT, int KS2, int KS3, int KSA, int KT, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook>
+// PRE: called as pre(IC<g>{}) at the top of section g, BEFORE the section's weight-fragment reads are issued: the place for a
+// software prefetch (a pinned LDS read) that must be OLDER than that burst, so that the wait for it one section later is
+// s_waitcnt lgkmcnt(burst size) and not a drain of the look-ahead.
+template <int NT, int KS2, int KS3, int KSA, int KT, bool SWAP, int L, int VALU_PER_MFMA = 0, bool ZERO = false, typename RING, typename HOOK = NoHook,
+          typename PRE = NoHook>
 __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 (&xh)[KSA], const i32x8 (&b6)[KT],
-                                             const F16::vec8 (&xl3)[KS3 > 0 ? KS3 : 1], RING& ring, HOOK hook = HOOK()) {
+                                             const F16::vec8 (&xl3)[KS3 > 0 ? KS3 : 1], RING& ring, HOOK hook = HOOK(), PRE pre = PRE()) {
     typedef F16 T;
     constexpr int KS = KS2 + KS3, P = NT / 2, G = KS * P, NB = L + 1;
     static_assert(NT % 2 == 0 && KS2 % 2 == 0 && KS <= KSA && KS2 / 2 <= KT && L >= 1 && L <= P, "look-ahead is at most one k-step");
@@ -562,6 +573,7 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (p == 0) H3D_TRACE(100 + s);
+        pre(gc);
         if constexpr (g + L < G) load_pair(IC<g + L>{});
         hook(gc);
         const Pair& b = buf[g % NB];

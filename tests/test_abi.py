@@ -86,3 +86,30 @@ def test_every_m0_write_in_the_library_is_a_weight_ring_dma(lib, tmp_path):
                 assert "global_load_lds_dwordx4" in text[i + 1], f"M0 write not followed by an LDS-DMA: {text[i + 1].strip()}"
                 n_writes += 1
     assert n_writes > 100        # the register engines' rings are in there
+
+
+def test_no_flat_memory_instruction_in_the_ring_kernels(lib, tmp_path):
+    """Round 5: a FLAT load / store (a generic pointer, e.g. one laundered through an empty asm) keeps LLVM's wait-count pass in
+    its "pending FLAT" state until a vmcnt(0) -- which the weight-ring kernels never execute -- and while it is pending EVERY LDS
+    wait is emitted as s_waitcnt lgkmcnt(0): the synthesis engines drained their whole fragment look-ahead at every table read
+    because of three FLAT stores of the RGB image.  No kernel that runs an LDS-DMA ring may contain a FLAT memory instruction."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    build = importlib.import_module("3dhumangan_amd._build")
+    so = shutil.copy(build.LIB, str(tmp_path / "libh3d.so"))
+    subprocess.run([objdump, "--offloading", so], cwd=str(tmp_path), capture_output=True, check=True)
+    objs = [str(tmp_path / f) for f in os.listdir(tmp_path) if "gfx950" in f]
+    ring_kernels = 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", o], capture_output=True, text=True, check=True).stdout
+        for body in re.split(r"\n(?=[0-9a-f]+ <)", text):                     # one chunk per symbol
+            if "global_load_lds_dwordx4" not in body:
+                continue
+            ring_kernels += 1
+            name = body.split("\n", 1)[0]
+            bad = [ln.strip() for ln in body.split("\n") if re.search(r"\bflat_(load|store|atomic)", ln)]
+            assert not bad, f"FLAT memory instruction in a weight-ring kernel {name}: {bad[:3]}"
+    assert ring_kernels >= 20
