@@ -738,6 +738,9 @@ def respawn_under_torchrun(a, argv):
     --master-port P bench.py ...).  Returns only when no re-exec is needed."""
     if a.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
         return
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but this node shows {have} GPU(s)")
     import socket
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))

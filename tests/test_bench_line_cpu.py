@@ -128,6 +128,12 @@ def test_gpus_n_respawns_under_torchrun(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     bench.respawn_under_torchrun(argparse.Namespace(gpus=1), ["--gpus", "1"])
     assert calls == []                                          # one GPU: plain process
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    with pytest.raises(SystemExit, match="--gpus 8 but this node shows 4"):
+        bench.respawn_under_torchrun(argparse.Namespace(gpus=8), ["--gpus", "8"])       # fewer GPUs than asked for: say so, do not spawn
+    assert calls == []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     bench.respawn_under_torchrun(argparse.Namespace(gpus=8), ["--gpus", "8", "--steps", "20", "--warmup", "5"])
     (exe, cmd, env), = calls
     assert exe == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
