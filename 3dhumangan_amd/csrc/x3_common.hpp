@@ -189,8 +189,17 @@ struct WeightRing {
         if (primed) return;
 #endif
 #ifndef H3D_RING_M0_PER_PIECE
-        if (C == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0" : : "s"(fill_m0), "v"(vslot), "s"(fill_g) : "m0");
-        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(vslot), "s"(fill_g), "n"(C * 1024));
+#if !defined(H3D_RING_POLICY_ID) || H3D_RING_POLICY_ID == 0      // cache-policy bits of the refill (experiments: 1 nt, 2 sc0, 3 sc1)
+#define H3D_RING_POLICY ""
+#elif H3D_RING_POLICY_ID == 1
+#define H3D_RING_POLICY " nt"
+#elif H3D_RING_POLICY_ID == 2
+#define H3D_RING_POLICY " sc0"
+#else
+#define H3D_RING_POLICY " sc1"
+#endif
+        if (C == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0" H3D_RING_POLICY : : "s"(fill_m0), "v"(vslot), "s"(fill_g) : "m0");
+        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" H3D_RING_POLICY : : "v"(vslot), "s"(fill_g), "n"(C * 1024));
 #else
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" : : "s"(fill_m0), "v"(vslot), "s"(fill_g), "n"(C * 1024) : "m0");
 #endif
