@@ -165,7 +165,7 @@ class SynthesisPlan:
         # Sampled error monitor of the x2 register engine (round 5): every forward re-evaluates ~16 of its 128-pixel tiles per
         # image on the fp32-class engine and raises the same device flag as the range guard when a sampled pixel differs by more
         # than `x2_monitor_tol` of the sample's channel maximum -- the bf16 engine behind it then redoes the batch.  The x2
-        # arithmetic uses up most of the 1e-3 parity budget (up to 9.5e-4 over 64 images, profiles/r5_x2_fullimage_error.txt):
+        # arithmetic uses up most of the 1e-3 parity budget (up to 9.6e-4 of the channel maximum over 192 images, profiles/r5_x2_fullimage_error.txt):
         # a pose / checkpoint that pushes it over is caught here instead of shipping.  H3D_SYNTH_MONITOR=0 switches it off.
         self.x2_monitor = os.environ.get("H3D_SYNTH_MONITOR", "1") != "0"
         self.x2_monitor_tol = float(os.environ.get("H3D_SYNTH_MONITOR_TOL", "1e-3"))

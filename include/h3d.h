@@ -442,7 +442,7 @@ int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* t
 
 /* Sampled error monitor of the x2 engine (round 5; replaces nothing in the reference -- its fp32 convolutions,
  * lib/components/map3d_layers.py:176-238, have no reduced-precision tier to watch).  The x2 arithmetic sits inside the 1e-3
- * parity budget with little room (measured over 64 images: up to 9.5e-4 of the channel maximum), so every forward checks a
+ * parity budget with little room (measured over 192 images: up to 9.6e-4 of the channel maximum, median 2.2e-4), so every forward checks a
  * sample of its own output against the fp32-class engine:
  *   h3d_synthesis_x3_tiles  h3d_synthesis_x3 (single launch, `stream` in the x3 format) restricted to the 128-pixel tiles
  *                           tile_first, tile_first + tile_step, .. of every sample; writes those pixels of `rgb` (a scratch
