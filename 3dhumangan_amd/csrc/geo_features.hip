@@ -109,7 +109,8 @@ template <bool FEATURES, bool SORTED>
 __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     const float* __restrict__ points, const float* __restrict__ joints, const float* __restrict__ vertices,
     const float* __restrict__ tpose, const float* __restrict__ vertex_ik, float* __restrict__ geo,
-    int32_t* __restrict__ nn_index, int64_t N, int V, int Vpad, int geo_stride, int legacy_mode) {
+    int32_t* __restrict__ nn_index, int64_t N, int V, int Vpad, int geo_stride, int legacy_mode, int tile_S, int tile_Wr,
+    int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* vx = smem;
     float* vy = smem + Vpad;
@@ -144,14 +145,35 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
     __syncthreads();
     const float v2max = __uint_as_float(*v2max_bits);
 
-    // A wave owns 256 consecutive points as 8 sets of 32: lane (m, hh) owns points (4*hh + k) * 32 + m, k = 0..3.
+    // A wave owns 256 points as 8 sets of 32: lane (m, hh) owns the wave's points i = (4*hh + k) * 32 + m, k = 0..3.
+    // Linear (tile_S == 0): point wbase + i -- 256 CONSECUTIVE points, i.e. 256 / S whole neighbouring rays: a thin slab as long as
+    // the rays.  Tiled (round 5; the points are [Hr, Wr, S] rays x samples): an 8 x 8 patch of rays x 4 consecutive samples -- a
+    // compact box, so that far fewer mesh chunks intersect the search spheres of ALL of the wave's points (the pruning rule is
+    // per wave) -- wave w of a pose = (patch row, patch column, sample block); the result is the exact arg-min either way.
     const int lane = t & 63, m = lane & 31, hh = lane >> 5;
-    const int64_t wbase = ((int64_t)blockIdx.x * kThreads + (t & ~63)) * kPts;
+    const int64_t wave_id = (int64_t)blockIdx.x * (kThreads / 64) + (t >> 6);
+    const int64_t wbase = wave_id * 256;
+    int64_t tile_base = 0;
+    bool tile_ok = true;
+    if (tile_S > 0) {
+        const int tiles_s = tile_S / 4;
+        const int sz = (int)(wave_id % tiles_s);
+        const int64_t pxy = wave_id / tiles_s;
+        const int px_ = (int)(pxy % tiles_x), py_ = (int)(pxy / tiles_x);
+        tile_ok = py_ < tiles_y;
+        tile_base = (((int64_t)py_ * 8) * tile_Wr + px_ * 8) * tile_S + sz * 4;         // point index of (ray 0 of the patch, sample 4 sz)
+    }
+    auto point_of = [&](int i) -> int64_t {
+        if (tile_S == 0) return wbase + i;
+        if (!tile_ok) return N;                                                          // past the last patch row: masked like n >= N
+        const int ri = i >> 2;                                                           // ray of the patch: (ri >> 3, ri & 7)
+        return tile_base + ((int64_t)(ri >> 3) * tile_Wr + (ri & 7)) * tile_S + (i & 3);
+    };
     float px[kPts], py[kPts], pz[kPts], best[kPts];
     int bi[kPts];
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        const int64_t n = wbase + (4 * hh + k) * 32 + m;
+        const int64_t n = point_of((4 * hh + k) * 32 + m);
         const bool ok = n < N;
         const float* p = points + ((int64_t)b * N + (ok ? n : 0)) * 3;
         px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void geo_features_kernel(
 
 #pragma unroll
     for (int k = 0; k < kPts; ++k) {
-        const int64_t n = wbase + (4 * hh + k) * 32 + m;
+        const int64_t n = point_of((4 * hh + k) * 32 + m);
         if (n >= N) continue;
         const int idx = bi[k];
         if constexpr (!FEATURES) {
@@ -440,7 +462,7 @@ int next_pow2(int v) {
 
 static int geo_launch(bool features, bool sorted, const float* points, const float* joints, const float* vertices,
                       const float* tpose_vertices, const float* vertex_ik, float* geo, int32_t* nn_index,
-                      int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream) {
+                      int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream, int Hr = 0, int Wr = 0, int S = 0) {
     H3D_REQUIRE(B >= 0 && B <= 65535 && N >= 0, "h3d_geo_features / h3d_nearest_vertex: bad B=%d N=%lld", B, (long long)N);
     H3D_REQUIRE(V >= 1, "h3d_geo_features / h3d_nearest_vertex: V=%d", V);
     if (B == 0 || N == 0) return H3D_OK;
@@ -453,14 +475,21 @@ static int geo_launch(bool features, bool sorted, const float* points, const flo
     H3D_ALLOW_MAX_LDS((geo_features_kernel<true, true>));
     H3D_ALLOW_MAX_LDS((geo_features_kernel<false, true>));
     const int64_t per_block = (int64_t)kThreads * kPts;
-    const int64_t gx = (N + per_block - 1) / per_block;
+    int64_t gx = (N + per_block - 1) / per_block;
+    // compact wave tiles (8 x 8 rays x 4 samples) when the caller says how the points are laid out and the shape divides
+    int tile_S = 0, tiles_x = 0, tiles_y = 0;
+    if (S > 0 && Hr > 0 && Wr > 0 && (int64_t)Hr * Wr * S == N && Hr % 8 == 0 && Wr % 8 == 0 && S % 4 == 0) {
+        tile_S = S; tiles_x = Wr / 8; tiles_y = Hr / 8;
+        const int64_t waves = (int64_t)tiles_x * tiles_y * (S / 4);
+        gx = (waves + kThreads / 64 - 1) / (kThreads / 64);
+    }
     H3D_REQUIRE(gx < (int64_t(1) << 31), "h3d_geo_features: N too large");
     h3d::pre_launch();
     const dim3 grid((unsigned)gx, B), block(kThreads);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define H3D_GEO_LAUNCH(F, S)                                                                                                    \
     hipLaunchKernelGGL((geo_features_kernel<F, S>), grid, block, lds, st, points, joints, vertices, tpose_vertices, vertex_ik, geo, \
-                       nn_index, N, V, Vpad, geo_stride, legacy_mode)
+                       nn_index, N, V, Vpad, geo_stride, legacy_mode, tile_S, Wr, tiles_x, tiles_y)
     if (features && sorted) H3D_GEO_LAUNCH(true, true);
     else if (features) H3D_GEO_LAUNCH(true, false);
     else if (sorted) H3D_GEO_LAUNCH(false, true);
@@ -519,6 +548,20 @@ extern "C" int h3d_geo_features_sorted(const float* points, const float* joints,
     H3D_REQUIRE(h3d::aligned16(vertex_ik) && h3d::aligned16(sorted_mesh), "h3d_geo_features_sorted: vertex_ik / sorted_mesh must be 16-byte aligned");
     return geo_launch(true, true, points, joints, static_cast<const float*>(sorted_mesh), tpose_vertices, vertex_ik, geo, nn_index, B, N, V,
                       geo_stride, legacy_mode, stream);
+}
+
+/* h3d_nearest_vertex_sorted for points that are the samples of a render grid, points [B, Hr, Wr, S, 3] (rays row-major, the S
+ * samples of a ray contiguous: what h3d_ray_setup writes): a wave then takes an 8 x 8 patch of rays x 4 consecutive samples
+ * instead of 256 consecutive points (= a few whole rays), a compact box that lets the bounding-sphere test skip far more of the
+ * mesh.  Same indices bit for bit.  Shapes that do not divide (Hr or Wr not a multiple of 8, S not a multiple of 4) fall back to
+ * the linear assignment. */
+extern "C" int h3d_nearest_vertex_sorted_rays(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int Hr, int Wr,
+                                              int S, int V, h3d_stream_t stream) {
+    H3D_REQUIRE(points && sorted_mesh && nn_index, "h3d_nearest_vertex_sorted_rays: null pointer");
+    H3D_REQUIRE(h3d::aligned16(sorted_mesh), "h3d_nearest_vertex_sorted_rays: sorted_mesh must be 16-byte aligned");
+    H3D_REQUIRE(Hr >= 1 && Wr >= 1 && S >= 1, "h3d_nearest_vertex_sorted_rays: bad grid %dx%dx%d", Hr, Wr, S);
+    return geo_launch(false, true, points, nullptr, static_cast<const float*>(sorted_mesh), nullptr, nullptr, nullptr, nn_index, B,
+                      (int64_t)Hr * Wr * S, V, 31, 0, stream, Hr, Wr, S);
 }
 
 extern "C" int h3d_nearest_vertex_sorted(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int64_t N, int V,

@@ -9,6 +9,7 @@ GEO_DIM = 31
 # H3D_NN_PRUNE=0: the full scan of the unsorted mesh (h3d_geo_features / h3d_nearest_vertex) instead of the pruned scan of the
 # Morton-sorted one (h3d_mesh_sort + h3d_*_sorted): the same indices bit for bit, for A/B measurements
 PRUNE = os.environ.get("H3D_NN_PRUNE", "1") != "0"
+TILED = os.environ.get("H3D_NN_TILED", "1") != "0"      # compact 8 x 8 x 4 boxes of samples per wave (nearest_vertex(ray_shape=...))
 
 
 def sort_mesh(vertices):
@@ -70,17 +71,23 @@ def get_geo_features(points, skeletons, vertices, tpose_vertices, fk_matrices, l
     return (geo, idx) if return_index else geo
 
 
-def nearest_vertex(points, vertices):
+def nearest_vertex(points, vertices, ray_shape=None):
     """K = 1 nearest mesh vertex of every point (the search inside get_geo_features; pytorch3d.ops.knn_points at
     lib/components/smpl.py:220 of the reference): points [B,N,3], vertices [B,V,3] -> int32 [B,N].  Feeds the fused render
-    kernels that build the geometry features themselves (COORDCONCATSIREN.render_geo)."""
+    kernels that build the geometry features themselves (COORDCONCATSIREN.render_geo).
+    ray_shape = (Hr, Wr, S): the points are the samples of a render grid, [B, Hr, Wr, S, 3] flattened (round 5) -- the pruned
+    search then works on compact 8 x 8 x 4 boxes of samples (h3d_nearest_vertex_sorted_rays; H3D_NN_TILED=0: the linear
+    assignment); the same indices either way."""
     _lib.need_cuda(points, vertices)
     B, N, _ = points.shape
     pts = points.contiguous().float()
     vt = vertices.contiguous().float()
     idx = torch.empty((B, N), device=pts.device, dtype=torch.int32)
     ws = sort_mesh(vt) if PRUNE and B > 0 and N > 0 else None
-    if ws is not None:
+    if ws is not None and ray_shape is not None and TILED and int(ray_shape[0]) * int(ray_shape[1]) * int(ray_shape[2]) == N:
+        rc = _lib.load().h3d_nearest_vertex_sorted_rays(_lib.ptr(pts), _lib.ptr(ws), _lib.ptr(idx), B, int(ray_shape[0]),
+                                                        int(ray_shape[1]), int(ray_shape[2]), vt.shape[1], _lib.stream_handle())
+    elif ws is not None:
         rc = _lib.load().h3d_nearest_vertex_sorted(_lib.ptr(pts), _lib.ptr(ws), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())
     else:
         rc = _lib.load().h3d_nearest_vertex(_lib.ptr(pts), _lib.ptr(vt), _lib.ptr(idx), B, N, vt.shape[1], _lib.stream_handle())

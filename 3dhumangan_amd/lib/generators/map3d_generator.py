@@ -413,7 +413,7 @@ class Map3DGenerator(nn.Module):
         with stage(self, "geo_features"):
             if geo_in:
                 vik = smpl.vertex_inverse_transforms(c["fk_matrices"], c["lbs_weights"])
-                nn_index = smpl.nearest_vertex(pts, c["vertices"])
+                nn_index = smpl.nearest_vertex(pts, c["vertices"], ray_shape=(render_height, render_width, S))
                 geo = None
             else:
                 geo = self.get_geo_features(pts, c["skeletons_xyz"], c["vertices"], c["tpose_vertices"], c["fk_matrices"],

@@ -110,6 +110,12 @@ int h3d_geo_features_sorted(const float* points, const float* joints, const void
                             int B, int64_t N, int V, int geo_stride, int legacy_mode, h3d_stream_t stream);
 int h3d_nearest_vertex_sorted(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int64_t N, int V,
                               h3d_stream_t stream);
+/* The same search for points that are the samples of a render grid, points [B, Hr, Wr, S, 3] (what h3d_ray_setup writes;
+ * reference: the `transformed_points` of lib/generators/map3d_generator.py:397-415 handed to get_geo_features): a wave takes an
+ * 8 x 8 patch of rays x 4 consecutive samples instead of 256 consecutive points -- a compact box, so the bounding-sphere test
+ * skips far more of the mesh.  Same indices bit for bit; shapes that do not divide (Hr, Wr % 8, S % 4) use the linear assignment. */
+int h3d_nearest_vertex_sorted_rays(const float* points, const void* sorted_mesh, int32_t* nn_index, int B, int Hr, int Wr, int S,
+                                   int V, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A5  pose-conditioned FiLM-SIREN == lib/implicit_funcitions/modulated.py:41-75 (COORDCONCATSIREN.forward)

@@ -127,6 +127,21 @@ def test_pruned_search_on_the_sorted_mesh_equals_the_full_scan_at_render_scale(m
     monkeypatch.setattr(smpl, "PRUNE", False)
     full = smpl.nearest_vertex(pts, c["vertices"])
     assert torch.equal(pruned, full)
+    # round 5: the same search with compact wave tiles (8 x 8 rays x 4 samples: h3d_nearest_vertex_sorted_rays) -- the same indices
+    monkeypatch.setattr(smpl, "PRUNE", True)
+    tiled = smpl.nearest_vertex(pts, c["vertices"], ray_shape=(96, 96, 64))
+    assert torch.equal(tiled, full)
+    monkeypatch.setattr(smpl, "TILED", False)
+    assert torch.equal(smpl.nearest_vertex(pts, c["vertices"], ray_shape=(96, 96, 64)), full)
+    monkeypatch.setattr(smpl, "TILED", True)
+    for hr, wr, ss in ((24, 16, 8), (20, 16, 8), (16, 12, 8), (16, 16, 6), (8, 8, 4)):     # dividing and non-dividing grids
+        n = hr * wr * ss
+        q = pts[:, 5000: 5000 + n].contiguous()
+        monkeypatch.setattr(smpl, "PRUNE", False)
+        want = smpl.nearest_vertex(q, c["vertices"])
+        monkeypatch.setattr(smpl, "PRUNE", True)
+        assert torch.equal(smpl.nearest_vertex(q, c["vertices"], ray_shape=(hr, wr, ss)), want), (hr, wr, ss)
+    monkeypatch.setattr(smpl, "PRUNE", False)
     sub = torch.randperm(pts.shape[1], generator=torch.Generator().manual_seed(1))[:6000]
     sub = torch.cat([sub, torch.arange(0, 7 * 300, 7)])             # some of the tied ones too
     _, ridx = O.nearest_vertex(pts[:, sub].cpu().float(), cond["vertices"].float())
