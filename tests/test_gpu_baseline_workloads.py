@@ -111,3 +111,21 @@ def test_cfg2_256sq_b8():
 def test_cfg3L_released_checkpoint_architecture_b4():
     """MAP3DBN512L (hidden 420, legacy geometry-feature order, isolated styles) at the cfg-3 geometry."""
     check_workload("MAP3DBN512L", (512, 512), (96, 96), 64, 4, oracle_items=(1,))
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_cfg3_bench_workload_more_seeds_checked_as_the_bench_checks_itself(seed):
+    """Three more (weights, latents, pose, jitter) draws of the bench workload through bench.py's own in-run check (self_check: the
+    oracle on a pixel / ray subset, errors relative to the whole image's channel maximum, rays excluded only where the ORACLE's
+    last-sample density is within the tolerance of zero, at most max(1, 5e-4 n) of them): the default engines with their guard and
+    monitor stay inside 1e-3 on draws the round's measurements were not tuned on."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    G, cfg, z, cond, jit = make("MAP3DBN512", (512, 512), (96, 96), 64, 16, seed)
+    chk = bench.self_check(G, cfg, z.to(DEV), {k: v.to(DEV) for k, v in cond.items()}, jit.to(DEV), [0, 11], n_cells=8)
+    print(f"seed {seed}: image {chk['max_rel_err']:.2e} (subset-normalised {chk['max_rel_err_subset_norm']:.2e}), render "
+          f"{chk['max_rel_err_render']:.2e}, excluded rays {chk['rays_excluded_as_ill_conditioned_in_the_oracle']}, monitor {chk['x2_monitor']}")
+    assert chk["ok"] and chk["max_rel_err"] < TOL and chk["max_rel_err_render"] < TOL
+    assert chk["synthesis_engine"] == "f16x2"
