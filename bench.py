@@ -826,9 +826,14 @@ def main():
     n_images = a.batch * world * a.steps
     value = n_images / dt
 
+    # every collective of the run is behind us (the MAX over ranks of the elapsed time): ALL ranks leave the process group here,
+    # together -- rank 0 then spends a minute on single-rank legs (roofline of A6, the oracle check) and must not find itself
+    # tearing down a communicator whose peers exited long ago
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        dist_on = False
     if rank != 0:
-        if dist_on:
-            torch.distributed.destroy_process_group()
         return
 
     kernels = kernel_rooflines(G, cfg, a.batch, stage_ms)
