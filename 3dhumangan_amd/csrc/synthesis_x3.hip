@@ -59,6 +59,7 @@ struct Args {
     int load_state, store_state;
     int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
     int n_walk, tile_first, tile_step;   // the tiles a launch covers: tile_first + i * tile_step, i < n_walk (all of them: 0, 1, n_tiles)
+    int heads;             // x2 plans with ToRGB head tables: no zero table of "no ToRGB" weights in LDS (the producers carry no ToRGB)
     int* ovf;              // x2: set to 1 when an activation leaves the range the f16 planes carry (nullable)
     const int* run_if;     // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 engine
 };
@@ -233,8 +234,19 @@ struct SpadeProducer {
 
 // conv GEMM dst (+)= W * frags(producer(src)) with the fragment epilogue of tile t+1 hidden behind the MFMAs of k-steps
 // 2t, 2t+1 (which only need tile t); only tile 0's epilogue is exposed.  src and dst are different register sets.
-template <int NT, bool ZERO, bool X2, typename V8, typename RING, typename PROD>
-__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], RING& ring, PROD& prod) {
+// HEAD (x2 only, round 5): the ToRGB of everything downstream of this convolution rides along as a NINTH output tile on
+// pre-multiplied weights -- rgb = sum_k Wr_k x_k over the skip blocks is (sum_k Wr_k) x_base + sum_j [(sum_{k >= j} Wr_k) W1_j] y_j,
+// so block j's second convolution also multiplies its input fragments y_j with the 3 x C matrix M_j = V_j W1_j (host:
+// SynthesisPlan.build_x3) in the same x2 arithmetic: per k-step one f16 product, per K-tile one fp6 product, accumulated in `hacc`
+// across ALL skip blocks.  Its A operand comes from a 4 KB LDS table per block -- [k-step][f16 hi fragment | half of the fp6
+// record][4 rows x 2 lane halves][16 B], lane (m, h) reads row m & 3 -- one k-step ahead of its use.  Replaces the 3 FMAs per
+// activation that the ToRGB used to cost in the producer of the NEXT block's first convolution (1 920 vector instructions per tile).
+template <int NT, bool ZERO, bool X2, bool HEAD = false, typename V8, typename RING, typename PROD>
+__device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 * NT], V8 (&xl)[2 * NT], i32x8 (&b6)[NT], RING& ring, PROD& prod,
+                                                 f32x16* hacc = nullptr, lds_ptr hbase = nullptr) {
+    static_assert(!HEAD || X2, "the ToRGB head tile exists in the x2 arithmetic only");
+    u32x4 hfrag = {}, hr0 = {}, hr1 = {};
+    (void)hfrag; (void)hr0; (void)hr1;
     prod.prime();
     static_for<0, 8>([&](auto c) __attribute__((always_inline)) { prod.template chunk<0, decltype(c)::value>(); });
     __builtin_amdgcn_sched_barrier(0);
@@ -247,6 +259,23 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
         if constexpr (t < NT) {
             static_for<0, PER>([&](auto q) __attribute__((always_inline)) { prod.template chunk<t, j * PER + decltype(q)::value>(); });
         }
+        if constexpr (HEAD) {
+            constexpr int P = NT / 2, ks = g / P, p = g % P;
+            if constexpr (p == 0) {                   // this k-step's head fragment (and, in an odd k-step, the K-tile's record halves)
+                hfrag = lds_ld<u32x4>(hbase + ks * 256);
+                if constexpr (ks % 2 == 1) {
+                    hr0 = lds_ld<u32x4>(hbase + (ks - 1) * 256 + 128);
+                    hr1 = lds_ld<u32x4>(hbase + ks * 256 + 128);
+                }
+            }
+            if constexpr (p == P / 2) {               // two sections later: the reads have landed behind the section's own matrix work
+                *hacc = F16::mfma(__builtin_bit_cast(F16::vec8, hfrag), xh[ks], *hacc);
+                if constexpr (ks % 2 == 1) {
+                    const i32x8 w6 = {(int)hr0[0], (int)hr0[1], (int)hr0[2], (int)hr0[3], (int)hr1[0], (int)hr1[1], (int)hr1[2], 0};
+                    *hacc = mm6<false>(w6, b6[ks / 2], *hacc);
+                }
+            }
+        }
     };
     if constexpr (X2) {
         const F16::vec8 none[1] = {};
@@ -256,9 +285,11 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
     }
 }
 
-template <int NT, int DEPTH, bool SEG, bool X2>
+template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT, kHdP = NT * 32;       // the host sets A.HdP = 32 NT: table strides are compile-time
+    constexpr bool kHeads = HEADS;                   // ToRGB of the skip blocks as a ninth tile of their second convolution (conv_progressive)
+    static_assert(!HEADS || (X2 && !SEG), "ToRGB heads: single-launch x2 plans only");
     typedef typename std::conditional<X2, F16, BF16>::type T;
     typedef typename T::vec8 frag8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -267,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     float* ab0 = tab0 + ((A.table_floats + 3) & ~3);         // [n_ab][2][HdP] this sample's constant-style affines
     float* cst0 = ab0 + A.n_ab * 2 * HdP;                    // [n_cst][128]   this sample's shared-MLP constants
     float* zero0 = cst0 + A.n_cst * kShared;                 // [3][HdP] zeros: ToRGB weights of "no ToRGB"
-    int* dtab = reinterpret_cast<int*>(zero0 + 3 * HdP);     // [H3D_MAX_BLOCKS + 1][kDescInts] the descriptor fields the block loops read
+    int* dtab = reinterpret_cast<int*>(zero0 + (HEADS ? 0 : 3 * HdP));     // [H3D_MAX_BLOCKS + 1][kDescInts] the descriptor fields the block loops read
     unsigned char* ring_lds = reinterpret_cast<unsigned char*>(dtab + (H3D_MAX_BLOCKS + 1) * kDescInts);
 
     if (A.run_if && *A.run_if == 0) return;          // guarded fallback: nothing to redo
@@ -292,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
                 d[3 + 4 * q] = bd.spade[q].ab_index; d[4 + 4 * q] = bd.spade[q].cst_index;
                 d[5 + 4 * q] = bd.spade[q].g_offset; d[6 + 4 * q] = (int)bd.spade[q].vec;
             }
+            d[11] = (int)bd.spade[1].b_conv;         // skip blocks of an x2 plan with ToRGB heads: float offset of the block's head table (else -1)
         } else {
             d[0] = A.D.n_blocks; d[1] = (int)A.D.w_in; d[2] = (int)A.D.b_in;
         }
@@ -301,7 +333,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     for (int i = t; i < A.table_floats; i += 256) tab0[i] = A.tables[i];
     for (int i = t; i < A.n_ab * 2 * HdP; i += 256) ab0[i] = A.ab[(int64_t)b * A.n_ab * 2 * HdP + i];
     for (int i = t; i < A.n_cst * kShared; i += 256) cst0[i] = A.cst[(int64_t)b * A.n_cst * kShared + i];
-    for (int i = t; i < 3 * HdP; i += 256) zero0[i] = 0.f;
+    if constexpr (!HEADS) {
+        for (int i = t; i < 3 * HdP; i += 256) zero0[i] = 0.f;
+    }
     __syncthreads();
 
     H3D_TRACE_INIT();
@@ -367,6 +401,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     frag8 xh[KS], xl[KS];
     i32x8 b6[NT];
     float rgb_acc[3] = {0.f, 0.f, 0.f};
+    f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // kHeads: rows r = head r & 3, all skip blocks
+    (void)hacc;
 
     const int64_t wtile = (int64_t)b * n_tiles * 4 + (int64_t)tile * 4 + wave;
     float4* st_io = reinterpret_cast<float4*>(A.state) + wtile * (NT * 4 + 1) * 64 + lane;
@@ -590,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 #ifdef H3D_EXPERIMENT_NO_RGB
             SpadeProducer<NT, true, false, X2, frag8> prod{x, xh, xl, b6, lane_base(abt + dget(blk, 3) * 2 * HdP, 32 * h), lane_base(wr_prev, 16 * h), rgb_acc, gmax};
 #else
-            SpadeProducer<NT, true, true, X2, frag8> prod{x, xh, xl, b6, lane_base(abt + dget(blk, 3) * 2 * HdP, 32 * h), lane_base(wr_prev, 16 * h), rgb_acc, gmax};
+            SpadeProducer<NT, true, !kHeads, X2, frag8> prod{x, xh, xl, b6, lane_base(abt + dget(blk, 3) * 2 * HdP, 32 * h), lane_base(wr_prev, 16 * h), rgb_acc, gmax};
 #endif
             conv_progressive<NT, true, X2>(acc, xh, xl, b6, ring, prod);
         }
@@ -598,7 +634,11 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         H3D_TRACE(21);
         {
             SpadeProducer<NT, true, false, X2, frag8> prod{acc, xh, xl, b6, lane_base(abt + dget(blk, 7) * 2 * HdP, 32 * h), nullptr, rgb_acc, gmax};
-            conv_progressive<NT, false, X2>(x, xh, xl, b6, ring, prod);
+            if constexpr (kHeads) {
+                conv_progressive<NT, false, X2, true>(x, xh, xl, b6, ring, prod, &hacc, lane_base(tab + dget(blk, 11), ((lane & 3) + 4 * h) * 16));
+            } else {
+                conv_progressive<NT, false, X2>(x, xh, xl, b6, ring, prod);
+            }
         }
         pin_agpr<NT>(x);
         if (dget(blk, 0) && h == 0) {          // bias of this block's ToRGB; its weights ride in the next block's conv 0
@@ -608,6 +648,11 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     }
     H3D_TRACE(5);
     if (n_blocks > first_skip && dget(n_blocks - 1, 0)) to_rgb(tab0 + dget(n_blocks - 1, 1), false);
+    if constexpr (kHeads) {
+        // the head tile: every lane holds the complete sums of its pixel (rows = heads, replicated); the store below adds the two
+        // lane halves, so only one of them contributes
+        if (h == 0) { rgb_acc[0] += hacc[0]; rgb_acc[1] += hacc[1]; rgb_acc[2] += hacc[2]; }
+    }
     H3D_TRACE(6);
     if (SEG && A.store_state) {
 #pragma unroll
@@ -637,13 +682,13 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
 }
 
 size_t lds_bytes(const Args& A, int NT, int depth) {
-    return sizeof(int) * (H3D_MAX_BLOCKS + 1) * kDescInts + sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared + 3 * (size_t)A.HdP) +
+    return sizeof(int) * (H3D_MAX_BLOCKS + 1) * kDescInts + sizeof(float) * ((size_t)((A.table_floats + 3) & ~3) + (size_t)A.n_ab * 2 * A.HdP + (size_t)A.n_cst * kShared + (A.heads ? 0 : 3 * (size_t)A.HdP)) +
            (size_t)depth * NT * 2048;
 }
 
-template <int NT, int DEPTH, bool SEG, bool X2>
+template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false>
 int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2>));
+    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS>));
     A.n_tiles = (int)groups;
     if (A.tile_step <= 0) { A.tile_first = 0; A.tile_step = 1; }
     A.n_walk = A.tile_first < A.n_tiles ? (A.n_tiles - A.tile_first + A.tile_step - 1) / A.tile_step : 0;
@@ -660,16 +705,19 @@ int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
     static const int per_cu = getenv("H3D_SYNTH_WG_PER_CU") ? atoi(getenv("H3D_SYNTH_WG_PER_CU")) : 4;      // 0: one tile per workgroup
     const int64_t per_sample = (SEG || per_cu <= 0) ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH + (X2 ? 1 : 0)), st, A);
     return h3d::launch_status(X2 ? "h3d_synthesis_x2" : "h3d_synthesis_x3");
 }
 
 template <int NT, int DEPTH, bool X2>
-int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+int launch_one(const Args& A, int B, int64_t groups, hipStream_t st, bool heads = false) {
     // the state load/store paths are compiled only into the segmented variant (they cost registers)
-    return (A.load_state || A.store_state) ? launch_seg<NT, DEPTH, true, X2>(A, B, groups, st)
-                                           : launch_seg<NT, DEPTH, false, X2>(A, B, groups, st);
+    if (A.load_state || A.store_state) return launch_seg<NT, DEPTH, true, X2>(A, B, groups, st);
+    if constexpr (X2) {
+        if (heads) return launch_seg<NT, DEPTH, false, true, true>(A, B, groups, st);
+    }
+    return launch_seg<NT, DEPTH, false, X2>(A, B, groups, st);
 }
 
 }  // namespace
@@ -744,7 +792,15 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
         return H3D_EUNSUPPORTED;
     }
     H3D_REQUIRE(!any_const || ab, "h3d_synthesis_x3: ab table missing");
-    H3D_REQUIRE(store_state || desc->block[desc->n_blocks - 1].to_rgb, "h3d_synthesis_x3: the last block must feed ToRGB");
+    H3D_REQUIRE(store_state || desc->block[desc->n_blocks - 1].to_rgb || (x2 && desc->block[desc->n_blocks - 1].spade[1].b_conv >= 0),
+                "h3d_synthesis_x3: the last block must feed ToRGB");
+    for (int k = 0; k < desc->n_blocks; ++k) {
+        const int64_t ho = desc->block[k].spade[1].b_conv;       // x2 plans: the ToRGB head table of a skip block (floats into `tables`)
+        if (ho < 0) continue;
+        H3D_REQUIRE(x2 && !load_state && !store_state && desc->block[k].skip && !desc->block[k].to_rgb && (ho & 3) == 0 &&
+                        ho + (int64_t)2 * NT * 64 <= table_floats,
+                    "h3d_synthesis_x2: bad ToRGB head table of block %d (offset %lld)", k, (long long)ho);
+    }
     H3D_REQUIRE((!load_state && !store_state) || (state && h3d::aligned16(state)), "h3d_synthesis_x3: state buffer missing");
     if (B == 0) return H3D_OK;
     Args A{};
@@ -757,6 +813,7 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     A.table_floats = table_floats; A.total_stages = (int)total_stages; A.g_channels = g_channels; A.Hr = Hr; A.Wr = Wr;
     if (!any_pixel) A.g_channels = 0;
     A.n_cst = n_cst; A.n_ab = n_ab; A.H = H; A.W = W; A.C = desc->C; A.HdP = NT * 32; A.first_skip = first_skip; A.n_pixel_blocks = n_pixel_blocks;
+    for (int k = 0; k < desc->n_blocks; ++k) A.heads = A.heads || desc->block[k].spade[1].b_conv >= 0;      // validated above: x2, single launch
     const int extra = x2 ? 1 : 0;                                      // x2 keeps one more ring buffer (WeightRing LAG = 1)
     const bool deep = lds_bytes(A, NT, 6 + extra) <= 160 * 1024;      // deepest weight ring the tables leave room for
     if (lds_bytes(A, NT, kRingDepth + extra) > 160 * 1024) {
@@ -766,13 +823,14 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     const int64_t groups = ((int64_t)H * W + 127) / 128;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_synthesis_x3: image too large");
     hipStream_t st = static_cast<hipStream_t>(stream_);
+    const bool heads = A.heads != 0;                                 // x2 plans: ToRGB head tables present
 #ifdef H3D_DEV_ONLY_HOT       // development: compile only the instantiation the BASELINE cfg-3 bench runs (fast ISA / resource turnaround)
     (void)deep;
-    return launch_seg<8, kRingDepth, false, true>(A, B, groups, st);
+    return heads ? launch_seg<8, kRingDepth, false, true, true>(A, B, groups, st) : launch_seg<8, kRingDepth, false, true>(A, B, groups, st);
 #else
     if (x2) {
-        if (NT == 8) return deep ? launch_one<8, 6, true>(A, B, groups, st) : launch_one<8, kRingDepth, true>(A, B, groups, st);
-        return deep ? launch_one<4, 6, true>(A, B, groups, st) : launch_one<4, kRingDepth, true>(A, B, groups, st);
+        if (NT == 8) return deep ? launch_one<8, 6, true>(A, B, groups, st, heads) : launch_one<8, kRingDepth, true>(A, B, groups, st, heads);
+        return deep ? launch_one<4, 6, true>(A, B, groups, st, heads) : launch_one<4, kRingDepth, true>(A, B, groups, st, heads);
     }
     if (NT == 8) return deep ? launch_one<8, 6, false>(A, B, groups, st) : launch_one<8, kRingDepth, false>(A, B, groups, st);
     return deep ? launch_one<4, 6, false>(A, B, groups, st) : launch_one<4, kRingDepth, false>(A, B, groups, st);
@@ -912,6 +970,8 @@ extern "C" int h3d_synthesis_check(const float* rgb, const float* rgb_ref, int B
 extern "C" int64_t h3d_synthesis_x3_lds_bytes(int table_floats, int n_ab, int n_cst, int C, int x2) {
     Args A{};
     A.table_floats = table_floats; A.n_ab = n_ab; A.n_cst = n_cst;
+    A.heads = (x2 & 2) != 0;                 // x2 = 1: the x2 engine; x2 = 3: an x2 plan with ToRGB head tables (no zero table in LDS)
+    x2 &= 1;
     const int NT = C > 128 ? 8 : 4;
     A.HdP = NT * 32;
     return (int64_t)lds_bytes(A, NT, kRingDepth + (x2 ? 1 : 0));

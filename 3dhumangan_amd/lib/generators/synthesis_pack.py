@@ -194,10 +194,11 @@ class SynthesisPlan:
         return self._x3_fits(False)
 
     def _x3_fits(self, x2):
-        x3 = self.build_x3()
+        x3 = self.build_x3(bool(x2))           # the plan that would run: an x2 plan with ToRGB heads has its own table set
         need = _lib.load().h3d_synthesis_x3_lds_bytes
-        return all(need(seg["tables"].numel(), len(self.const_ids), len(self.pixel_ids), self.C, int(x2)) <= 160 * 1024
-                   for seg in x3["segments"])
+        heads = lambda seg: any(seg["desc"].block[j].spade[1].b_conv >= 0 for j in range(seg["desc"].n_blocks))
+        return all(need(seg["tables"].numel(), len(self.const_ids), len(self.pixel_ids), self.C,
+                        (3 if heads(seg) else 1) if x2 else 0) <= 160 * 1024 for seg in x3["segments"])
 
     # |x| < 2^15 keeps both f16 planes of the x2 arithmetic finite (hi = f16(x); lo * 2^12 <= ulp(hi) * 2^11): csrc/synthesis_x3.hip
     X2_LIMIT = 32768.0
@@ -449,6 +450,7 @@ class SynthesisPlan:
             desc.w_in = add(torch.cat([_pad(self._w_in[:, 0], HdP), _pad(self._w_in[:, 1], HdP)]))
             desc.b_in = add(_pad(self._b_in, HdP))
             stream, stages = [], 0
+            rgb_tables = {}                                         # block j of this segment -> (Wr [3, C], br' [3]) as written to the tables
             for j, k in enumerate(blocks):
                 src, dst = self.desc.block[k], desc.block[j]
                 dst.skip, dst.to_rgb = src.skip, src.to_rgb
@@ -474,11 +476,57 @@ class SynthesisPlan:
                 if dst.to_rgb:
                     wr, br = self._rgb[k]
                     br = br.float() + wr.float() @ carry[: wr.shape[1]]
-                    dst.w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
+                    rgb_tables[j] = (wr.float(), br)
+            # ToRGB tables: one per block -- or, x2 single-launch plans, the head tiles of the skip blocks (_torgb_heads), which
+            # replace the tables of the skip blocks and of the block in front of them (the LDS has no room for both)
+            merged = self._torgb_heads(desc, blocks, rgb_tables, add, NT, HdP) if (x2 and self.X2_HEADS and len(ranges) == 1) else ()
+            for j, (wr, br) in rgb_tables.items():
+                if j not in merged:
+                    desc.block[j].w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
             segments.append(dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
                                  stages=stages, blocks=blocks))
         setattr(self, cache, dict(segments=segments, HdP=HdP, NT=NT, state=None, ab_carry=ab_carry))
         return getattr(self, cache)
+
+    X2_HEADS = os.environ.get("H3D_SYNTH_HEADS", "1") != "0"
+
+    def _torgb_heads(self, desc, blocks, rgb_tables, add, NT, HdP):
+        """x2 register engine, round 5: the ToRGB layers of the skip blocks as a NINTH output tile of each block's second
+        convolution (csrc/synthesis_x3.hip: conv_progressive HEAD).  With x_k = x_{k-1} + W1_k y_k along the skip chain (biases
+        live in the carries, build_x3), sum_k Wr_k x_k over the skip blocks k >= fs that feed ToRGB is
+
+            (sum_k Wr_k) x_{fs-1}  +  sum_{j >= fs} M_j y_j,      M_j = (sum_{k >= j} Wr_k) W1_j   [3, C]
+
+        -- exact algebra on the reference's graph (lib/generators/map3d_generator.py:82-86: rgb accumulates ToRGB of every block's
+        output).  The first term joins the ToRGB table of block fs - 1 (weights summed, biases of all the later ToRGBs added);
+        M_j travels as a 4 KB table per block, [k-step][f16 hi fragment | half of the fp6 record][4 rows x 2 lane halves][16 B] --
+        the 8 lanes (rows 0-3, both halves) of a one-tile x2 stream of M_j padded to 32 rows -- at the float offset stored in the
+        block's spade[1].b_conv (unused by this engine otherwise: biases are folded); the skip blocks' to_rgb flags are cleared."""
+        fs = next((j for j in range(len(blocks)) if desc.block[j].skip), None)
+        if fs is None or fs == 0 or not any(j in rgb_tables for j in range(fs, len(blocks))):
+            return ()
+        C = self.C
+        V = torch.zeros(3, C, dtype=torch.float64, device=self.device)
+        bias = torch.zeros(3, dtype=torch.float64, device=self.device)
+        heads = {}
+        for j in range(len(blocks) - 1, fs - 1, -1):
+            if j in rgb_tables:
+                V = V + rgb_tables[j][0].double()
+                bias = bias + rgb_tables[j][1].double()
+            w1 = self._raw[2 * blocks[j] + 1]["conv_w"].double()                      # [C_out, C_in] of the block's second convolution
+            heads[j] = V @ w1                                                          # [3, C_in]
+        # entry term: block fs - 1's table takes (its own ToRGB, if any) + V x_{fs-1} and every later bias
+        w0, b0 = rgb_tables.get(fs - 1, (torch.zeros(3, C, device=self.device), torch.zeros(3, device=self.device)))
+        wm, bm = (w0.double() + V).float(), (b0.double() + bias).float()
+        desc.block[fs - 1].to_rgb = 1
+        desc.block[fs - 1].w_rgb = add(torch.cat([_pad(wm[0], HdP), _pad(wm[1], HdP), _pad(wm[2], HdP), _pad(bm, 4)]))
+        lanes = torch.tensor([0, 1, 2, 3, 32, 33, 34, 35], device=self.device)
+        for j in range(fs, len(blocks)):
+            st = self.pack_stream_x2(heads[j].float(), 2 * NT, 1, acc_order=True, dense=False)            # [KS][1][2][64][8] int16
+            tab = st.view(2 * NT, 2, 64, 8)[:, :, lanes].contiguous()                                     # [KS][hi | rec][8 lanes][16 B]
+            desc.block[j].to_rgb = 0
+            desc.block[j].spade[1].b_conv = add(tab.view(torch.float32))
+        return set(range(fs - 1, len(blocks)))               # blocks whose own ToRGB table is superseded
 
     def per_forward_tables(self, feature_maps, fixed_style, HdP=None):
         """feature_maps [B,R,F] (rendered, channels last), fixed_style [B,F] -> (G, cst, ab)."""

@@ -406,7 +406,8 @@ int h3d_synthesis(const void* blob, const h3d_synth_desc* desc, const float* G, 
  * W a multiple of 32 and 32 consecutive output pixels touching at most 8 low-res columns (31*Wr < 6*W). */
 int h3d_synthesis_x3_geometry_ok(int H, int W, int Hr, int Wr);
 /* HOST helper: LDS bytes h3d_synthesis_x3 (x2 = 0) / h3d_synthesis_x2 (x2 = 1) needs for a network of width C with
- * `table_floats` floats of static tables, n_ab constant-style and n_cst per-pixel-style SPADEs (must be <= 160 KiB). */
+ * `table_floats` floats of static tables, n_ab constant-style and n_cst per-pixel-style SPADEs (must be <= 160 KiB);
+ * x2 = 3: an h3d_synthesis_x2 plan with ToRGB head tables (below), which keeps no zero ToRGB table in LDS (3 * 4C bytes less). */
 int64_t h3d_synthesis_x3_lds_bytes(int table_floats, int n_ab, int n_cst, int C, int x2);
 
 int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tables, int table_floats,
@@ -422,7 +423,13 @@ int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tabl
  * below detects a violation.  Same arguments, limits and return codes as
  * h3d_synthesis_x3; the stream holds, per stage, [tile][1 KiB f16 hi fragment][1 KiB half of the K-tile's fp6 records]
  * (record layout as for h3d_field_pack_x2; SynthesisPlan.pack_stream_x2), and the kernel needs
- * h3d_synthesis_x2_extra_lds(C) more bytes of LDS than h3d_synthesis_x3 (one more ring buffer). */
+ * h3d_synthesis_x2_extra_lds(C) more bytes of LDS than h3d_synthesis_x3 (one more ring buffer).
+ * ToRGB heads (round 5, single-launch x2 plans only): a skip block whose spade[1].b_conv is >= 0 (this engine folds conv biases on
+ * the host, so the field is free) carries at that FLOAT offset of `tables` a 4 KB table [k-step][f16 hi fragment | half of the
+ * fp6 record][4 rows x 2 lane halves][16 B] = the x2 operands of M_j = (sum of the ToRGB weights of this and every later block)
+ * x W_conv1 of the block, 3 rows used: the block's second convolution multiplies it with its own input fragments as a ninth
+ * output tile, accumulated over all skip blocks into the image.  Such blocks have to_rgb = 0, and the block in front of the
+ * first skip block carries the summed ToRGB weights and biases (exact algebra on lib/generators/map3d_generator.py:82-86). */
 int h3d_synthesis_x2(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,

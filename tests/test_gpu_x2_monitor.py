@@ -105,3 +105,35 @@ def test_tile_subset_launch_writes_the_sampled_tiles_only():
     bad.flatten(2)[0, 0, p] = float("nan")
     chk(bad, 1e-3)
     assert int(flag.item()) == 1 and not torch.isfinite(err[0])
+
+
+@pytest.mark.parametrize("width", [128, 256])
+def test_torgb_head_tiles_give_the_image_of_the_riding_torgb(width):
+    """x2 plans fold the ToRGB of every skip block into a ninth output tile of that block's second convolution
+    (SynthesisPlan._torgb_heads: sum_k Wr_k x_k = (sum_k Wr_k) x_f + sum_j (V_j W1_j) y_j).  The plan with heads and the plan
+    without (per-block ToRGB riding in the next producer) are the same function: equal within the x2 arithmetic's own noise, and
+    both inside the budget of the oracle (lib/generators/map3d_generator.py:82-86, map3d_layers.py:346-352)."""
+    G, meta, sd = make(width, 128, 128, 24, 24, seed=4)
+    plan = G.synthesis_plan(DEV)
+    assert plan.engine == "f16x2" and plan.X2_HEADS
+    fmap, style = torch.randn(2, 576, width), torch.randn(2, width)
+    want = oracle_rgb(sd, meta, fmap, style)
+    with_heads = run(G, meta, fmap, style)
+    desc = plan.build_x3(True)["segments"][0]["desc"]
+    assert any(desc.block[k].spade[1].b_conv >= 0 for k in range(desc.n_blocks))          # the head tables are in the plan
+    assert not plan.x2_fell_back()
+    plan.X2_HEADS = False
+    plan._x2 = None                                                                       # rebuild without heads
+    try:
+        without = run(G, meta, fmap, style)
+        desc = plan.build_x3(True)["segments"][0]["desc"]
+        assert all(desc.block[k].spade[1].b_conv < 0 for k in range(desc.n_blocks))
+        assert not plan.x2_fell_back()
+    finally:
+        plan.X2_HEADS = True
+        plan._x2 = None
+    den = want.abs().amax(dim=(0, 2, 3), keepdim=True)
+    e = lambda a: float(((a.cpu() - want).abs() / den).max())
+    d = float(((with_heads - without).abs().cpu() / den).max())
+    print(f"width {width}: heads {e(with_heads):.2e}, riding {e(without):.2e}, heads vs riding {d:.2e}")
+    assert e(with_heads) < 1e-3 and e(without) < 1e-3 and 0 < d < 6e-4

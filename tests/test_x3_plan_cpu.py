@@ -103,7 +103,7 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
         Gmap = G.double().view(B, Hr, Wr, -1).permute(0, 3, 1, 2)
         Gup = torch.nn.functional.interpolate(Gmap, (H, W), mode="bilinear").permute(0, 2, 3, 1).reshape(B, H * W, -1)
     rgb = torch.zeros(B, H * W, 3, dtype=torch.float64)
-    stage = 0
+    stage, heads = 0, 0
     lrelu = lambda v: torch.maximum(v, 0.2 * v)
     for k in range(desc.n_blocks):
         bk = desc.block[k]
@@ -124,10 +124,21 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
                 y = 1.5 * u + u.abs()
             Wc = decode(stream, stage, 2 * NT, NT); stage += 2 * NT
             x = mm(y, Wc) + (x_in if (s == 1 and bk.skip) else 0.0)
+            if x2 and s == 1 and d.b_conv >= 0:
+                # ToRGB head table of a skip block (round 5): the 8 lanes (rows 0-3, both halves) of a one-tile x2 stream of
+                # M_j = V_j W1_j -- scattered back into a full tile and decoded like any other x2 matrix; rows 0-2 are r, g, b
+                heads += 1
+                t8 = seg["tables"][d.b_conv: d.b_conv + 2 * NT * 64].contiguous().view(torch.int16).view(2 * NT, 2, 8, 8)
+                full = torch.zeros(2 * NT, 1, 2, 64, 8, dtype=torch.int16)
+                full[:, 0][:, :, [0, 1, 2, 3, 32, 33, 34, 35]] = t8
+                rgb = rgb + mm(y, decode_x2(full.flatten(), 0, 2 * NT, 1, dense=False))[..., :3]
         if bk.to_rgb:
             wr = torch.stack([vec(bk.w_rgb), vec(bk.w_rgb + HdP), vec(bk.w_rgb + 2 * HdP)])          # [3, HdP]
             rgb = rgb + x @ wr.t() + vec(bk.w_rgb + 3 * HdP, 3)
     assert stage == seg["stages"]
+    if x2 and plan.X2_HEADS and any(desc.block[k].skip for k in range(desc.n_blocks)):
+        assert heads == sum(1 for k in range(desc.n_blocks) if desc.block[k].skip)      # every skip block of an x2 plan carries one
+        assert not any(desc.block[k].to_rgb for k in range(desc.n_blocks) if desc.block[k].skip)
     return rgb.view(B, H, W, 3).permute(0, 3, 1, 2)
 
 
@@ -175,4 +186,6 @@ def test_planner_uses_the_kernels_own_lds_count():
     assert lib.h3d_synthesis_x3_lds_bytes(11544 + 4, 12, 6, 256, 0) - base == 16          # 4 more table floats
     assert lib.h3d_synthesis_x3_lds_bytes(11544, 13, 6, 256, 0) - base == 2 * 256 * 4     # one more constant-style SPADE
     assert lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 1) <= 160 * 1024             # MAP3DBN512 (the bench workload) fits x2
+    assert lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 1) - lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 3) == 3 * 256 * 4   # heads: no zero table
+    assert lib.h3d_synthesis_x3_lds_bytes(12804, 12, 6, 256, 3) <= 160 * 1024 < lib.h3d_synthesis_x3_lds_bytes(12804, 12, 6, 256, 1)    # ... which is what makes the head tables fit
     assert lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 1) > 160 * 1024 >= lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 0)
