@@ -160,7 +160,7 @@ __device__ __forceinline__ unsigned split2_act(float a, float b, unsigned& lo) {
 }
 
 // x2: the lo halves travel multiplied by rho = 2^12 (they only feed the fp6 conversion and the heads' scaled plane)
-__device__ __forceinline__ unsigned split2_act_x2(float a, float b, unsigned& lo) { return split2_x2(a, b, lo); }
+__device__ __forceinline__ unsigned split2_act_x2(float a, float b, unsigned& lo) { return split2_x2_bounded(a, b, lo); }   // |sin| <= 1
 
 // two fp32 (already scaled) -> packed f16 hi halves (returned) and packed f16 lo halves
 __device__ __forceinline__ unsigned split2_f16(float a, float b, unsigned& lo) {

@@ -516,6 +516,23 @@ __device__ __forceinline__ unsigned split2_x2(float a, float b, unsigned& lo) {
 #endif
 }
 
+// ... for |a|, |b| < 16 (the field: sine outputs), one instruction less per pair: hi * 2^12 is still an f16 (exact), and one
+// mixed FMA per value gives f16(a * 2^12 - hi * 2^12) -- the same single rounding of the same exact residual, so the same bits.
+__device__ __forceinline__ unsigned split2_x2_bounded(float a, float b, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#ifdef H3D_X2_SPLIT_GENERAL
+    return split2_x2(a, b, lo);
+#endif
+    const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, h2));
+    unsigned hs, lw;
+    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(hs) : "v"(hw), "s"(0x6C006C00u));                 // (4096, 4096) as f16
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lw) : "v"(a), "s"(kX2Rho), "v"(hs));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw) : "v"(b), "s"(kX2Rho), "v"(hs));
+    lo = lw;
+    return hw;
+}
+
 // The fp6 record of a K-tile whose largest |activation| of this lane is amax = m * 2^e (1 <= m < 2): codes = q6(y / cs) with
 // cs = 2^(e-2) when m < 1.875 (largest hi code < 7.5: no saturation) and 2^(e-1) otherwise.  lo' = lo * 2^12 <= 2^(e+1) can
 // reach code 8 in the first case and is then clipped to 7.5 (an error of 2^-4 of a term that is 2^-12 of the product).
