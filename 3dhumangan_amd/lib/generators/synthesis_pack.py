@@ -485,6 +485,14 @@ class SynthesisPlan:
                     desc.block[j].w_rgb = add(torch.cat([_pad(wr[0], HdP), _pad(wr[1], HdP), _pad(wr[2], HdP), _pad(br, 4)]))
             segments.append(dict(desc=desc, tables=torch.cat(chunks).contiguous(), stream=torch.cat(stream).contiguous(),
                                  stages=stages, blocks=blocks))
+        if x2 and self.X2_HEADS and len(ranges) == 1:
+            # the head tables are 4 KB per skip block (minus the 3 KB zero table): a plan they push past the 160 KB of LDS keeps
+            # the riding ToRGB instead (the kernel would refuse the launch, and the plan would otherwise fall to the x3 engine)
+            seg = segments[0]
+            if any(seg["desc"].block[j].spade[1].b_conv >= 0 for j in range(seg["desc"].n_blocks)) and \
+                    _lib.load().h3d_synthesis_x3_lds_bytes(seg["tables"].numel(), len(self.const_ids), len(self.pixel_ids), self.C, 3) > 160 * 1024:
+                self.X2_HEADS = False
+                return self.build_x3(True)
         setattr(self, cache, dict(segments=segments, HdP=HdP, NT=NT, state=None, ab_carry=ab_carry))
         return getattr(self, cache)
 

@@ -189,3 +189,26 @@ def test_planner_uses_the_kernels_own_lds_count():
     assert lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 1) - lib.h3d_synthesis_x3_lds_bytes(11544, 12, 6, 256, 3) == 3 * 256 * 4   # heads: no zero table
     assert lib.h3d_synthesis_x3_lds_bytes(12804, 12, 6, 256, 3) <= 160 * 1024 < lib.h3d_synthesis_x3_lds_bytes(12804, 12, 6, 256, 1)    # ... which is what makes the head tables fit
     assert lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 1) > 160 * 1024 >= lib.h3d_synthesis_x3_lds_bytes(11544, 16, 6, 256, 0)
+
+
+def test_head_tables_that_do_not_fit_the_lds_leave_the_plan_on_x2_with_the_riding_torgb():
+    """MAP3DBN512's widths with a tenth block: 14 constant-style SPADEs leave 112 B of the 160 KB after the x2 ring -- the ToRGB
+    head tables (4 KB per skip block for 3 KB of zero table) do not fit, and the plan keeps the x2 engine with the per-block ToRGB
+    instead of failing at launch or dropping to the x3 engine.  With 9 blocks (the shipped config) the heads fit."""
+    lib = importlib.import_module("3dhumangan_amd._lib").load()
+    for n_blocks, want_heads in ((9, True), (10, False)):
+        meta = dict(load_golden("gen_tiny_mixed")["meta"])
+        meta.update(map3d_mode="mixed", hidden_dim=256, latent_dim=256, feature_dim=256, gen_height=32, gen_width=32, render_height=8,
+                    render_width=8, synthesis_blocks=n_blocks, mod_blocks=[0, 1, 2])
+        meta["neural_field_cls"] = impl.COORDCONCATSIREN
+        torch.manual_seed(0)
+        sd = {k: v.detach().clone() for k, v in gens.Map3DGenerator(**meta).eval().state_dict().items()}
+        plan = sp.SynthesisPlan(sd, "synthesis_network", "synthesis_input", n_blocks, (0, 1, 2), "mixed", torch.device("cpu"))
+        seg = plan.build_x3(True)["segments"][0]
+        heads = any(seg["desc"].block[j].spade[1].b_conv >= 0 for j in range(seg["desc"].n_blocks))
+        assert heads == want_heads and plan.X2_HEADS == want_heads
+        assert plan._x3_fits(True)
+        assert lib.h3d_synthesis_x3_lds_bytes(seg["tables"].numel(), len(plan.const_ids), len(plan.pixel_ids), 256, 3 if heads else 1) <= 160 * 1024
+        if not heads:          # every block that feeds ToRGB kept its own table
+            assert all(seg["desc"].block[j].w_rgb >= 0 for j in range(seg["desc"].n_blocks) if seg["desc"].block[j].to_rgb)
+            assert sum(int(seg["desc"].block[j].to_rgb) for j in range(seg["desc"].n_blocks)) > 0
