@@ -126,6 +126,9 @@ __device__ __forceinline__ f32x4 ldt4_pinned(lds_ptr base, int float_index) {
 // which is ordered against the (asm volatile) DMA issues: round 3's index arithmetic (stage index * 16 KiB as a 64-bit shift,
 // buffer index * 16 KiB, 64-bit vector adds per stage) was hoisted by the compiler to the head of each GEMM, sixteen stages
 // at a time, and spilled from there (v_writelane: 129 spilled SGPRs in synthesis_x3_kernel<8, 4, false, true>).
+#ifndef H3D_DMA_SLOT
+#define H3D_DMA_SLOT 0
+#endif
 template <int NT, int DEPTH = H3D_RING_DEPTH, int LAG = 0>
 struct WeightRing {
     static constexpr int kBuf = DEPTH;
@@ -369,9 +372,23 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
             if constexpr (s % 4 == 0) H3D_TRACE(3);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // refill chunk owed to the latest acquire (its place in the section: H3D_DMA_SLOT, an experiment knob; 0 = after the MFMAs)
+        auto dma = [&]() __attribute__((always_inline)) {
+            constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
+            if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
+        };
+#if H3D_DMA_SLOT == 1
+        dma();
+#endif
         if constexpr (g + L < G) load_pair(IC<g + L>{});
+#if H3D_DMA_SLOT == 2
+        dma();
+#endif
 #ifndef H3D_EXPERIMENT_NO_HOOK
         hook(gc);
+#endif
+#if H3D_DMA_SLOT == 3
+        dma();
 #endif
         const Pair& b = buf[g % NB];
         constexpr int n0 = 2 * p, n1 = 2 * p + 1;
@@ -396,8 +413,9 @@ __device__ __forceinline__ void gemm_x3_roll(f32x16 (&acc)[NT], const typename T
 #endif
         // refill chunk owed to the latest acquire: acquires sit at section (s*P + P-L) for s+1 < KS, each followed by
         // P chunks in the next P sections; the prologue acquire was refilled by ring.issue()
-        constexpr int since = g - (P - L);                    // sections since the first in-loop acquire position
-        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
+#if H3D_DMA_SLOT == 0
+        dma();
+#endif
         if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -599,9 +617,22 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (p == 0) H3D_TRACE(100 + s);
+        auto dma = [&]() __attribute__((always_inline)) {
+            constexpr int since = g - (P - L);
+            if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
+        };
+#if H3D_DMA_SLOT == 1
+        dma();
+#endif
         pre(gc);
         if constexpr (g + L < G) load_pair(IC<g + L>{});
+#if H3D_DMA_SLOT == 2
+        dma();
+#endif
         hook(gc);
+#if H3D_DMA_SLOT == 3
+        dma();
+#endif
         const Pair& b = buf[g % NB];
         constexpr int n0 = 2 * p, n1 = 2 * p + 1;
         if constexpr (ZERO && s == 0) {
@@ -626,8 +657,9 @@ __device__ __forceinline__ void gemm_x2_roll(f32x16 (&acc)[NT], const F16::vec8 
                 acc[n0 + i] = mm6<SWAP>(w6, b6[s / 2], acc[n0 + i]);
             }
         }
-        constexpr int since = g - (P - L);
-        if constexpr (since >= 0 && since / P + 1 < KS) ring.template issue_slot<since % P>();
+#if H3D_DMA_SLOT == 0
+        dma();
+#endif
         if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < n_mfma; ++i) {
