@@ -9,6 +9,11 @@ LIB = os.path.join(CSRC, "libh3d.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 
+# Per-file additions.  field_x3.hip: without LLVM's post-register-allocation scheduler the hand-placed section order of the render
+# engine survives as written -- same-lease A/B of bench.py, two leases: render stage 16.30 / 16.17 -> 15.79 / 15.98 ms and 16.36 /
+# 16.31 -> 16.22 / 16.13 ms (profiles/r5_ab_sched_flags.json).  The same flag costs synthesis_x3.hip 1.2-1.6 %, so it stays per file.
+FILE_FLAGS = {"field_x3.hip": ["-mllvm", "-enable-post-misched=false"]}
+
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -34,12 +39,12 @@ def build_lib(force=False, verbose=False):
     for src in sources():
         obj = src[:-4] + ".o"
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + headers):
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {os.path.basename(src)}:\n{r.stderr[-4000:]}")
