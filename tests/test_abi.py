@@ -113,3 +113,14 @@ def test_no_flat_memory_instruction_in_the_ring_kernels(lib, tmp_path):
             bad = [ln.strip() for ln in body.split("\n") if re.search(r"\bflat_(load|store|atomic)", ln)]
             assert not bad, f"FLAT memory instruction in a weight-ring kernel {name}: {bad[:3]}"
     assert ring_kernels >= 20
+
+
+def test_per_file_build_flags_name_existing_sources():
+    """_build.FILE_FLAGS (per-file compiler options: round 5 compiles field_x3.hip without LLVM's post-RA scheduler) must name
+    files that exist, or the option silently stops applying when a file is renamed."""
+    import importlib
+    import os
+    b = importlib.import_module("3dhumangan_amd._build")
+    names = {os.path.basename(s) for s in b.sources()}
+    assert b.FILE_FLAGS and set(b.FILE_FLAGS) <= names
+    assert b.FILE_FLAGS["field_x3.hip"] == ["-mllvm", "-enable-post-misched=false"]
