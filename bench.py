@@ -451,6 +451,8 @@ def self_check(G, cfg, z, cond, jitter, items, n_cells=16, seed=5):
     excluded rays is capped (`max_excluded`), beyond it the check fails."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import h3d_oracle as O
+    # torchrun exports OMP_NUM_THREADS=1 to its ranks when N > 1: the oracle leg of rank 0 would run on one thread
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
     out = G.forward(z, cond, jitter=jitter, **cfg)
     rgb, ren = out["rgbs"].cpu(), out["rgbs_render"].cpu()
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
