@@ -40,6 +40,8 @@ _SIGNATURES = {
     "h3d_nearest_vertex_sorted_rays": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "h3d_render_fused_x2_geo": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "h3d_render_fused_x3_geo": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
+    "h3d_render_fused_x2_geo_ref": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _f, _f, _p, _p, _i, _p]),
+    "h3d_render_fused_x3_geo_units": (C.c_int, [_p] * 7 + [_i, _i] + [_p] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p, _i, _p]),
     "h3d_field_pack_size": (C.c_int64, [_i, _i]),
     "h3d_field_pack": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
     "h3d_neural_field": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),

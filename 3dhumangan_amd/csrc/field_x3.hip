@@ -130,6 +130,15 @@ struct Args {
     const float* tpose;          // [B, V, 3]
     const float* vertex_ik;      // [B, V, 16] blended inverse bone transforms
     int V, legacy_mode;
+    // Refinement of ill-conditioned last samples (round 6, fused kernels): the reference gives a ray's last sample delta = 1e9
+    // (lib/generators/volume_rendering.py:21), so its alpha is 0 or 1 by the SIGN of its density -- a density within the
+    // arithmetic's error of zero flips the ray's background term.  ref_mode 1 (the x2 launch): a wave unit (one ray when S > 32)
+    // whose ray has |sigma_last| <= ref_eps * max(max_s |sigma_s|, ref_scale) appends its index to ref_list[b][..] (ref_count[b]
+    // counts them, also beyond ref_cap).  ref_mode 2 (the x3 launch behind it): the launch covers exactly the listed units.
+    int* ref_list;               // [B, ref_cap] wave-unit indices
+    int* ref_count;              // [B]
+    int ref_cap, ref_mode;
+    float ref_eps, ref_scale;
 };
 
 constexpr int kHeadPad = 64;       // bytes behind every head's fragment rows in LDS (bank staggering)
@@ -371,6 +380,15 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    // refinement launch (ref_mode 2): the units the x2 launch listed for this batch item; usually none -- leave before the tables
+    int ref_units = 0;
+    if constexpr (FUSED) {
+        if (A.ref_mode == 2) {
+            ref_units = __builtin_amdgcn_readfirstlane(min(A.ref_count[b], A.ref_cap));
+            if ((int)blockIdx.x * 4 >= ref_units) return;
+        }
+    }
+    (void)ref_units;
     const int Hd = A.Hd, F = A.F, S = A.S;
     const int64_t N = A.N;
     const float* __restrict__ invs = reinterpret_cast<const float*>(A.blob + L.inv_scale);
@@ -436,7 +454,17 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     Ring ring;
     ring.init(A.blob + L.w[0], ring_lds, L.stages, wave, lane);
     int n_groups = A.n_groups;
+    if constexpr (FUSED) {
+        if (A.ref_mode == 2) n_groups = (ref_units + 3) >> 2;
+    }
     asm volatile("" : "+s"(n_groups));           // pinned: not re-loaded from the kernarg segment inside the loop
+    // refinement state in vector registers (see the pointers below): mode, threshold factor, floor of the scale, list of this item
+    int ref_mode = FUSED ? A.ref_mode : 0;
+    float ref_eps = A.ref_eps, ref_scale = A.ref_scale;
+    typedef __attribute__((address_space(1))) int* gi32;
+    gi32 ref_list = (gi32)A.ref_list + (int64_t)b * A.ref_cap, ref_count = (gi32)A.ref_count + b;
+    int ref_cap = A.ref_cap;
+    asm volatile("" : "+v"(ref_mode), "+v"(ref_eps), "+v"(ref_scale), "+v"(ref_list), "+v"(ref_count), "+v"(ref_cap));
     // The per-step global pointers live in VECTOR registers (the kernel has ~60 to spare, and every one of them is only ever
     // used in per-lane address arithmetic): as scalar values they were the bulk of the kernel's 70-85 spilled SGPRs, each
     // reloaded with v_readlane where it was used.
@@ -456,9 +484,17 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
     // blockIdx.x + gridDim.x, .. with the weight ring running across them (the stream wraps at the end of every step).
 #pragma unroll 1
     for (int ug = blockIdx.x; ug < n_groups; ug += gridDim.x) {
-    const int64_t u0 = ((int64_t)ug * 4 + wave) * unit;     // may lie beyond N: such waves only keep the ring going
+    int64_t uidx = (int64_t)ug * 4 + wave;                  // this wave's unit
+    if constexpr (FUSED) {
+        if (ref_mode == 2) {                                // refinement launch: the unit listed in slot ug * 4 + wave (or none)
+            const int slot = ug * 4 + wave;
+            uidx = slot < ref_units ? (int64_t)__builtin_amdgcn_readfirstlane(ref_list[slot < ref_units ? slot : 0]) : N;      // N * unit >= N: idle
+        }
+    }
+    const int64_t u0 = uidx * unit;                         // may lie beyond N: such waves only keep the ring going
     // ray of sample n (fused): no 64-bit division -- S > 32: one ray per wave unit; S <= 32: S is a power of two
-    const int64_t unit_ray = (int64_t)b * A.R + ((int64_t)ug * 4 + wave);
+    const int64_t unit_ray = (int64_t)b * A.R + uidx;
+    float smax = 0.f;                                       // largest |density| of the unit's rays so far (ref_mode 1)
     auto ray_of = [&](int64_t nn) -> int64_t { return A.log2S < 0 ? unit_ray : (int64_t)b * A.R + (nn >> A.log2S); };
 
     float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
@@ -605,12 +641,17 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             // compositing weights of these 32 samples (both lane halves compute identical values)
             const int s_idx = A.log2S < 0 ? si * 32 + m : (int)(n & (S - 1));
             float alpha = 0.f, f = 1.f, z = 0.f;
+            float last_abs = -1.f;                          // |density| of a ray's last sample held by this lane (ref_mode 1), else -1
             if (ok) {
                 z = a_z[gi];
                 const float delta = (s_idx == S - 1) ? 1e9f : a_z[gi + 1] - z;
                 const float sgn = sigma + (a_noise ? a_noise[gi] : 0.f);
                 alpha = 1.f - expf(-delta * density(sgn, A.clamp_mode));
                 f = (1.f - alpha) + 1e-12f;
+                if (ref_mode == 1) {
+                    smax = fmaxf(smax, fabsf(sgn));
+                    if (s_idx == S - 1) last_abs = fabsf(sgn);
+                }
             }
             const int sl = m & (seglen - 1);
             float incl = f;
@@ -639,6 +680,21 @@ __global__ __launch_bounds__(256, 1) void field_x3_kernel(Args A) {
             }
             if (ok && h == 0) a_weights[gi] = w;
             if (h == 0) { wl_lds[m] = w; wl_lds[32 + m] = bg; }
+            if (ref_mode == 1 && last_step) {
+                // the largest |density| of each ray of this unit (all steps), floored by ref_scale; a unit with a last sample
+                // inside ref_eps of that scale is listed for the refinement launch (one list entry per unit, written by lane 0)
+                float rmax = smax;
+                for (int off = 1; off < seglen; off <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off, 32));
+                const bool ill = last_abs >= 0.f && last_abs <= ref_eps * fmaxf(rmax, ref_scale);
+                if (__any(ill)) {
+                    if (lane == 0) {
+                        // (an address-space-1 pointer: a GLOBAL atomic -- through a generic pointer it would be a FLAT access, see the
+                        // note on the rgb stores in synthesis_x3.hip; the wait behind it sits on this rare path only)
+                        const int slot = __hip_atomic_fetch_add(ref_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (slot < ref_cap) ref_list[slot] = (int)uidx;
+                    }
+                }
+            }
         }
 
         // ---- feature head, sample-major accumulator: Y = film_color(X)^T * Wf^T  (+ colour heads on film_color(X))
@@ -777,7 +833,9 @@ int launch_one(Args A, int B, int64_t groups, hipStream_t st) {
             cus = 256;
     }
     static const int per_cu = getenv("H3D_FIELD_WG_PER_CU") ? atoi(getenv("H3D_FIELD_WG_PER_CU")) : 4;      // 0: one unit group per workgroup
-    const int64_t per_sample = per_cu <= 0 ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
+    int64_t per_sample = per_cu <= 0 ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
+    // refinement launch: a handful of listed units per batch item (workgroups beyond the list leave at once)
+    if (A.ref_mode == 2) per_sample = std::max<int64_t>(1, std::min<int64_t>((A.ref_cap + 3) / 4, 8));
     h3d::pre_launch();
     hipLaunchKernelGGL((field_x3_kernel<NT, FUSED, X2, GEOIN>), dim3((unsigned)per_sample, (unsigned)B), dim3(256), lds_bytes(A.L, GEOIN), st, A);
     return h3d::launch_status(FUSED ? (X2 ? "h3d_render_fused_x2" : "h3d_render_fused_x3") : (X2 ? "h3d_neural_field_x2" : "h3d_neural_field_x3"));
@@ -1112,13 +1170,24 @@ struct GeoIn {            // A4 inside the fused kernel (h3d_render_fused_x2_geo
     const float *joints, *vertices, *tpose, *vertex_ik;
     int V, legacy_mode;
 };
+struct RefIn {            // refinement of ill-conditioned last samples (Args::ref_*): mode 1 = list (x2), 2 = redo the listed units (x3)
+    int mode;
+    float eps, scale;
+    int* list;
+    int* count;
+    int cap;
+};
 
 static int render_fused_x(bool x2, const void* packed, const float* points, const float* geo, const float* dirs,
                           const float* freq, const float* phase, const float* z_vals, const float* noise,
                           float* feats, float* depth, float* weights, int B, int R, int S, int Hd, int F,
                           int geo_stride, float input_scaler, int clamp_mode, int last_back, int white_back,
-                          h3d_stream_t stream, const GeoIn* gin = nullptr) {
+                          h3d_stream_t stream, const GeoIn* gin = nullptr, const RefIn* ref = nullptr) {
     const int64_t N = (int64_t)R * S;
+    if (ref) {
+        H3D_REQUIRE(ref->list && ref->count && ref->cap >= 1 && ref->cap <= 65536, "h3d_render_fused_x*: refinement list / count / cap=%d", ref->cap);
+        H3D_REQUIRE(ref->mode == 2 || (ref->eps >= 0.f && ref->scale >= 0.f), "h3d_render_fused_x2_*_ref: eps and scale must be >= 0");
+    }
     if (gin) {
         H3D_REQUIRE(gin->nn_index && gin->joints && gin->vertices && gin->tpose && gin->vertex_ik, "h3d_render_fused_x*_geo: null pointer");
         H3D_REQUIRE(gin->V >= 1 && h3d::aligned16(gin->vertex_ik), "h3d_render_fused_x*_geo: V=%d, vertex_ik must be 16-byte aligned", gin->V);
@@ -1154,6 +1223,14 @@ static int render_fused_x(bool x2, const void* packed, const float* points, cons
     const int64_t units = (N + unit - 1) / unit;
     const int64_t groups = (units + 3) / 4;
     H3D_REQUIRE(groups < (int64_t(1) << 31), "h3d_render_fused_x3: too many rays");
+    if (ref) {
+        A.ref_mode = ref->mode; A.ref_eps = ref->eps; A.ref_scale = ref->scale; A.ref_list = ref->list; A.ref_count = ref->count;
+        A.ref_cap = ref->cap;
+        if (ref->mode == 1 && hipMemsetAsync(ref->count, 0, sizeof(int) * (size_t)B, static_cast<hipStream_t>(stream)) != hipSuccess) {
+            h3d::set_error("h3d_render_fused_x2_*_ref: hipMemsetAsync failed");
+            return H3D_ELAUNCH;
+        }
+    }
 #ifdef H3D_EXPERIMENT_TRACE
     {   // development build: dump the cycle trace of workgroup (1000, 3) to $H3D_TRACE_FILE after every launch
         static unsigned long long* tb = nullptr;
@@ -1223,4 +1300,40 @@ extern "C" int h3d_render_fused_x3_geo(const void* packed, const float* points, 
     const GeoIn g{nn_index, joints, vertices, tpose_vertices, vertex_ik, V, legacy_mode};
     return render_fused_x(false, packed, points, nullptr, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F, 31,
                           input_scaler, clamp_mode, last_back, white_back, stream, &g);
+}
+
+/* Refinement of ill-conditioned last samples (round 6).  The reference gives the last sample of a ray delta = 1e9
+ * (lib/generators/volume_rendering.py:21): its alpha is 0 or 1 by the SIGN of its density, and with white_back the background
+ * term flips by the whole remaining transmittance -- so a ray whose last density lies within the ARITHMETIC's error of zero
+ * comes out wrong by O(1).  The x2 arithmetic's density error (~1e-4 of the densities' scale) makes that ~100 times likelier than
+ * fp32-class arithmetic does.  h3d_render_fused_x2_geo_ref is h3d_render_fused_x2_geo that also lists, per batch item, the wave
+ * units (a unit = one ray when S > 32, else the 32 / S rays of 32 consecutive samples) holding a ray with
+ *     |sigma_last| <= ref_eps * max(max_s |sigma_s|, ref_scale)
+ * in ref_list[b][0 .. ref_cap) (unit indices, any order) and counts them in ref_count[b] (zeroed by the call on `stream`; it
+ * keeps counting beyond ref_cap).  h3d_render_fused_x3_geo_units is h3d_render_fused_x3_geo (`packed` in the x3 format) restricted
+ * to exactly the listed units of every item: it overwrites their feats / depth / weights with the three-product engine's, so that
+ * those rays take the sign of an fp32-class density.  Back to back on one stream: no host synchronisation. */
+extern "C" int h3d_render_fused_x2_geo_ref(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                           const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                           int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                           const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                           int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                           int white_back, float ref_eps, float ref_scale, int32_t* ref_list, int32_t* ref_count,
+                                           int ref_cap, h3d_stream_t stream) {
+    const GeoIn g{nn_index, joints, vertices, tpose_vertices, vertex_ik, V, legacy_mode};
+    const RefIn r{1, ref_eps, ref_scale, ref_list, ref_count, ref_cap};
+    return render_fused_x(true, packed, points, nullptr, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F, 31,
+                          input_scaler, clamp_mode, last_back, white_back, stream, &g, &r);
+}
+extern "C" int h3d_render_fused_x3_geo_units(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                             const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                             int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                             const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                             int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                             int white_back, const int32_t* ref_list, const int32_t* ref_count, int ref_cap,
+                                             h3d_stream_t stream) {
+    const GeoIn g{nn_index, joints, vertices, tpose_vertices, vertex_ik, V, legacy_mode};
+    const RefIn r{2, 0.f, 0.f, const_cast<int32_t*>(ref_list), const_cast<int32_t*>(ref_count), ref_cap};
+    return render_fused_x(false, packed, points, nullptr, dirs, freq, phase, z_vals, noise, feats, depth, weights, B, R, S, Hd, F, 31,
+                          input_scaler, clamp_mode, last_back, white_back, stream, &g, &r);
 }

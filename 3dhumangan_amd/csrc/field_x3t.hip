@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         const unsigned char* wblob = blob + opaque;
+#ifdef H3D_EXPERIMENT_ALIAS_W        // timing experiment (wrong results): every hidden matrix reads FiLM 1's bytes (0.8 MB: L2-resident)
+        auto wmat = [&](int wi) { return wblob + L.w[wi >= W_F0 ? W_F1 : wi]; };
+#else
         auto wmat = [&](int wi) { return wblob + L.w[wi]; };
+#endif
         X3tUnits<NTF, NX> U = U0;
 #pragma unroll
         for (int i = 0; i < NTF + NX; ++i) asm volatile("" : "+s"(U.nt[i]));

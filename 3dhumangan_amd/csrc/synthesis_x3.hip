@@ -60,8 +60,8 @@ struct Args {
     int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
     int n_walk, tile_first, tile_step;   // the tiles a launch covers: tile_first + i * tile_step, i < n_walk (all of them: 0, 1, n_tiles)
     int heads;             // x2 plans with ToRGB head tables: no zero table of "no ToRGB" weights in LDS (the producers carry no ToRGB)
-    int* ovf;              // x2: set to 1 when an activation leaves the range the f16 planes carry (nullable)
-    const int* run_if;     // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 engine
+    int* ovf;              // x2: int[B], ovf[b] set to 1 when an activation of sample b leaves the range the f16 planes carry (nullable)
+    const int* run_if;     // int[B] (nullable): sample b is skipped when run_if[b] == 0 -- the guarded fallback of the x2 engine
 };
 
 // x2 range guard: the hi plane is f16 and the lo plane travels as f16(lo * 2^12) with |lo| <= ulp(hi) / 2, so both planes are
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     int* dtab = reinterpret_cast<int*>(zero0 + (HEADS ? 0 : 3 * HdP));     // [H3D_MAX_BLOCKS + 1][kDescInts] the descriptor fields the block loops read
     unsigned char* ring_lds = reinterpret_cast<unsigned char*>(dtab + (H3D_MAX_BLOCKS + 1) * kDescInts);
 
-    if (A.run_if && *A.run_if == 0) return;          // guarded fallback: nothing to redo
+    if (A.run_if && A.run_if[blockIdx.y] == 0) return;          // guarded fallback: nothing to redo for this sample
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane & 31, h = lane >> 5;
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     }
     }   // tiles
     if constexpr (X2) {
-        // sticky range flag: an activation beyond the f16 planes' range anywhere in this launch (NaN compares false below too)
-        if (A.ovf && !(gmax < kX2ActLimit)) atomicOr(A.ovf, 1);
+        // sticky range flag of this sample: an activation beyond the f16 planes' range anywhere in its tiles (NaN compares false below too)
+        if (A.ovf && !(gmax < kX2ActLimit)) atomicOr(A.ovf + b, 1);
     }
     ring.drain();
     H3D_TRACE(9);
@@ -703,7 +703,10 @@ int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
             cus = 256;
     }
     static const int per_cu = getenv("H3D_SYNTH_WG_PER_CU") ? atoi(getenv("H3D_SYNTH_WG_PER_CU")) : 4;      // 0: one tile per workgroup
-    const int64_t per_sample = (SEG || per_cu <= 0) ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
+    // (a fallback launch -- run_if -- usually redoes ONE sample of the batch: that sample's workgroups must fill the chip by themselves)
+    const int64_t per_sample = (SEG || per_cu <= 0) ? groups
+                             : A.run_if ? std::min<int64_t>(groups, cus)
+                             : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
     hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH + (X2 ? 1 : 0)), st, A);
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(256) void synthesis_check_partial(const float* __re
         }
         for (int64_t i = n4 * 4 + (int64_t)sl * 256 + t; i < HW; i += (int64_t)kCheckSlices * 256) m[c] = fold(m[c], fabsf(p[i]));
     }
-    for (int tile = tile_first + sl * tile_step; tile < n_tiles; tile += kCheckSlices * tile_step) {
+    for (int64_t tile = tile_first + (int64_t)sl * tile_step; tile < n_tiles; tile += (int64_t)kCheckSlices * tile_step) {
         for (int i = t; i < 128; i += 256) {
             const int64_t p = (int64_t)tile * 128 + i;
             if (p >= HW) continue;
@@ -939,7 +942,7 @@ __global__ void synthesis_check_final(const unsigned* __restrict__ work, int B, 
     }
     if (bad) err = __builtin_inff();
     if (err_out) err_out[b] = err;
-    if (!(err <= tol)) atomicOr(flag, 1);
+    if (!(err <= tol)) atomicOr(flag + b, 1);
 }
 }  // namespace
 

@@ -31,8 +31,8 @@ struct Args {
     const float* ab;              // [B, n_ab, 2, HdP]
     float* rgb;                   // [B, 3, H, W]
     int g_channels, Hr, Wr, n_cst, n_ab, H, W, NT, first_skip;
-    int* ovf;                     // x2 tier: set to 1 when an activation leaves the range of the f16 planes (nullable)
-    const int* run_if;            // the launch is a no-op when *run_if == 0 (nullable): the guarded fallback of the x2 tier
+    int* ovf;                     // x2 tier: int[B], ovf[b] set to 1 when an activation of sample b leaves the range of the f16 planes (nullable)
+    const int* run_if;            // int[B] (nullable): sample b is skipped when run_if[b] == 0 -- the guarded fallback of the x2 tier
 };
 
 __device__ __forceinline__ float lrelu(float v) { return vmax(v, 0.2f * v); }
@@ -138,14 +138,39 @@ struct Block {
             }
         });
     }
-    // dst (+)= bias + Wconv * actT
+    __device__ __forceinline__ const unsigned char* conv_w(const h3d_spade_desc& Sp) const {
+#ifdef H3D_EXPERIMENT_ALIAS_W        // timing experiment (wrong results): every convolution reads the first one's bytes (L2-resident)
+        return wblob + A.D.block[0].spade[0].w_conv;
+#else
+        return wblob + Sp.w_conv;
+#endif
+    }
+    // Request the first k-steps of this SPADE's convolution weights into the (idle) register ring: called BEFORE the epilogue and
+    // the barrier in front of the convolution, so that their L2 round trip (~2 000 cycles, once per GEMM: 30 GEMMs per tile) hides
+    // behind that work instead of stalling the GEMM's first MFMA (round 6; the field kernel has done this since round 3).
+    __device__ __forceinline__ void prefetch_conv(const h3d_spade_desc& Sp) const {
+#ifndef H3D_X3T_NO_PREFETCH
+        x3t_prefetch<NTF, NX, P>(ring, conv_w(Sp), KS, 0, U, lane);
+#endif
+    }
+    // dst (+)= bias + Wconv * actT   (the ring holds the requests of prefetch_conv)
     template <bool ADD>
     __device__ __forceinline__ void conv(f32x16 (&dst)[NU], const h3d_spade_desc& Sp) const {
         add_vec<ADD>(dst, tables + Sp.b_conv);
-        gemm_x3t<T, NTF, NX, false, false, false, P>(dst, actT, act_stride, wblob + Sp.w_conv, KS, 0, KS, U, lane, ring);
+#ifndef H3D_X3T_NO_PREFETCH
+        gemm_x3t<T, NTF, NX, false, false, true, P>(dst, actT, act_stride, conv_w(Sp), KS, 0, KS, U, lane, ring);
+#else
+        gemm_x3t<T, NTF, NX, false, false, false, P>(dst, actT, act_stride, conv_w(Sp), KS, 0, KS, U, lane, ring);
+#endif
     }
     // per-pixel-style SPADE: fragments of lrelu((x*sc + sh) * (1 + gamma) + beta) -> actT; g is the gamma / beta scratch
     __device__ __forceinline__ void store_pixel(f32x16 (&x)[NU], f32x16 (&g)[NU], const h3d_spade_desc& Sp) const {
+#ifndef H3D_X3T_NO_PREFETCH
+        constexpr bool kPre = true;
+        x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_gamma, kKSA, 0, U, lane);      // gamma's first k-steps: under the bilinear gathers below
+#else
+        constexpr bool kPre = false;
+#endif
         // ---- shared-MLP activations a = relu(bilinear(G) + cst) as B fragments (natural K order): wave w covers
         //      channels 32w .. 32w+31 = k-steps 2w, 2w+1; lane = pixel
         {
@@ -208,12 +233,16 @@ struct Block {
                 }
             }
         }
+        H3D_TRACE(30);
         __syncthreads();
+        H3D_TRACE(31);
         // ---- gamma: g = (1 + bias_gamma) + Wg a ;  g <- (x*sc + sh) * g + bias_beta ;  beta: g += Wb a
         const float* __restrict__ vec = tables + Sp.vec;
         constexpr int a_stride = kKSA * 2048;
         add_vec<false>(g, vec);
-        gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
+        if constexpr (kPre) x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_beta, kKSA, 0, U, lane);       // beta's: under the affine pass below
+        H3D_TRACE(32);
         for_tiles([&](auto, int nt, int u0, int nu) __attribute__((always_inline)) {
             f32x4 bt[4], sc[4], sh[4];
 #pragma unroll
@@ -235,7 +264,10 @@ struct Block {
                 }
             }
         });
-        gemm_x3t<T, NTF, NX, false, false, false, P>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
+        H3D_TRACE(33);
+        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
+        prefetch_conv(Sp);                                                          // the convolution's: under the fragment stores below
+        H3D_TRACE(34);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             pin1(g[u]);
@@ -312,7 +344,9 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
     int* tap = reinterpret_cast<int*>(cj + 64);                       // [64][4] low-res tap offsets (pixel index)
     float* tw = reinterpret_cast<float*>(tap + 256);                  // [64][2] (ty, tx)
 
-    if (A.run_if && *A.run_if == 0) return;          // guarded fallback: nothing to redo
+    if (A.run_if && A.run_if[blockIdx.y] == 0) return;          // guarded fallback: nothing to redo for this sample
+    H3D_TRACE_INIT();
+    H3D_TRACE(0);
     const int t = threadIdx.x, lane0 = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m = lane0 & 31, h = lane0 >> 5;
@@ -346,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
     }
     __syncthreads();
 
+    H3D_TRACE(1);
     f32x16 cur[NU];                     // raw activations of this wave's units (lane = pixel, registers = channels)
     X3tRing<NTF + NX> ring;
     float rgb_acc = 0.f;                // threads < 192: (channel t>>6, pixel t&63)
@@ -370,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         }
     }
 
+    H3D_TRACE(2);
     auto block_view = [&]() __attribute__((always_inline)) {
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
@@ -391,17 +427,24 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
 #pragma unroll 1
         for (int s = 0; s < 2; ++s) {
             const h3d_spade_desc& Sp = Bk.spade[s];
+            H3D_TRACE(10);
             if (Sp.pixel_style) {
                 f32x16 acc[NU];
-                K.store_pixel(cur, acc, Sp);
+                K.store_pixel(cur, acc, Sp);          // (requests the convolution's first weights itself, behind its own GEMMs)
             } else {
+                K.prefetch_conv(Sp);
                 K.store_const(cur, Sp);
             }
+            H3D_TRACE(11);
             __syncthreads();
+            H3D_TRACE(12);
             K.template conv<false>(cur, Sp);          // the old cur is dead: it went into the fragments
+            H3D_TRACE(13);
             __syncthreads();                  // every wave finished reading actT / aT before the next stage rewrites them
+            H3D_TRACE(14);
         }
         if (Bk.to_rgb) K.to_rgb(cur, Bk, rgb_acc);
+        H3D_TRACE(15);
     }
     // ================= blocks from the first skip connection on (constant style only, checked by the host) =========
     // conv 0 runs into `acc` while `cur` keeps the block input; conv 1 then accumulates on top of it (x + conv1(...)) in
@@ -412,24 +455,37 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3t_kernel(Args A) {
         const h3d_block_desc& Bk = D.block[blk];
         const Block<NTF, NX, T, P> K = block_view();
         f32x16 acc[NU];
+        H3D_TRACE(20);
+        K.prefetch_conv(Bk.spade[0]);
         K.store_const(cur, Bk.spade[0]);
+        H3D_TRACE(21);
         __syncthreads();
+        H3D_TRACE(22);
         K.template conv<false>(acc, Bk.spade[0]);
+        H3D_TRACE(23);
         __syncthreads();                      // every wave finished reading actT
+        H3D_TRACE(24);
+        K.prefetch_conv(Bk.spade[1]);
         K.store_const(acc, Bk.spade[1]);
+        H3D_TRACE(25);
         __syncthreads();
+        H3D_TRACE(26);
         K.template conv<true>(cur, Bk.spade[1]);
+        H3D_TRACE(27);
         __syncthreads();
+        H3D_TRACE(28);
         if (Bk.to_rgb) K.to_rgb(cur, Bk, rgb_acc);
+        H3D_TRACE(29);
     }
     if (t < 192) {
         const int c = t >> 6, pm = t & 63;
         const int64_t p = p0 + pm;
         if (p < HW) A.rgb[((int64_t)b * 3 + c) * HW + p] = rgb_acc;
     }
+    H3D_TRACE_DUMP(A.rgb);         // development builds only: the trace of workgroup (1000, 3) overwrites the head of the image
     if constexpr (P == 4) {
-        // sticky range flag of the x2 tier: |activation| >= 2^15 (or non-finite) somewhere in this launch
-        if (A.ovf && !(gmax < 32768.f)) atomicOr(A.ovf, 1);
+        // sticky range flag of the x2 tier, per sample: |activation| >= 2^15 (or non-finite) somewhere in this sample's tiles
+        if (A.ovf && !(gmax < 32768.f)) atomicOr(A.ovf + b, 1);
     }
 }
 

@@ -104,7 +104,9 @@ __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigne
         for (int i = 0; i < NA; ++i) {
             const unsigned char* q = W + ((int64_t)U.nt[i] * KStot + ks0 + d) * 2048;
             x3t_gload<0>(R.a[d].h[i], q, lane_off);
+#ifndef H3D_EXPERIMENT_NO_WREC
             if constexpr (P >= 2) x3t_gload<1024>(R.a[d].l[i], q, lane_off);
+#endif
         }
 }
 
@@ -134,7 +136,11 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
                                          const X3tUnits<NTF, NX>& U, int lane, X3tRing<NTF + NX>& R) {
     constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
     constexpr bool X2 = P == 4;
+#ifdef H3D_EXPERIMENT_NO_WREC                       // timing experiment (wrong results): the weights' second plane is never loaded
+    constexpr bool WLO = false, XLO = P >= 3;
+#else
     constexpr bool WLO = P >= 2, XLO = P >= 3;       // which lo planes are read
+#endif
     constexpr int NLA = (WLO ? 2 : 1) * NA;          // weight loads per k-step
     static_assert(P >= 1 && P <= 4, "1, 2 or 3 partial products, or 4 = x2");
     static_assert(!X2 || (D % 2 == 0 && !GUARD), "x2: k-step parity follows the ring slot; short phases stay on three products");
@@ -247,7 +253,7 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
                 } else if constexpr (i < NA + 2 * NBH) {
                     constexpr int r = i - NA - NBH;
                     bread(IC<(NTF > 0 ? r : 2)>{}, IC<1>{});
-                } else wload(IC<i - NA - 2 * NBH>{}, IC<1>{});
+                } else if constexpr (WLO) wload(IC<i - NA - 2 * NBH>{}, IC<1>{});
             } else if constexpr (i < NLA) {
                 constexpr int tile = WLO ? i / 2 : i, plane = WLO ? i % 2 : 0;
                 wload(IC<tile>{}, IC<plane>{});

@@ -160,18 +160,25 @@ class SynthesisPlan:
         # products); "f16x1t" plain f16 products.
         default = ("f16x2" if self.x2_supported() else "bf16x3" if self.x3_supported()
                    else ("f16x2t" if self.x2_weights_in_range() else "bf16x3t") if self.x3t_supported() else "f32")
-        self._x2_flag = None          # int32 [1] on the device: the x2 engine's range flag of the LAST run (see run())
+        self._x2_flag = None          # int32 [B] on the device: the x2 engine's per-item range / monitor flags of the LAST run (see run())
         self.x2_guard = os.environ.get("H3D_SYNTH_GUARD", "1") != "0"
-        # Sampled error monitor of the x2 register engine (round 5): every forward re-evaluates ~16 of its 128-pixel tiles per
-        # image on the fp32-class engine and raises the same device flag as the range guard when a sampled pixel differs by more
-        # than `x2_monitor_tol` of the sample's channel maximum -- the bf16 engine behind it then redoes the batch.  The x2
-        # arithmetic uses up most of the 1e-3 parity budget (up to 9.6e-4 of the channel maximum over 192 images, profiles/r5_x2_fullimage_error.txt):
-        # a pose / checkpoint that pushes it over is caught here instead of shipping.  H3D_SYNTH_MONITOR=0 switches it off.
+        # Sampled error monitor of the x2 register engine (round 5): every forward re-evaluates `x2_monitor_tiles` of its
+        # 128-pixel tiles per image on the fp32-class engine and raises the item's device flag (the range guard's) when a sampled
+        # pixel differs by more than `x2_monitor_tol` of the image's channel maximum -- the bf16 engine behind it then redoes THAT
+        # ITEM (round 6: one flag per item; rounds 4-5 redid the batch, so an image depended on its batch mates).
+        # The tolerance carries the sampling factor (round 6): over 192 bench-size images the full-image maximum of |x2 - x3| was
+        # 1.2 - 1.65 times the maximum over a 16-tile sample (profiles/r5_x2_fullimage_error.txt: 9.6e-4 full vs 6.6e-4 sampled,
+        # 5.7e-4 vs 3.5e-4, 5.2e-4 vs 3.2e-4), so a sample is held to X2_MONITOR_BUDGET / X2_SAMPLING_FACTOR = 6e-4 / 1.7 = 3.5e-4:
+        # an item whose sample passes has a full-image error of <= 6e-4 by that ratio, 40 % inside the 1e-3 budget.
+        # H3D_SYNTH_MONITOR=0 switches the monitor off, H3D_SYNTH_MONITOR_TOL / _TILES override the two numbers.
         self.x2_monitor = os.environ.get("H3D_SYNTH_MONITOR", "1") != "0"
-        self.x2_monitor_tol = float(os.environ.get("H3D_SYNTH_MONITOR_TOL", "1e-3"))
-        self.x2_monitor_tiles = 16
+        self.x2_monitor_tol = float(os.environ.get("H3D_SYNTH_MONITOR_TOL", self.X2_MONITOR_BUDGET / self.X2_SAMPLING_FACTOR))
+        self.x2_monitor_tiles = int(os.environ.get("H3D_SYNTH_MONITOR_TILES", "32"))
         self._x2_monitor_buf = None   # (scratch image [B,3,H,W], per-item sampled error [B]) of the last run
         self.engine = os.environ.get("H3D_SYNTH_PRECISION", default)
+
+    X2_MONITOR_BUDGET = 6e-4      # full-image |x2 - x3| an item may carry, relative to its channel maximum (budget 1e-3)
+    X2_SAMPLING_FACTOR = 1.7      # largest measured (full-image maximum) / (sampled maximum) of that error, rounded up
 
     # ------------------------------------------------------------------ split-bf16 ("x3") engine
     def x3_supported(self):
@@ -560,13 +567,14 @@ class SynthesisPlan:
 
     def _shared_first_layer(self, feature_maps):
         """The SPADEs' shared 1x1 convolution at LOW resolution (it commutes with the bilinear resize): [B,R,F] x [F, 128 np].
-        58 GFLOP at the bench size -- on the package's own split-bf16 matrix-core GEMM (ops/linear.py: gemm_x3, fp32-class, ~1e-6)
+        58 GFLOP at the bench size -- on the package's own split-bf16 matrix-core GEMM (ops/linear.py: gemm_x3, fp32-class: 16 significant bits per operand, ~2e-5 worst case, ~1e-6 typical)
         when the widths are multiples of 64 and the rows are many (round 5: the last library GEMM of the inference path that was not
         a GEMV); the library's fp32 GEMM otherwise (CPU plans of the host-logic tests, hidden 420)."""
         B, R, F = feature_maps.shape
-        # (the row threshold sits below one image of every shipped geometry, so a batch and its items alone take the same kernel
-        # and stay bit-identical: the x2 arithmetic behind it turns a 1e-6 difference of its input into 1e-4 of quantisation noise)
-        if feature_maps.is_cuda and os.environ.get("H3D_SHARED_GEMM", "x3") == "x3" and B * R >= 1024:
+        # (the choice looks at the rows of ONE item, never at the batch: a batch and its items alone take the same kernel and stay
+        # bit-identical -- the x2 arithmetic behind it turns a 1e-6 difference of its input into 1e-4 of quantisation noise; every
+        # shipped geometry has R >= 2048)
+        if feature_maps.is_cuda and os.environ.get("H3D_SHARED_GEMM", "x3") == "x3" and R >= 1024:
             from ..components.ops import linear
             if linear._native_ok(self.ws_pixel.shape[0], F):
                 # the rendered maps arrive as a channel slice [.., 3:] of the [B,R,F+3] render output (row stride F + 3, 12 bytes
@@ -617,9 +625,7 @@ class SynthesisPlan:
                 # behind it on the same flag and only does work when the x2 launch left its f16 range
                 alt_tier = self.X3T_TIERS["bf16x3t"]
                 alt = self.build_x3t(alt_tier[0], alt_tier[3])
-                if self._x2_flag is None or self._x2_flag.device != fixed_style.device:
-                    self._x2_flag = torch.zeros(1, dtype=torch.int32, device=fixed_style.device)
-                self._x2_flag.zero_()
+                self._flags(B, fixed_style.device)
                 call = lambda blk, tr: _lib.load().h3d_synthesis_x3t_tier_guarded(
                     _lib.ptr(blk["wblob"]), _lib.ptr(blk["tables"]), ctypes.byref(blk["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr,
                     _lib.ptr(cst), len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W, tr[1], tr[2],
@@ -644,14 +650,12 @@ class SynthesisPlan:
                 lib, rc = _lib.load(), 0
                 entry = lib.h3d_synthesis_x2 if x2 else lib.h3d_synthesis_x3
                 if x2 and self.x2_guard and len(segs) == 1 and state is None:
-                    # Range-guarded x2: the kernel raises a device flag when an activation leaves the range its f16 planes carry
-                    # (|x| >= 2^15, inf, NaN upstream); the bf16 engine, launched right behind it on the same stream, returns at
-                    # once when the flag is clear and recomputes the image when it is set.  No host synchronisation; the x3
+                    # Range-guarded x2: the kernel raises an item's device flag when an activation of that item leaves the range
+                    # its f16 planes carry (|x| >= 2^15, inf, NaN upstream); the bf16 engine, launched right behind it on the same
+                    # stream, skips the items whose flag is clear and recomputes the others.  No host synchronisation; the x3
                     # stream shares descriptor, tables and per-forward tables with the x2 one (only the weight format differs).
                     seg, alt = segs[0], self.build_x3(False)["segments"][0]
-                    if self._x2_flag is None or self._x2_flag.device != fixed_style.device:
-                        self._x2_flag = torch.zeros(1, dtype=torch.int32, device=fixed_style.device)
-                    self._x2_flag.zero_()
+                    self._flags(B, fixed_style.device)
                     common = lambda sg: (_lib.ptr(sg["stream"]), sg["stages"], _lib.ptr(sg["tables"]), sg["tables"].numel(),
                                          ctypes.byref(sg["desc"]), _lib.ptr(G), self.g_channels, Hr, Wr, _lib.ptr(cst),
                                          len(self.pixel_ids), _lib.ptr(ab), len(self.const_ids), _lib.ptr(rgb), B, H, W,
@@ -686,6 +690,14 @@ class SynthesisPlan:
         _lib.check(rc, what)
         return rgb
 
+    def _flags(self, B, device):
+        """The per-item flags of a guarded run, zeroed on the current stream."""
+        if self._x2_flag is None or self._x2_flag.device != device or self._x2_flag.numel() != B:
+            self._x2_flag = torch.zeros(B, dtype=torch.int32, device=device)
+        else:
+            self._x2_flag.zero_()
+        return self._x2_flag
+
     def monitor_tiles(self, H, W):
         """(first, step) of the 128-pixel tiles the x2 monitor samples: ~x2_monitor_tiles of them, an odd step so that the
         samples walk through the columns of the image as well as down its rows."""
@@ -693,14 +705,22 @@ class SynthesisPlan:
         step = max(1, n_tiles // max(1, self.x2_monitor_tiles)) | 1
         return min(step // 2, n_tiles - 1), step
 
+    def monitor_tile_count(self, H, W):
+        first, step = self.monitor_tiles(H, W)
+        return len(range(first, (H * W + 127) // 128, step))
+
     def x2_monitor_errors(self):
         """Per-item sampled error of the LAST guarded x2 run (device tensor [B]; reading it synchronises), or None."""
         return None if self._x2_monitor_buf is None else self._x2_monitor_buf[1]
 
     def x2_fell_back(self):
-        """True when the last run() of the guarded x2 engine left its f16 range and the image came from the bf16 engine
-        (reads the device flag: synchronises; for tests and diagnostics)."""
-        return self._x2_flag is not None and bool(int(self._x2_flag.item()))        # register engine and LDS-resident x2 tier alike
+        """True when ANY item of the last run() of the guarded x2 engine left its f16 range (or its sampled error tolerance) and
+        came from the bf16 engine (reads the device flags: synchronises; for tests and diagnostics)."""
+        return self._x2_flag is not None and bool(int(self._x2_flag.max().item()))   # register engine and LDS-resident x2 tier alike
+
+    def x2_fallback_items(self):
+        """Batch indices the bf16 engine redid in the last guarded run (synchronises)."""
+        return [] if self._x2_flag is None else torch.nonzero(self._x2_flag).flatten().tolist()
 
     def _launch(self, G, cst, ab, rgb, B, Hr, Wr, H, W):
         return _lib.load().h3d_synthesis(_lib.ptr(self.blob), ctypes.byref(self.desc), _lib.ptr(G), self.g_channels, Hr, Wr,

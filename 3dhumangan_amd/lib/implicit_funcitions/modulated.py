@@ -68,6 +68,12 @@ class COORDCONCATSIREN(nn.Module):
         widest = max(hidden_dim, feature_dim)
         default = "f16x2" if widest <= 256 else "f16x2t" if widest <= 448 else "f32"
         self.precision = os.environ.get("H3D_FIELD_PRECISION", default)
+        # x2 render: refinement of ill-conditioned last samples on the three-product engine (render_geo; round 6)
+        self.refine_last_sample = os.environ.get("H3D_FIELD_REFINE", "1") != "0"
+        self.refine_eps = float(os.environ.get("H3D_FIELD_REFINE_EPS", "1e-3"))
+        self.refine_capacity = int(os.environ.get("H3D_FIELD_REFINE_CAP", "128"))       # listed units per batch item
+        self._refine_buf = None
+        self._sigma_scale_cache = None
 
     # ---- weight packing (host, once per weight version)
     def _params_for_pack(self):
@@ -242,10 +248,45 @@ class COORDCONCATSIREN(nn.Module):
         weights = torch.empty((B, R, S, 1), device=pts.device, dtype=torch.float32)
         blob = self.packed_weights(pts.device)
         mode = {"relu": 0, "softplus": 1}[clamp_mode]
-        fn = getattr(_lib.load(), self._GEO_ENGINES[self.precision])
-        rc = fn(_lib.ptr(blob), _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vik),
-                vt.shape[1], int(bool(legacy_mode)), _lib.ptr(dirs), _lib.ptr(fr), _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz),
-                _lib.ptr(feats), _lib.ptr(depth), _lib.ptr(weights), B, R, S, H, F, float(input_scaler), mode,
-                int(bool(last_back)), int(bool(white_back)), _lib.stream_handle())
+        lib = _lib.load()
+        common = lambda b: (_lib.ptr(b), _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(sk), _lib.ptr(vt), _lib.ptr(tv), _lib.ptr(vik),
+                            vt.shape[1], int(bool(legacy_mode)), _lib.ptr(dirs), _lib.ptr(fr), _lib.ptr(ph), _lib.ptr(z), _lib.ptr(nz),
+                            _lib.ptr(feats), _lib.ptr(depth), _lib.ptr(weights), B, R, S, H, F, float(input_scaler), mode,
+                            int(bool(last_back)), int(bool(white_back)))
+        if self.precision == "f16x2" and self.refine_last_sample:
+            # Round 6: rays whose LAST sample's density lies within `refine_eps` of zero (relative to the ray's largest density, floored
+            # by the density head's weight norm) are listed by the x2 launch and redone by the three-product engine right behind it:
+            # the reference's delta = 1e9 on the last sample (lib/generators/volume_rendering.py:21) turns the SIGN of that density
+            # into an alpha of 0 or 1, and the x2 arithmetic's ~1e-4 density error must not decide it.  No host synchronisation.
+            cap = self.refine_capacity
+            buf = self._refine_buf
+            if buf is None or buf[0].device != pts.device or buf[0].shape != (B, cap):
+                buf = (torch.zeros(B, cap, dtype=torch.int32, device=pts.device), torch.zeros(B, dtype=torch.int32, device=pts.device))
+                self._refine_buf = buf
+            keep, self.precision = self.precision, "f16x3"
+            try:
+                blob3 = self.packed_weights(pts.device)           # the same weights in the x3 format (cached per weight version)
+            finally:
+                self.precision = keep
+            scale = self._sigma_scale(pts.device)
+            rc = lib.h3d_render_fused_x2_geo_ref(*common(blob), float(self.refine_eps), scale, _lib.ptr(buf[0]), _lib.ptr(buf[1]), cap,
+                                                 _lib.stream_handle())
+            rc = rc or lib.h3d_render_fused_x3_geo_units(*common(blob3), _lib.ptr(buf[0]), _lib.ptr(buf[1]), cap, _lib.stream_handle())
+        else:
+            rc = getattr(lib, self._GEO_ENGINES[self.precision])(*common(blob), _lib.stream_handle())
         _lib.check(rc, "h3d_render_fused_geo")
         return feats, depth, weights
+
+    def _sigma_scale(self, device):
+        """Euclidean norm of the density head's weights (the scale of a density whose inputs are sines), cached per weight version:
+        the floor of the refinement threshold's scale."""
+        w = self.sigma_layer.weight
+        key = (w.data_ptr(), w._version, str(device))
+        if self._sigma_scale_cache is None or self._sigma_scale_cache[0] != key:
+            self._sigma_scale_cache = (key, float(w.detach().float().norm()))
+        return self._sigma_scale_cache[1]
+
+    def refined_units(self):
+        """Per-item number of wave units the LAST render_geo call listed for the three-product refinement (device tensor [B]; reading
+        it synchronises), or None."""
+        return None if self._refine_buf is None else self._refine_buf[1]

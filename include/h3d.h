@@ -291,6 +291,34 @@ int h3d_render_fused_x3_geo(const void* packed, const float* points, const int32
                             int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
                             int white_back, h3d_stream_t stream);
 
+/* Refinement of ill-conditioned last samples (round 6).  lib/generators/volume_rendering.py:21 gives a ray's last sample
+ * delta = 1e9: its alpha is 0 or 1 by the SIGN of its density (and with white_back the background term flips by the whole
+ * remaining transmittance, :48-49), so a ray whose last density lies within the ARITHMETIC's error of zero comes out wrong by
+ * O(1).  The x2 arithmetic's density error (~1e-4 of the densities' scale) makes that ~100 times likelier than fp32-class
+ * arithmetic does.  h3d_render_fused_x2_geo_ref is h3d_render_fused_x2_geo that also lists, per batch item, the wave units (a
+ * unit = one ray when S > 32, else the 32 / S rays of 32 consecutive samples; unit u covers samples [u, u + 1) * max(S, 32))
+ * holding a ray with
+ *     |sigma_last| <= ref_eps * max(max_s |sigma_s|, ref_scale)          (sigma: the density as integrated, noise added)
+ * in ref_list [B, ref_cap] int32 (any order) and counts them in ref_count [B] int32 (zeroed by the call on `stream`; it keeps
+ * counting beyond ref_cap: units past the capacity stay on the x2 arithmetic).  h3d_render_fused_x3_geo_units is
+ * h3d_render_fused_x3_geo (`packed` in the x3 format) restricted to exactly the listed units of every item: it overwrites their
+ * feats / depth / weights, so that those rays take the sign of an fp32-class density.  Launched back to back on one stream:
+ * no host synchronisation.  1 <= ref_cap <= 65536. */
+int h3d_render_fused_x2_geo_ref(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                int white_back, float ref_eps, float ref_scale, int32_t* ref_list, int32_t* ref_count,
+                                int ref_cap, h3d_stream_t stream);
+int h3d_render_fused_x3_geo_units(const void* packed, const float* points, const int32_t* nn_index, const float* joints,
+                                  const float* vertices, const float* tpose_vertices, const float* vertex_ik, int V,
+                                  int legacy_mode, const float* dirs, const float* freq, const float* phase,
+                                  const float* z_vals, const float* noise, float* feats, float* depth, float* weights,
+                                  int B, int R, int S, int Hd, int F, float input_scaler, int clamp_mode, int last_back,
+                                  int white_back, const int32_t* ref_list, const int32_t* ref_count, int ref_cap,
+                                  h3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A5 / A5+A6, split-operand arithmetic as the _x3 entry points, for hidden widths up to 448 ("x3t": the activations of
  * a 64-sample tile live in LDS as ready-made MFMA fragments and the output features are split over the four waves, so
@@ -438,11 +466,13 @@ int h3d_synthesis_x2_extra_lds(int C);
 
 /* Range-guarded pair (round 4).  The x2 engine's operand planes are f16: hi = f16(x) and f16(lo * 2^12) with |lo| <= ulp(hi)/2
  * are finite exactly for |x| < 2^15.  h3d_synthesis_x2_guarded is h3d_synthesis_x2 (single launch: no state) that also ORs 1
- * into *overflow (int32 in device memory, zeroed by the caller on the same stream) when any activation it fed to the matrix
- * cores was >= 2^15 in magnitude or not finite -- its image is then not to be used.  h3d_synthesis_x3_if is h3d_synthesis_x3
- * (bf16 planes: fp32 exponent range; `stream` in the x3 format) that returns at once, leaving rgb untouched, when
- * *run_if == 0.  Launched back to back on one stream with the same flag the pair is "x2, redone on x3 when out of range"
- * without a host synchronisation (SynthesisPlan.run does exactly that; replaces nothing in the reference -- its fp32
+ * into overflow[b] (int32[B] in device memory, zeroed by the caller on the same stream; round 6: ONE FLAG PER SAMPLE of the
+ * batch, rounds 4-5 had one per launch) when any activation of sample b it fed to the matrix cores was >= 2^15 in magnitude or
+ * not finite -- that sample's image is then not to be used.  h3d_synthesis_x3_if is h3d_synthesis_x3 (bf16 planes: fp32
+ * exponent range; `stream` in the x3 format) that leaves the image of every sample with run_if[b] == 0 untouched (its
+ * workgroups return at once) and recomputes the others, each on a grid that fills the chip by itself.  Launched back to back on
+ * one stream with the same flags the pair is "x2, the samples out of range redone on x3" -- a sample's pixels never depend on
+ * its batch mates -- without a host synchronisation (SynthesisPlan.run does exactly that; replaces nothing in the reference -- its fp32
  * convolutions, lib/components/map3d_layers.py:193-238, have no range limit to guard). */
 int h3d_synthesis_x2_guarded(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                              const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
@@ -462,10 +492,12 @@ int h3d_synthesis_x3_if(const void* stream, int64_t total_stages, const float* t
  *                           image of the full [B,3,H,W] shape) and nothing else;
  *   h3d_synthesis_check     per sample: err = max over channels of (max|rgb - rgb_ref| over exactly those tiles) / (max|rgb|
  *                           over the WHOLE image: the scale the 1e-3 budget is relative to), written to err_out[b] when
- *                           err_out != NULL; ORs 1 into *flag (int32, device memory) when err > tol or anything it read is
- *                           not finite.
- * Launched behind h3d_synthesis_x2_guarded and in front of h3d_synthesis_x3_if with the same flag this is "x2, redone on x3
- * when a sampled pixel leaves the budget", without a host synchronisation (SynthesisPlan.run).  tile_step >= 1. */
+ *                           err_out != NULL; ORs 1 into flag[b] (int32[B], device memory) when err > tol or anything it
+ *                           read of sample b is not finite.
+ * Launched behind h3d_synthesis_x2_guarded and in front of h3d_synthesis_x3_if with the same flags this is "x2, a sample redone
+ * on x3 when one of ITS sampled pixels leaves the tolerance", without a host synchronisation (SynthesisPlan.run; the default
+ * tolerance there is the 1e-3 budget divided by the measured ratio of a full image's maximum to its sample's).  tile_step >= 1
+ * (a step beyond the tile count samples tile_first alone). */
 int h3d_synthesis_x3_tiles(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                            const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                            const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,
@@ -497,9 +529,10 @@ int h3d_synthesis_x3t_tier(const void* wblob, const float* tables, const h3d_syn
                            int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H,
                            int W, int dtype, int products, h3d_stream_t stream);
 /* Range-guarded pair of this engine (round 4; as h3d_synthesis_x2_guarded / h3d_synthesis_x3_if): with products == 4 (the x2
- * tier) the launch ORs 1 into *flag (int32, device memory, zeroed by the caller) when an activation it converted to the f16
- * planes was >= 2^15 in magnitude or non-finite; with any other tier -- use (dtype 0, products 3): bf16 planes, fp32 exponent
- * range, `wblob` in that tier's format -- it returns at once, leaving rgb untouched, when *flag == 0. */
+ * tier) the launch ORs 1 into flag[b] (int32[B], device memory, zeroed by the caller: one flag per sample) when an activation
+ * of sample b it converted to the f16 planes was >= 2^15 in magnitude or non-finite; with any other tier -- use (dtype 0,
+ * products 3): bf16 planes, fp32 exponent range, `wblob` in that tier's format -- it recomputes exactly the samples with
+ * flag[b] != 0 and leaves the others' images untouched. */
 int h3d_synthesis_x3t_tier_guarded(const void* wblob, const float* tables, const h3d_synth_desc* desc, const float* G,
                                    int g_channels, int Hr, int Wr, const float* cst, int n_cst, const float* ab, int n_ab,
                                    float* rgb, int B, int H, int W, int dtype, int products, int* flag, h3d_stream_t stream);

@@ -50,8 +50,10 @@ def _recorded(big=True):
                   "cfg4_trainstep_b4": {"ms_per_iteration": 203.4, "workload": "v" * 300},
                   "cfg4_trainstep_b4_amp_fp16": {"ms_per_iteration": 142.0},
                   "cpu_baseline_cfg1": {"value": 0.0902}, "cpu_baseline_cfg2_b8": {"value": 0.1062}},
-        "checked": {"max_rel_err": 6.894e-4, "max_rel_err_render": 1.4e-6, "tolerance": 1e-3, "ok": True, "batch_items": list(range(16)),
-                    "per_item_max_rel_err": [1e-4] * 16, "rays_excluded_as_ill_conditioned_in_the_oracle": 0, "pixels": 300, "rays": 44},
+        "checked": {"max_rel_err": 6.894e-4, "max_rel_err_render": 1.4e-6, "max_rel_err_image_norm": 4.1e-4, "tolerance": 1e-3, "ok": True,
+                    "batch_items": list(range(16)), "per_item_max_rel_err": [1e-4] * 16, "rays_excluded_as_ill_conditioned_in_the_oracle": 0,
+                    "pixels_per_item": 13800, "rays_per_item": 532, "pixel_fraction": 0.0526, "x2_fallback_items": [9],
+                    "x2_monitor": {"tolerance": 3.5e-4, "max_sampled_err": 4.1e-4, "tiles_per_image": 32}},
         "cpu_baseline": {"value": 0.01256, "unit": "images/s", "cores": 64, "kind": "port", "cpu": "AMD EPYC", "runs": [19.9, 20.1],
                          "sample": "1 image at 1/2 linear size (256x256 px, 48x48 rays x 64 samples, same widths): 1 warm-up + 2 timed "
                                    "runs, median 19.9 s -> 80 s per full-size image (work is linear in rays and pixels); pure-PyTorch "
@@ -89,6 +91,10 @@ def test_line_is_one_short_strict_json_line_with_the_contract_keys():
     c = line["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and len(c["sample"]) <= 260
     assert line["checked"]["ok"] is True and line["checked"]["tolerance"] == 1e-3 and line["checked"]["items"] == 16
+    # round 6: both norms, the norm's name, the checked fraction and the per-item fallbacks are in the contract line
+    assert line["checked"]["max_rel_err_image_norm"] == 4.1e-4 and "oracle" in line["checked"]["norm"]
+    assert line["checked"]["pixel_fraction_per_item"] >= 0.05 and line["checked"]["x2_fallback_items"] == [9]
+    assert line["checked"]["x2_monitor_tol"] == 3.5e-4
     assert _no_long_arrays(line) and len(line["extra"]) <= 10
     assert "kernels" not in line and "telemetry" not in line and "step_ms" not in line
     # the non-finite side numbers were dropped, not printed as NaN / Infinity

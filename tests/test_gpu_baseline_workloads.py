@@ -55,10 +55,10 @@ def check_workload(cfg_name, gen_hw, render_hw, S, B, oracle_items, n_cells=24, 
     out = G.forward(z.to(DEV), cd, jitter=jit.to(DEV), **cfg)
     rgb, ren = out["rgbs"].cpu(), out["rgbs_render"].cpu()
     plan = G.synthesis_plan(DEV)
-    batch_fell_back = plan.x2_fell_back()         # range guard / sampled error monitor of the x2 engine: the batch was redone on x3
+    redone = plan.x2_fallback_items()             # range guard / sampled error monitor of the x2 engine: the items redone on x3
     if plan.x2_monitor_errors() is not None:
         print(f"{cfg_name} {gen_hw} B={B}: x2 monitor sampled errors {[round(float(v), 6) for v in plan.x2_monitor_errors().cpu()]}, "
-              f"fell back: {batch_fell_back}")
+              f"items redone on x3: {redone}")
     assert rgb.shape == (B, 3) + tuple(gen_hw) and torch.isfinite(rgb).all()
     # ---- oracle on a subset of pixels (and the rays they need) for a few batch items
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
@@ -79,9 +79,11 @@ def check_workload(cfg_name, gen_hw, render_hw, S, B, oracle_items, n_cells=24, 
     for i in sorted(set([0, B - 1] + list(oracle_items))):
         ci = {k: v[i:i + 1].to(DEV) for k, v in cond.items()}
         one = G.forward(z[i:i + 1].to(DEV), ci, jitter=jit[i:i + 1].to(DEV), **cfg)
-        # the same engine -> the same image; when the monitor sent only one of the two runs to the x3 engine (the flag is per
-        # launch: one item over the tolerance redoes its whole batch) both images are within the budget of the reference
-        same_engine = plan.x2_fell_back() == batch_fell_back
+        # round 6: the guard / monitor flags are per item, so an item takes the same engine alone and in its batch and its image
+        # does not depend on its batch mates (an item whose sampled error sits within rounding of the tolerance could still differ
+        # in that decision: the two runs' table GEMMs are not bit-identical)
+        same_engine = plan.x2_fell_back() == (i in redone)
+        assert same_engine or abs(float(plan.x2_monitor_errors()[0]) - plan.x2_monitor_tol) < 1e-5
         assert rel_err_channels(one["rgbs"].cpu(), rgb[i:i + 1]) < (2e-5 if same_engine else 1e-3)
         assert rel_err_channels(one["rgbs_render"].cpu(), ren[i:i + 1]) < 2e-5
     return G
@@ -124,8 +126,9 @@ def test_cfg3_bench_workload_more_seeds_checked_as_the_bench_checks_itself(seed)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     G, cfg, z, cond, jit = make("MAP3DBN512", (512, 512), (96, 96), 64, 16, seed)
-    chk = bench.self_check(G, cfg, z.to(DEV), {k: v.to(DEV) for k, v in cond.items()}, jit.to(DEV), [0, 11], n_cells=8)
-    print(f"seed {seed}: image {chk['max_rel_err']:.2e} (subset-normalised {chk['max_rel_err_subset_norm']:.2e}), render "
+    chk = bench.self_check(G, cfg, z.to(DEV), {k: v.to(DEV) for k, v in cond.items()}, jit.to(DEV), [0, 11])
+    assert chk["pixel_fraction"] >= 0.05
+    print(f"seed {seed}: image {chk['max_rel_err']:.2e} (image-normalised {chk['max_rel_err_image_norm']:.2e}), render "
           f"{chk['max_rel_err_render']:.2e}, excluded rays {chk['rays_excluded_as_ill_conditioned_in_the_oracle']}, monitor {chk['x2_monitor']}")
     assert chk["ok"] and chk["max_rel_err"] < TOL and chk["max_rel_err_render"] < TOL
     assert chk["synthesis_engine"] == "f16x2"

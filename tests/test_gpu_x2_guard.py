@@ -53,6 +53,7 @@ def test_guard_is_quiet_in_range_and_changes_nothing(width):
     G, meta, sd = make(width, 64, 64, 12, 12, seed=1)
     plan = G.synthesis_plan(DEV)
     assert plan.engine == "f16x2" and plan.x2_guard
+    plan.x2_monitor = False                             # the RANGE guard is under test here (the sampled error monitor: test_gpu_x2_monitor.py)
     B = 2
     fmap, style = torch.randn(B, 144, width), torch.randn(B, width)
     out = run(G, meta, fmap, style)
@@ -70,13 +71,22 @@ def test_activations_beyond_the_f16_planes_are_recomputed_on_bf16(width):
     G, meta, sd = make(width, 64, 64, 12, 12, seed=2)
     plan = G.synthesis_plan(DEV)
     assert plan.engine == "f16x2"
+    plan.x2_monitor = False                             # the RANGE guard alone
     B = 2
     fmap, style = torch.randn(B, 144, width) * 6e4, torch.randn(B, width)
     ref = oracle_rgb(sd, meta, fmap, style)
     assert torch.isfinite(ref).all()
     out = run(G, meta, fmap, style)
-    assert plan.x2_fell_back()
+    assert plan.x2_fell_back() and plan.x2_fallback_items() == [0, 1]
     assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-3
+    # one item out of range, one in range: only the first is redone, the second keeps its x2 pixels (round 6: per-item flags)
+    mixed = torch.cat([fmap[:1], torch.randn(1, 144, width)])
+    out = run(G, meta, mixed, style)
+    assert plan.x2_fallback_items() == [0]
+    plan.x2_guard = False
+    assert torch.equal(run(G, meta, mixed, style)[1], out[1])
+    plan.x2_guard = True
+    assert rel_err(out.cpu(), oracle_rgb(sd, meta, mixed, style)) < 1e-3
     plan.x2_guard = False
     raw = run(G, meta, fmap, style).cpu()
     assert (not torch.isfinite(raw).all()) or rel_err(raw, ref) > 1e-2, "the scenario no longer breaks the unguarded x2 engine"
