@@ -14,6 +14,7 @@
 // operands so that the sum over a ray's samples is a sum over accumulator registers -- the [N, F+4] field tensor never
 // exists in HBM.  MFMA-bound: 2*(7*Hd^2 + 41*Hd) flop per sample (x3 products issued).
 #include "x3t_common.hpp"
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,8 +45,15 @@ struct LayoutT {           // offsets in BYTES into the blob (all multiples of 1
 };
 
 int kstot_of(int wi, int KS) { return wi == W_COORD ? 1 : wi == W_GEO ? 2 : wi == W_F0 ? 2 * KS : wi == W_COLOR ? KS + 1 : KS; }
+// bytes of one tile of matrix wi: the two input layers always travel in the x3 format; with `x2c` (the x2 tier's blob) the
+// accumulator-fed matrices are in the x2c format (x3t_common.hpp: 3 KiB per K-tile, the colour layer's trailing view-direction
+// k-step in the x3 format)
+__host__ __device__ inline int64_t tile_bytes_of(int wi, int KS, bool x2c) {
+    const int n = wi == W_COORD ? 1 : wi == W_GEO ? 2 : wi == W_F0 ? 2 * KS : wi == W_COLOR ? KS + 1 : KS;
+    return (x2c && wi >= W_F0) ? x3t_tile_bytes<true>(n) : x3t_tile_bytes<false>(n);
+}
 
-LayoutT make_layout(int Hd, int F) {
+LayoutT make_layout(int Hd, int F) {       // (one layout for both blob kinds: the x2c tiles use the first three quarters of their regions)
     LayoutT L;
     const int w = Hd > F ? Hd : F;
     int nt = (w + 31) / 32;
@@ -82,6 +90,7 @@ struct Args {
     float* weights;
     int64_t N;
     int Hd, F, geo_stride, S, clamp_mode, last_back, white_back;
+    int n_groups;          // sample groups (64 samples, or one ray when S > 64) per batch item; a workgroup walks blockIdx.x, + gridDim.x, ..
     float input_scaler;
     LayoutT L;
 };
@@ -159,17 +168,23 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
     H3D_TRACE(0);
     const int group_pts = FUSED ? (S > 64 ? S : 64) : 64;
     const int tiles = group_pts / 64;
-    const int64_t g0 = (int64_t)blockIdx.x * group_pts;
     const int seglen = FUSED ? (S < 64 ? S : 64) : 64;
     const float inv_f = invs[W_FEAT];
-
+    SplitF16 split;
+    // Persistent workgroups (round 6): the batch item's activation tables above are built once, then the workgroup walks the
+    // sample groups blockIdx.x, blockIdx.x + gridDim.x, .. (rounds 2-5 launched one workgroup per 64 samples: 147 456 table
+    // builds of 7 x HdP entries per launch at the bench size)
+    int n_groups = A.n_groups;
+    asm volatile("" : "+s"(n_groups));
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t g0 = (int64_t)grp * group_pts;
     // state carried across the tiles of a multi-tile ray (wave 0 lanes hold identical copies)
     float carryT = 1.f, carryW = 0.f, carryD = 0.f, rgbacc = 0.f;
     float rayacc[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) rayacc[u] = 0.f;
 
-    SplitF16 split;
     for (int ti = 0; ti < tiles; ++ti) {
         const int64_t n0 = g0 + (int64_t)ti * 64;
         const bool last_tile = ti == tiles - 1;
@@ -184,6 +199,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
 #else
         auto wmat = [&](int wi) { return wblob + L.w[wi]; };
 #endif
+        // tile stride of matrix wi and byte offset of its k-step ks0 (a K-tile boundary, or the colour layer's trailing k-step)
+        auto wstride = [&](int wi) { return tile_bytes_of(wi, KS, X2); };
+        auto woff = [&](int wi, int ks0) { return (X2 && wi >= W_F0) ? x3t_kstep_off<true>(ks0) : x3t_kstep_off<false>(ks0); };
         X3tUnits<NTF, NX> U = U0;
 #pragma unroll
         for (int i = 0; i < NTF + NX; ++i) asm volatile("" : "+s"(U.nt[i]));
@@ -403,20 +421,20 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
                                     // epilogue and barriers in front of it (x3t_prefetch)
         // ---- coordinate layer (K = 3) -> sine -> FiLM 0, coordinate half
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_COORD * 2048, in_stride, wmat(W_COORD), 1, 0, 1, U, lane, ring);
-        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), 2 * KS, 0, U, lane);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_COORD * 2048, in_stride, wmat(W_COORD), wstride(W_COORD), 0, 1, U, lane, ring);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), wstride(W_F0), 0, U, lane);
         H3D_TRACE(2);
         store_film(acc, ST_COORD);
         H3D_TRACE(3);
         __syncthreads();
         H3D_TRACE(4);
         zero(acc2);
-        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), wstride(W_F0), 0, KS, U, lane, ring);
         H3D_TRACE(5);
         // ---- geometry layer (K = 31) -> sine -> FiLM 0, geometry half (same accumulators)
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_GEO * 2048, in_stride, wmat(W_GEO), 2, 0, 2, U, lane, ring);
-        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), 2 * KS, KS, U, lane);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_GEO * 2048, in_stride, wmat(W_GEO), wstride(W_GEO), 0, 2, U, lane, ring);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0), wstride(W_F0), woff(W_F0, KS), U, lane);
         H3D_TRACE(6);
         __syncthreads();          // every wave has finished reading the coordinate activations
         H3D_TRACE(7);
@@ -424,8 +442,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(8);
         __syncthreads();
         H3D_TRACE(9);
-        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), 2 * KS, KS, KS, U, lane, ring);
-        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F1), KS, 0, U, lane);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc2, actT, act_stride, wmat(W_F0), wstride(W_F0), woff(W_F0, KS), KS, U, lane, ring);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_F1), wstride(W_F1), 0, U, lane);
         H3D_TRACE(10);
         __syncthreads();
         H3D_TRACE(11);
@@ -437,8 +455,8 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
             zero(acc);
-            gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_F0 + l), KS, 0, KS, U, lane, ring);
-            x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0 + l + 1), l == 3 ? KS + 1 : KS, 0, U, lane);      // FiLM l+1, or the colour layer
+            gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_F0 + l), wstride(W_F0 + l), 0, KS, U, lane, ring);
+            x3t_prefetch<NTF, NX, P>(ring, wmat(W_F0 + l + 1), wstride(W_F0 + l + 1), 0, U, lane);      // FiLM l+1, or the colour layer
             H3D_TRACE(14);
             __syncthreads();
             H3D_TRACE(15);
@@ -506,9 +524,9 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(20);
         // ---- colour FiLM on [x, dir]: KS k-steps over the hidden features + one k-step carrying the view direction
         zero(acc);
-        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_COLOR), KS + 1, 0, KS, U, lane, ring);
-        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_DIR * 2048, in_stride, wmat(W_COLOR), KS + 1, KS, 1, U, lane, ring);
-        x3t_prefetch<NTF, NX, P>(ring, wmat(W_FEAT), KS, 0, U, lane);
+        gemm_x3t<F16, NTF, NX, false, false, true, P>(acc, actT, act_stride, wmat(W_COLOR), wstride(W_COLOR), 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, false, true>(acc, inT + IN_DIR * 2048, in_stride, wmat(W_COLOR), wstride(W_COLOR), woff(W_COLOR, KS), 1, U, lane, ring);
+        x3t_prefetch<NTF, NX, P>(ring, wmat(W_FEAT), wstride(W_FEAT), 0, U, lane);
         H3D_TRACE(21);
         __syncthreads();
         H3D_TRACE(22);
@@ -522,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         H3D_TRACE(25);
         f32x16 (&accF)[NU] = acc2;
         zero(accF);
-        gemm_x3t<F16, NTF, NX, true, false, true, P>(accF, actT, act_stride, wmat(W_FEAT), KS, 0, KS, U, lane, ring);
+        gemm_x3t<F16, NTF, NX, true, false, true, P>(accF, actT, act_stride, wmat(W_FEAT), wstride(W_FEAT), 0, KS, U, lane, ring);
         H3D_TRACE(26);
         __syncthreads();
         H3D_TRACE(27);
@@ -631,6 +649,7 @@ __global__ __launch_bounds__(256, 1) void field_x3t_kernel(Args A) {
         __syncthreads();     // actT / inT / part / wgt are rewritten by the next tile
         H3D_TRACE(29);
     }
+    }   // sample groups
     H3D_TRACE_DUMP(A.out);
 }
 
@@ -640,10 +659,20 @@ size_t lds_bytes(const LayoutT& L) {
 }
 
 template <int NTF, int NX, bool FUSED, int P>
-int launch_one(const Args& A, int B, int64_t groups, hipStream_t st) {
+int launch_one(Args A, int B, int64_t groups, hipStream_t st) {
     H3D_ALLOW_MAX_LDS((field_x3t_kernel<NTF, NX, FUSED, P>));
+    A.n_groups = (int)groups;
+    // about eight persistent workgroups per CU in total (one resident per CU: LDS): tables once per many groups, short tail
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    static const int per_cu = getenv("H3D_FIELD_X3T_WG_PER_CU") ? atoi(getenv("H3D_FIELD_X3T_WG_PER_CU")) : 8;      // 0: one group per workgroup
+    const int64_t per_sample = per_cu <= 0 ? groups : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((field_x3t_kernel<NTF, NX, FUSED, P>), dim3((unsigned)groups, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
+    hipLaunchKernelGGL((field_x3t_kernel<NTF, NX, FUSED, P>), dim3((unsigned)per_sample, (unsigned)B), dim3(256), lds_bytes(A.L), st, A);
     return h3d::launch_status(FUSED ? "h3d_render_fused_x3t" : "h3d_neural_field_x3t");
 }
 
@@ -720,46 +749,48 @@ int field_pack_t(const h3d_field_params* p, int Hd, int F, void* blob_, bool x2)
     memset(blob, 0, L.total);
     float* invs = reinterpret_cast<float*>(blob + L.inv_scale);
     const float target = 8192.f;
-    auto dst = [&](int wi) { return reinterpret_cast<uint16_t*>(blob + L.w[wi]); };
-    // accumulator-order matrices: x3 (hi + lo fragments) or x2 (hi fragments + fp6 records)
-    auto pack_acc = [&](const float* w, int ld, int in_begin, int in_count, int n_out, int KStot, int ks0, int KSm, float sc, int wi) {
-        if (x2) x3t_pack_x2(w, ld, in_begin, in_count, n_out, L.NT, KStot, ks0, KSm, sc, blob + L.w[wi]);
-        else x3t_pack_f16(w, ld, in_begin, in_count, n_out, L.NT, KStot, ks0, KSm, sc, dst(wi), true);
+    auto dst = [&](int wi) { return blob + L.w[wi]; };
+    // accumulator-order matrices: x3 format (hi + lo fragments) or, the x2 tier's blob, x2c (hi fragments + lo records, 3 KiB per K-tile)
+    auto pack_acc = [&](const float* w, int ld, int in_begin, int in_count, int n_out, int ks0, int KSm, float sc, int wi) {
+        const int64_t stride = tile_bytes_of(wi, L.KS, x2);
+        if (x2) x3t_pack_x2(w, ld, in_begin, in_count, n_out, L.NT, stride, x3t_kstep_off<true>(ks0), KSm, sc, dst(wi));
+        else x3t_pack_f16(w, ld, in_begin, in_count, n_out, L.NT, stride, x3t_kstep_off<false>(ks0), KSm, sc, dst(wi), true);
     };
     // input layers: natural K order
     {
         const float sc = pow2_scale(p->w_coord, (int64_t)Hd * 3, target);
-        x3t_pack_f16(p->w_coord, 3, 0, 3, Hd, L.NT, 1, 0, 1, sc, dst(W_COORD), false);
+        x3t_pack_f16(p->w_coord, 3, 0, 3, Hd, L.NT, tile_bytes_of(W_COORD, L.KS, x2), 0, 1, sc, dst(W_COORD), false);
         invs[W_COORD] = 1.f / (sc * kSInT);
     }
     {
         const float sc = pow2_scale(p->w_geo, (int64_t)Hd * 31, target);
-        x3t_pack_f16(p->w_geo, 31, 0, 31, Hd, L.NT, 2, 0, 2, sc, dst(W_GEO), false);
+        x3t_pack_f16(p->w_geo, 31, 0, 31, Hd, L.NT, tile_bytes_of(W_GEO, L.KS, x2), 0, 2, sc, dst(W_GEO), false);
         invs[W_GEO] = 1.f / (sc * kSInT);
     }
     // FiLM 0: both K halves accumulate into the same registers -> one scale; k-steps [0, KS) coordinate half, [KS, 2KS) geometry half
     {
         const float sc = pow2_scale(p->w_film[0], (int64_t)Hd * 2 * Hd, target);
-        pack_acc(p->w_film[0], 2 * Hd, 0, Hd, Hd, 2 * L.KS, 0, L.KS, sc, W_F0);
-        pack_acc(p->w_film[0], 2 * Hd, Hd, Hd, Hd, 2 * L.KS, L.KS, L.KS, sc, W_F0);
+        pack_acc(p->w_film[0], 2 * Hd, 0, Hd, Hd, 0, L.KS, sc, W_F0);
+        pack_acc(p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, L.KS, sc, W_F0);
         invs[W_F0] = 1.f / sc;
     }
     for (int l = 1; l < 4; ++l) {
         const float sc = pow2_scale(p->w_film[l], (int64_t)Hd * Hd, target);
-        pack_acc(p->w_film[l], Hd, 0, Hd, Hd, L.KS, 0, L.KS, sc, W_F0 + l);
+        pack_acc(p->w_film[l], Hd, 0, Hd, Hd, 0, L.KS, sc, W_F0 + l);
         invs[W_F0 + l] = 1.f / sc;
     }
     // colour layer: KS k-steps over the hidden features (columns 3..), one k-step over the view direction (columns
     // 0..2, natural order); one scale for the whole matrix (same accumulators), both inputs unscaled
     {
         const float sc = pow2_scale(p->w_color, (int64_t)Hd * (Hd + 3), target);
-        pack_acc(p->w_color, Hd + 3, 3, Hd, Hd, L.KS + 1, 0, L.KS, sc, W_COLOR);
-        x3t_pack_f16(p->w_color, Hd + 3, 0, 3, Hd, L.NT, L.KS + 1, L.KS, 1, sc, dst(W_COLOR), false);
+        pack_acc(p->w_color, Hd + 3, 3, Hd, Hd, 0, L.KS, sc, W_COLOR);
+        x3t_pack_f16(p->w_color, Hd + 3, 0, 3, Hd, L.NT, tile_bytes_of(W_COLOR, L.KS, x2),
+                     x2 ? x3t_kstep_off<true>(L.KS) : x3t_kstep_off<false>(L.KS), 1, sc, dst(W_COLOR), false);
         invs[W_COLOR] = 1.f / sc;
     }
     {
         const float sc = pow2_scale(p->w_feat, (int64_t)F * Hd, target);
-        pack_acc(p->w_feat, Hd, 0, Hd, F, L.KS, 0, L.KS, sc, W_FEAT);
+        pack_acc(p->w_feat, Hd, 0, Hd, F, 0, L.KS, sc, W_FEAT);
         invs[W_FEAT] = 1.f / sc;
     }
     float* bias = reinterpret_cast<float*>(blob + L.bias);

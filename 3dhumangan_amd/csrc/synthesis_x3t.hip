@@ -150,7 +150,7 @@ struct Block {
     // behind that work instead of stalling the GEMM's first MFMA (round 6; the field kernel has done this since round 3).
     __device__ __forceinline__ void prefetch_conv(const h3d_spade_desc& Sp) const {
 #ifndef H3D_X3T_NO_PREFETCH
-        x3t_prefetch<NTF, NX, P>(ring, conv_w(Sp), KS, 0, U, lane);
+        x3t_prefetch<NTF, NX, P>(ring, conv_w(Sp), x3t_tile_bytes<X2>(KS), 0, U, lane);
 #endif
     }
     // dst (+)= bias + Wconv * actT   (the ring holds the requests of prefetch_conv)
@@ -158,16 +158,16 @@ struct Block {
     __device__ __forceinline__ void conv(f32x16 (&dst)[NU], const h3d_spade_desc& Sp) const {
         add_vec<ADD>(dst, tables + Sp.b_conv);
 #ifndef H3D_X3T_NO_PREFETCH
-        gemm_x3t<T, NTF, NX, false, false, true, P>(dst, actT, act_stride, conv_w(Sp), KS, 0, KS, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, true, P>(dst, actT, act_stride, conv_w(Sp), x3t_tile_bytes<X2>(KS), 0, KS, U, lane, ring);
 #else
-        gemm_x3t<T, NTF, NX, false, false, false, P>(dst, actT, act_stride, conv_w(Sp), KS, 0, KS, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, false, P>(dst, actT, act_stride, conv_w(Sp), x3t_tile_bytes<X2>(KS), 0, KS, U, lane, ring);
 #endif
     }
     // per-pixel-style SPADE: fragments of lrelu((x*sc + sh) * (1 + gamma) + beta) -> actT; g is the gamma / beta scratch
     __device__ __forceinline__ void store_pixel(f32x16 (&x)[NU], f32x16 (&g)[NU], const h3d_spade_desc& Sp) const {
 #ifndef H3D_X3T_NO_PREFETCH
         constexpr bool kPre = true;
-        x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_gamma, kKSA, 0, U, lane);      // gamma's first k-steps: under the bilinear gathers below
+        x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_gamma, x3t_tile_bytes<X2>(kKSA), 0, U, lane);      // gamma's first k-steps: under the bilinear gathers below
 #else
         constexpr bool kPre = false;
 #endif
@@ -240,8 +240,8 @@ struct Block {
         const float* __restrict__ vec = tables + Sp.vec;
         constexpr int a_stride = kKSA * 2048;
         add_vec<false>(g, vec);
-        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_gamma, kKSA, 0, kKSA, U, lane, ring);
-        if constexpr (kPre) x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_beta, kKSA, 0, U, lane);       // beta's: under the affine pass below
+        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_gamma, x3t_tile_bytes<X2>(kKSA), 0, kKSA, U, lane, ring);
+        if constexpr (kPre) x3t_prefetch<NTF, NX, P>(ring, wblob + Sp.w_beta, x3t_tile_bytes<X2>(kKSA), 0, U, lane);       // beta's: under the affine pass below
         H3D_TRACE(32);
         for_tiles([&](auto, int nt, int u0, int nu) __attribute__((always_inline)) {
             f32x4 bt[4], sc[4], sh[4];
@@ -265,7 +265,7 @@ struct Block {
             }
         });
         H3D_TRACE(33);
-        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_beta, kKSA, 0, kKSA, U, lane, ring);
+        gemm_x3t<T, NTF, NX, false, false, kPre, P>(g, aT, a_stride, wblob + Sp.w_beta, x3t_tile_bytes<X2>(kKSA), 0, kKSA, U, lane, ring);
         prefetch_conv(Sp);                                                          // the convolution's: under the fragment stores below
         H3D_TRACE(34);
 #pragma unroll

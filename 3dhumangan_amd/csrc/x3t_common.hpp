@@ -91,23 +91,68 @@ struct X3tRing {
     AF a[kX3tDepth];
 };
 
-// Request k-steps ks0 .. ks0+D-2 of the wave's tiles of matrix W into ring slots 0 .. D-2 (2*NA*(D-1) loads).  Between
-// this call and the GEMM that consumes it (PRE = true) the caller must not start another GEMM on the same ring.
+// Weight layouts of a matrix, per tile (x3t_pack_f16 / x3t_pack_x2):
+//   x3 format   [k-step][hi | lo][64 lanes][16 B]: 2 KiB per k-step (tiers P = 1, 2, 3; the short input phases of every tier)
+//   x2c format  (round 6, tier P = 4) per K-tile T (k-steps 2T, 2T + 1) 3 KiB:
+//                   +0     f16 hi fragment of k-step 2T
+//                   +1024  lo record, 16 B per lane: the 16 six-bit e2m3 codes of lo * 2^12 * alpha (dwords 3-5 of the fp6 A
+//                          operand) and the lane's block-scale dword (the e8m0 byte of 1 / alpha in bits 0-7, zeros above)
+//                   +2048  f16 hi fragment of k-step 2T + 1
+//               The 16 hi codes of the fp6 operand (dwords 0-2) are NOT stored: the kernel converts them from the two f16 hi
+//               fragments it holds anyway (v_cvt_scalef32_pk32_fp6_f16 with the lane's scale) -- 3 bytes per weight through the
+//               vector-memory path instead of 4.  Measured (profiles/r6_wide_*): the engine's GEMM loops run at the 64 B/clk/CU of
+//               that path (28 KiB of weights per k-step and 64-sample tile at width 448 against 336 matrix-pipe cycles).
+//               A trailing odd k-step of a matrix (the colour layer's view-direction k-step) keeps the x3 format.
+template <bool X2C>
+__host__ __device__ inline int64_t x3t_tile_bytes(int KStot) { return X2C ? (int64_t)(KStot >> 1) * 3072 + (KStot & 1) * 2048 : (int64_t)KStot * 2048; }
+template <bool X2C>
+__host__ __device__ inline int x3t_kstep_off(int ks) { return X2C ? (ks >> 1) * 3072 + (ks & 1) * 2048 : ks * 2048; }
+
+// x2c, odd k-step (gemm_x3t): memory operation `op` is issued behind matrix instruction j(op), the j with
+// j * NOPS / NM <= op < (j + 1) * NOPS / NM.  The fp6 instructions are j = 0 .. NU - 1; those of weight tile i are j = 2 i, 2 i + 1
+// (the extra unit's: 2 NTF).  Operation NBH + i refills weight tile i's hi fragment: not before the tile's last fp6 instruction;
+// operations >= NBH + NA read / load record halves: not before the last fp6 instruction of the k-step.
+template <int NTF, int NX>
+constexpr bool x2c_order_ok(int NBH, int NOPS, int NM) {
+    auto behind = [&](int op) { int j = 0; while ((j + 1) * NOPS / NM <= op) ++j; return j; };
+    const int NA = NTF + NX, NU = 2 * NTF + NX;
+    for (int i = 0; i < NA; ++i)
+        if (behind(NBH + i) < (i < NTF ? 2 * i + 1 : 2 * NTF)) return false;
+    return behind(NBH + NA) >= NU - 1;
+}
+
+// Request the first D-1 k-steps of a phase (starting at byte `phase_off` of every tile, tiles `tile_stride` bytes apart) of the
+// wave's tiles of matrix W into ring slots 0 .. D-2.  Between this call and the GEMM that consumes it (PRE = true) the caller must
+// not start another GEMM on the same ring.  P = 4: the phase is in the x2c format and starts on a K-tile boundary.
 template <int NTF, int NX, int P = 3>
-__device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigned char* __restrict__ W, int KStot, int ks0,
+__device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigned char* __restrict__ W, int64_t tile_stride, int phase_off,
                                              const X3tUnits<NTF, NX>& U, int lane) {
     constexpr int NA = NTF + NX;
+    constexpr bool X2 = P == 4;
     const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
     for (int d = 0; d < kX3tDepth - 1; ++d)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned char* q = W + ((int64_t)U.nt[i] * KStot + ks0 + d) * 2048;
+            const unsigned char* q = W + (int64_t)U.nt[i] * tile_stride + phase_off + x3t_kstep_off<X2>(d);
             x3t_gload<0>(R.a[d].h[i], q, lane_off);
-#ifndef H3D_EXPERIMENT_NO_WREC
-            if constexpr (P >= 2) x3t_gload<1024>(R.a[d].l[i], q, lane_off);
-#endif
+            if constexpr (X2) { if ((d & 1) == 0) x3t_gload<1024>(R.a[d].l[i], q, lane_off); }      // the K-tile's lo record rides with its even k-step
+            else if constexpr (P >= 2) x3t_gload<1024>(R.a[d].l[i], q, lane_off);
         }
+}
+
+// fp6 A operand of a K-tile (x2c format): dwords 0-2 = the hi codes, converted here from the two f16 hi fragments with the lane's
+// block scale; dwords 3-5 = the lo codes and dword 6 = the scale, as loaded (lr).  (The upper 16 inputs of the conversion are
+// don't-cares: its dwords 3-5 are discarded.)
+__device__ __forceinline__ i32x8 x2c_record(const u32x4& h0, const u32x4& h1, const u32x4& lr) {
+    typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+    const F16::vec8 a = __builtin_bit_cast(F16::vec8, h0), b = __builtin_bit_cast(F16::vec8, h1);
+    const f16x16 hi = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f16x32 v = __builtin_shufflevector(hi, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                             -1, -1, -1, -1, -1, -1);            // upper half undefined: no copies
+    const float cs = __builtin_bit_cast(float, lr[3] << 23);                    // 1 / alpha = 2^(byte - 127): the dword holds the byte alone
+    const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, cs);
+    return i32x8{(int)r[0], (int)r[1], (int)r[2], (int)lr[0], (int)lr[1], (int)lr[2], (int)lr[3], 0};
 }
 
 // acc[u] += W(tile(u), ks) x X(mt(u), ks), ks = 0 .. KS-1 (KS a multiple of kX3tDepth unless GUARD).
@@ -132,34 +177,34 @@ __device__ __forceinline__ void x3t_prefetch(X3tRing<NTF + NX>& R, const unsigne
 //                                 behind the last fp6 instruction (operation order: weight hi, fragment hi, fragment lo, weight lo).
 template <typename T, int NTF, int NX, bool SWAP, bool GUARD = false, bool PRE = false, int P = 3>
 __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsigned char* bT, int mt_stride,
-                                         const unsigned char* __restrict__ W, int KStot, int ks0, int KS,
+                                         const unsigned char* __restrict__ W, int64_t tile_stride, int phase_off, int KS,
                                          const X3tUnits<NTF, NX>& U, int lane, X3tRing<NTF + NX>& R) {
     constexpr int NA = NTF + NX, NU = 2 * NTF + NX, D = kX3tDepth;
     constexpr bool X2 = P == 4;
-#ifdef H3D_EXPERIMENT_NO_WREC                       // timing experiment (wrong results): the weights' second plane is never loaded
-    constexpr bool WLO = false, XLO = P >= 3;
-#else
     constexpr bool WLO = P >= 2, XLO = P >= 3;       // which lo planes are read
-#endif
     constexpr int NLA = (WLO ? 2 : 1) * NA;          // weight loads per k-step
     static_assert(P >= 1 && P <= 4, "1, 2 or 3 partial products, or 4 = x2");
-    static_assert(!X2 || (D % 2 == 0 && !GUARD), "x2: k-step parity follows the ring slot; short phases stay on three products");
+    static_assert(!X2 || (D == 4 && !GUARD), "x2: k-step parity follows the ring slot (the in-flight counts below assume depth 4); short phases stay on three products");
+    // loads that may stay in flight while waiting for a k-step's fragments: those of the D - 2 k-steps behind it -- x2c: one even
+    // k-step (hi + lo record: 2 NA loads) and one odd one (hi: NA loads) per pair
+    constexpr int kInflight = X2 ? (D - 2) / 2 * 3 * NA : (D - 2) * NLA;
     static_assert(!(GUARD && PRE), "short phases load everything themselves");
     typedef typename X3tRing<NA>::AF AF;
     struct BF { u32x4 h[2], l[2], xh, xl; };
     AF (&a)[D] = R.a;
     const unsigned char* wp[NA];              // uniform: first k-step of this phase of the wave's tiles
 #pragma unroll
-    for (int i = 0; i < NA; ++i) wp[i] = W + ((int64_t)U.nt[i] * KStot + ks0) * 2048;
+    for (int i = 0; i < NA; ++i) wp[i] = W + (int64_t)U.nt[i] * tile_stride + phase_off;
     const unsigned lane_off = (unsigned)lane * 16u;
     const unsigned char* bp = bT + lane * 16;
     const unsigned char* bx = bp + U.xmt * mt_stride;
-    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {      // NLA loads, always all of them
+    auto loadA = [&](AF& f, int ks) __attribute__((always_inline)) {      // all loads of k-step ks (x2c: the lo record rides with the even one)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned char* q = wp[i] + ks * 2048;     // one scalar address per tile and k-step; lo plane 1 KB further
+            const unsigned char* q = wp[i] + x3t_kstep_off<X2>(ks);     // one scalar address per tile and k-step; lo plane / record 1 KB further
             x3t_gload<0>(f.h[i], q, lane_off);
-            if constexpr (WLO) x3t_gload<1024>(f.l[i], q, lane_off);
+            if constexpr (X2) { if ((ks & 1) == 0) x3t_gload<1024>(f.l[i], q, lane_off); }
+            else if constexpr (WLO) x3t_gload<1024>(f.l[i], q, lane_off);
         }
     };
     auto loadB = [&](BF& f, int ks) __attribute__((always_inline)) {
@@ -178,17 +223,20 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
     // MFMA j of a k-step, j = 0 .. P*NU-1: pass j / NU (hi*hi, then lo*hi, then hi*lo) over all units -- consecutive MFMAs
     // never share an accumulator.  x2 (ODD k-step): j < NU are the fp6 instructions of the K-tile (record halves of the
     // previous k-step ap / bp and of this one), j >= NU the f16 ones; even k-step: f16 only.
+    i32x8 wrec[NA];                           // x2: the fp6 A operands of the current K-tile (live from a tile's first fp6 instruction to its last)
     auto mfma1 = [&](auto jc, auto oddc, const AF& a, const BF& b, const AF& ap, const BF& bp) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         constexpr bool ODD = decltype(oddc)::value != 0;
         if constexpr (X2) {
             if constexpr (ODD && j < NU) {
                 constexpr int u = j, sl = u < 2 * NTF ? u / 2 : NTF;
-                const u32x4 w0 = ap.l[sl], w1 = a.l[sl];
+                // the K-tile's weight record: hi codes converted from the two hi fragments (previous, even k-step: ap.h; this one:
+                // a.h), lo codes + scale from the record loaded with the even k-step (ap.l) -- built once per tile, in front of its
+                // first instruction
+                if constexpr (u >= 2 * NTF || (u & 1) == 0) wrec[sl] = x2c_record(ap.h[sl], a.h[sl], ap.l[sl]);
                 const u32x4 x0 = u < 2 * NTF ? bp.l[u & 1] : bp.xl, x1 = u < 2 * NTF ? b.l[u & 1] : b.xl;
-                const i32x8 w6 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
                 const i32x8 x6 = {(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
-                acc[u] = mm6<SWAP>(w6, x6, acc[u]);
+                acc[u] = mm6<SWAP>(wrec[sl], x6, acc[u]);
             } else {
                 constexpr int u = ODD ? j - NU : j, sl = u < 2 * NTF ? u / 2 : NTF;
                 const u32x4 xv = u < 2 * NTF ? b.h[u & 1] : b.xh;
@@ -216,13 +264,17 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
     auto kstep = [&](auto la, auto lb, auto oddc, const AF& a_cur, const BF& b_cur, AF& a_nxt, int ka, BF& b_nxt, int kb) __attribute__((always_inline)) {
         constexpr bool LA = decltype(la)::value != 0, LB = decltype(lb)::value != 0, ODD = decltype(oddc)::value != 0;
         constexpr int XP = XLO ? 2 : 1;                            // fragment planes read per sample tile
-        constexpr int NBF = NTF > 0 ? 2 * XP : 0, NB = NBF + (NX ? XP : 0), NOPS = NLA + NB;
+        // x2c: this k-step requests k-step `ka` of the OTHER parity (the ring depth is even): an odd k-step requests an even one
+        // (hi fragments + lo records: 2 NA loads), an even k-step an odd one (hi fragments: NA loads)
+        constexpr int NLK = X2 ? (ODD ? 2 * NA : NA) : NLA;
+        constexpr int NBF = NTF > 0 ? 2 * XP : 0, NB = NBF + (NX ? XP : 0), NOPS = NLK + NB;
         constexpr int NM = X2 ? (ODD ? 2 * NU : NU) : P * NU;
         constexpr int NBH = (NTF > 0 ? 2 : 0) + (NX ? 1 : 0);      // x2: fragment hi reads (= lo reads)
         auto wload = [&](auto tc, auto pc) __attribute__((always_inline)) {
             constexpr int tile = decltype(tc)::value, plane = decltype(pc)::value;
             if constexpr (LA) {
-                const unsigned char* q = wp[tile] + ka * 2048;
+                // (x2c: ka has the parity opposite to this k-step's, so its offset inside the K-tile is a compile-time constant)
+                const unsigned char* q = X2 ? wp[tile] + (ka >> 1) * 3072 + (ODD ? 0 : 2048) : wp[tile] + ka * 2048;
                 if constexpr (plane == 0) x3t_gload<0>(a_nxt.h[tile], q, lane_off);
                 else x3t_gload<1024>(a_nxt.l[tile], q, lane_off);
             }
@@ -244,16 +296,15 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         auto memop = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
             if constexpr (X2) {
-                // weight hi (NA), fragment hi (NBH), fragment lo (NBH), weight lo (NA): the first half of the operations touches
-                // no record half
-                if constexpr (i < NA) wload(IC<i>{}, IC<0>{});
-                else if constexpr (i < NA + NBH) {
-                    constexpr int r = i - NA;
-                    bread(IC<(NTF > 0 ? r : 2)>{}, IC<0>{});
-                } else if constexpr (i < NA + 2 * NBH) {
-                    constexpr int r = i - NA - NBH;
-                    bread(IC<(NTF > 0 ? r : 2)>{}, IC<1>{});
-                } else if constexpr (WLO) wload(IC<i - NA - 2 * NBH>{}, IC<1>{});
+                // fragment hi (NBH), weight hi (NA), fragment lo = record halves (NBH), weight lo records (NA, odd k-steps only).
+                // In an odd k-step the slots being refilled (a_nxt, b_nxt) are the previous, even k-step's, whose weight hi
+                // fragments, weight lo records and fragment record halves feed this k-step's fp6 instructions: the refill of
+                // weight tile i comes behind the tile's last fp6 instruction, every read / load into a record (half) behind the
+                // LAST fp6 instruction (x2c_order_ok, checked where the operations are placed)
+                if constexpr (i < NBH) bread(IC<(NTF > 0 ? i : 2)>{}, IC<0>{});
+                else if constexpr (i < NBH + NA) wload(IC<i - NBH>{}, IC<0>{});
+                else if constexpr (i < 2 * NBH + NA) bread(IC<(NTF > 0 ? i - NBH - NA : 2)>{}, IC<1>{});
+                else wload(IC<i - 2 * NBH - NA>{}, IC<1>{});
             } else if constexpr (i < NLA) {
                 constexpr int tile = WLO ? i / 2 : i, plane = WLO ? i % 2 : 0;
                 wload(IC<tile>{}, IC<plane>{});
@@ -263,6 +314,9 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
                 else bread(IC<2>{}, IC<r - NBF>{});
             }
         };
+        if constexpr (X2 && ODD) {
+            static_assert(x2c_order_ok<NTF, NX>(NBH, NOPS, NM), "x2c: a refill would overtake the fp6 instructions that read its slot");
+        }
         static_for<0, NM>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             mfma1(jc, oddc, a_cur, b_cur, a_nxt, b_nxt);
@@ -298,18 +352,25 @@ __device__ __forceinline__ void gemm_x3t(f32x16 (&acc)[2 * NTF + NX], const unsi
         // slot d of a trip: the fragments of its k-step were requested D-1 slots ago; the requests of the D-2 slots in
         // between -- (D-2) * NLA loads -- may stay in flight.  Its own requests (k-step +D-1) follow inside kstep.
         for (int ks = 0; ks < KS - D; ks += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                x3t_wait_frags<(D - 2) * NLA, NA, WLO>(a[d].h, a[d].l);
+            static_for<0, D>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int d = decltype(dc)::value;
+#ifdef H3D_EXPERIMENT_TRACE_FINE
+                H3D_TRACE(50 + d);                    // before the wait for k-step ks + d
+#endif
+                x3t_wait_frags<kInflight, NA, (X2 ? (d & 1) == 0 : WLO)>(a[d].h, a[d].l);      // (x2c: only even k-steps carry a record)
+#ifdef H3D_EXPERIMENT_TRACE_FINE
+                H3D_TRACE(60 + d);                    // after it
+#endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (d & 1) kstep(IC<1>{}, IC<1>{}, IC<1>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
-                else kstep(IC<1>{}, IC<1>{}, IC<0>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
-            }
+                kstep(IC<1>{}, IC<1>{}, IC<(d & 1)>{}, a[d], b[d & 1], a[(d + D - 1) % D], ks + d + D - 1, b[(d + 1) & 1], ks + d + 1);
+            });
         }
         // the last D k-steps: one more request, then the ring drains
         static_for<0, D>([&](auto dc) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
-            x3t_wait_frags<(d == 0 ? D - 2 : D - 1 - d) * NLA, NA, WLO>(a[d].h, a[d].l);
+            // in flight behind tail k-step d: k-steps d + 1 .. min(d + 2, D - 1) of the tail (x2c: odd ones NA loads, even ones 2 NA)
+            constexpr int kTail = !X2 ? (d == 0 ? D - 2 : D - 1 - d) * NLA : (d <= 1 ? 3 * NA : d == 2 ? NA : 0);
+            x3t_wait_frags<kTail, NA, (X2 ? (d & 1) == 0 : WLO)>(a[d].h, a[d].l);
             __builtin_amdgcn_sched_barrier(0);
             kstep(IC<(d == 0)>{}, IC<(d < D - 1)>{}, IC<(d & 1)>{}, a[d], b[d & 1], a[(d + D - 1) % D], KS - 1, b[(d + 1) & 1], KS - D + d + 1);
         });
@@ -440,10 +501,10 @@ inline float x3t_f16_to_f32(uint16_t v) {
     return f;
 }
 
-// W [n_out, ld] row-major, K range [in_begin, in_begin + in_count) -> A fragments [NT][KStot][2][64][8] f16 (scaled),
-// written into k-steps ks0 .. ks0+KSm-1 of every tile.
-inline void x3t_pack_f16(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int KStot, int ks0, int KSm,
-                         float scale, uint16_t* dst, bool acc_order) {
+// W [n_out, ld] row-major, K range [in_begin, in_begin + in_count) -> A fragments in the x3 format, [k-step][hi | lo][64][8] f16
+// (scaled), KSm k-steps starting at byte `phase_off` of every tile; tiles are `tile_stride` bytes apart.
+inline void x3t_pack_f16(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int64_t tile_stride, int64_t phase_off, int KSm,
+                         float scale, unsigned char* dst8, bool acc_order) {
     for (int nt = 0; nt < NT; ++nt)
         for (int ks = 0; ks < KSm; ++ks)
             for (int lane = 0; lane < 64; ++lane)
@@ -454,9 +515,9 @@ inline void x3t_pack_f16(const float* w, int ld, int in_begin, int in_count, int
                     if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
                     const uint16_t hi = x3t_f32_to_f16_rn(v);
                     const uint16_t lo = x3t_f32_to_f16_rn(v - x3t_f16_to_f32(hi));
-                    const int64_t base = (((int64_t)nt * KStot + ks0 + ks) * 2) * 64 * 8;
-                    dst[base + lane * 8 + e] = hi;
-                    dst[base + 64 * 8 + lane * 8 + e] = lo;
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(dst8 + (int64_t)nt * tile_stride + phase_off + (int64_t)ks * 2048);
+                    dst[lane * 8 + e] = hi;
+                    dst[64 * 8 + lane * 8 + e] = lo;
                 }
 }
 
@@ -497,12 +558,13 @@ inline void x2_make_record(const float (&hi)[16], const float (&lo)[16], unsigne
     rec[6] = rec[7] = (unsigned)(127 - ea) * 0x01010101u;
 }
 
-// x3t_pack_f16 for the x2 tier: accumulator-order matrices only (KSm even); hi planes as x3t_pack_f16, the "lo" planes hold
-// the record halves.  head_rows > 0: a head tile (only rows < head_rows of the 32 are real: w is [head_rows, ld]).
-inline void x3t_pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int KStot, int ks0, int KSm,
+// x3t_pack_f16 for the x2 tier, x2c format (see x3t_tile_bytes): accumulator-order matrices only, KSm (even) k-steps starting at
+// byte `phase_off` (a K-tile boundary) of every tile: per K-tile [hi fragment 2T | lo record | hi fragment 2T + 1], 3 KiB.
+inline void x3t_pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, int64_t tile_stride, int64_t phase_off, int KSm,
                         float scale, unsigned char* dst) {
     for (int nt = 0; nt < NT; ++nt)
-        for (int T = 0; T < KSm / 2; ++T)
+        for (int T = 0; T < KSm / 2; ++T) {
+            unsigned char* kt = dst + (int64_t)nt * tile_stride + phase_off + (int64_t)T * 3072;
             for (int lane = 0; lane < 64; ++lane) {
                 const int nn = 32 * nt + (lane & 31), hh = lane >> 5;
                 float hi[16], lo[16];
@@ -514,16 +576,17 @@ inline void x3t_pack_x2(const float* w, int ld, int in_begin, int in_count, int 
                         const uint16_t h16 = x3t_f32_to_f16_rn(v);
                         hi[8 * j + e] = x3t_f16_to_f32(h16);
                         lo[8 * j + e] = v - hi[8 * j + e];
-                        uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)nt * KStot + ks0 + 2 * T + j) * 2) * 1024);
-                        hd[lane * 8 + e] = h16;
+                        reinterpret_cast<uint16_t*>(kt + j * 2048)[lane * 8 + e] = h16;
                     }
                 unsigned rec[8];
                 x2_make_record(hi, lo, rec);
-                for (int j = 0; j < 2; ++j) {
-                    unsigned* cd = reinterpret_cast<unsigned*>(dst + (((int64_t)nt * KStot + ks0 + 2 * T + j) * 2 + 1) * 1024);
-                    for (int d = 0; d < 4; ++d) cd[lane * 4 + d] = rec[4 * j + d];
-                }
+                // lo record: code dwords 3-5 (slots 16-31) and the scale dword; the hi codes (dwords 0-2) are what
+                // v_cvt_scalef32_pk32_fp6_f16 makes of the hi fragments with that scale: not stored
+                unsigned* cd = reinterpret_cast<unsigned*>(kt + 1024);
+                for (int d = 0; d < 3; ++d) cd[lane * 4 + d] = rec[3 + d];
+                cd[lane * 4 + 3] = rec[6] & 0xffu;                   // the scale byte alone (the matrix instruction reads byte 0, the conversion shifts it)
             }
+        }
 }
 
 }  // namespace h3d

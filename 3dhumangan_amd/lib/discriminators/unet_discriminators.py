@@ -61,6 +61,15 @@ class Conv2d(nn.Conv2d):
                         return conv_ops.conv2d(xh, self.weight, self.bias)
             elif conv_ops.supported(x, self.weight):
                 return conv_ops.conv2d(x, self.weight, self.bias)
+            if x.is_cuda and not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") != torch.float16):
+                # round 6: no silent library path on the GPU -- a call the native kernels do not cover (a kernel size other than
+                # 1 / 3, a dtype other than fp32 / f16) is an error, as it is in the generator; H3D_DISC_CONV=torch opts into
+                # torch's convolution for the whole discriminator.  (CPU tensors run torch's convolution: the world-2 gloo tests of
+                # the trainers' control flow need the module on the host; autocast types other than float16 go to the library, above.)
+                from ... import _lib
+                raise _lib.H3DError(f"UNetDiscriminator: {tuple(x.shape)} {x.dtype} * {tuple(self.weight.shape)} is not covered by "
+                                    "h3d_conv_x3 (kernel sizes 1 and 3, fp32 / f16 activations); set H3D_DISC_CONV=torch to run the "
+                                    "discriminator on torch's convolutions")
         return super().forward(x)
 
 

@@ -320,6 +320,20 @@ class SynthesisPlan:
         out[:, :, 1] = rec
         return out.view(torch.int16).flatten()
 
+    @classmethod
+    def pack_tiles_x2c(cls, w_out_in, KS, NT, acc_order=True):
+        """[n_out, n_in] -> the x2 tier's weights of the LDS-resident engine in the x2c format (round 6, csrc/x3t_common.hpp), tile-major
+        [NT][K-tile T][3 KiB] as int16 bit patterns: +0 the f16 hi fragment of k-step 2T, +1024 the lo record -- 16 B per lane: the
+        16 six-bit codes of lo * 2^12 * alpha (dwords 3-5 of the fp6 A operand) and a dword holding the lane's block-scale byte --, +2048 the hi
+        fragment of k-step 2T + 1.  The 16 hi codes (dwords 0-2) are not stored: the kernel converts them from the hi fragments
+        (v_cvt_scalef32_pk32_fp6_f16, the lane's scale), so a weight costs 3 bytes of the vector-memory path instead of 4."""
+        st = cls.pack_stream_x2(w_out_in, KS, NT, acc_order=acc_order, dense=False).view(torch.uint8).view(KS, NT, 2, 64, 16)
+        T = KS // 2
+        ev, od = st[0::2], st[1::2]                                   # [T, NT, plane, 64 lanes, 16 B]
+        rec = torch.cat([ev[:, :, 1, :, 12:16], od[:, :, 1, :, 0:9], torch.zeros_like(od[:, :, 1, :, 0:3])], dim=-1)   # dwords 3 | 4, 5 | scale byte, 0, 0, 0
+        out = torch.stack([ev[:, :, 0], rec, od[:, :, 0]], dim=2)     # [T, NT, 3, 64, 16]
+        return out.permute(1, 0, 2, 3, 4).contiguous().view(torch.int16).flatten()       # [NT][T][3][64][16 B]
+
     # ------------------------------------------------------------------ split-bf16 engine with LDS-resident activations
     def x3t_supported(self):
         """C <= 448, per-pixel styles only in blocks without skip connection, no plain block after the first skip block
@@ -355,12 +369,12 @@ class SynthesisPlan:
         wchunks, woff, tchunks, toff = [], [0], [], [0]
 
         def add_w(w_out_in, ks, acc_order):
-            if fmt == "x2":        # f16 hi fragments + fp6 records (same bytes per stage)
-                frag = self.pack_stream_x2(w_out_in, ks, NT, acc_order=acc_order, dense=False).view(ks, NT, 2 * 64 * 8)
+            o = woff[0]
+            if fmt == "x2":        # x2c: f16 hi fragments + lo records, [NT][K-tile][3 KiB]
+                wchunks.append(self.pack_tiles_x2c(w_out_in, ks, NT, acc_order=acc_order))
             else:
                 frag = self.pack_stream_bf16(w_out_in, ks, NT, acc_order=acc_order, dtype=dtype).view(ks, NT, 2 * 64 * 8)
-            o = woff[0]
-            wchunks.append(frag.transpose(0, 1).contiguous().flatten())          # [NT][ks][2][64][8]
+                wchunks.append(frag.transpose(0, 1).contiguous().flatten())      # [NT][ks][2][64][8]
             woff[0] += wchunks[-1].numel() * 2
             return o
 

@@ -36,11 +36,34 @@ def decode_matrix(wblob_i16, byte_off, KS, NT, acc_order):
 
 
 def decode_x2(wblob_i16, byte_off, KS, NT, acc_order):
-    """x2 blob [NT][KS][f16 hi fragment | record halves] -> (Whi, groups) of tests/x2_emulation.x2_operands_matmul."""
+    """x2c blob (round 6) [NT][K-tile][hi fragment 2T | lo record | hi fragment 2T + 1] -> (Whi, groups) of
+    tests/x2_emulation.x2_operands_matmul.  The hi codes are not stored: the kernel converts them from the hi fragments with the
+    lane's block scale (v_cvt_scalef32_pk32_fp6_f16) -- restated here with the packer's own e2m3 rounding -- and the stream decoder
+    of the register engine's tests takes the re-assembled full records."""
     from test_x3_plan_cpu import decode_x2 as decode_stream
-    n = NT * KS * 1024
-    st = wblob_i16[byte_off // 2: byte_off // 2 + n].view(NT, KS, 1024).transpose(0, 1).contiguous().flatten()
-    return decode_stream(st, 0, KS, NT, order=None if acc_order else (lambda ks, h, e: 16 * ks + 8 * h + e), dense=False)
+    T = KS // 2
+    n = NT * T * 3 * 512                                                           # int16 elements
+    t = wblob_i16[byte_off // 2: byte_off // 2 + n].view(NT, T, 3, 512)
+    hi = torch.stack([t[:, :, 0], t[:, :, 2]], dim=2)                              # [NT, T, 2, 512] hi fragments of k-steps 2T, 2T + 1
+    lorec = t[:, :, 1].contiguous().view(torch.uint8).view(NT, T, 64, 16).to(torch.int64)
+    scale_byte = lorec[..., 12]
+    assert not lorec[..., 13:16].any()                                              # the scale byte alone in its dword
+    alpha = torch.exp2((127 - scale_byte).double())                                # [NT, T, 64]
+    hv = hi.contiguous().view(torch.float16).double().view(NT, T, 2, 64, 8).permute(0, 1, 3, 2, 4).reshape(NT, T, 64, 16)
+    codes = sp.SynthesisPlan.e2m3_codes((hv * alpha.unsqueeze(-1)).float())      # slots 0-15: 8 j + e  [NT, T, 64, 16]
+    c = codes.view(NT, T, 64, 4, 4)
+    b0 = c[..., 0] | ((c[..., 1] & 3) << 6)
+    b1 = (c[..., 1] >> 2) | ((c[..., 2] & 15) << 4)
+    b2 = (c[..., 2] >> 4) | (c[..., 3] << 2)
+    hib = torch.stack([b0, b1, b2], dim=-1).reshape(NT, T, 64, 12)                 # dwords 0-2 of the record
+    sc4 = scale_byte.unsqueeze(-1).expand(-1, -1, -1, 4)
+    full = torch.cat([hib, lorec[..., 0:12], sc4, sc4], dim=-1).to(torch.uint8)     # [NT, T, 64, 32 B]: dwords 0-2 | 3-5 | 6 | 7
+    st = torch.zeros(KS, NT, 2, 1024, dtype=torch.uint8)
+    for j in range(2):
+        st[j::2, :, 0] = hi[:, :, j].contiguous().view(torch.uint8).view(NT, T, 1024).transpose(0, 1)
+        st[j::2, :, 1] = full[..., 16 * j: 16 * j + 16].reshape(NT, T, 1024).transpose(0, 1)
+    return decode_stream(st.view(torch.int16).flatten(), 0, KS, NT, order=None if acc_order else (lambda ks, h, e: 16 * ks + 8 * h + e),
+                         dense=False)
 
 
 def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):

@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
     const size_t bytes = (size_t)total * NT * 2048;
     unsigned char* d; float* o;
     hipMalloc(&d, bytes); hipMemset(d, 0, bytes); hipMalloc(&o, 4096);
-    const size_t lds = (size_t)H3D_RING_DEPTH * NT * 2048;
+    // OCC = 1: pad the allocation past half the LDS so that ONE workgroup is resident per CU whatever the register count is
+    const size_t lds = (size_t)H3D_RING_DEPTH * NT * 2048 + (OCC == 1 ? 48 * 1024 : 0);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, probe, 256, lds);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
