@@ -116,35 +116,44 @@ def test_field_x2_pack_is_the_emulated_arithmetic(Hd):
 
 
 def decode_x2t(blob, off, KStot, ks0, KS, NT):
-    """Tile-major x2 stages of the LDS-resident engine, [tile][KStot][hi fragment 1 KiB | record half 1 KiB] -> as decode_x2."""
-    st = blob[off: off + NT * KStot * 2048].view(NT, KStot, 2, 1024)[:, ks0: ks0 + KS]
+    """Tile-major x2c tiles of the LDS-resident engine (round 6, csrc/x3t_common.hpp): per K-tile 3 KiB = [hi fragment of k-step 2T |
+    lo record: 12 B of lo codes + the scale byte in a dword | hi fragment of k-step 2T + 1]; a trailing odd k-step of the matrix (the
+    colour layer's view-direction k-step) keeps the 2 KiB x3 format behind the K-tiles -> as decode_x2.  The hi codes are not stored:
+    the kernel converts them from the hi fragments with the lane's scale (v_cvt_scalef32_pk32_fp6_f16); restated here with q_e2m3."""
+    tile_bytes = (KStot // 2) * 3072 + (KStot & 1) * 2048
+    assert ks0 % 2 == 0 and KS % 2 == 0
+    tiles = blob[off: off + NT * tile_bytes].view(NT, tile_bytes)
+    kt = tiles[:, (ks0 // 2) * 3072: (ks0 // 2 + KS // 2) * 3072].reshape(NT, KS // 2, 3, 1024)
     Whi = torch.zeros(32 * NT, 16 * KS, dtype=torch.float64)
-    hi = st[:, :, 0].contiguous().view(torch.float16).double().view(NT, KS, 64, 8)
+    hi = torch.stack([kt[:, :, 0], kt[:, :, 2]], dim=2).contiguous().view(torch.float16).double().view(NT, KS, 64, 8)
     for ks in range(KS):
         for h in range(2):
             for e in range(8):
                 Whi[:, acc_k(ks, h, e)] = hi[:, ks, 32 * h: 32 * h + 32, e].reshape(-1)
     recs = {}
-    half = st[:, :, 1].contiguous().view(torch.int32).view(NT, KS, 64, 4)
+    lorec = kt[:, :, 1].contiguous().view(torch.int32).view(NT, KS // 2, 64, 4)
     for T in range(KS // 2):
-        rec = torch.cat([half[:, 2 * T], half[:, 2 * T + 1]], dim=-1).numpy().astype(np.uint32)      # [NT, 64, 8]
-        bits = np.zeros((NT, 64, 32), dtype=np.int64)
-        for s in range(32):
-            b = 6 * s
-            v = rec[..., b // 32].astype(np.uint64) >> np.uint64(b & 31)
-            if (b & 31) > 26:
-                v |= rec[..., b // 32 + 1].astype(np.uint64) << np.uint64(32 - (b & 31))
-            bits[..., s] = (v & np.uint64(63)).astype(np.int64)
-        vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)
-        sb = rec[..., 6]
-        assert np.all(sb == (sb & 255) * 0x01010101) and np.all(rec[..., 7] == sb)        # the scale again in dword 7
-        recs[T] = (vals, torch.from_numpy(np.ldexp(1.0, (sb & 255).astype(np.int64) - 127)))
+        rec = lorec[:, T].numpy().astype(np.uint32)                          # [NT, 64, 4]: code dwords 3, 4, 5 and the scale dword
+        sb = rec[..., 3]
+        assert np.all(sb == (sb & 255))                                      # the scale byte alone
+        scale = torch.from_numpy(np.ldexp(1.0, sb.astype(np.int64) - 127))   # 1 / alpha
+        bits = np.zeros((NT, 64, 16), dtype=np.int64)
+        for s_ in range(16):
+            b_ = 6 * s_
+            v = rec[..., b_ // 32].astype(np.uint64) >> np.uint64(b_ & 31)
+            if (b_ & 31) > 26:
+                v |= rec[..., b_ // 32 + 1].astype(np.uint64) << np.uint64(32 - (b_ & 31))
+            bits[..., s_] = (v & np.uint64(63)).astype(np.int64)
+        lo_vals = CODES[torch.from_numpy(bits & 31)] * torch.where(torch.from_numpy(bits & 32) > 0, -1.0, 1.0)     # [NT, 64, 16]
+        hv = hi[:, 2 * T: 2 * T + 2].permute(0, 2, 1, 3).reshape(NT, 64, 16)                # slot 8 j + e = element e of k-step 2T + j
+        hi_vals = q_e2m3(hv / scale.unsqueeze(-1))                                          # what the conversion makes of the fragments
+        recs[T] = (torch.cat([hi_vals, lo_vals], dim=-1), scale)
     return Whi, recs
 
 
 @pytest.mark.parametrize("Hd", [64, 420])
 def test_field_x2t_pack_is_the_emulated_arithmetic(Hd):
-    """h3d_field_pack_x2t (the x2 tier of the LDS-resident engine: same layout as h3d_field_pack_x3t, hi fragments + fp6 records)."""
+    """h3d_field_pack_x2t (the x2 tier of the LDS-resident engine: the matrix offsets of h3d_field_pack_x3t, tiles in the x2c format)."""
     F = Hd
     torch.manual_seed(Hd + 2)
     net = impl.COORDCONCATSIREN(input_dim=3, latent_dim=Hd, hidden_dim=Hd, geo_feature_dim=31, output_dim=F + 4, feature_dim=F,
