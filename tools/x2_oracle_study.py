@@ -1,0 +1,69 @@
+"""GPU + host: the default engines as they ship (x2 field with the last-sample refinement, x2 synthesis with the per-item monitor and
+fallback) against the CPU ORACLE on >= 5 % of the pixels of every item, over several (weights-seed-independent) draws of latents /
+pose / jitter of bench.py's workload -- VERDICT r5 item 1's acceptance run.  Per seed: bench.self_check over all 16 items (error
+normalised by the oracle's maximum over the checked pixels AND by the whole image's maximum, rays the oracle calls ill-conditioned,
+discontinuity signatures on well-conditioned rays, items redone on x3, units refined), then the same batch on the x3 engines and --
+full images, every pixel -- the default engines' error against them.  Flip rates per tier: rays whose rendered colour differs from the
+oracle's by the discontinuity signature, for the x2 field without refinement, with it, and the x3 field.
+usage: python tools/x2_oracle_study.py [seeds=1234,1,2,...] > profiles/r6_x2_oracle_study.jsonl"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bench  # noqa: E402
+
+seeds = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1234,1,2,3,4,5,6,7,8,9,10,11").split(",")]
+dev = torch.device("cuda", 0)
+G, cfg = bench.build_generator("MAP3DBN512", (512, 512), (96, 96), 64, dev)
+nf, plan = G.neural_field, G.synthesis_plan(dev)
+rows = []
+t_all = time.perf_counter()
+for seed in seeds:
+    z, cond, jitter = bench.make_inputs(cfg, 16, dev, seed=seed)
+    # ---- the shipped default against the oracle, >= 5 % of every item's pixels
+    nf.precision, plan.engine, nf.refine_last_sample = "f16x2", "f16x2", True
+    chk = bench.self_check(G, cfg, z, cond, jitter, list(range(16)))
+    dflt = G.forward(z, cond, jitter=jitter, **cfg)
+    row = dict(seed=seed, tier="default (x2 field + refinement, x2 synthesis + per-item monitor)",
+               max_rel_err_oracle_norm=chk["max_rel_err"], max_rel_err_image_norm=chk["max_rel_err_image_norm"],
+               max_rel_err_patch_norm=chk["max_rel_err_patch_norm"],
+               max_rel_err_render=chk["max_rel_err_render"], per_item_oracle_norm=chk["per_item_max_rel_err"],
+               per_item_image_norm=chk["per_item_max_rel_err_image_norm"], pixel_fraction=chk["pixel_fraction"],
+               rays_checked=chk["rays_checked"], rays_excluded=chk["rays_excluded_as_ill_conditioned_in_the_oracle"],
+               ill_band=chk["ill_conditioned_band"], flips_on_well_conditioned_rays=chk["discontinuity_signatures_on_well_conditioned_rays"],
+               x2_fallback_items=chk["x2_fallback_items"], refined_units=chk["refined_units"], ok=chk["ok"],
+               oracle_seconds=round(chk["oracle_seconds"], 1))
+    # ---- flip census of the RENDER per field tier, full images: rays whose colour differs from the x3 field's by the signature
+    nf.precision, plan.engine = "f16x3", "bf16x3"
+    x3 = G.forward(z, cond, jitter=jitter, **cfg)
+    nf.precision, plan.engine, nf.refine_last_sample = "f16x2", "f16x2", False
+    raw = G.forward(z, cond, jitter=jitter, **cfg)
+    nf.refine_last_sample = True
+    sig = lambda a, b: int(bench.discontinuity_rays((a["rgbs_render"] - b["rgbs_render"]).flatten(2).cpu()).sum())
+    row["render_flips_vs_x3_field_per_147456_rays"] = dict(x2_without_refinement=sig(raw, x3), x2_with_refinement=sig(dflt, x3))
+    # ---- the default's full images against the x3 engines', every pixel
+    den = x3["rgbs"].double().abs().amax(dim=(2, 3), keepdim=True)
+    d = ((dflt["rgbs"].double() - x3["rgbs"].double()).abs() / den).amax(dim=(1, 2, 3))
+    row["full_image_vs_x3_engines_per_item"] = [round(float(v), 6) for v in d]
+    row["full_image_vs_x3_engines_max"] = float(d.max())
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+tot = dict(seeds=seeds, items=16 * len(seeds),
+           max_rel_err_oracle_norm=max(r["max_rel_err_oracle_norm"] for r in rows),
+           max_rel_err_image_norm=max(r["max_rel_err_image_norm"] for r in rows),
+           max_rel_err_patch_norm=max(r["max_rel_err_patch_norm"] for r in rows),
+           full_image_vs_x3_max=max(r["full_image_vs_x3_engines_max"] for r in rows),
+           batches_with_an_excluded_ray=sum(1 for r in rows if r["rays_excluded"] > 0),
+           rays_excluded=sum(r["rays_excluded"] for r in rows), rays_checked=sum(r["rays_checked"] for r in rows),
+           flips_on_well_conditioned_rays=sum(r["flips_on_well_conditioned_rays"] for r in rows),
+           items_redone_on_x3=sum(len(r["x2_fallback_items"] or []) for r in rows),
+           render_flips_x2_without_refinement=sum(r["render_flips_vs_x3_field_per_147456_rays"]["x2_without_refinement"] for r in rows),
+           render_flips_x2_with_refinement=sum(r["render_flips_vs_x3_field_per_147456_rays"]["x2_with_refinement"] for r in rows),
+           all_ok=all(r["ok"] for r in rows), wall_seconds=round(time.perf_counter() - t_all, 1))
+print(json.dumps(tot), flush=True)
