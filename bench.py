@@ -505,7 +505,7 @@ def self_check(G, cfg, z, cond, jitter, items, frac=0.05, seed=5):
     ocfg = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
     Hr, Wr = cfg["render_height"], cfg["render_width"]
     worst, worst_r, worst_img, rays, per_item, per_item_img, excluded, n_rays, n_pix, flips = 0.0, 0.0, 0.0, 0, [], [], 0, 0, 0, 0
-    worst_patch = 0.0
+    worst_patch, flips_excl = 0.0, 0
     zc, jc = z.cpu(), jitter.cpu()
     K = 0
     # the band of last-sample densities the ORACLE calls ill-conditioned for the arithmetic under test: 1e-3 of the item's largest
@@ -532,6 +532,7 @@ def self_check(G, cfg, z, cond, jitter, items, frac=0.05, seed=5):
         n_rays += int(ill.numel())
         n_pix += int(len(pix))
         flips += int((discontinuity_rays(dr)[0] & keep_ray).sum())        # a flip on a ray the oracle calls well-conditioned: counted as error below
+        flips_excl += int((discontinuity_rays(dr)[0] & ill).sum())        # ... and how many of the excluded rays actually flipped
         w_i, w_img = 0.0, 0.0
         for c in range(3):
             d = ((got[:, c] - ref["rgbs"][:, c]).abs() * keep_px).max()
@@ -560,7 +561,8 @@ def self_check(G, cfg, z, cond, jitter, items, frac=0.05, seed=5):
                 rays_excluded_as_ill_conditioned_in_the_oracle=excluded, max_excluded=max_excluded, rays_checked=n_rays,
                 ill_conditioned_band=ill_rel,
                 refined_units=(nf.refined_units().tolist() if getattr(nf, "refined_units", None) and nf.refined_units() is not None else None),
-                discontinuity_signatures_on_well_conditioned_rays=flips, oracle_seconds=time.perf_counter() - t0,
+                discontinuity_signatures_on_well_conditioned_rays=flips, discontinuity_signatures_on_excluded_rays=flips_excl,
+                oracle_seconds=time.perf_counter() - t0,
                 synthesis_engine=plan.engine, field_engine=G.neural_field.precision,
                 x2_fallback_items=plan.x2_fallback_items() if x2 else None,
                 x2_monitor=(dict(tolerance=plan.x2_monitor_tol, max_sampled_err=float(mon.max()),

@@ -37,6 +37,7 @@ for seed in seeds:
                per_item_image_norm=chk["per_item_max_rel_err_image_norm"], pixel_fraction=chk["pixel_fraction"],
                rays_checked=chk["rays_checked"], rays_excluded=chk["rays_excluded_as_ill_conditioned_in_the_oracle"],
                ill_band=chk["ill_conditioned_band"], flips_on_well_conditioned_rays=chk["discontinuity_signatures_on_well_conditioned_rays"],
+               flips_on_excluded_rays=chk["discontinuity_signatures_on_excluded_rays"],
                x2_fallback_items=chk["x2_fallback_items"], refined_units=chk["refined_units"], ok=chk["ok"],
                oracle_seconds=round(chk["oracle_seconds"], 1))
     # ---- flip census of the RENDER per field tier, full images: rays whose colour differs from the x3 field's by the signature
@@ -62,6 +63,7 @@ tot = dict(seeds=seeds, items=16 * len(seeds),
            batches_with_an_excluded_ray=sum(1 for r in rows if r["rays_excluded"] > 0),
            rays_excluded=sum(r["rays_excluded"] for r in rows), rays_checked=sum(r["rays_checked"] for r in rows),
            flips_on_well_conditioned_rays=sum(r["flips_on_well_conditioned_rays"] for r in rows),
+           flips_on_excluded_rays=sum(r["flips_on_excluded_rays"] for r in rows),
            items_redone_on_x3=sum(len(r["x2_fallback_items"] or []) for r in rows),
            render_flips_x2_without_refinement=sum(r["render_flips_vs_x3_field_per_147456_rays"]["x2_without_refinement"] for r in rows),
            render_flips_x2_with_refinement=sum(r["render_flips_vs_x3_field_per_147456_rays"]["x2_with_refinement"] for r in rows),
