@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const T* __restrict__ x,
     }
 }
 
+constexpr int64_t kStreamBytes = int64_t(64) << 20;      // outputs from this size on are written with non-temporal stores
 constexpr int kTileW = 64, kTileH = 16;          // output tile of the tiled kernel (256 threads x 4 rows each)
 constexpr size_t kMaxTileLds = 60 * 1024;        // staged input tile + filter must fit the default dynamic-LDS limit
 
@@ -156,7 +157,7 @@ struct Poly {
     static_assert((VX * DX) % UX == 0 && (VY * DY) % UY == 0, "patch origin must keep the phase");
 };
 
-template <typename T, typename P>
+template <typename T, typename P, bool NT>
 __global__ __launch_bounds__(256) void upfirdn2d_poly(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y,
                                                       Params p, int vec_ok) {
     __shared__ __attribute__((aligned(16))) float tile[P::IN_H * P::LD];
@@ -211,7 +212,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_poly(const T* __restrict__ x, c
         T* o = yb + (int64_t)(oy + vy) * p.outW + ox;
         if (vec_ok && ox + P::VX <= p.outW) {
             typedef T vecT __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<vecT*>(o) = vecT{(T)acc[0], (T)acc[1], (T)acc[2], (T)acc[3]};
+            // NT: streaming (non-temporal) stores for an output larger than the caches (round 6: 3.5 -> 5.2 TB/s on the 2x-up shape
+            // of the roofline table, profiles/r6_ops_nt_stores.txt).  A template parameter, not a run-time branch: the optimiser
+            // merges `if (c) nt-store else store` into ONE plain store.
+            if constexpr (NT) __builtin_nontemporal_store(vecT{(T)acc[0], (T)acc[1], (T)acc[2], (T)acc[3]}, reinterpret_cast<vecT*>(o));
+            else *reinterpret_cast<vecT*>(o) = vecT{(T)acc[0], (T)acc[1], (T)acc[2], (T)acc[3]};
         } else {
 #pragma unroll
             for (int vx = 0; vx < P::VX; ++vx)
@@ -226,11 +231,15 @@ template <typename T, typename P>
 int launch_poly(const void* x, const float* f, void* y, const Params& p, hipStream_t st) {
     const int64_t planes = (int64_t)p.B * p.C;
     const int vec_ok = (p.outW % 4 == 0) && (reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T)) == 0);
+    const bool stream = vec_ok && planes * p.outH * p.outW * (int64_t)sizeof(T) >= kStreamBytes;      // streaming stores (see the kernel)
     for (int64_t z0 = 0; z0 < planes; z0 += 65535) {
         const unsigned nz = (unsigned)((planes - z0) < 65535 ? (planes - z0) : 65535);
+        const dim3 grid((p.outW + P::TW - 1) / P::TW, (p.outH + P::TH - 1) / P::TH, nz);
         h3d::pre_launch();
-        hipLaunchKernelGGL((upfirdn2d_poly<T, P>), dim3((p.outW + P::TW - 1) / P::TW, (p.outH + P::TH - 1) / P::TH, nz), dim3(256), 0, st,
-                           (const T*)x + z0 * p.H * p.W, f, (T*)y + z0 * p.outH * p.outW, p, vec_ok);
+        if (stream) hipLaunchKernelGGL((upfirdn2d_poly<T, P, true>), grid, dim3(256), 0, st, (const T*)x + z0 * p.H * p.W, f,
+                                       (T*)y + z0 * p.outH * p.outW, p, vec_ok);
+        else hipLaunchKernelGGL((upfirdn2d_poly<T, P, false>), grid, dim3(256), 0, st, (const T*)x + z0 * p.H * p.W, f,
+                                (T*)y + z0 * p.outH * p.outW, p, vec_ok);
         const int rc = h3d::launch_status("h3d_upfirdn2d");
         if (rc) return rc;
     }

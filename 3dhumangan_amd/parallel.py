@@ -309,8 +309,10 @@ def reducer_of(module, **kw):
     the old one's hooks removed first -- when the process group appears / disappears or when the set of parameters that
     require gradients changes (a frozen sub-network, a new training phase)."""
     red = getattr(module, "_h3d_grad_reducer", None)
-    want_active = dist.is_initialized() and dist.get_world_size(kw.get("group")) > 1
     sig = tuple(id(p) for p in module.parameters() if p.requires_grad)
+    # (a reducer over NO trainable parameter is inactive whatever the process group says: compare like with like, or a module
+    # without trainable parameters gets a new reducer at every call)
+    want_active = dist.is_initialized() and dist.get_world_size(kw.get("group")) > 1 and bool(sig)
     if red is None or want_active != red.active or sig != red.signature():
         if red is not None:
             red.close()
