@@ -60,6 +60,7 @@ struct Args {
     int n_tiles;           // 128-pixel tiles per sample (a workgroup walks tiles blockIdx.x, + gridDim.x, ..)
     int n_walk, tile_first, tile_step;   // the tiles a launch covers: tile_first + i * tile_step, i < n_walk (all of them: 0, 1, n_tiles)
     int heads;             // x2 plans with ToRGB head tables: no zero table of "no ToRGB" weights in LDS (the producers carry no ToRGB)
+    int mid_x3;            // x2 plans: the constant-style blocks in front of the first skip block travel / run in the x3 format (MIDX3)
     int* ovf;              // x2: int[B], ovf[b] set to 1 when an activation of sample b leaves the range the f16 planes carry (nullable)
     const int* run_if;     // int[B] (nullable): sample b is skipped when run_if[b] == 0 -- the guarded fallback of the x2 engine
 };
@@ -285,11 +286,17 @@ __device__ __forceinline__ void conv_progressive(f32x16 (&dst)[NT], V8 (&xh)[2 *
     }
 }
 
-template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false>
+// MIDX3 (x2 plans, round 6): the constant-style blocks between the per-pixel blocks and the first skip block (block 3 of the shipped
+// configs: the base of the residual stream, whose error every later block and every ToRGB head inherits -- the largest single
+// contribution in the per-contraction attribution, profiles/r5_x2_error_attribution_item14.txt) run on three bf16 products: their
+// stages travel in the x3 format and their fragments are bf16 hi / lo.  Same registers (the 64 of the fp6 records hold the lo
+// fragments), same ring (single-stage acquires, as the x3 tail of gemm_x2_roll).
+template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false, bool MIDX3 = false>
 __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
     constexpr int KS = 2 * NT, kHdP = NT * 32;       // the host sets A.HdP = 32 NT: table strides are compile-time
     constexpr bool kHeads = HEADS;                   // ToRGB of the skip blocks as a ninth tile of their second convolution (conv_progressive)
     static_assert(!HEADS || (X2 && !SEG), "ToRGB heads: single-launch x2 plans only");
+    static_assert(!MIDX3 || (X2 && !SEG), "three-product middle blocks: single-launch x2 plans only");
     typedef typename std::conditional<X2, F16, BF16>::type T;
     typedef typename T::vec8 frag8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -596,12 +603,31 @@ __global__ __launch_bounds__(256, 1) void synthesis_x3_kernel(Args A) {
         for (int s = 0; s < 2; ++s) {
             // constant style before the first skip block: x is both source and destination, so the fragments
             // are completed before the conv starts
-            const_frags(x, abt + dget(blk, 3 + 4 * s) * 2 * HdP);
-            if constexpr (X2) {
-                const F16::vec8 none[1] = {};
-                gemm_x2_roll<NT, KS, 0, KS, NT, false, look_x2<NT>(), 0, true>(x, xh, b6, none, ring);
+            if constexpr (X2 && MIDX3) {
+                // three bf16 products for this convolution (see MIDX3 above): bf16 hi / lo fragments of lrelu(x a + b), the x3 GEMM
+                // on the x2 kernel's ring; the same table as the x2 path (the 0.4-scaled affine)
+                typedef BF16::vec8 bfrag;
+                bfrag yh[KS], yl[KS];
+                const lds_ptr ab = lane_base(abt + dget(blk, 3 + 4 * s) * 2 * HdP, 32 * h);
+                make_frags<NT, false>(yh, yl, b6, x, gmax, [&](int nt, int rg) {
+                    const int n = nt * 32 + rg * 8;
+                    const f32x4 ta = ldt4(ab, 2 * n), tb = ldt4(ab, 2 * n + 4);
+                    float4 y;
+                    y.x = lrelu_from_scaled(fmaf(x[nt][rg * 4 + 0], ta.x, ta.z));
+                    y.y = lrelu_from_scaled(fmaf(x[nt][rg * 4 + 1], ta.y, ta.w));
+                    y.z = lrelu_from_scaled(fmaf(x[nt][rg * 4 + 2], tb.x, tb.z));
+                    y.w = lrelu_from_scaled(fmaf(x[nt][rg * 4 + 3], tb.y, tb.w));
+                    return y;
+                });
+                gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, yh, yl, ring);
             } else {
-                gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+                const_frags(x, abt + dget(blk, 3 + 4 * s) * 2 * HdP);
+                if constexpr (X2) {
+                    const F16::vec8 none[1] = {};
+                    gemm_x2_roll<NT, KS, 0, KS, NT, false, look_x2<NT>(), 0, true>(x, xh, b6, none, ring);
+                } else {
+                    gemm_x3_roll<BF16, NT, KS, KS, false, kLook, 0, true>(x, xh, xl, ring);
+                }
             }
             pin_agpr<NT>(x);
         }
@@ -686,9 +712,9 @@ size_t lds_bytes(const Args& A, int NT, int depth) {
            (size_t)depth * NT * 2048;
 }
 
-template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false>
+template <int NT, int DEPTH, bool SEG, bool X2, bool HEADS = false, bool MIDX3 = false>
 int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS>));
+    H3D_ALLOW_MAX_LDS((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS, MIDX3>));
     A.n_tiles = (int)groups;
     if (A.tile_step <= 0) { A.tile_first = 0; A.tile_step = 1; }
     A.n_walk = A.tile_first < A.n_tiles ? (A.n_tiles - A.tile_first + A.tile_step - 1) / A.tile_step : 0;
@@ -708,7 +734,7 @@ int launch_seg(Args A, int B, int64_t groups, hipStream_t st) {
                              : A.run_if ? std::min<int64_t>(groups, cus)
                              : std::max<int64_t>(1, std::min<int64_t>(groups, ((int64_t)per_cu * cus + B - 1) / B));
     h3d::pre_launch();
-    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
+    hipLaunchKernelGGL((synthesis_x3_kernel<NT, DEPTH, SEG, X2, HEADS, MIDX3>), dim3((unsigned)per_sample, (unsigned)B), dim3(256),
                        lds_bytes(A, NT, DEPTH + (X2 ? 1 : 0)), st, A);
     return h3d::launch_status(X2 ? "h3d_synthesis_x2" : "h3d_synthesis_x3");
 }
@@ -718,6 +744,8 @@ int launch_one(const Args& A, int B, int64_t groups, hipStream_t st, bool heads 
     // the state load/store paths are compiled only into the segmented variant (they cost registers)
     if (A.load_state || A.store_state) return launch_seg<NT, DEPTH, true, X2>(A, B, groups, st);
     if constexpr (X2) {
+        if (A.mid_x3) return heads ? launch_seg<NT, DEPTH, false, true, true, true>(A, B, groups, st)
+                                   : launch_seg<NT, DEPTH, false, true, false, true>(A, B, groups, st);
         if (heads) return launch_seg<NT, DEPTH, false, true, true>(A, B, groups, st);
     }
     return launch_seg<NT, DEPTH, false, X2>(A, B, groups, st);
@@ -786,6 +814,14 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
                            "use h3d_synthesis_x3t / h3d_synthesis", k);
             return H3D_EUNSUPPORTED;
         }
+    // x2 plans (round 6): a constant-style SPADE in front of the first skip block with g_offset == 1 has its convolution's stages in
+    // the x3 format (bf16 hi | lo) and runs on three products; all of those blocks or none
+    int mid_marked = 0, mid_total = 0;
+    for (int k = n_pixel_blocks; k < first_skip; ++k)
+        for (int s = 0; s < 2; ++s) { ++mid_total; mid_marked += desc->block[k].spade[s].g_offset == 1; }
+    H3D_REQUIRE(mid_marked == 0 || (x2 && mid_marked == mid_total && !load_state && !store_state),
+                "h3d_synthesis_x2: %d of %d middle-block convolutions are marked for the x3 format (all or none; single-launch x2 plans only)",
+                mid_marked, mid_total);
     H3D_REQUIRE(want == total_stages, "h3d_synthesis_x3: stream has %lld stages, descriptor needs %lld",
                 (long long)total_stages, (long long)want);
     H3D_REQUIRE(!any_pixel || (G && cst && (g_channels & 3) == 0 && h3d::aligned16(G)), "h3d_synthesis_x3: G/cst missing");
@@ -809,6 +845,7 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     Args A{};
     A.state = state; A.load_state = load_state; A.store_state = store_state;
     A.ovf = ovf; A.run_if = run_if;
+    A.mid_x3 = mid_marked > 0;
     H3D_REQUIRE(tile_first >= 0 && tile_step >= 1, "h3d_synthesis_x3: tile subset (%d, %d)", tile_first, tile_step);
     A.tile_first = tile_first; A.tile_step = tile_step;
     A.stream = static_cast<const unsigned char*>(stream);
@@ -829,7 +866,8 @@ static int synthesis_x(bool x2, const void* stream, int64_t total_stages, const 
     const bool heads = A.heads != 0;                                 // x2 plans: ToRGB head tables present
 #ifdef H3D_DEV_ONLY_HOT       // development: compile only the instantiation the BASELINE cfg-3 bench runs (fast ISA / resource turnaround)
     (void)deep;
-    return heads ? launch_seg<8, kRingDepth, false, true, true>(A, B, groups, st) : launch_seg<8, kRingDepth, false, true>(A, B, groups, st);
+    return A.mid_x3 ? launch_seg<8, kRingDepth, false, true, true, true>(A, B, groups, st)
+         : heads ? launch_seg<8, kRingDepth, false, true, true>(A, B, groups, st) : launch_seg<8, kRingDepth, false, true>(A, B, groups, st);
 #else
     if (x2) {
         if (NT == 8) return deep ? launch_one<8, 6, true>(A, B, groups, st, heads) : launch_one<8, kRingDepth, true>(A, B, groups, st, heads);

@@ -476,6 +476,9 @@ class SynthesisPlan:
                 src, dst = self.desc.block[k], desc.block[j]
                 dst.skip, dst.to_rgb = src.skip, src.to_rgb
                 c_in = carry
+                # the constant-style blocks between the per-pixel blocks and the first skip block (block 3 of the shipped configs)
+                mid_block = (not src.skip and not any(self.desc.block[q].skip for q in range(k))
+                             and not self._raw[2 * k]["pixel"] and not self._raw[2 * k + 1]["pixel"] and len(ranges) == 1)
                 for s in range(2):
                     raw = self._raw[2 * k + s]
                     d, so = dst.spade[s], src.spade[s]
@@ -488,7 +491,13 @@ class SynthesisPlan:
                         d.vec = add(torch.cat([_pad(raw["bgam"] + 1.0, HdP), _pad(raw["bbet"], HdP), sc, sh + sc * carry]))
                     else:
                         ab_carry[so.ab_index] = carry
-                    stream.append(pack(raw["conv_w"], 2 * NT, NT))
+                    if x2 and self.X2_MID_X3 and mid_block:
+                        # round 6: this convolution on three bf16 products inside the x2 kernel (csrc/synthesis_x3.hip: MIDX3): its
+                        # stages in the x3 format, the SPADE marked through its (otherwise unused) g_offset
+                        stream.append(self.pack_stream_bf16(raw["conv_w"], 2 * NT, NT))
+                        d.g_offset = 1
+                    else:
+                        stream.append(pack(raw["conv_w"], 2 * NT, NT))
                     stages += 2 * NT
                     d.b_conv = -1                                   # folded: the kernel has no bias add
                     carry = _pad(raw["conv_b"], HdP)
@@ -518,6 +527,9 @@ class SynthesisPlan:
         return getattr(self, cache)
 
     X2_HEADS = os.environ.get("H3D_SYNTH_HEADS", "1") != "0"
+    # x2 plans: the base of the residual stream (the constant-style block in front of the first skip block) on three bf16 products
+    # -- the per-contraction attribution's largest contributor (b3.conv1 4.8e-4, b3.conv0 2.3e-4 of an all-x2 7.9e-4)
+    X2_MID_X3 = os.environ.get("H3D_SYNTH_MID_X3", "1") != "0"
 
     def _torgb_heads(self, desc, blocks, rgb_tables, add, NT, HdP):
         """x2 register engine, round 5: the ToRGB layers of the skip blocks as a NINTH output tile of each block's second

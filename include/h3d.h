@@ -457,7 +457,12 @@ int h3d_synthesis_x3(const void* stream, int64_t total_stages, const float* tabl
  * fp6 record][4 rows x 2 lane halves][16 B] = the x2 operands of M_j = (sum of the ToRGB weights of this and every later block)
  * x W_conv1 of the block, 3 rows used: the block's second convolution multiplies it with its own input fragments as a ninth
  * output tile, accumulated over all skip blocks into the image.  Such blocks have to_rgb = 0, and the block in front of the
- * first skip block carries the summed ToRGB weights and biases (exact algebra on lib/generators/map3d_generator.py:82-86). */
+ * first skip block carries the summed ToRGB weights and biases (exact algebra on lib/generators/map3d_generator.py:82-86).
+ * Three-product middle blocks (round 6, single-launch x2 plans only): the constant-style blocks between the per-pixel-style blocks
+ * and the first skip block (block 3 of the shipped configurations: the base of the residual stream) may carry g_offset = 1 in both
+ * of their SPADEs (the field is unused for pixel_style = 0): their convolutions' stages are then in the h3d_synthesis_x3 format
+ * (bf16 hi | lo) and run on three bf16 products inside this kernel -- all such blocks or none.  SynthesisPlan.build_x3(x2=True)
+ * does that by default (H3D_SYNTH_MID_X3=0: all-x2 stream). */
 int h3d_synthesis_x2(const void* stream, int64_t total_stages, const float* tables, int table_floats,
                      const h3d_synth_desc* desc, const float* G, int g_channels, int Hr, int Wr,
                      const float* cst, int n_cst, const float* ab, int n_ab, float* rgb, int B, int H, int W,

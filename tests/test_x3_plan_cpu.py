@@ -104,6 +104,7 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
         Gup = torch.nn.functional.interpolate(Gmap, (H, W), mode="bilinear").permute(0, 2, 3, 1).reshape(B, H * W, -1)
     rgb = torch.zeros(B, H * W, 3, dtype=torch.float64)
     stage, heads = 0, 0
+    mid_x3 = [0]
     lrelu = lambda v: torch.maximum(v, 0.2 * v)
     for k in range(desc.n_blocks):
         bk = desc.block[k]
@@ -122,6 +123,13 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
                 sh = t4[:, :, 1, :].reshape(B, 1, HdP)
                 u = x * sc + sh                                      # the tables carry 0.4 * (sc, sh): lrelu(t) = 1.5 u + |u|
                 y = 1.5 * u + u.abs()
+            if x2 and not d.pixel_style and d.g_offset == 1:
+                # round 6 (MIDX3): this convolution travels in the x3 format and runs on three bf16 products inside the x2 kernel
+                assert not bk.skip
+                Wc = decode_matrix(stream, stage, 2 * NT, NT); stage += 2 * NT
+                mid_x3[0] += 1
+                x = y @ Wc.t()
+                continue
             Wc = decode(stream, stage, 2 * NT, NT); stage += 2 * NT
             x = mm(y, Wc) + (x_in if (s == 1 and bk.skip) else 0.0)
             if x2 and s == 1 and d.b_conv >= 0:
@@ -136,6 +144,10 @@ def emulate(plan, fmap_lowres, fixed_style, Hr, Wr, H, W, x2=False):
             wr = torch.stack([vec(bk.w_rgb), vec(bk.w_rgb + HdP), vec(bk.w_rgb + 2 * HdP)])          # [3, HdP]
             rgb = rgb + x @ wr.t() + vec(bk.w_rgb + 3 * HdP, 3)
     assert stage == seg["stages"]
+    if x2:      # the constant-style blocks in front of the first skip block (one in the shipped layouts): both convolutions in the x3 format
+        n_mid = sum(2 for k in range(desc.n_blocks) if not desc.block[k].skip and not desc.block[k].spade[0].pixel_style
+                    and not any(desc.block[q].skip for q in range(k)))
+        assert mid_x3[0] == (n_mid if plan.X2_MID_X3 else 0)
     if x2 and plan.X2_HEADS and any(desc.block[k].skip for k in range(desc.n_blocks)):
         assert heads == sum(1 for k in range(desc.n_blocks) if desc.block[k].skip)      # every skip block of an x2 plan carries one
         assert not any(desc.block[k].to_rgb for k in range(desc.n_blocks) if desc.block[k].skip)
