@@ -167,3 +167,31 @@ def test_ill_conditioned_rays_looks_at_the_oracle_densities_only():
     sigma[0, 0, 0] = 10.0                                       # max |sigma| = 10 -> threshold 1e-2
     sigma[0, :, -1] = torch.tensor([5.0, 9e-3, -9e-3, 1.1e-2, -4.0])
     assert bench.ill_conditioned_rays(sigma).tolist() == [[False, True, True, False, False]]
+
+
+def test_check_cells_cover_five_percent_and_the_brightest_pixels():
+    """Round 6: bench.self_check compares every item on a contiguous patch of >= 5 % of its pixels plus the cells that hold each
+    channel's largest |value| -- the oracle's maximum over the checked pixels is then the image's scale (a dim patch alone would
+    inflate the relative error, a bright one deflate it)."""
+    import torch
+    sys.path.insert(0, os.path.join(bench.ROOT, "oracle"))
+    import h3d_oracle as O
+    cfg = dict(gen_height=512, gen_width=512, render_height=96, render_width=96)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(3, 512, 512, generator=g)
+    img[1, 500, 3] = 40.0                                              # a bright pixel near a corner
+    bright = bench.brightest_cells(img, (96, 96))
+    assert len(bright) == 3
+    for item in (0, 7):
+        cells, K = bench.check_cells(cfg, item, 0.05, 5, bright)
+        pix = O.pixels_of_cells(cells, (512, 512), (96, 96))
+        assert K == 22 and len(pix) >= 0.05 * 512 * 512
+        for c in range(3):
+            assert int(img[c].abs().argmax()) in set(pix.tolist())       # the channel's maximum is among the checked pixels
+    a, _ = bench.check_cells(cfg, 0, 0.05, 5)
+    b, _ = bench.check_cells(cfg, 1, 0.05, 5)
+    assert a != b                                                       # the patch moves from item to item
+    # small geometries: the patch never exceeds the render grid
+    small = dict(gen_height=16, gen_width=8, render_height=8, render_width=4)
+    cells, K = bench.check_cells(small, 0, 0.05, 5)
+    assert all(0 <= cy < 8 and 0 <= cx < 4 for cy, cx in cells) and K >= 1

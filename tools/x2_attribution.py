@@ -118,6 +118,7 @@ def main():
                             cfg["map3d_mode"], torch.device("cpu"))
     plan.X2_HEADS = False          # per-block ToRGB tables (the ToRGB head tiles of the shipped x2 plan are one more contraction each)
     plan.X2_MID_X3 = False         # the all-x2 stream: the attribution is what decided to put block 3 on three products (round 6)
+    plan._x2 = None                # (the constructor's fit test has built and cached the default stream)
     fm = ref["feature_maps"][0].t().unsqueeze(0).contiguous()                     # [1, Rs, F] channels last
     G_rays, _, _ = plan.x3_forward_tables(fm.float(), ref["styles"].reshape(1, -1).float(), True)
     Y, X = pix // W, pix % W
