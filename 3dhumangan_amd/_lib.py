@@ -49,6 +49,7 @@ _SIGNATURES = {
                                    _i, _p]),
     "h3d_field_pack_x3_size": (C.c_int64, [_i, _i]),
     "h3d_field_pack_x3": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
+    "h3d_field_pack_x3_device": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p, _p]),
     "h3d_field_x3_layout": (C.c_int, [_i, _i, C.POINTER(C.c_int64), _i]),
     "h3d_neural_field_x3": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),
     "h3d_render_fused_x3": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i,
@@ -68,6 +69,7 @@ _SIGNATURES = {
     "h3d_conv_wgrad_x3": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_field_pack_x2_size": (C.c_int64, [_i, _i]),
     "h3d_field_pack_x2": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p]),
+    "h3d_field_pack_x2_device": (C.c_int, [C.POINTER(FieldParams), _i, _i, _p, _p]),
     "h3d_field_x2_layout": (C.c_int, [_i, _i, C.POINTER(C.c_int64), _i]),
     "h3d_neural_field_x2": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _i, _f, _p]),
     "h3d_render_fused_x2": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i,
@@ -121,6 +123,7 @@ _SIGNATURES = {
     "h3d_wgrad_x3_slices": (C.c_int, [_l, _i, _i]),
     "h3d_wgrad_x3": (C.c_int, [_p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_x3_bias": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "h3d_wgrad_reduce": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "h3d_spade_rows": (C.c_int, []),
     "h3d_channel_moments": (C.c_int, [_p, _p, _i, _l, _i, _p]),
     "h3d_spade_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),

@@ -869,7 +869,7 @@ int launch(const Args& A, int B, int64_t groups, hipStream_t st) {
 
 // ---------------------------------------------------------------- host-side packing
 
-uint16_t f32_to_f16_rn(float f) {            // round-to-nearest-even, handles subnormals; inputs are finite
+__host__ __device__ inline uint16_t f32_to_f16_rn(float f) {            // round-to-nearest-even, handles subnormals; inputs are finite
     uint32_t x;
     memcpy(&x, &f, 4);
     const uint32_t sign = (x >> 16) & 0x8000u;
@@ -890,7 +890,7 @@ uint16_t f32_to_f16_rn(float f) {            // round-to-nearest-even, handles s
     return (uint16_t)(sign | r);
 }
 
-float f16_to_f32(uint16_t v) {
+__host__ __device__ inline float f16_to_f32(uint16_t v) {
     const uint32_t sign = (uint32_t)(v & 0x8000u) << 16;
     uint32_t e = (v >> 10) & 0x1f, m = v & 0x3ffu, x;
     if (e == 0) {
@@ -906,44 +906,60 @@ float f16_to_f32(uint16_t v) {
     return f;
 }
 
+// floor(log2(q)) of a positive finite q, from the exponent field (exact; log2f may round up to the next integer just below a
+// power of two, and host and device must agree bit for bit: h3d_field_pack_*_device)
+__host__ __device__ inline int floor_log2(float q) {
+    uint32_t x;
+    memcpy(&x, &q, 4);
+    const int e = (int)((x >> 23) & 0xffu);
+    if (e) return e - 127;
+    int s = 0;                                   // subnormal
+    for (uint32_t m = x & 0x7fffffu; m && !(m & 0x400000u); m <<= 1) ++s;
+    return -127 - s;
+}
+// the largest power of two 2^e with mx * 2^e <= target (1 for an all-zero matrix)
+__host__ __device__ inline float pow2_scale_of(float mx, float target) { return mx > 0.f ? ldexpf(1.f, floor_log2(target / mx)) : 1.f; }
+
 float pow2_scale(const float* w, int64_t n, float target) {
     float mx = 0.f;
     for (int64_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
-    if (mx == 0.f) return 1.f;
-    return exp2f(floorf(log2f(target / mx)));
+    return pow2_scale_of(mx, target);
 }
 
 // input feature of k-slot (half hh, element e) of k-step ks when the consumer's B fragments are accumulator registers
 // (see FilmProducer): tile ks/2, accumulator register r = 8*(ks & 1) + e  ->  row (r & 3) + 8*(r >> 2) + 4*hh
-int acc_k(int ks, int hh, int e) { return 32 * (ks / 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh; }
+__host__ __device__ inline int acc_k(int ks, int hh, int e) { return 32 * (ks / 2) + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hh; }
 
 // W [n_out, ld] row-major; K range [in_begin, in_begin+in_count) -> [KSm][NT][2][64][8] f16, scaled by `scale`.
 // acc_order: K runs in accumulator-register order (the input comes from a previous layer's accumulators) instead of
 // the natural order (inputs assembled from memory: coordinates, geometry features, view direction).
+__host__ __device__ inline void pack_x3_unit(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, float scale,
+                                             uint16_t* dst, bool acc_order, int ks, int nt, int lane) {
+    for (int e = 0; e < 8; ++e) {
+        const int k = acc_order ? acc_k(ks, lane >> 5, e) : 16 * ks + 8 * (lane >> 5) + e, nn = 32 * nt + (lane & 31);
+        float v = 0.f;
+        if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+        const uint16_t hi = f32_to_f16_rn(v);
+        const uint16_t lo = f32_to_f16_rn(v - f16_to_f32(hi));
+        const int64_t base = (((int64_t)ks * NT + nt) * 2) * 64 * 8;
+        dst[base + lane * 8 + e] = hi;
+        dst[base + 64 * 8 + lane * 8 + e] = lo;
+    }
+}
 void pack_x3(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, uint16_t* dst,
              bool acc_order) {
     for (int ks = 0; ks < KSm; ++ks)
         for (int nt = 0; nt < NT; ++nt)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int k = acc_order ? acc_k(ks, lane >> 5, e) : 16 * ks + 8 * (lane >> 5) + e, nn = 32 * nt + (lane & 31);
-                    float v = 0.f;
-                    if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
-                    const uint16_t hi = f32_to_f16_rn(v);
-                    const uint16_t lo = f32_to_f16_rn(v - f16_to_f32(hi));
-                    const int64_t base = (((int64_t)ks * NT + nt) * 2) * 64 * 8;
-                    dst[base + lane * 8 + e] = hi;
-                    dst[base + 64 * 8 + lane * 8 + e] = lo;
-                }
+            for (int lane = 0; lane < 64; ++lane) pack_x3_unit(w, ld, in_begin, in_count, n_out, NT, scale, dst, acc_order, ks, nt, lane);
 }
 
 // ---- x2 packing: fp6 (e2m3) codes and block scales
-float e2m3_value(unsigned c) {
+__host__ __device__ inline float e2m3_value(unsigned c) {
     const int e = (c >> 3) & 3, m = c & 7;
     const float r = e ? ldexpf(1.f + m / 8.f, e - 1) : m / 8.f;
     return (c & 32) ? -r : r;
 }
-unsigned e2m3_code(float v) {            // round-to-nearest-even on the code grid, saturating at 7.5
+__host__ __device__ inline unsigned e2m3_code(float v) {            // round-to-nearest-even on the code grid, saturating at 7.5
     const unsigned sign = v < 0.f ? 32u : 0u;
     const float a = fminf(fabsf(v), 7.5f);
     const float step = a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f;
@@ -958,54 +974,56 @@ unsigned e2m3_code(float v) {            // round-to-nearest-even on the code gr
 // W [n_out, ld] row-major; K range [in_begin, in_begin + in_count) in accumulator order over KSm (even) k-steps ->
 // stages [KSm][NT][hi fragment 1 KiB | fp6 half-record 1 KiB], weights scaled by `scale` (the f16 scale of the matrix);
 // the destination must be zero-initialised (the odd stages' half-records end in 256 B of padding)
+__host__ __device__ inline void pack_x2_unit(const float* w, int ld, int in_begin, int in_count, int n_out, int NT, float scale,
+                                             unsigned char* dst, int T, int nt, int lane) {
+    const int nn = 32 * nt + (lane & 31), hh = lane >> 5;
+    float hi[16], lo[16], mx = 0.f;
+    for (int j = 0; j < 2; ++j)
+        for (int e = 0; e < 8; ++e) {
+            const int k = acc_k(2 * T + j, hh, e);
+            float v = 0.f;
+            if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
+            const uint16_t h16 = f32_to_f16_rn(v);
+            hi[8 * j + e] = f16_to_f32(h16);
+            lo[8 * j + e] = v - hi[8 * j + e];
+            mx = fmaxf(mx, fabsf(hi[8 * j + e]));
+            uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2) * 1024);
+            hd[lane * 8 + e] = h16;
+        }
+    // block scale alpha = 2^ea: the largest with |hi| * alpha <= 7.5 unless a lo code would saturate (then half of
+    // it); the instruction multiplies the codes by 2^(byte - 127) = 1 / alpha
+    int ea = mx > 0.f ? floor_log2(7.5f / mx) : 0;
+    if (ea > 100) ea = 100;
+    if (ea < -100) ea = -100;
+    // (f16-subnormal hi values leave lo up to 2^-1 of hi instead of 2^-11: several steps then)
+    for (bool sat = true; sat && ea > -100;) {
+        sat = false;
+        for (int i = 0; i < 16; ++i) sat = sat || fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f;
+        if (sat) --ea;
+    }
+    const float alpha = ldexpf(1.f, ea);
+    unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < 32; ++sl) {
+        const float v = sl < 16 ? hi[sl] * alpha : lo[sl - 16] * alpha * kX2Rho;
+        const uint64_t code = e2m3_code(v);
+        const int bit = 6 * sl;
+        rec[bit / 32] |= (unsigned)(code << (bit & 31));
+        if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
+    }
+    rec[6] = (unsigned)(127 - ea) * 0x01010101u;
+    // even stage: code dwords 0-3, 16 B per lane; odd stage: code dwords 4-5 as [64 lanes][8 B], then the scale dwords as
+    // [64 lanes][4 B], then 256 B of zeros -- dense, so that gemm_x2_roll's 64- and 32-bit reads are bank-conflict-free
+    unsigned* ev = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T) * NT + nt) * 2 + 1) * 1024);
+    unsigned* od = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + 1) * NT + nt) * 2 + 1) * 1024);
+    for (int d = 0; d < 4; ++d) ev[lane * 4 + d] = rec[d];
+    od[lane * 2 + 0] = rec[4];
+    od[lane * 2 + 1] = rec[5];
+    od[128 + lane] = rec[6];
+}
 void pack_x2(const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int NT, float scale, unsigned char* dst) {
     for (int T = 0; T < KSm / 2; ++T)
         for (int nt = 0; nt < NT; ++nt)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int nn = 32 * nt + (lane & 31), hh = lane >> 5;
-                float hi[16], lo[16], mx = 0.f;
-                for (int j = 0; j < 2; ++j)
-                    for (int e = 0; e < 8; ++e) {
-                        const int k = acc_k(2 * T + j, hh, e);
-                        float v = 0.f;
-                        if (k < in_count && nn < n_out) v = w[(int64_t)nn * ld + in_begin + k] * scale;
-                        const uint16_t h16 = f32_to_f16_rn(v);
-                        hi[8 * j + e] = f16_to_f32(h16);
-                        lo[8 * j + e] = v - hi[8 * j + e];
-                        mx = fmaxf(mx, fabsf(hi[8 * j + e]));
-                        uint16_t* hd = reinterpret_cast<uint16_t*>(dst + (((int64_t)(2 * T + j) * NT + nt) * 2) * 1024);
-                        hd[lane * 8 + e] = h16;
-                    }
-                // block scale alpha = 2^ea: the largest with |hi| * alpha <= 7.5 unless a lo code would saturate (then half of
-                // it); the instruction multiplies the codes by 2^(byte - 127) = 1 / alpha
-                int ea = mx > 0.f ? (int)floorf(log2f(7.5f / mx)) : 0;
-                if (ea > 100) ea = 100;
-                if (ea < -100) ea = -100;
-                // (f16-subnormal hi values leave lo up to 2^-1 of hi instead of 2^-11: several steps then)
-                for (bool sat = true; sat && ea > -100;) {
-                    sat = false;
-                    for (int i = 0; i < 16; ++i) sat = sat || fabsf(lo[i]) * kX2Rho * ldexpf(1.f, ea) > 7.5f;
-                    if (sat) --ea;
-                }
-                const float alpha = ldexpf(1.f, ea);
-                unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int sl = 0; sl < 32; ++sl) {
-                    const float v = sl < 16 ? hi[sl] * alpha : lo[sl - 16] * alpha * kX2Rho;
-                    const uint64_t code = e2m3_code(v);
-                    const int bit = 6 * sl;
-                    rec[bit / 32] |= (unsigned)(code << (bit & 31));
-                    if ((bit & 31) > 26) rec[bit / 32 + 1] |= (unsigned)(code >> (32 - (bit & 31)));
-                }
-                rec[6] = (unsigned)(127 - ea) * 0x01010101u;
-                // even stage: code dwords 0-3, 16 B per lane; odd stage: code dwords 4-5 as [64 lanes][8 B], then the scale dwords as
-                // [64 lanes][4 B], then 256 B of zeros -- dense, so that gemm_x2_roll's 64- and 32-bit reads are bank-conflict-free
-                unsigned* ev = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T) * NT + nt) * 2 + 1) * 1024);
-                unsigned* od = reinterpret_cast<unsigned*>(dst + (((int64_t)(2 * T + 1) * NT + nt) * 2 + 1) * 1024);
-                for (int d = 0; d < 4; ++d) ev[lane * 4 + d] = rec[d];
-                od[lane * 2 + 0] = rec[4];
-                od[lane * 2 + 1] = rec[5];
-                od[128 + lane] = rec[6];
-            }
+            for (int lane = 0; lane < 64; ++lane) pack_x2_unit(w, ld, in_begin, in_count, n_out, NT, scale, dst, T, nt, lane);
 }
 
 }  // namespace
@@ -1040,7 +1058,7 @@ static int field_pack(const h3d_field_params* p, int Hd, int F, void* blob_, boo
         float mx = 0.f;
         for (int nn = 0; nn < n_out; ++nn)
             for (int k = 0; k < in_count; ++k) mx = fmaxf(mx, fabsf(w[(int64_t)nn * ld + in_begin + k]));
-        const float sc = mx > 0.f ? exp2f(floorf(log2f(target / mx))) : 1.f;
+        const float sc = pow2_scale_of(mx, target);
         if (x2 && acc_order) pack_x2(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, blob + L.w[wi]);
         else pack_x3(w, ld, in_begin, in_count, n_out, KSm, L.NT, sc, reinterpret_cast<uint16_t*>(blob + L.w[wi]), acc_order);
         invs[wi] = 1.f / (sc * in_scale);
@@ -1103,6 +1121,149 @@ static int field_pack(const h3d_field_params* p, int Hd, int F, void* blob_, boo
         hb[hd] = hd == 0 ? p->b_sigma[0] : p->b_rgb[hd - 1];
     }
     return H3D_OK;
+}
+
+
+// ---------------------------------------------------------------- device-side packing (round 6)
+// The same blob from parameters that live on the DEVICE, in one launch: weights that change every optimiser step (the D step's
+// no-grad generator forward, /root/reference/lib/trainers/phase_trainer.py:355-362) reach the fused render without the D2H copy,
+// host pack and H2D copy of field_pack (~10 ms and a stream synchronisation per weight version).  The arithmetic is the host
+// packer's own (pack_x3_unit / pack_x2_unit / pow2_scale_of are __host__ __device__; every operation in them is exact or an
+// IEEE-rounded division), so the blobs are bit-identical (tests/test_gpu_field_pack_device.py).
+namespace {
+
+struct PackJob {
+    const float* w;                       // matrix to pack (rows of `ld` floats)
+    int ld, in_begin, in_count, n_out, KSm;
+    int kind;                             // 0: x3, natural K order; 1: x3, accumulator K order; 2: x2 (accumulator order)
+    int64_t dst;                          // byte offset of the matrix in the blob
+    int s_rows, s_ld, s_begin, s_count;   // the slice of `w` the scale is taken over (rows x columns)
+    int inv_slot;                         // index into inv_scale[] (or -1)
+    float in_scale;
+};
+constexpr int kPackJobs = 10, kPackSplit = 8;
+struct PackArgs {
+    PackJob job[kPackJobs];
+    h3d_field_params p;
+    LayoutX3 L;
+    unsigned char* blob;
+    int Hd, F, x2;
+};
+
+__device__ inline float block_max(float v, float* red) {       // 256 threads; every thread returns the maximum
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    const float m = red[0];
+    __syncthreads();
+    return m;
+}
+
+__global__ __launch_bounds__(256) void field_pack_kernel(PackArgs A) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    const float target = 8192.f;
+    const LayoutX3& L = A.L;
+    unsigned char* blob = A.blob;
+    if ((int)blockIdx.x == kPackJobs) {
+        // biases and the four heads (one workgroup)
+        if (blockIdx.y) return;
+        float* bias = reinterpret_cast<float*>(blob + L.bias);
+        for (int nn = t; nn < A.Hd; nn += 256) {
+            bias[ST_GEO * L.HdP + nn] = A.p.b_geo[nn];
+            bias[ST_COORD * L.HdP + nn] = A.p.b_coord[nn];
+            for (int l = 0; l < 4; ++l) bias[(ST_FILM0 + l) * L.HdP + nn] = A.p.b_film[l][nn];
+            bias[ST_COLOR * L.HdP + nn] = A.p.b_color[nn];
+        }
+        float* bf = reinterpret_cast<float*>(blob + L.b_feat);
+        for (int nn = t; nn < A.F; nn += 256) bf[nn] = A.p.b_feat[nn];
+        const int PL = L.head_planes;
+        uint16_t* hw = reinterpret_cast<uint16_t*>(blob + L.head_w);
+        float* hinv = reinterpret_cast<float*>(blob + L.head_inv);
+        float* hb = reinterpret_cast<float*>(blob + L.head_b);
+        for (int hd = 0; hd < 4; ++hd) {
+            const float* w = hd == 0 ? A.p.w_sigma : A.p.w_rgb + (int64_t)(hd - 1) * A.Hd;
+            float mx = 0.f;
+            for (int k = t; k < A.Hd; k += 256) mx = fmaxf(mx, fabsf(w[k]));
+            const float sc = pow2_scale_of(block_max(mx, red), target);
+            for (int u = t; u < L.KS * 16; u += 256) {
+                const int ks = u >> 4, hh = (u >> 3) & 1, e = u & 7;
+                const int k = acc_k(ks, hh, e);
+                const float v = k < A.Hd ? w[k] * sc : 0.f;
+                const uint16_t hi = f32_to_f16_rn(v), lo = f32_to_f16_rn(v - f16_to_f32(hi));
+                hw[((((int64_t)hd * PL + 0) * L.KS + ks) * 2 + hh) * 8 + e] = hi;
+                hw[((((int64_t)hd * PL + 1) * L.KS + ks) * 2 + hh) * 8 + e] = lo;
+                if (A.x2) hw[((((int64_t)hd * PL + 2) * L.KS + ks) * 2 + hh) * 8 + e] = f32_to_f16_rn(f16_to_f32(hi) / kX2Rho);
+            }
+            if (t == 0) {
+                hinv[hd] = 1.f / (sc * kSA);
+                hb[hd] = hd == 0 ? A.p.b_sigma[0] : A.p.b_rgb[hd - 1];
+            }
+        }
+        return;
+    }
+    const PackJob& J = A.job[blockIdx.x];
+    // every workgroup of a matrix takes the scale itself (<= 66 k values from the L2) and packs its share of the units
+    float mx = 0.f;
+    for (int i = t; i < J.s_rows * J.s_count; i += 256) {
+        const int r = i / J.s_count, c = i - r * J.s_count;
+        mx = fmaxf(mx, fabsf(J.w[(int64_t)r * J.s_ld + J.s_begin + c]));
+    }
+    const float sc = pow2_scale_of(block_max(mx, red), target);
+    if (t == 0 && blockIdx.y == 0 && J.inv_slot >= 0) reinterpret_cast<float*>(blob + L.inv_scale)[J.inv_slot] = 1.f / (sc * J.in_scale);
+    const int rows = J.kind == 2 ? J.KSm / 2 : J.KSm;               // k-steps (x3) or k-step pairs (x2)
+    const int units = rows * L.NT * 64;
+    for (int u = (int)blockIdx.y * 256 + t; u < units; u += kPackSplit * 256) {
+        const int lane = u & 63, nt = (u >> 6) % L.NT, r = (u >> 6) / L.NT;
+        if (J.kind == 2) pack_x2_unit(J.w, J.ld, J.in_begin, J.in_count, J.n_out, L.NT, sc, blob + J.dst, r, nt, lane);
+        else pack_x3_unit(J.w, J.ld, J.in_begin, J.in_count, J.n_out, L.NT, sc, reinterpret_cast<uint16_t*>(blob + J.dst), J.kind == 1, r, nt, lane);
+    }
+}
+
+int field_pack_device(const h3d_field_params* p, int Hd, int F, void* blob_, bool x2, h3d_stream_t stream) {
+    H3D_REQUIRE(p && blob_, "h3d_field_pack_x3_device / _x2_device: null pointer");
+    H3D_REQUIRE(Hd >= 1 && F >= 1 && Hd <= 256 && F <= 256, "h3d_field_pack_x3_device / _x2_device: widths up to 256 (got %d, %d)", Hd, F);
+    H3D_REQUIRE(h3d::aligned16(blob_), "h3d_field_pack_x3_device / _x2_device: the blob must be 16-byte aligned");
+    H3D_REQUIRE(p->w_coord && p->b_coord && p->w_geo && p->b_geo && p->w_sigma && p->b_sigma && p->w_color && p->b_color && p->w_rgb &&
+                p->b_rgb && p->w_feat && p->b_feat, "h3d_field_pack_x3_device / _x2_device: null parameter pointer");
+    for (int l = 0; l < 4; ++l) H3D_REQUIRE(p->w_film[l] && p->b_film[l], "h3d_field_pack_x3_device / _x2_device: null FiLM parameter pointer");
+    PackArgs A{};
+    A.L = make_layout(Hd, F, x2);
+    A.p = *p; A.blob = static_cast<unsigned char*>(blob_); A.Hd = Hd; A.F = F; A.x2 = x2 ? 1 : 0;
+    const LayoutX3& L = A.L;
+    int n = 0;
+    auto job = [&](int64_t dst, const float* w, int ld, int in_begin, int in_count, int n_out, int KSm, int kind, int s_rows, int s_begin,
+                   int s_count, int inv_slot, float in_scale) {
+        A.job[n++] = PackJob{w, ld, in_begin, in_count, n_out, KSm, kind, dst, s_rows, ld, s_begin, s_count, inv_slot, in_scale};
+    };
+    const int acc = x2 ? 2 : 1;
+    job(L.w[W_COORD], p->w_coord, 3, 0, 3, Hd, 1, 0, Hd, 0, 3, W_COORD, kSIn);
+    job(L.w[W_GEO], p->w_geo, 31, 0, 31, Hd, 2, 0, Hd, 0, 31, W_GEO, kSIn);
+    job(L.w[W_F0A], p->w_film[0], 2 * Hd, 0, Hd, Hd, L.KS, acc, Hd, 0, 2 * Hd, W_F0A, kSA);      // both halves: one scale (same accumulators)
+    job(L.w[W_F0B], p->w_film[0], 2 * Hd, Hd, Hd, Hd, L.KS, acc, Hd, 0, 2 * Hd, W_F0B, kSA);
+    for (int l = 1; l < 4; ++l) job(L.w[W_F1 + l - 1], p->w_film[l], Hd, 0, Hd, Hd, L.KS, acc, Hd, 0, Hd, W_F1 + l - 1, kSA);
+    job(L.w[W_COLOR], p->w_color, Hd + 3, 3, Hd, Hd, L.KS, acc, Hd, 0, Hd + 3, W_COLOR, kSA);
+    job(L.w[W_COLOR] + (int64_t)L.KS * L.NT * 2 * 64 * 8 * 2, p->w_color, Hd + 3, 0, 3, Hd, 1, 0, Hd, 0, Hd + 3, -1, kSA);
+    job(L.w[W_FEAT], p->w_feat, Hd, 0, Hd, F, L.KS, acc, F, 0, Hd, W_FEAT, kSA);
+    if (n != kPackJobs) return H3D_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h3d::pre_launch();
+    if (hipMemsetAsync(A.blob, 0, (size_t)L.total, st) != hipSuccess) return h3d::launch_status("h3d_field_pack_device (memset)");
+    hipLaunchKernelGGL(field_pack_kernel, dim3(kPackJobs + 1, kPackSplit), dim3(256), 0, st, A);
+    return h3d::launch_status("h3d_field_pack_device");
+}
+
+}  // namespace
+
+extern "C" int h3d_field_pack_x3_device(const h3d_field_params* p, int Hd, int F, void* blob, h3d_stream_t stream) {
+    return field_pack_device(p, Hd, F, blob, false, stream);
+}
+extern "C" int h3d_field_pack_x2_device(const h3d_field_params* p, int Hd, int F, void* blob, h3d_stream_t stream) {
+    return field_pack_device(p, Hd, F, blob, true, stream);
 }
 
 extern "C" int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob) { return field_pack(p, Hd, F, blob, false); }

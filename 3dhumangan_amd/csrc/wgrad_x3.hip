@@ -549,3 +549,61 @@ static int conv_wgrad_any(const void* dY, const void* X, int half, float* partia
 #undef H3D_CASE
     return H3D_EUNSUPPORTED;
 }
+
+// ---------------------------------------------------------------- the slices' sum (round 6)
+// dW[co][ci][tap] = sum_s partial[tap][s][co][ci] and dB[co] = sum_s colsum[s][co] in ONE launch, written in the parameter's own
+// layout [Co, Ci, k, k] -- what was `partial.sum(1).view(k, k, Co, Ci).permute(2, 3, 0, 1).contiguous()` + `colsum.sum(0)` on
+// torch's reduction and copy kernels (three launches and an intermediate per weight gradient, 215 weight gradients per
+// config-4 iteration).  A workgroup sums 256 consecutive (co, ci) elements of one tap: four waves take every fourth slice as 16-byte
+// loads, the four partial sums meet in LDS in a fixed order (deterministic, like the slices themselves).
+namespace {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ colsum,
+                                                           float* __restrict__ dw, float* __restrict__ db, int taps, int slices,
+                                                           int64_t n_w, int n_b) {
+    __shared__ float4 part[3][64];
+    const bool bias = (int)blockIdx.y == taps;                    // the extra row of workgroups sums colsum
+    const int tap = bias ? 0 : (int)blockIdx.y;
+    const int64_t n = bias ? n_b : n_w;
+    const float* src = bias ? colsum : partial + (int64_t)tap * slices * n_w;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    if ((int64_t)blockIdx.x * 256 >= n) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n) {
+        for (int s = grp; s < slices; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * n + e);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    if (grp) part[grp - 1][lane] = acc;
+    __syncthreads();
+    if (grp || e >= n) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float4 v = part[g][lane];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (bias) { *reinterpret_cast<float4*>(db + e) = acc; return; }
+    if (taps == 1) { *reinterpret_cast<float4*>(dw + e) = acc; return; }
+    dw[(e + 0) * taps + tap] = acc.x;
+    dw[(e + 1) * taps + tap] = acc.y;
+    dw[(e + 2) * taps + tap] = acc.z;
+    dw[(e + 3) * taps + tap] = acc.w;
+}
+}  // namespace
+
+extern "C" int h3d_wgrad_reduce(const float* partial, const float* colsum, float* dw, float* db, int taps, int slices, int Co, int Ci,
+                                h3d_stream_t stream) {
+    H3D_REQUIRE(partial && dw, "h3d_wgrad_reduce: null pointer");
+    H3D_REQUIRE((colsum == nullptr) == (db == nullptr), "h3d_wgrad_reduce: colsum and db come together");
+    H3D_REQUIRE(taps >= 1 && taps <= 9 && slices >= 1 && Co >= 1 && Ci >= 1, "h3d_wgrad_reduce: bad shape");
+    H3D_REQUIRE(Co % 4 == 0 && Ci % 4 == 0, "h3d_wgrad_reduce: Co and Ci must be multiples of 4 (got %d, %d)", Co, Ci);
+    H3D_REQUIRE(h3d::aligned16(partial) && h3d::aligned16(dw) && h3d::aligned16(colsum) && h3d::aligned16(db),
+                "h3d_wgrad_reduce: buffers must be 16-byte aligned");
+    const int64_t n_w = (int64_t)Co * Ci;
+    const dim3 grid((unsigned)((n_w + 255) / 256), (unsigned)(taps + (colsum ? 1 : 0)));
+    h3d::pre_launch();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), partial, colsum, dw, db, taps, slices,
+                       n_w, Co);
+    return h3d::launch_status("h3d_wgrad_reduce");
+}

@@ -54,6 +54,7 @@ _stream_cache = {}
 # autocast rounds it: one matrix product per weight, half the weight stream (h3d_conv_x3_f16x1); 2 = f16 hi + lo (the weight to
 # max(2^-22 |W|, 2^-25): more precise than what it is compared with, twice the matrix work) -- the opt-in tier.
 AMP_WEIGHT_PLANES = int(os.environ.get("H3D_AMP_WEIGHT_PLANES", "1"))
+FUSED_REDUCE = os.environ.get("H3D_WGRAD_REDUCE", "fused") != "torch"      # the slices' sum on h3d_wgrad_reduce (round 6)
 
 
 def pack_stream(w, transposed=False, half=False, owner=None, planes=2):
@@ -159,8 +160,22 @@ def _run_wgrad(x, g, k, with_bias=False):
         entry = lib.h3d_conv_wgrad_x3 if x.dtype == torch.float32 else lib.h3d_conv_wgrad_x3_f16
         rc = entry(_lib.ptr(g), _lib.ptr(x), _lib.ptr(partial), B, H, W, co, ci, k, ldg, ldx, slices, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_wgrad_x3")
-    dw = partial.sum(dim=1).view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()
-    return (dw, colsum.sum(dim=0)) if with_bias else dw
+    return reduce_slices(partial, colsum if with_bias else None, k * k, slices, co, ci, (co, ci, k, k))
+
+
+def reduce_slices(partial, colsum, taps, slices, co, ci, shape):
+    """partial [taps, slices, co, ci] (, colsum [slices, co]) -> dw `shape` = [co, ci (, k, k)] (, db [co]): the slices' sum, the
+    layout change and the bias gradient's sum in ONE launch (h3d_wgrad_reduce; torch: a reduction, a permuted copy and a second
+    reduction -- three launches per weight gradient)."""
+    if not FUSED_REDUCE:                  # H3D_WGRAD_REDUCE=torch: the round-5 tensor operations (A/B switch)
+        dw = partial.view(taps, slices, co, ci).sum(dim=1).permute(1, 2, 0).contiguous().view(shape)
+        return dw if colsum is None else (dw, colsum.sum(dim=0))
+    dw = torch.empty(shape, device=partial.device, dtype=torch.float32)
+    db = None if colsum is None else torch.empty((co,), device=partial.device, dtype=torch.float32)
+    rc = _lib.load().h3d_wgrad_reduce(_lib.ptr(partial), _lib.ptr(colsum), _lib.ptr(dw), _lib.ptr(db), taps, slices, co, ci,
+                                      _lib.stream_handle())
+    _lib.check(rc, "h3d_wgrad_reduce")
+    return dw if colsum is None else (dw, db)
 
 
 def _transposed(w):

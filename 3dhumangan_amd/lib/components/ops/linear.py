@@ -78,8 +78,10 @@ def wgrad_x3(dy, x, with_bias=False):
     rc = entry(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(partial), _lib.ptr(colsum), M, Co, Ci, dy.stride(0), x.stride(0),
                                slices, _lib.stream_handle())
     _lib.check(rc, "h3d_wgrad_x3")
-    dw = partial.sum(dim=0) if slices > 1 else partial[0]
-    return (dw, colsum.sum(dim=0)) if with_bias else dw
+    if slices == 1:
+        return (partial[0], colsum[0]) if with_bias else partial[0]
+    from . import conv
+    return conv.reduce_slices(partial, colsum, 1, slices, Co, Ci, (Co, Ci))      # both sums in one launch
 
 
 def wgrad_narrow(wide, narrow, wide_sum=False, narrow_sum=False):

@@ -274,6 +274,11 @@ class Map3DGenerator(nn.Module):
         # eval-mode render: nearest-vertex search + fused field kernel that builds the geometry features itself (default), or
         # h3d_geo_features + fused field kernel (H3D_FUSE_GEO=0 / .fuse_geo = False)
         self.fuse_geo = os.environ.get("H3D_FUSE_GEO", "1") != "0"
+        # Train-mode forward that nothing records (the D step's no-grad generator forward, reference
+        # lib/trainers/phase_trainer.py:355-362): the field + integration run on the fused render with device-packed weights (round 6).
+        # "x3" (default): three f16 products, the differentiable path's own error class (~1e-5); "x2": the inference default's tier;
+        # "off": lib/generators/differentiable.py as in rounds 2-5.  The field has no batch statistics: train and eval mode coincide.
+        self.train_field = os.environ.get("H3D_TRAIN_FIELD", "x3")
         for flag in ("2d_semantic_input", "2d_label_input", "2d_latent_input"):
             if k.get(flag, False):
                 raise NotImplementedError(f"{flag}=True is not used by any shipped config and has no HIP path")
@@ -387,6 +392,16 @@ class Map3DGenerator(nn.Module):
                 differentiable=False, **kwargs):
         if hierarchical_sample and differentiable:
             raise NotImplementedError("hierarchical_sample=True has no differentiable path (no shipped config trains with it)")
+        nf = self.neural_field
+        if (differentiable and not torch.is_grad_enabled() and not hierarchical_sample and fused and self.train_field in ("x3", "x2")
+                and nf.device_pack and nf.precision in ("f16x2", "f16x3") and nf.fused_supported(int(coarse_steps))):
+            keep, nf.precision = nf.precision, "f16x3" if self.train_field == "x3" else "f16x2"
+            try:
+                return self._render(freq, phase, conditions, render_width, render_height, ray_start, ray_end, coarse_steps, fine_steps,
+                                    h_stddev, v_stddev, h_mean, v_mean, False, sample_dist, lock_view_dependence, staged, max_points,
+                                    jitter, noise, fused, differentiable=False, **kwargs)
+            finally:
+                nf.precision = keep
         if hierarchical_sample:
             return self._render_hierarchical(freq, phase, conditions, render_width, render_height, ray_start, ray_end,
                                              int(coarse_steps), int(coarse_steps if fine_steps is None else fine_steps),

@@ -70,6 +70,8 @@ class COORDCONCATSIREN(nn.Module):
         self.precision = os.environ.get("H3D_FIELD_PRECISION", default)
         # x2 render: refinement of ill-conditioned last samples on the three-product engine (render_geo; round 6)
         self.refine_last_sample = os.environ.get("H3D_FIELD_REFINE", "1") != "0"
+        # weights packed on the device they live on (round 6; H3D_FIELD_PACK=host: the D2H copy + host packer + H2D copy of rounds 1-5)
+        self.device_pack = os.environ.get("H3D_FIELD_PACK", "device") != "host"
         self.refine_eps = float(os.environ.get("H3D_FIELD_REFINE_EPS", "1e-3"))
         self.refine_capacity = int(os.environ.get("H3D_FIELD_REFINE_CAP", "128"))       # listed units per batch item
         self._refine_buf = None
@@ -92,6 +94,9 @@ class COORDCONCATSIREN(nn.Module):
                    64, (4,)),
         "f32": ("h3d_field_pack_size", "h3d_field_pack", "h3d_neural_field", "h3d_render_fused", 64, ()),
     }
+
+    # packers with a device-side twin (csrc/field_x3.hip: field_pack_kernel)
+    _DEVICE_PACKERS = {"h3d_field_pack_x3": "h3d_field_pack_x3_device", "h3d_field_pack_x2": "h3d_field_pack_x2_device"}
 
     def _engine(self):
         if self.precision not in self._ENGINES:
@@ -118,7 +123,14 @@ class COORDCONCATSIREN(nn.Module):
             return hit[1]
         lib = _lib.load()
         H, F = self.hidden_dim, self.feature_dim
-        host = [(l.weight.detach().float().cpu().contiguous(), l.bias.detach().float().cpu().contiguous()) for l in lins]
+        on_device = (self.device_pack and pack_name in self._DEVICE_PACKERS and device.type == "cuda"
+                     and all(p.device == device for l in lins for p in (l.weight, l.bias)))
+        if on_device:
+            # round 6: packed where the parameters live (one memset + one launch, no synchronisation, bit-identical blob) -- what lets
+            # a weight that changes every optimiser step use the fused render (the D step's no-grad generator forward)
+            host = [(l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous()) for l in lins]
+        else:
+            host = [(l.weight.detach().float().cpu().contiguous(), l.bias.detach().float().cpu().contiguous()) for l in lins]
         P = _lib.FieldParams()
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         P.w_coord, P.b_coord = vp(host[0][0]), vp(host[0][1])
@@ -133,9 +145,15 @@ class COORDCONCATSIREN(nn.Module):
         nbytes = size_fn(H, F)
         if nbytes <= 0:
             raise _lib.H3DError(f"field engine {self.precision} does not support widths {H}/{F}")
-        blob = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
-        _lib.check(pack_fn(ctypes.byref(P), H, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack")
-        dev_blob = blob.to(device)
+        if on_device:
+            with torch.cuda.device(device):
+                dev_blob = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+                rc = getattr(lib, self._DEVICE_PACKERS[pack_name])(ctypes.byref(P), H, F, _lib.ptr(dev_blob), _lib.stream_handle())
+            _lib.check(rc, self._DEVICE_PACKERS[pack_name])
+        else:
+            blob = torch.empty((nbytes + 3) // 4, dtype=torch.float32)
+            _lib.check(pack_fn(ctypes.byref(P), H, F, ctypes.c_void_p(blob.data_ptr())), "h3d_field_pack")
+            dev_blob = blob.to(device)
         self._packed[x3] = (key, dev_blob)
         return dev_blob
 

@@ -176,6 +176,11 @@ int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B,
  */
 int64_t h3d_field_pack_x3_size(int Hd, int F);
 int h3d_field_pack_x3(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+/* The same blob from parameters that live on the DEVICE (round 6): `p` (a HOST struct) holds DEVICE pointers to contiguous fp32
+ * tensors, `blob` is DEVICE memory of h3d_field_pack_x3_size bytes, 16-byte aligned; one memset + one launch on `stream`, no
+ * synchronisation.  Bit-identical to h3d_field_pack_x3's blob.  For weights that change every optimiser step: the D step's
+ * no-grad generator forward (/root/reference/lib/trainers/phase_trainer.py:355-362) runs the fused render on them. */
+int h3d_field_pack_x3_device(const h3d_field_params* p, int Hd, int F, void* blob /* DEVICE */, h3d_stream_t stream);
 /* Layout of the blob h3d_field_pack_x3 writes (HOST helper, for tools and tests).  out[0..19] = tiles, k-steps per
  * hidden GEMM, padded width, weight-stream stages per 32-sample step, then BYTE offsets of the nine stream matrices in
  * consumption order (coord [1 k-step], film0 coord half, geo [2], film0 geo half, film1, film2, film3, colour [k-steps
@@ -262,6 +267,8 @@ int h3d_conv_wgrad_x3_fused(int B, int H, int W, int Co, int Ci);
  */
 int64_t h3d_field_pack_x2_size(int Hd, int F);
 int h3d_field_pack_x2(const h3d_field_params* p, int Hd, int F, void* blob /* HOST */);
+/* h3d_field_pack_x2 from DEVICE parameters into DEVICE memory (see h3d_field_pack_x3_device); bit-identical blob. */
+int h3d_field_pack_x2_device(const h3d_field_params* p, int Hd, int F, void* blob /* DEVICE */, h3d_stream_t stream);
 int h3d_field_x2_layout(int Hd, int F, int64_t* out, int n_out);
 int h3d_neural_field_x2(const void* packed, const float* points, const float* geo, const float* dirs,
                         const float* freq, const float* phase, float* out,
@@ -598,6 +605,14 @@ int h3d_wgrad_x3(const float* dY, const float* X, float* partial, int64_t M, int
  * sums the slices).  colsum may be NULL. */
 int h3d_wgrad_x3_bias(const float* dY, const float* X, float* partial, float* colsum, int64_t M, int Co, int Ci, int ldy,
                       int ldx, int slices, h3d_stream_t stream_handle);
+/* The slices' sum of h3d_wgrad_x3[_bias] (taps = 1) and h3d_conv_wgrad_x3[_bias] (taps = k * k) in one launch, written in the
+ * parameter's layout:  dw[Co][Ci][taps] = sum_s partial[tap][s][Co][Ci];  db[Co] = sum_s colsum[s][Co] (colsum and db both NULL:
+ * no bias gradient).  Replaces torch's `partial.sum(1)...permute(2, 3, 0, 1).contiguous()` + `colsum.sum(0)` -- the grad_weight /
+ * grad_bias a library convolution_backward returns ready-made (reference: the autograd of
+ * /root/reference/lib/discriminators/unet_discriminators.py:32-47).  Deterministic (fixed summation order).  Co, Ci multiples
+ * of 4, taps <= 9, 16-byte aligned buffers. */
+int h3d_wgrad_reduce(const float* partial, const float* colsum, float* dw, float* db, int taps, int slices, int Co, int Ci,
+                     h3d_stream_t stream_handle);
 
 /* Weight gradient with one narrow side: out[j][c] = sum_r narrow[r][j] * wide[r][c], j < nn <= 4 (ToRGB 3 x C, density /
  * colour heads, the coordinate layer transposed).  wide [M, C] fp32 with leading dimension ldw, narrow [M, nn] fp32 contiguous;

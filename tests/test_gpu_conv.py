@@ -177,3 +177,21 @@ def test_misaligned_views_fall_back_to_a_copy_instead_of_raising():
     up = rs.bilinear_resize_cl(t, (4, 3), (16, 12))
     want = torch.nn.functional.interpolate(t.view(1, 4, 3, 16).permute(0, 3, 1, 2), (16, 12), mode="bilinear", align_corners=False)
     assert float((up.view(1, 16, 12, 16).permute(0, 3, 1, 2) - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("taps,slices,co,ci,bias", [(9, 170, 128, 128, True), (9, 2, 512, 512, False), (1, 37, 256, 256, True),
+                                                     (9, 5, 64, 4, True), (1, 1, 8, 12, True), (4, 3, 260, 68, False)])
+def test_the_slices_sum_kernel_equals_the_tensor_operations(taps, slices, co, ci, bias):
+    """h3d_wgrad_reduce: the slices' sum, the [k, k, Co, Ci] -> [Co, Ci, k, k] layout change and the bias gradient's sum in one launch."""
+    g = torch.Generator().manual_seed(taps * 1000 + slices)
+    partial = torch.randn(taps, slices, co, ci, generator=g).to(DEV)
+    colsum = torch.randn(slices, co, generator=g).to(DEV) if bias else None
+    out = conv.reduce_slices(partial, colsum, taps, slices, co, ci, (co, ci, taps))
+    dw, db = out if bias else (out, None)
+    want = partial.double().sum(dim=1).permute(1, 2, 0)
+    assert dw.shape == (co, ci, taps) and dw.is_contiguous()
+    assert rel_err(dw, want) < 1e-6
+    if bias:
+        assert rel_err(db, colsum.double().sum(dim=0)) < 1e-6
+    again = conv.reduce_slices(partial, colsum, taps, slices, co, ci, (co, ci, taps))
+    assert torch.equal(dw, again[0] if bias else again)          # deterministic
