@@ -54,6 +54,7 @@ _stream_cache = {}
 # autocast rounds it: one matrix product per weight, half the weight stream (h3d_conv_x3_f16x1); 2 = f16 hi + lo (the weight to
 # max(2^-22 |W|, 2^-25): more precise than what it is compared with, twice the matrix work) -- the opt-in tier.
 AMP_WEIGHT_PLANES = int(os.environ.get("H3D_AMP_WEIGHT_PLANES", "1"))
+FUSED_PAD = os.environ.get("H3D_CONV_PAD", "fused") != "torch"             # channel padding on h3d_pad_channels_cl (round 6)
 FUSED_REDUCE = os.environ.get("H3D_WGRAD_REDUCE", "fused") != "torch"      # the slices' sum on h3d_wgrad_reduce (round 6)
 
 
@@ -259,21 +260,51 @@ class _ConvWB(torch.autograd.Function):
         return gx, gg, None
 
 
+def _pad_channels(x, cop):
+    """x [B, C, H, W] (any layout, fp32 / f16) -> [B, cop, H, W] channels-last with channels C .. cop zero; no autograd (h3d_pad_channels_cl)."""
+    x = x.detach()
+    B, C, H, W = x.shape
+    if not FUSED_PAD:                      # H3D_CONV_PAD=torch: the round-5 tensor operations (A/B switch)
+        x = x.contiguous(memory_format=torch.channels_last)
+        out = torch.cat([x, x.new_zeros((B, cop - C, H, W)).contiguous(memory_format=torch.channels_last)], dim=1)
+        return out.contiguous(memory_format=torch.channels_last)
+    sb, sc, sh, sw = x.stride()
+    if H > 1 and sh != W * sw:             # rows that do not follow each other: not a pixel-strided layout
+        x = x.contiguous(memory_format=torch.channels_last)
+        sb, sc, sh, sw = x.stride()
+    out = torch.empty((B, cop, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    rc = _lib.load().h3d_pad_channels_cl(_lib.ptr(x), _lib.ptr(out), B, C, cop, H * W, sb, sc, sw, int(x.dtype == torch.float16),
+                                         _lib.stream_handle())
+    _lib.check(rc, "h3d_pad_channels_cl")
+    return out
+
+
+class _PadChannels(torch.autograd.Function):
+    """torch.cat([x, zeros], dim=1) in channels-last, one pass (h3d_pad_channels_cl); the adjoint of _NarrowChannels, and its
+    backward is _NarrowChannels: the pair is closed under differentiation (the R1 double backward goes through the stem)."""
+
+    @staticmethod
+    def forward(ctx, x, cop):
+        ctx.ci = x.shape[1]
+        return _pad_channels(x, cop)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _NarrowChannels.apply(g, ctx.ci), None
+
+
 class _NarrowChannels(torch.autograd.Function):
     """y[:, :co] whose gradient stays channels-last (torch's slice backward builds an NCHW-contiguous zero-padded tensor, which the
-    next convolution would have to copy); differentiable again (a concatenation)."""
+    next convolution would have to copy); differentiable again (_PadChannels)."""
 
     @staticmethod
     def forward(ctx, y, co):
-        ctx.extra = y.shape[1] - co
+        ctx.full = y.shape[1]
         return y[:, :co]
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous(memory_format=torch.channels_last)
-        pad = torch.empty((g.shape[0], ctx.extra) + tuple(g.shape[2:]), device=g.device, dtype=g.dtype,
-                          memory_format=torch.channels_last).zero_()
-        return torch.cat([g, pad], dim=1), None
+        return _PadChannels.apply(g, ctx.full), None
 
 
 def conv2d(x, weight, bias=None):
@@ -284,8 +315,7 @@ def conv2d(x, weight, bias=None):
     co, ci = weight.shape[:2]
     cip, cop = _up64(ci), _up64(co)
     if cip != ci:
-        x = x.contiguous(memory_format=torch.channels_last)
-        x = torch.cat([x, x.new_zeros((x.shape[0], cip - ci) + tuple(x.shape[2:])).contiguous(memory_format=torch.channels_last)], dim=1)
+        x = _PadChannels.apply(x, cip) if (x.requires_grad and torch.is_grad_enabled()) else _pad_channels(x, cip)
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cip - ci))
     weight = weight.float()                 # parameters stay fp32 under autocast: the kernels split them to bf16 hi / lo themselves
     if cop != co:

@@ -592,6 +592,14 @@ int h3d_ray_integrate_bwd(const float* field, const float* z_vals, const float* 
                           const float* g_depth, const float* g_weights, float* d_field, int64_t n_rays, int S, int C,
                           int clamp_mode, int last_back, int white_back, h3d_stream_t stream);
 
+/* Zero-padded channels, channels-last:  out[b][p][c] = in[b*sb + c*sc + p*sp] for c < Cin, 0 for Cin <= c < Cout  (out [B, HW, Cout]
+ * contiguous, 16-byte aligned, Cout % 4 == 0; element strides sb, sc, sp: any input layout; dtype 0 = f32, 1 = f16).  The padding in
+ * front of a native convolution with a channel count that is not a multiple of 64 (the discriminator's RGB stem,
+ * /root/reference/lib/discriminators/unet_discriminators.py:117) and the gradient of a narrowed output (its heads, :145-146):
+ * one pass instead of torch's zero fill + layout copy + concatenation. */
+int h3d_pad_channels_cl(const void* in, void* out, int B, int Cin, int Cout, int64_t HW, int64_t sb, int64_t sc, int64_t sp, int dtype,
+                        h3d_stream_t stream);
+
 /* Weight gradient of a dense layer of the training path:  dW[Co,Ci] = dY[M,Co]^T X[M,Ci]  (the `grad_weight` torch's
  * AddmmBackward computes for F.linear; lib/generators/differentiable.py routes every layer with enough rows here).
  * Split-K over the M rows on the bf16 matrix cores with split operands (fp32-class: 16 mantissa bits per operand, fp32

@@ -195,3 +195,37 @@ def test_the_slices_sum_kernel_equals_the_tensor_operations(taps, slices, co, ci
         assert rel_err(db, colsum.double().sum(dim=0)) < 1e-6
     again = conv.reduce_slices(partial, colsum, taps, slices, co, ci, (co, ci, taps))
     assert torch.equal(dw, again[0] if bias else again)          # deterministic
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last", "slice", "one_channel"])
+def test_channel_padding_kernel(layout, dtype):
+    """h3d_pad_channels_cl: zero-padded channels in channels-last from any input layout, and the closed _PadChannels /
+    _NarrowChannels pair through a double backward."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 12, 20
+    if layout == "nchw":
+        x = torch.randn(B, 3, H, W, generator=g)
+    elif layout == "channels_last":
+        x = torch.randn(B, 26, H, W, generator=g).contiguous(memory_format=torch.channels_last)
+    elif layout == "slice":
+        x = torch.randn(B, 64, H, W, generator=g).contiguous(memory_format=torch.channels_last)[:, :26]
+    else:
+        x = torch.randn(B, 1, H, W, generator=g)
+    x = x.to(DEV).to(dtype)
+    out = conv._pad_channels(x, 64)
+    assert out.shape == (B, 64, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    C = x.shape[1]
+    assert torch.equal(out[:, :C], x) and float(out[:, C:].abs().max()) == 0.0
+    if dtype == torch.float32:
+        xr = x.clone().requires_grad_(True)
+        y = conv._PadChannels.apply(xr, 64)
+        w = torch.randn(B, 64, H, W, generator=g).to(DEV)
+        (gx,) = torch.autograd.grad((y * w).sum(), xr, create_graph=True)          # = w[:, :C], through _NarrowChannels
+        assert torch.equal(gx, w[:, :C])
+        v = torch.randn(B, 64, H, W, generator=g).to(DEV).requires_grad_(True)
+        z = conv._NarrowChannels.apply(v, C)
+        (gv,) = torch.autograd.grad((z * xr).sum(), v, create_graph=True)          # = pad(xr): depends on xr
+        assert gv.is_contiguous(memory_format=torch.channels_last) and torch.equal(gv[:, :C], xr) and float(gv.detach()[:, C:].abs().max()) == 0.0
+        (gxx,) = torch.autograd.grad((gv * w).sum(), xr)                           # second order: back through the pair
+        assert torch.equal(gxx, w[:, :C])
