@@ -32,6 +32,8 @@ struct Args {
     int64_t P;                     // B * H * W
     int H, W, Cin, Cout, k, n_chunks, stages_per_oblk;
     int ldx, ldo;                  // row strides (elements) of x and out: >= Cin / Cout (channel slices of wider tensors)
+    const void* add;               // optional [P, Cout] addend of the output's type (a residual connection), row stride lda; or null
+    int lda;
 };
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
     if (okp) {
         TX* __restrict__ o = static_cast<TX*>(A.out) + p * A.ldo + oblk * (NT * 32);
+        const TX* __restrict__ ad = A.add ? static_cast<const TX*>(A.add) + p * A.lda + oblk * (NT * 32) : nullptr;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
@@ -150,6 +153,16 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
                 if (A.bias) {
                     const float4 b = *reinterpret_cast<const float4*>(A.bias + oblk * (NT * 32) + n);
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                if (ad) {                        // the residual connection's other branch, added in fp32 before the one rounding
+                    if constexpr (HALF) {
+                        const uint2 r = *reinterpret_cast<const uint2*>(ad + n);
+                        const h16x2 r0 = __builtin_bit_cast(h16x2, r.x), r1 = __builtin_bit_cast(h16x2, r.y);
+                        v.x += (float)r0[0]; v.y += (float)r0[1]; v.z += (float)r1[0]; v.w += (float)r1[1];
+                    } else {
+                        const float4 r = *reinterpret_cast<const float4*>(ad + n);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
                 }
                 if constexpr (HALF) {            // round to f16 once, after the fp32 accumulation and the bias
                     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -246,7 +259,7 @@ extern "C" int h3d_conv_x3_pack_f16x1(const float* w, void* stream, int Cout, in
 }
 
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
-                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_);
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add = nullptr, int lda = 0);
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     return conv_x3_any(0, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
@@ -268,8 +281,20 @@ extern "C" int h3d_conv_x3_f16x1(const void* x, const void* stream, const float*
     H3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0, "h3d_conv_x3_f16x1: row strides must be multiples of 8 halves (ldx=%d ldo=%d)", ldx, ldo);
     return conv_x3_any(2, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
 }
+/* h3d_conv_x3 / _f16 / _f16x1 (mode 0 / 1 / 2) with a residual connection in the epilogue (round 6):
+ * out = conv(x) + bias + add, `add` [B, H, W, Cout] of the output's type with row stride lda (elements; a multiple of 4 / 8 as ldo),
+ * added in fp32 before the store -- the `x = h + x_in` of a skip block without a pass of its own. */
+extern "C" int h3d_conv_x3_add(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, int B, int H,
+                               int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, h3d_stream_t stream_) {
+    H3D_REQUIRE(mode >= 0 && mode <= 2, "h3d_conv_x3_add: mode %d (0 = fp32, 1 = f16 two planes, 2 = f16 one plane)", mode);
+    H3D_REQUIRE(add && h3d::aligned16(add), "h3d_conv_x3_add: null or misaligned addend");
+    const int gran = mode ? 8 : 4;
+    H3D_REQUIRE(lda >= Cout && lda % gran == 0 && ldx % gran == 0 && ldo % gran == 0,
+                "h3d_conv_x3_add: row strides must be multiples of %d (ldx=%d ldo=%d lda=%d)", gran, ldx, ldo, lda);
+    return conv_x3_any(mode, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_, add, lda);
+}
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
-                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add, int lda) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
     H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
@@ -282,7 +307,7 @@ static int conv_x3_any(int mode, const void* x, const void* stream, const float*
     }
     if (B == 0) return H3D_OK;
     Args A{};
-    A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out;
+    A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out; A.add = add; A.lda = lda;
     A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
     A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * (mode == 2 ? til[2] / 2 : til[2]); A.ldx = ldx; A.ldo = ldo;
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");

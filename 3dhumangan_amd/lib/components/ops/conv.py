@@ -121,9 +121,10 @@ def _rows(x):
     return _lib.aligned16(x.contiguous(memory_format=torch.channels_last)), C
 
 
-def _run_conv(x, w, bias=None, transposed=False, owner=None):
+def _run_conv(x, w, bias=None, transposed=False, owner=None, add=None):
     """x [B, Ci, H, W] (any layout), w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd.  transposed: w is
-    [Ci, Co, k, k] and the backward-data convolution of w runs instead (x has w's OUTPUT channel count)."""
+    [Ci, Co, k, k] and the backward-data convolution of w runs instead (x has w's OUTPUT channel count).  add [B, Co, H, W] of x's
+    type: added to the output in the kernel's epilogue (h3d_conv_x3_add: a residual connection without a pass of its own)."""
     x, ldx = _rows(x)
     B, ci, H, W = x.shape
     k = w.shape[2]
@@ -134,6 +135,15 @@ def _run_conv(x, w, bias=None, transposed=False, owner=None):
     out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
     lib = _lib.load()
+    if add is not None:
+        if add.dtype != x.dtype or tuple(add.shape) != (B, co, H, W):
+            raise ValueError(f"addend {tuple(add.shape)} {add.dtype} does not match the output {(B, co, H, W)} {x.dtype}")
+        add, lda = _rows(add)
+        mode = 0 if not half else (2 if AMP_WEIGHT_PLANES == 1 else 1)
+        rc = lib.h3d_conv_x3_add(mode, _lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(add), _lib.ptr(out), B, H, W, ci, co, k, ldx,
+                                 co, lda, _lib.stream_handle())
+        _lib.check(rc, "h3d_conv_x3_add")
+        return out
     entry = lib.h3d_conv_x3 if not half else (lib.h3d_conv_x3_f16x1 if AMP_WEIGHT_PLANES == 1 else lib.h3d_conv_x3_f16)   # f16 in -> f16 out (AMP)
     rc = entry(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
                                  _lib.stream_handle())

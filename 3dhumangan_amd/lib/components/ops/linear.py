@@ -18,6 +18,7 @@ from .... import _lib
 MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this the library GEMM is as good
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
+FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # residual addend in the GEMM epilogue (round 6; A/B switch)
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
 
 
@@ -48,12 +49,13 @@ def _as_image(t2):
     return torch.as_strided(t2, (1, C, 1, M), (M * ld, 1, M * ld, ld))
 
 
-def gemm_x3(x2, w, bias=None, transposed=False):
-    """x2 [M, Ci] @ w[Co, Ci]^T (+ bias) -> [M, Co]; transposed: x2 [M, Co] @ w[Co, Ci] -> [M, Ci].  Split-bf16 matrix-core kernel."""
+def gemm_x3(x2, w, bias=None, transposed=False, add=None):
+    """x2 [M, Ci] @ w[Co, Ci]^T (+ bias) (+ add [M, Co]) -> [M, Co]; transposed: x2 [M, Co] @ w[Co, Ci] -> [M, Ci].  Split-bf16
+    matrix-core kernel; the addend (a residual connection) joins in the epilogue."""
     from . import conv
     # owner=w: the packed weight stream is cached on the caller's (long-lived) weight, not on this per-call view of it
     y = conv._run_conv(_as_image(x2), w.detach()[:, :, None, None], bias, transposed=transposed,
-                       owner=w if w.dtype == torch.float32 else None)
+                       owner=w if w.dtype == torch.float32 else None, add=None if add is None else _as_image(add))
     return y.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
 
 
@@ -120,12 +122,14 @@ def _rows(t):
 
 class _LinearX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, add=None):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         if _native_ok(*w.shape):
-            return gemm_x3(_rows(x), w, b).view(*x.shape[:-1], w.shape[0])
-        return F.linear(x, w, b)
+            a2 = None if add is None else _rows(add.detach())
+            return gemm_x3(_rows(x), w, b, add=a2).view(*x.shape[:-1], w.shape[0])
+        y = F.linear(x, w, b)
+        return y if add is None else y + add
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -153,7 +157,7 @@ class _LinearX3(torch.autograd.Function):
                 dw = wgrad_x3(dy2, _rows(x))
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)          # the addend's gradient is the output's
 
 
 class _LinearAmp(torch.autograd.Function):
@@ -205,10 +209,19 @@ class _LinearAmp(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x, w, b=None):
-    """F.linear(x, w, b); the weight gradient goes to the HIP kernel when the problem is one it is built for."""
+def linear(x, w, b=None, add=None):
+    """F.linear(x, w, b) (+ add: a residual connection, fused into the native GEMM's epilogue where that runs); the weight gradient
+    goes to the HIP kernel when the problem is one it is built for."""
     Co, Ci = w.shape
     rows = x.numel() // max(Ci, 1)
+    if add is not None:
+        fp32 = (FUSED_ADD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and add.dtype == torch.float32
+                and not torch.is_autocast_enabled() and rows >= MIN_ROWS and _native_ok(Co, Ci) and add.shape == x.shape[:-1] + (Co,))
+        if fp32 and ENABLED and torch.is_grad_enabled() and w.requires_grad and Co >= 32 and Ci >= 32:
+            return _LinearX3.apply(x, w, b, add)
+        if fp32 and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or add.requires_grad)):
+            return gemm_x3(_rows(x), w, b, add=_rows(add)).view(*x.shape[:-1], Co)
+        return linear(x, w, b) + add
     if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
             and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.float32 and rows >= MIN_ROWS
             and ((Co % 8 == 0 and Ci % 8 == 0 and Co >= 32 and Ci >= 32) or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):
@@ -217,7 +230,7 @@ def linear(x, w, b=None):
             and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS
             and ((Co % 4 == 0 and Ci % 4 == 0 and Co >= 32 and Ci >= 32)           # h3d_wgrad_x3
                  or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):             # h3d_wgrad_narrow (heads, ToRGB, coordinates)
-        return _LinearX3.apply(x, w, b)
+        return _LinearX3.apply(x, w, b, None)
     if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled() and rows >= MIN_ROWS
             and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and _native_ok(Co, Ci)):
         return gemm_x3(_rows(x), w, b).view(*x.shape[:-1], Co)          # nothing to record (the D step's generator forward)

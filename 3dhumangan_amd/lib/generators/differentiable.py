@@ -134,7 +134,8 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         else:
             off_all = torch.cat([linear(fixed, m.weight.flatten(1), m.bias) for m in shared], dim=-1)      # [B, 1, 128 * len(pix)]
             low = linear(fmap_low, w_all) + off_all
-        up = _resize_channels_last(low, render_hw, gen_hw)                                      # [B, P, 128 * len(pix)]
+        # ... and so is the ReLU: one pass over the whole map instead of one per (strided) piece
+        up = torch.relu(_resize_channels_last(low, render_hw, gen_hw))                          # [B, P, 128 * len(pix)]
         # split, not slices: the backward of a split is ONE concatenation of the pieces' gradients; slices would each
         # zero-fill a full-width gradient and add them up (6 x 1.6 GB at config 4)
         shared_up = dict(zip(pix, torch.split(up, 128, dim=-1)))
@@ -143,7 +144,7 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         sp = getattr(sn.network[blk_name], spade_name)
         ws, bs = sp.mlp_shared[0].weight.flatten(1), sp.mlp_shared[0].bias
         if per_pixel(idx):
-            a = torch.relu(shared_up[(blk_name, spade_name)])                  # the offset travelled through the resize
+            a = shared_up[(blk_name, spade_name)]                              # offset and ReLU happened in front of the split
         else:
             a = torch.relu(linear(fixed, ws, bs))                              # [B,1,128]
         gamma = linear(a, sp.mlp_gamma.weight.flatten(1), sp.mlp_gamma.bias)
@@ -157,8 +158,8 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels)
         h = linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
         h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels)
-        h = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias)
-        x = h + x_in if idx >= nb // 2 else h
+        # skip blocks: the residual connection joins in the GEMM's epilogue (h3d_conv_x3_add) instead of a pass of its own
+        x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in if idx >= nb // 2 else None)
         if idx >= nb // 2 - 1:
             lin = sn.to_rgbs[name].linear
             o = linear(x, lin.weight.flatten(1), lin.bias)

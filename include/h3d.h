@@ -239,6 +239,11 @@ int h3d_conv_x3_f16(const void* x, const void* stream, const float* bias, void* 
 int h3d_conv_x3_pack_f16x1(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_handle);
 int h3d_conv_x3_f16x1(const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_handle);
+/* h3d_conv_x3 / _f16 / _f16x1 (mode 0 / 1 / 2) with a residual connection in the epilogue (round 6):  out = conv(x) + bias + add;
+ * `add` [B, H, W, Cout] of the output's element type with row stride lda, added in fp32 before the store -- the skip block's
+ * `x = h + x_in` (/root/reference/lib/components/map3d_layers.py:236) without a pass of its own. */
+int h3d_conv_x3_add(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, int B, int H, int W,
+                    int Cin, int Cout, int k, int ldx, int ldo, int lda, h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int ldy,
                           int ldx, int slices, h3d_stream_t stream);
 /* ... with the convolution's bias gradient riding along (round 4): colsum [slices][Co] fp32 = column sums of dY over each slice's

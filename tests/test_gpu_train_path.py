@@ -230,6 +230,45 @@ def test_linear_with_hip_weight_gradient_matches_autograd():
         assert rel_err(a, e) < tol, name
 
 
+@pytest.mark.parametrize("Co,Ci", [(256, 256), (128, 64), (96, 64)])
+def test_linear_with_a_residual_addend(Co, Ci):
+    """linear(x, w, b, add=r) = F.linear(x, w, b) + r with the addend joined in the GEMM's epilogue (h3d_conv_x3_add) where the
+    native GEMM runs (multiples of 64), recorded and unrecorded; the addend's gradient is the output's."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(Co + Ci)
+    x = torch.randn(3, 7000, Ci, generator=g)
+    w, b, r = torch.randn(Co, Ci, generator=g) * 0.1, torch.randn(Co, generator=g), torch.randn(3, 7000, Co, generator=g)
+    p = torch.randn(3, 7000, Co, generator=g)
+    outs = []
+    for dt, dev in ((torch.float64, "cpu"), (torch.float32, DEV)):
+        xx, ww, bb, rr = (t.to(dev, dt).requires_grad_(True) for t in (x, w, b, r))
+        y = torch.nn.functional.linear(xx, ww, bb) + rr if dev == "cpu" else lin.linear(xx, ww, bb, add=rr)
+        (y * p.to(dev, dt)).sum().backward()
+        outs.append((y.detach().cpu(), xx.grad.cpu(), ww.grad.cpu(), bb.grad.cpu(), rr.grad.cpu()))
+    for a, e, name, tol in zip(outs[1], outs[0], ("y", "dx", "dw", "db", "dr"), (2e-5, 2e-5, 1e-4, 1e-5, 1e-7)):
+        assert rel_err(a, e) < tol, name
+    with torch.no_grad():
+        y = lin.linear(x.to(DEV), w.to(DEV), b.to(DEV), add=r.to(DEV))
+    assert rel_err(y.cpu(), outs[0][0]) < 2e-5
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_conv_epilogue_addend_in_half_precision(planes, monkeypatch):
+    """h3d_conv_x3_add on f16 activations: the addend joins in fp32 before the one rounding of the output."""
+    conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+    monkeypatch.setattr(conv, "AMP_WEIGHT_PLANES", planes)
+    g = torch.Generator().manual_seed(planes)
+    x = torch.randn(2, 64, 24, 16, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    w, b = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(DEV), torch.randn(128, generator=g).to(DEV)
+    r = torch.randn(2, 128, 24, 16, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    got = conv._run_conv(x, w, b, add=r)
+    wq = w.half().double() if planes == 1 else w.double()
+    want = torch.nn.functional.conv2d(x.double(), wq, b.double(), padding=1) + r.double()
+    assert got.dtype == torch.float16 and rel_err(got.double(), want) < 1e-3
+    plain = conv._run_conv(x, w, b)
+    assert rel_err(got.float(), plain.float() + r.float()) < 1e-3
+
+
 # ------------------------------------------------------------------ SPADE kernels
 
 @pytest.mark.parametrize("B,P,C", [(2, 1300, 32), (3, 513, 40), (2, 700, 30), (2, 2100, 256), (1, 600, 420), (2, 64, 1028)])
