@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void spade_bwd_apply(const TA* __restrict
                                                             const float* __restrict__ c1, const float* __restrict__ c2,
                                                             TA* __restrict__ dx, TA* __restrict__ dgamma,
                                                             TA* __restrict__ dbeta, float* __restrict__ partial, int64_t P,
-                                                            int C, float slope) {
+                                                            int C, float slope, const TA* __restrict__ add1, const TA* __restrict__ add2) {
     __shared__ float red[2][kThreads][V];
     Tile T;
     T.init<V>(P, C);
@@ -242,6 +242,20 @@ __global__ __launch_bounds__(kThreads) void spade_bwd_apply(const TA* __restrict
                     o_b[k] = du;
                     sg[k] += o_g[k];
                     sb[k] += du;
+                }
+                // gradients that reach x along other edges of the graph (a residual connection, a ToRGB head) join here instead of
+                // in accumulation passes of their own (h3d_spade_bwd_apply_acc)
+                if (add1) {
+                    float a[V];
+                    ld<V>(add1 + off, a);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v[k] += a[k];
+                }
+                if (add2) {
+                    float a[V];
+                    ld<V>(add2 + off, a);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v[k] += a[k];
                 }
                 st<V>(dx + off, v);
                 if (PIX) { st<V>(dgamma + off, o_g); st<V>(dbeta + off, o_b); }
@@ -324,7 +338,7 @@ template <typename T>
 static int spade_bwd_apply_any(const T* x, const float* mean, const float* rstd, const float* g, const float* b,
                                const void* gamma, const void* beta, const T* dy, const float* c1, const float* c2,
                                T* dx, T* dgamma, T* dbeta, float* partial, int B, int64_t P, int C,
-                               int per_pixel, float slope, h3d_stream_t stream) {
+                               int per_pixel, float slope, h3d_stream_t stream, const T* add1 = nullptr, const T* add2 = nullptr) {
     if (int rc = check_shape("h3d_spade_bwd_apply", B, P, C)) return rc;
     if (B == 0 || P == 0) return H3D_OK;
     H3D_REQUIRE(x && mean && rstd && g && b && gamma && beta && dy && c1 && c2 && dx, "h3d_spade_bwd_apply: null pointer");
@@ -332,10 +346,10 @@ static int spade_bwd_apply_any(const T* x, const float* mean, const float* rstd,
                 "h3d_spade_bwd_apply: %s", per_pixel ? "per-pixel mode needs dgamma and dbeta" : "per-sample mode needs partial");
     const dim3 grid((unsigned)((P + kRows - 1) / kRows), (unsigned)B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta});
+    const bool v4 = vec_ok(C, {x, mean, rstd, g, b, gamma, beta, dy, c1, c2, dx, dgamma, dbeta, add1, add2});
     h3d::pre_launch();
 #define H3D_GO(V, PIX) hipLaunchKernelGGL((spade_bwd_apply<V, PIX, T>), grid, dim3(kThreads), 0, s, x, mean, rstd, g, b, \
-        static_cast<const typename Mod<PIX, T>::type*>(gamma), static_cast<const typename Mod<PIX, T>::type*>(beta), dy, c1, c2, dx, dgamma, dbeta, partial, P, C, slope)
+        static_cast<const typename Mod<PIX, T>::type*>(gamma), static_cast<const typename Mod<PIX, T>::type*>(beta), dy, c1, c2, dx, dgamma, dbeta, partial, P, C, slope, add1, add2)
     if (v4) { if (per_pixel) H3D_GO(4, true); else H3D_GO(4, false); }
     else { if (per_pixel) H3D_GO(1, true); else H3D_GO(1, false); }
 #undef H3D_GO
@@ -383,4 +397,22 @@ extern "C" int h3d_spade_bwd_apply_f16(const void* x, const float* mean, const f
     return spade_bwd_apply_any<_Float16>(static_cast<const _Float16*>(x), mean, rstd, g, b, gamma, beta, static_cast<const _Float16*>(dy), c1, c2,
                                          static_cast<_Float16*>(dx), static_cast<_Float16*>(dgamma), static_cast<_Float16*>(dbeta), partial, B, P, C,
                                          per_pixel, slope, stream);
+}
+
+/* h3d_spade_bwd_apply[_f16] (dtype 0 / 1) whose dx also receives up to two more gradients of x (same type and shape as x, or NULL):
+ * dx = (the SPADE term) + add1 + add2.  x of a skip block feeds the SPADE, the residual connection and the previous block's ToRGB
+ * head (/root/reference/lib/components/map3d_layers.py:228-236, 268-272); autograd would add the three gradients in two passes of
+ * its own (round 6). */
+extern "C" int h3d_spade_bwd_apply_acc(int dtype, const void* x, const float* mean, const float* rstd, const float* g, const float* b,
+                                       const void* gamma, const void* beta, const void* dy, const float* c1, const float* c2,
+                                       const void* add1, const void* add2, void* dx, void* dgamma, void* dbeta, float* partial, int B,
+                                       int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream) {
+    H3D_REQUIRE(dtype == 0 || dtype == 1, "h3d_spade_bwd_apply_acc: dtype %d (0 = f32, 1 = f16)", dtype);
+    if (dtype == 0)
+        return spade_bwd_apply_any<float>(static_cast<const float*>(x), mean, rstd, g, b, gamma, beta, static_cast<const float*>(dy), c1, c2,
+                                          static_cast<float*>(dx), static_cast<float*>(dgamma), static_cast<float*>(dbeta), partial, B, P, C,
+                                          per_pixel, slope, stream, static_cast<const float*>(add1), static_cast<const float*>(add2));
+    return spade_bwd_apply_any<_Float16>(static_cast<const _Float16*>(x), mean, rstd, g, b, gamma, beta, static_cast<const _Float16*>(dy), c1, c2,
+                                         static_cast<_Float16*>(dx), static_cast<_Float16*>(dgamma), static_cast<_Float16*>(dbeta), partial, B,
+                                         P, C, per_pixel, slope, stream, static_cast<const _Float16*>(add1), static_cast<const _Float16*>(add2));
 }

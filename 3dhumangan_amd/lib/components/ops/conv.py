@@ -279,11 +279,12 @@ def _pad_channels(x, cop):
         out = torch.cat([x, x.new_zeros((B, cop - C, H, W)).contiguous(memory_format=torch.channels_last)], dim=1)
         return out.contiguous(memory_format=torch.channels_last)
     sb, sc, sh, sw = x.stride()
-    if H > 1 and sh != W * sw:             # rows that do not follow each other: not a pixel-strided layout
+    if H > 1 and W > 1 and sh != W * sw:   # rows that do not follow each other: not a pixel-strided layout
         x = x.contiguous(memory_format=torch.channels_last)
         sb, sc, sh, sw = x.stride()
+    sp = sh if W == 1 else sw              # a dimension of size one carries an arbitrary stride
     out = torch.empty((B, cop, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
-    rc = _lib.load().h3d_pad_channels_cl(_lib.ptr(x), _lib.ptr(out), B, C, cop, H * W, sb, sc, sw, int(x.dtype == torch.float16),
+    rc = _lib.load().h3d_pad_channels_cl(_lib.ptr(x), _lib.ptr(out), B, C, cop, H * W, sb, sc, sp, int(x.dtype == torch.float16),
                                          _lib.stream_handle())
     _lib.check(rc, "h3d_pad_channels_cl")
     return out

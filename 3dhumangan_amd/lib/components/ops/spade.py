@@ -57,18 +57,26 @@ class HipKernels:
                    "h3d_spade_bwd_reduce")
         return partial.double().sum(dim=(0, 1))
 
-    def backward_apply(self, x, mean, rstd, g, b, gamma, beta, dy, c1, c2):
-        """-> dx, dgamma, dbeta (shaped like gamma / beta)."""
+    def backward_apply(self, x, mean, rstd, g, b, gamma, beta, dy, c1, c2, add1=None, add2=None):
+        """-> dx, dgamma, dbeta (shaped like gamma / beta).  add1 / add2 (x's shape and type): further gradients of x, added into dx
+        by the same pass (h3d_spade_bwd_apply_acc)."""
         B, P, C = x.shape
         pix = gamma.dim() == 3
         dx = torch.empty_like(x)
         dgamma = torch.empty_like(x) if pix else None
         dbeta = torch.empty_like(x) if pix else None
         partial = None if pix else torch.empty((B, self._nblk(P), 2, C), device=x.device, dtype=torch.float32)
-        _lib.check(self._fn("h3d_spade_bwd_apply", x)(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
-                                                   _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(c1), _lib.ptr(c2),
-                                                   _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(partial), B, P, C,
-                                                   int(pix), SLOPE, _lib.stream_handle()), "h3d_spade_bwd_apply")
+        if add1 is not None or add2 is not None:
+            rc = _lib.load().h3d_spade_bwd_apply_acc(int(x.dtype == torch.float16), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g),
+                                                     _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(c1), _lib.ptr(c2),
+                                                     _lib.ptr(add1), _lib.ptr(add2), _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                     _lib.ptr(partial), B, P, C, int(pix), SLOPE, _lib.stream_handle())
+            _lib.check(rc, "h3d_spade_bwd_apply_acc")
+        else:
+            _lib.check(self._fn("h3d_spade_bwd_apply", x)(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(g), _lib.ptr(b),
+                                                       _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(c1), _lib.ptr(c2),
+                                                       _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(partial), B, P, C,
+                                                       int(pix), SLOPE, _lib.stream_handle()), "h3d_spade_bwd_apply")
         if not pix:
             sums = partial.sum(dim=1)
             dgamma, dbeta = sums[:, 0], sums[:, 1]
@@ -85,17 +93,21 @@ def _sync_on(group):
 
 class _SpadeNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, b, gamma, beta, mean, rstd, count, group, kernels):
+    def forward(ctx, x, g, b, gamma, beta, mean, rstd, count, group, kernels, aliases=0):
         # count: global number of rows behind mean / rstd when they are batch statistics (device scalar), None for running ones
+        # aliases (round 6): the node also hands out that many views of x.  What reads x through them (the residual connection, a
+        # ToRGB head) sends its gradient HERE, where the backward pass adds it into dx as it writes it -- instead of autograd
+        # summing the gradients of x's consumers in passes of its own.
         scale = (rstd * g).contiguous()
         shift = (b - mean * scale).contiguous()
         ctx.save_for_backward(x, g, b, gamma, beta, mean, rstd, count)
         ctx.group, ctx.kernels = group, kernels
-        return kernels.forward(x, scale, shift, gamma, beta)
+        y = kernels.forward(x, scale, shift, gamma, beta)
+        return y if not aliases else (y,) + tuple(x.view_as(x) for _ in range(aliases))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *d_alias):
         x, g, b, gamma, beta, mean, rstd, count = ctx.saved_tensors
         k = ctx.kernels
         dy = dy.contiguous().to(x.dtype)
@@ -109,15 +121,22 @@ class _SpadeNormAct(torch.autograd.Function):
             c1, c2 = c[0].contiguous(), c[1].contiguous()
         else:
             c1 = c2 = torch.zeros_like(mean)
-        dx, dgamma, dbeta = k.backward_apply(x, mean, rstd, g, b, gamma, beta, dy, c1, c2)
+        extra = [d.contiguous().to(x.dtype) for d in d_alias if d is not None]
+        if extra and isinstance(k, HipKernels) and len(extra) <= 2:
+            dx, dgamma, dbeta = k.backward_apply(x, mean, rstd, g, b, gamma, beta, dy, c1, c2, *extra)
+        else:
+            dx, dgamma, dbeta = k.backward_apply(x, mean, rstd, g, b, gamma, beta, dy, c1, c2)
+            for d in extra:
+                dx = dx + d
         if gamma.dim() == 2:
             dgamma, dbeta = dgamma.contiguous(), dbeta.contiguous()
-        return dx, d_g, d_b, dgamma, dbeta, None, None, None, None, None
+        return dx, d_g, d_b, dgamma, dbeta, None, None, None, None, None, None
 
 
-def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1, kernels=None):
+def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1, kernels=None, aliases=0):
     """x [B,P,C]; norm: the first_norm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked);
-    gamma / beta [B,P,C] or [B,1,C].  training: batch statistics (all-reduced over `group`) + running-statistics update."""
+    gamma / beta [B,P,C] or [B,1,C].  training: batch statistics (all-reduced over `group`) + running-statistics update.
+    aliases > 0: -> (y, x_1, .., x_aliases), views of x whose gradients are added into dx by the backward kernel itself."""
     k = _HIP if kernels is None else kernels
     if k is _HIP:
         _lib.need_cuda(x, gamma, beta)
@@ -150,4 +169,4 @@ def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentu
         mean, var = norm.running_mean.float(), norm.running_var.float()
     rstd = torch.rsqrt(var + eps)
     return _SpadeNormAct.apply(x, norm.weight.float(), norm.bias.float(), gamma, beta, mean.contiguous(), rstd.contiguous(),
-                               count, group, k)
+                               count, group, k, int(aliases))

@@ -19,6 +19,8 @@ one is initialised -- the reference uses nn.SyncBatchNorm, lib/components/map3d_
 updates, and one spectral-norm power iteration per conv and call (torch.nn.utils.spectral_norm as used at
 lib/components/map3d_layers.py:205-206).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -26,6 +28,8 @@ from ..components.ops.film import film_sin
 from ..components.ops.linear import linear
 from ..components.ops.spade import spade_norm_act
 from ..components.resample import bilinear_resize_cl
+
+ALIAS_GRADS = os.environ.get("H3D_SPADE_ALIAS", "1") != "0"      # gradients of a skip block's input summed inside the SPADE backward kernel (round 6)
 
 
 # ------------------------------------------------------------------------------------------------ A5: the implicit function
@@ -152,16 +156,30 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         return sp.first_norm, gamma, beta
 
     rgb = None
+    pending = None      # ToRGB head of the previous block's output, evaluated on a view the next block's first SPADE hands out
     for idx, name in enumerate(names):
         blk = sn.network[name]
-        x_in = x
-        h = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels)
+        skip = idx >= nb // 2
+        # A skip block's input feeds its first SPADE, its residual connection and the previous block's ToRGB head.  When autograd
+        # records, the last two read x through views handed out by the SPADE node, whose backward kernel adds their gradients into
+        # dx as it writes it (h3d_spade_bwd_apply_acc) -- two accumulation passes over [B, P, C] less per block (round 6).
+        n_alias = (int(skip) + int(pending is not None)) if (ALIAS_GRADS and torch.is_grad_enabled() and x.requires_grad) else 0
+        out = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels, aliases=n_alias)
+        h, views = (out[0], list(out[1:])) if n_alias else (out, [])
+        x_in = (views.pop(0) if views else x) if skip else None
+        if pending is not None:
+            o = linear(views.pop(0) if views else x, pending.weight.flatten(1), pending.bias)
+            rgb = o if rgb is None else o + rgb
+            pending = None
         h = linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
         h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels)
         # skip blocks: the residual connection joins in the GEMM's epilogue (h3d_conv_x3_add) instead of a pass of its own
-        x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in if idx >= nb // 2 else None)
+        x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in)
         if idx >= nb // 2 - 1:
             lin = sn.to_rgbs[name].linear
-            o = linear(x, lin.weight.flatten(1), lin.bias)
-            rgb = o if rgb is None else o + rgb
+            if idx + 1 < nb:
+                pending = lin
+            else:
+                o = linear(x, lin.weight.flatten(1), lin.bias)
+                rgb = o if rgb is None else o + rgb
     return rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)

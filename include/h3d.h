@@ -685,6 +685,14 @@ int h3d_spade_bwd_reduce_f16(const void* x, const float* mean, const float* rstd
 int h3d_spade_bwd_apply_f16(const void* x, const float* mean, const float* rstd, const float* g, const float* b, const void* gamma,
                             const void* beta, const void* dy, const float* c1, const float* c2, void* dx, void* dgamma, void* dbeta,
                             float* partial, int B, int64_t P, int C, int per_pixel, float slope, h3d_stream_t stream);
+/* h3d_spade_bwd_apply[_f16] (dtype 0 / 1) whose dx also receives up to two more gradients of x (add1, add2: x's type and shape, or
+ * NULL):  dx = (the SPADE term) + add1 + add2 -- x of a skip block feeds the SPADE, the residual connection and the previous
+ * block's ToRGB head (/root/reference/lib/components/map3d_layers.py:228-236, 268-272); autograd would add the three gradients in
+ * two passes of its own. */
+int h3d_spade_bwd_apply_acc(int dtype, const void* x, const float* mean, const float* rstd, const float* g, const float* b,
+                            const void* gamma, const void* beta, const void* dy, const float* c1, const float* c2, const void* add1,
+                            const void* add2, void* dx, void* dgamma, void* dbeta, float* partial, int B, int64_t P, int C,
+                            int per_pixel, float slope, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)

@@ -198,7 +198,7 @@ def test_the_slices_sum_kernel_equals_the_tensor_operations(taps, slices, co, ci
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("layout", ["nchw", "channels_last", "slice", "one_channel"])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last", "slice", "one_channel", "column", "row"])
 def test_channel_padding_kernel(layout, dtype):
     """h3d_pad_channels_cl: zero-padded channels in channels-last from any input layout, and the closed _PadChannels /
     _NarrowChannels pair through a double backward."""
@@ -210,9 +210,14 @@ def test_channel_padding_kernel(layout, dtype):
         x = torch.randn(B, 26, H, W, generator=g).contiguous(memory_format=torch.channels_last)
     elif layout == "slice":
         x = torch.randn(B, 64, H, W, generator=g).contiguous(memory_format=torch.channels_last)[:, :26]
+    elif layout == "column":            # [B, P, C] rows as a [B, C, P, 1] image: the size-one dimension's stride says nothing
+        x = torch.randn(B, 11, 32, generator=g).permute(0, 2, 1).unsqueeze(-1)
+    elif layout == "row":
+        x = torch.randn(B, 11, 32, generator=g).permute(0, 2, 1).unsqueeze(2)
     else:
         x = torch.randn(B, 1, H, W, generator=g)
     x = x.to(DEV).to(dtype)
+    H, W = x.shape[2:]
     out = conv._pad_channels(x, 64)
     assert out.shape == (B, 64, H, W) and out.is_contiguous(memory_format=torch.channels_last)
     C = x.shape[1]

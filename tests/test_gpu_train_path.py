@@ -298,6 +298,37 @@ def test_spade_kernels_vs_torch_stand_in(B, P, C, per_pixel):
     for a, e, name in zip(got, want, ("dx", "dgamma", "dbeta")):
         assert a.shape == e.shape, name
         assert rel_err(a.cpu(), e) < 2e-5, name
+    # further gradients of x joined into dx by the same pass (h3d_spade_bwd_apply_acc): one, and two
+    a1, a2 = torch.randn(B, P, C, generator=gen), torch.randn(B, P, C, generator=gen)
+    for extra in ((a1,), (a1, a2)):
+        acc = hip.backward_apply(*d(*args, c1, c2, *extra))
+        assert rel_err(acc[0].cpu(), want[0] + sum(e.double() for e in extra)) < 2e-5
+        for a, e in zip(acc[1:], got[1:]):
+            assert torch.equal(a, e)
+
+
+def test_spade_node_sums_the_gradients_of_its_aliases():
+    """spade_norm_act(.., aliases=2): what reads x through the views sends its gradient into the node's backward kernel; the result
+    is the gradient autograd computes when the consumers read x itself."""
+    spade = importlib.import_module("3dhumangan_amd.lib.components.ops.spade")
+    gen = torch.Generator().manual_seed(17)
+    B, P, C = 2, 900, 64
+    x0 = torch.randn(B, P, C, generator=gen).to(DEV)
+    gamma, beta = (torch.randn(B, 1, C, generator=gen) * 0.3).to(DEV), (torch.randn(B, 1, C, generator=gen) * 0.3).to(DEV)
+    w1, w2, w3 = (torch.randn(B, P, C, generator=gen).to(DEV) for _ in range(3))
+    norm = torch.nn.BatchNorm1d(C, affine=True).to(DEV)
+    grads = []
+    for aliases in (0, 2):
+        norm.running_mean.zero_(); norm.running_var.fill_(1.0)
+        x = x0.clone().requires_grad_(True)
+        xs = x * 1.0                                  # a non-leaf, as in the network
+        out = spade.spade_norm_act(xs, norm, gamma, beta, True, group=False, aliases=aliases)
+        y, v1, v2 = out if aliases else (out, xs, xs)
+        if aliases:
+            assert v1.data_ptr() == xs.data_ptr() and v2.data_ptr() == xs.data_ptr()
+        ((y * w1).sum() + (v1 * w2).sum() + (v2 * v2 * w3).sum()).backward()
+        grads.append(x.grad.clone())
+    assert rel_err(grads[1], grads[0]) < 1e-6
 
 
 # ------------------------------------------------------------------ the differentiable generator
