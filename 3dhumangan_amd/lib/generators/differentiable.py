@@ -52,7 +52,7 @@ def field_forward(nf, points, freq, phase, geo, dirs, input_scaler=1.0, geo_feat
     if dirs is None:                       # lock_view_dependence: the direction is the constant (0,0,-1) -> part of the bias
         c = linear(x, wc[:, 3:], bc - wc[:, 2])
     else:
-        c = linear(x, wc[:, 3:], bc) + linear(dirs, wc[:, :3])
+        c = linear(x, wc[:, 3:], bc, add=linear(dirs, wc[:, :3]))       # the view-direction term joins in the GEMM's epilogue
     c = film_sin(c, fr[:, -H:], phase[:, -H:])
     rgb = torch.sigmoid(linear(c, nf.color_layer_linear.weight, nf.color_layer_linear.bias))
     feat = linear(c, nf.feature_layer_linear.weight, nf.feature_layer_linear.bias)
