@@ -9,6 +9,7 @@ BatchNorm moment all-reduces inside the forward / backward (2C floats per layer)
 gradients (parallel.allreduce_gradients), the exchange DDP does implicitly in the reference.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -51,9 +52,17 @@ def topk_count(meta, d_step_count, batch):
     return math.ceil(share * batch)
 
 
+# The reference leaves the discriminator's parameters trainable during the generator step (phase_trainer.py:326-337): autograd then
+# computes every weight gradient of D for a loss that only optimizer_G steps on, and the next discriminator step zeroes them unread
+# (:302).  Nothing observable depends on them, so by default they are not computed here (the parameters are frozen for the duration
+# of the step: ~1/4 of D's weight-gradient work per iteration); H3D_G_STEP_D_GRADS=1 / d_param_grads=True computes them as the
+# reference does.
+G_STEP_D_GRADS = os.environ.get("H3D_G_STEP_D_GRADS", "0") == "1"
+
+
 def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=None, distributed=False, d_step_count=0,
                    gen_modal="rgbs", latent_indices=None, generator_kwargs=None, amp_dtype=None, scaler=None,
-                   update_scaler=True):
+                   update_scaler=True, d_param_grads=None):
     """-> dict of detached scalars.  meta: the config dict (gan_lambda, segmentation_lambda, label_dim, grad_clip and every
     forward key of the generator).  ``gt_segments`` [B,H,W] int64 (the rasterised body-part labels of the conditions) feeds
     the segmentation term; the unconditional phase of the reference (latent_lambda = perceptual = photometric = 0 in every
@@ -67,6 +76,19 @@ def generator_step(G, D, optimizer, z, conditions, meta, gt_segments=None, ema=N
     fwd = {k: v for k, v in meta.items() if isinstance(k, str)}
     fwd.update(generator_kwargs or {})
     fwd.update(latent_indices=latent_indices, disable_synthesis=(gen_modal != "rgbs"))
+    frozen = [] if (G_STEP_D_GRADS if d_param_grads is None else d_param_grads) else [p for p in D.parameters() if p.requires_grad]
+    for p in frozen:
+        p.requires_grad_(False)
+    try:
+        return _generator_step(G, D, optimizer, z, conditions, meta, gt_segments, ema, distributed, d_step_count, gen_modal, fwd,
+                               gan_lambda, seg_lambda, amp_dtype, scaler, update_scaler)
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+
+
+def _generator_step(G, D, optimizer, z, conditions, meta, gt_segments, ema, distributed, d_step_count, gen_modal, fwd, gan_lambda,
+                    seg_lambda, amp_dtype, scaler, update_scaler):
     with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
         out = G(z, conditions, **fwd)
         d_out = D(out[gen_modal], conditions, 1.0)

@@ -224,6 +224,7 @@ def train_step_bench(a, rank, world, dist_on, dev, emit=True):
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: {a.config} 512x256, 96x48 rays x 32, batch {a.batch}/GPU; UNetDiscriminator "
                                    "6 blocks; R1 every step; GAN + segmentation losses; Adam on both networks; EMA",
+                       "g_step_discriminator_weight_gradients": trainers.g_step.G_STEP_D_GRADS,      # the reference computes them and zeroes them unread
                        "global_batch": a.batch * world,
                        "parallelism": f"batch-sharded x{world}: SyncBN moment all-reduces, RCCL all-gather of the R1 statistics, "
                                       "bucketed gradient all-reduce"},

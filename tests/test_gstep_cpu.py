@@ -66,6 +66,28 @@ def test_generator_step_loss_and_gradients_match_train_generator():
             assert p.grad is None or float(p.grad.abs().max()) == 0, n
 
 
+def test_discriminator_weight_gradients_are_skipped_unless_asked_for():
+    """The reference computes D's weight gradients in the generator step and zeroes them unread (phase_trainer.py:302, 326-337); the
+    default here does not compute them: same loss, same generator gradients, D's parameters trainable again afterwards."""
+    info, g = _info(), load_golden("gstep_tiny")
+    runs = {}
+    for with_d in (False, True):
+        G = _StubG()
+        G.load_state_dict(g["stub"])
+        D = disc.UNetDiscriminator(**info["disc_kwargs"]).eval()
+        D.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in g["disc"].items()})
+        res = trainers.generator_step(G, D, torch.optim.SGD(G.parameters(), lr=0.0), g["z"], {}, dict(info["meta"]),
+                                      gt_segments=g["data"]["rasterized_segments"], d_step_count=info["d_step"], d_param_grads=with_d)
+        assert all(p.requires_grad for p in D.parameters())
+        got = [p.grad is not None for p in D.parameters()]
+        assert any(got) if with_d else not any(got)
+        runs[with_d] = (float(res["loss"]), {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None})
+    assert runs[False][0] == runs[True][0]
+    assert runs[False][1].keys() == runs[True][1].keys()
+    for n, v in runs[False][1].items():
+        assert torch.equal(v, runs[True][1][n]), n
+
+
 def test_topk_schedule():
     meta = dict(topk_interval=2000, topk_v=0.6)
     assert trainers.g_step.topk_count({}, 123, 8) == 8                       # no schedule in the config: the whole batch
