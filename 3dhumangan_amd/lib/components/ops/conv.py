@@ -189,6 +189,27 @@ def reduce_slices(partial, colsum, taps, slices, co, ci, shape):
     return dw if colsum is None else (dw, db)
 
 
+# torch.autograd.grad(.., inputs=[x]) prunes NODES that do not lead to x, but inside a custom Function ctx.needs_input_grad is what the
+# forward call saw: _Conv.backward would compute its weight and bias gradients in the R1 penalty's first-order pass
+# (losses.r1_gradient: d prediction / d image, phase_trainer.py:259-283), where the engine drops them unread -- one full set of the
+# discriminator's weight gradients per iteration.  A library convolution gets this pruning from the engine's output mask; here the
+# caller says so.  Module-global on purpose: the backward pass runs on the autograd engine's device thread, inside the blocking call.
+_INPUT_GRADS_ONLY = False
+
+
+class input_grads_only:
+    """with input_grads_only(): torch.autograd.grad(y, [x], ..) -- the native convolutions return no weight / bias gradients."""
+
+    def __enter__(self):
+        global _INPUT_GRADS_ONLY
+        self.keep, _INPUT_GRADS_ONLY = _INPUT_GRADS_ONLY, True
+
+    def __exit__(self, *exc):
+        global _INPUT_GRADS_ONLY
+        _INPUT_GRADS_ONLY = self.keep
+        return False
+
+
 def _transposed(w):
     return w.flip(2, 3).transpose(0, 1).contiguous()
 
@@ -208,6 +229,8 @@ class _Conv(torch.autograd.Function):
         gx = _ConvT.apply(g, w) if ctx.needs_input_grad[0] else None
         want_b = len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
         gw = gb = None
+        if _INPUT_GRADS_ONLY:
+            return gx, None, None
         if ctx.needs_input_grad[1] and want_b:
             gw, gb = _ConvWB.apply(x, g, w.shape[2])          # the bias gradient rides along the weight-gradient pass over g
         elif ctx.needs_input_grad[1]:
@@ -230,7 +253,7 @@ class _ConvT(torch.autograd.Function):
         g, w = ctx.saved_tensors
         h = h.to(g.dtype)
         gg = _Conv.apply(h, w) if ctx.needs_input_grad[0] else None
-        gw = _ConvW.apply(h, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        gw = _ConvW.apply(h, g, w.shape[2]) if (ctx.needs_input_grad[1] and not _INPUT_GRADS_ONLY) else None
         return gg, gw
 
 

@@ -8,8 +8,15 @@ the following `view(size(0), -1).pow(2).sum(1).mean()` then averages the squared
 mode="per_sample" is the textbook ||grad_x D||^2 per sample (opt-in: about C times stronger at the same r1_lambda).  In
 the multi-GPU step either statistic is all-gathered across the ranks (parallel.r1_allgather).
 """
+import contextlib
+import os
+
 import torch
 import torch.nn.functional as F
+
+from ..components.ops import conv as conv_ops
+
+R1_INPUT_GRADS_ONLY = os.environ.get("H3D_R1_INPUT_GRADS_ONLY", "1") != "0"      # A/B switch (round 6)
 
 
 def logistic_d_loss(pred_real, pred_gen, gan_lambda=1.0):
@@ -25,9 +32,12 @@ def r1_gradient(d_input_real, d_output_real, gan_lambda=1.0, scale=None):
         target = d_output_real["prediction"].sum()
     else:
         target = torch.softmax(d_output_real["segments"], dim=1).sum()
-    if scale is None or (not torch.is_tensor(scale) and scale == 1.0):
-        return torch.autograd.grad(outputs=target, inputs=d_input_real, create_graph=True)[0]
-    grad = torch.autograd.grad(outputs=target * scale, inputs=d_input_real, create_graph=True)[0]
+    # only the image's gradient is asked for: the native convolutions skip their weight / bias gradients in this pass (the engine
+    # would drop them unread; ops/conv.py: input_grads_only)
+    with conv_ops.input_grads_only() if R1_INPUT_GRADS_ONLY else contextlib.nullcontext():
+        if scale is None or (not torch.is_tensor(scale) and scale == 1.0):
+            return torch.autograd.grad(outputs=target, inputs=d_input_real, create_graph=True)[0]
+        grad = torch.autograd.grad(outputs=target * scale, inputs=d_input_real, create_graph=True)[0]
     return grad * (1.0 / scale)                     # `scale` may be a device scalar: no host round trip
 
 
