@@ -295,6 +295,7 @@ class _ConvWB(torch.autograd.Function):
 
 def _pad_channels(x, cop):
     """x [B, C, H, W] (any layout, fp32 / f16) -> [B, cop, H, W] channels-last with channels C .. cop zero; no autograd (h3d_pad_channels_cl)."""
+    _lib.need_cuda(x)
     x = x.detach()
     B, C, H, W = x.shape
     if not FUSED_PAD:                      # H3D_CONV_PAD=torch: the round-5 tensor operations (A/B switch)
