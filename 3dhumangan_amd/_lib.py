@@ -136,6 +136,9 @@ _SIGNATURES = {
     "h3d_spade_bwd_reduce_f16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_spade_bwd_apply_f16": (C.c_int, [_p] * 14 + [_i, _l, _i, _i, _f, _p]),
     "h3d_spade_bwd_apply_acc": (C.c_int, [_i] + [_p] * 16 + [_i, _l, _i, _i, _f, _p]),
+    "h3d_rows_sum_f64": (C.c_int, [_p, _p, _l, _i, _p]),
+    "h3d_bn_finish": (C.c_int, [_p] * 7 + [_i, _f, _f, _p]),
+    "h3d_bn_bwd_finish": (C.c_int, [_p] * 7 + [_i, _p]),
     "h3d_bias_act": (C.c_int, [_p, _p, _p, _l, _i, _l, _l, _i, _f, _f, _f, _p]),
     "h3d_bias_act_grad": (C.c_int, [_p, _p, _p, _p, _p, _p, _l, _i, _l, _l, _i, _i, _f, _f, _f, _p]),
     "h3d_upfirdn2d": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_l), _i, _i, _i, _i, C.POINTER(_l),

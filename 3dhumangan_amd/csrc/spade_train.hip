@@ -416,3 +416,96 @@ extern "C" int h3d_spade_bwd_apply_acc(int dtype, const void* x, const float* me
                                          static_cast<_Float16*>(dx), static_cast<_Float16*>(dgamma), static_cast<_Float16*>(dbeta), partial, B,
                                          P, C, per_pixel, slope, stream, static_cast<const _Float16*>(add1), static_cast<const _Float16*>(add2));
 }
+
+// ---------------------------------------------------------------- the bookkeeping between the passes (round 6)
+// Around every SPADE the per-workgroup partial sums were finished by ~20 tensor operations on 256-element vectors (a double copy, a
+// reduction, divisions, a clamp, two lerps, casts ...): 36 SPADE calls x 20 launches per config-4 iteration -- 12 % of its launches,
+// ~3 ms of GPU time and, under AMP where the iteration is launch-bound, more than that of wall time.  Three small kernels instead:
+//   h3d_rows_sum_f64    sums[c] = sum_r partial[r][c] in fp64 (what partial.double().sum(0) computed)
+//   h3d_bn_finish       sums, count -> mean, rstd (fp32) and the running-statistics update of nn.BatchNorm (momentum lerp with the
+//                       unbiased variance, num_batches_tracked += 1): /root/reference/lib/components/map3d_layers.py:162
+//   h3d_bn_bwd_finish   backward sums, count -> d_bias, d_weight and the two batch-statistics terms c1, c2 (all fp32)
+namespace {
+__global__ __launch_bounds__(1024) void rows_sum_f64_kernel(const float* __restrict__ partial, double* __restrict__ out, int64_t n_rows,
+                                                            int n_cols) {
+    __shared__ double part[16][64];
+    const int col = (int)blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < n_cols)
+        for (int64_t r = grp; r < n_rows; r += 16) acc += (double)partial[r * n_cols + col];
+    part[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && col < n_cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
+        out[col] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ sums, const double* __restrict__ count,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                        float* __restrict__ run_var, int64_t* __restrict__ tracked, int C, float eps,
+                                                        float momentum) {
+    const int c = (int)blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && tracked) *tracked += 1;
+    if (c >= C) return;
+    const double n = count[0];
+    const double m = sums[c] / n;
+    double v = sums[C + c] / n - m * m;
+    v = v > 0.0 ? v : 0.0;
+    const float mf = (float)m, vf = (float)v;
+    mean[c] = mf;
+    rstd[c] = 1.0f / sqrtf(vf + eps);
+    if (run_mean) run_mean[c] += momentum * (mf - run_mean[c]);
+    if (run_var) {
+        const double d = n - 1.0 > 1.0 ? n - 1.0 : 1.0;
+        run_var[c] += momentum * ((float)(v * (n / d)) - run_var[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __restrict__ local, const double* __restrict__ global,
+                                                            const double* __restrict__ count, float* __restrict__ d_b,
+                                                            float* __restrict__ d_g, float* __restrict__ c1, float* __restrict__ c2, int C) {
+    const int c = (int)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    d_b[c] = (float)local[c];
+    d_g[c] = (float)local[C + c];
+    if (count) {
+        const double n = count[0];
+        c1[c] = (float)(global[c] / n);
+        c2[c] = (float)(global[C + c] / n);
+    } else {
+        c1[c] = 0.f;
+        c2[c] = 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int h3d_rows_sum_f64(const float* partial, double* out, int64_t n_rows, int n_cols, h3d_stream_t stream) {
+    H3D_REQUIRE(partial && out && n_rows >= 0 && n_cols >= 1, "h3d_rows_sum_f64: bad arguments");
+    h3d::pre_launch();
+    hipLaunchKernelGGL(rows_sum_f64_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, out,
+                       n_rows, n_cols);
+    return h3d::launch_status("h3d_rows_sum_f64");
+}
+
+extern "C" int h3d_bn_finish(const double* sums, const double* count, float* mean, float* rstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, int C, float eps, float momentum, h3d_stream_t stream) {
+    H3D_REQUIRE(sums && count && mean && rstd && C >= 1, "h3d_bn_finish: bad arguments");
+    h3d::pre_launch();
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sums, count, mean,
+                       rstd, running_mean, running_var, num_batches_tracked, C, eps, momentum);
+    return h3d::launch_status("h3d_bn_finish");
+}
+
+extern "C" int h3d_bn_bwd_finish(const double* local_sums, const double* global_sums, const double* count, float* d_bias, float* d_weight,
+                                 float* c1, float* c2, int C, h3d_stream_t stream) {
+    H3D_REQUIRE(local_sums && d_bias && d_weight && c1 && c2 && C >= 1, "h3d_bn_bwd_finish: bad arguments");
+    H3D_REQUIRE((count == nullptr) || global_sums, "h3d_bn_bwd_finish: batch statistics need the (all-reduced) sums");
+    h3d::pre_launch();
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), local_sums,
+                       global_sums, count, d_bias, d_weight, c1, c2, C);
+    return h3d::launch_status("h3d_bn_bwd_finish");
+}
+

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from .... import _lib
 
 MIN_ROWS = int(os.environ.get("H3D_WGRAD_MIN_ROWS", 16384))      # below this the library GEMM is as good
+SMALL_ROWS = int(os.environ.get("H3D_AMP_FP32_ROWS", 64))            # AMP: layers with fewer rows than this run in fp32 (0: autocast decides)
 ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
 FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # residual addend in the GEMM epilogue (round 6; A/B switch)
@@ -234,4 +235,11 @@ def linear(x, w, b=None, add=None):
     if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled() and rows >= MIN_ROWS
             and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)) and _native_ok(Co, Ci)):
         return gemm_x3(_rows(x), w, b).view(*x.shape[:-1], Co)          # nothing to record (the D step's generator forward)
+    if x.is_cuda and rows < SMALL_ROWS and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16:
+        # a handful of rows (per-sample style vectors: the constant SPADEs' modulation, the shared layers' offsets) under float16
+        # autocast: computed in fp32 (round 6).  Autocast would convert both parameters on every call -- the weight handed in is a
+        # view of the parameter, which its cache never holds -- and their gradients back: 4 launches per layer and pass, ~350 per
+        # config-4 iteration, for products of 4 x 128 x 256.
+        with torch.autocast("cuda", enabled=False):
+            return F.linear(x.float(), w.float(), None if b is None else b.float())
     return F.linear(x, w, b)

@@ -10,6 +10,8 @@ terms of the BatchNorm backward are applied analytically (no graph through mean 
 The arithmetic lives behind a four-function kernel set (`HipKernels`); the collective algebra around it is independent of it,
 which is what the world-2 gloo test exercises with a stand-in kernel set of its own (there is no CPU kernel set in the
 product)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,13 +33,47 @@ class HipKernels:
         rows = _lib.load().h3d_spade_rows()
         return (P + rows - 1) // rows
 
+    @staticmethod
+    def _sum_rows(partial):
+        """partial [B, nblk, 2, C] fp32 -> [2, C] float64, one launch (h3d_rows_sum_f64; was a double copy + a reduction)."""
+        if not FUSED_BOOKKEEPING:
+            return partial.double().sum(dim=(0, 1))
+        B, nb, _, C = partial.shape
+        out = torch.empty((2, C), device=partial.device, dtype=torch.float64)
+        _lib.check(_lib.load().h3d_rows_sum_f64(_lib.ptr(partial), _lib.ptr(out), B * nb, 2 * C, _lib.stream_handle()), "h3d_rows_sum_f64")
+        return out
+
     def moments(self, x):
         """-> [2, C] float64: sum x, sum x^2 over all rows."""
         B, P, C = x.shape
         partial = torch.empty((B, self._nblk(P), 2, C), device=x.device, dtype=torch.float32)
         _lib.check(self._fn("h3d_channel_moments", x)(_lib.ptr(x), _lib.ptr(partial), B, P, C, _lib.stream_handle()),
                    "h3d_channel_moments")
-        return partial.double().sum(dim=(0, 1))
+        return self._sum_rows(partial)
+
+    @staticmethod
+    def finish(sums, count, norm, eps, momentum):
+        """sums [2, C] f64, count [1] f64 (device) -> mean, rstd [C] fp32 + the running-statistics update of `norm`, one launch
+        (h3d_bn_finish; was ~15 tensor operations on [C] vectors)."""
+        C = sums.shape[1]
+        mean = torch.empty(C, device=sums.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        rc = _lib.load().h3d_bn_finish(_lib.ptr(sums), _lib.ptr(count), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(norm.running_mean),
+                                       _lib.ptr(norm.running_var), _lib.ptr(norm.num_batches_tracked), C, float(eps), float(momentum),
+                                       _lib.stream_handle())
+        _lib.check(rc, "h3d_bn_finish")
+        return mean, rstd
+
+    @staticmethod
+    def backward_finish(local, glob, count):
+        """local / glob [2, C] f64 (this rank's / the all-reduced backward sums), count [1] f64 or None -> d_bias, d_weight, c1, c2
+        [C] fp32, one launch (h3d_bn_bwd_finish)."""
+        C = local.shape[1]
+        out = torch.empty((4, C), device=local.device, dtype=torch.float32)
+        rc = _lib.load().h3d_bn_bwd_finish(_lib.ptr(local), _lib.ptr(glob), _lib.ptr(count), _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                           _lib.ptr(out[2]), _lib.ptr(out[3]), C, _lib.stream_handle())
+        _lib.check(rc, "h3d_bn_bwd_finish")
+        return out[0], out[1], out[2], out[3]
 
     def forward(self, x, scale, shift, gamma, beta):
         B, P, C = x.shape
@@ -55,7 +91,7 @@ class HipKernels:
                                                     _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dy), _lib.ptr(partial), B, P, C,
                                                     int(gamma.dim() == 3), SLOPE, _lib.stream_handle()),
                    "h3d_spade_bwd_reduce")
-        return partial.double().sum(dim=(0, 1))
+        return self._sum_rows(partial)
 
     def backward_apply(self, x, mean, rstd, g, b, gamma, beta, dy, c1, c2, add1=None, add2=None):
         """-> dx, dgamma, dbeta (shaped like gamma / beta).  add1 / add2 (x's shape and type): further gradients of x, added into dx
@@ -84,6 +120,17 @@ class HipKernels:
 
 
 _HIP = HipKernels()
+FUSED_BOOKKEEPING = os.environ.get("H3D_SPADE_BOOKKEEPING", "fused") != "torch"      # round 6: h3d_rows_sum_f64 / h3d_bn_finish / h3d_bn_bwd_finish
+_row_counts = {}
+
+
+def _row_count(n, device):
+    """[float(n)] as a float64 device tensor, made once per (n, device): a host-to-device copy per SPADE call otherwise."""
+    key = (int(n), str(device))
+    t = _row_counts.get(key)
+    if t is None:
+        t = _row_counts[key] = torch.tensor([float(n)], device=device, dtype=torch.float64)
+    return t
 
 
 def _sync_on(group):
@@ -112,15 +159,22 @@ class _SpadeNormAct(torch.autograd.Function):
         k = ctx.kernels
         dy = dy.contiguous().to(x.dtype)
         sums = k.backward_sums(x, mean, rstd, g, b, gamma, beta, dy)              # local: they are d_b, d_g
-        d_b, d_g = sums[0].float(), sums[1].float()
-        if count is not None:
-            if _sync_on(ctx.group):
-                sums = sums.clone()
-                dist.all_reduce(sums, group=ctx.group)
-            c = (sums / count.double()).float()
-            c1, c2 = c[0].contiguous(), c[1].contiguous()
+        if isinstance(k, HipKernels) and FUSED_BOOKKEEPING:
+            glob = sums
+            if count is not None and _sync_on(ctx.group):
+                glob = sums.clone()
+                dist.all_reduce(glob, group=ctx.group)
+            d_b, d_g, c1, c2 = k.backward_finish(sums, glob if count is not None else None, count)
         else:
-            c1 = c2 = torch.zeros_like(mean)
+            d_b, d_g = sums[0].float(), sums[1].float()
+            if count is not None:
+                if _sync_on(ctx.group):
+                    sums = sums.clone()
+                    dist.all_reduce(sums, group=ctx.group)
+                c = (sums / count.double()).float()
+                c1, c2 = c[0].contiguous(), c[1].contiguous()
+            else:
+                c1 = c2 = torch.zeros_like(mean)
         extra = [d.contiguous().to(x.dtype) for d in d_alias if d is not None]
         if extra and isinstance(k, HipKernels) and len(extra) <= 2:
             dx, dgamma, dbeta = k.backward_apply(x, mean, rstd, g, b, gamma, beta, dy, c1, c2, *extra)
@@ -151,6 +205,19 @@ def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentu
         gamma, beta = gamma.to(dt), beta.to(dt)
     gamma, beta = gamma.contiguous(), beta.contiguous()
     count = None
+    fused = (training and isinstance(k, HipKernels) and FUSED_BOOKKEEPING and norm.running_mean is not None
+             and norm.running_mean.dtype == torch.float32 and norm.running_var.dtype == torch.float32
+             and norm.running_mean.is_contiguous() and norm.running_var.is_contiguous())
+    if fused:
+        with torch.no_grad():
+            sums = k.moments(x)
+            count = _row_count(B * P, x.device)
+            if _sync_on(group):
+                packed = torch.cat([sums.flatten(), count])
+                dist.all_reduce(packed, group=group)
+                sums, count = packed[:-1].reshape(2, C).contiguous(), packed[-1:].contiguous()
+            mean, rstd = k.finish(sums, count, norm, eps, momentum)
+        return _SpadeNormAct.apply(x, norm.weight.float(), norm.bias.float(), gamma, beta, mean, rstd, count, group, k, int(aliases))
     if training:
         with torch.no_grad():
             sums = k.moments(x)

@@ -137,7 +137,8 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
             low = linear(fmap_low, w_all, torch.cat([m.bias for m in shared], dim=0))
         else:
             off_all = torch.cat([linear(fixed, m.weight.flatten(1), m.bias) for m in shared], dim=-1)      # [B, 1, 128 * len(pix)]
-            low = linear(fmap_low, w_all) + off_all
+            low = linear(fmap_low, w_all)
+            low = low + off_all.to(low.dtype)
         # ... and so is the ReLU: one pass over the whole map instead of one per (strided) piece
         up = torch.relu(_resize_channels_last(low, render_hw, gen_hw))                          # [B, P, 128 * len(pix)]
         # split, not slices: the backward of a split is ONE concatenation of the pieces' gradients; slices would each

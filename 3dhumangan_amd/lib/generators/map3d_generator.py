@@ -122,10 +122,14 @@ class FullyConnectedLayer(nn.Module):
             b = None if self.bias is None else self.bias.float() * self.bias_gain
         else:
             wt, b = self.folded()
-        y = x.float() @ wt
-        if self.activation == "linear":
-            return y if b is None else y + b
-        return bias_act(y, b, act=self.activation)
+        # [B, 512] x [512, 512] products: under float16 autocast they stay in fp32 (round 6) -- autocast would convert the activation
+        # and both parameters of every layer and call (the folded weight is a non-leaf, so its conversion is never cached) for a
+        # product that costs nothing: 3 launches + 3 in the backward per layer, ~100 launches per iteration
+        with torch.autocast("cuda", enabled=False):
+            y = x.float() @ wt
+            if self.activation == "linear":
+                return y if b is None else y + b
+            return bias_act(y, b, act=self.activation)
 
 
 class TwoPartMappingNetwork(nn.Module):

@@ -693,6 +693,21 @@ int h3d_spade_bwd_apply_acc(int dtype, const void* x, const float* mean, const f
                             const void* gamma, const void* beta, const void* dy, const float* c1, const float* c2, const void* add1,
                             const void* add2, void* dx, void* dgamma, void* dbeta, float* partial, int B, int64_t P, int C,
                             int per_pixel, float slope, h3d_stream_t stream);
+/* The bookkeeping between the SPADE passes (round 6): ~20 tensor operations on [C] vectors per call become three launches.
+ *   h3d_rows_sum_f64   out[c] = sum_r partial[r][c] accumulated in fp64 (partial [n_rows, n_cols] fp32: the per-workgroup sums of
+ *                      h3d_channel_moments / h3d_spade_bwd_reduce viewed as rows of 2 C columns)
+ *   h3d_bn_finish      sums [2, C] fp64 (sum x, sum x^2; all-reduced by the caller when a process group is on), count [1] fp64 (rows
+ *                      behind them, DEVICE) -> mean, rstd = 1 / sqrt(var + eps) [C] fp32, and nn.BatchNorm's train-mode side
+ *                      effects: running_mean / running_var (fp32, may be NULL) moved by `momentum` towards mean / the UNBIASED
+ *                      variance, num_batches_tracked (int64, may be NULL) += 1  (/root/reference/lib/components/map3d_layers.py:162)
+ *   h3d_bn_bwd_finish  local_sums [2, C] fp64 -> d_bias, d_weight [C] fp32; global_sums / count -> c1, c2 [C] fp32, the
+ *                      batch-statistics terms h3d_spade_bwd_apply takes (count NULL: running statistics, c1 = c2 = 0)
+ */
+int h3d_rows_sum_f64(const float* partial, double* out, int64_t n_rows, int n_cols, h3d_stream_t stream);
+int h3d_bn_finish(const double* sums, const double* count, float* mean, float* rstd, float* running_mean, float* running_var,
+                  int64_t* num_batches_tracked, int C, float eps, float momentum, h3d_stream_t stream);
+int h3d_bn_bwd_finish(const double* local_sums, const double* global_sums, const double* count, float* d_bias, float* d_weight, float* c1,
+                      float* c2, int C, h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * P1  bias_act forward == _plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)

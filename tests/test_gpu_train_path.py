@@ -553,3 +553,35 @@ def test_train_step_under_autocast(amp):
     # distance to the AMP run is the AMP run's own distance to the truth, and the distance to the truth must not be worse
     assert c_32 > max(c_ref, 0.99) - 2e-3
     assert c_amp > c_ref - 5e-3
+
+
+def test_spade_bookkeeping_kernels_equal_the_tensor_operations(monkeypatch):
+    """h3d_rows_sum_f64 / h3d_bn_finish / h3d_bn_bwd_finish against the tensor operations they replace: the same forward output,
+    running statistics, num_batches_tracked and gradients from spade_norm_act in train mode."""
+    spade = importlib.import_module("3dhumangan_amd.lib.components.ops.spade")
+    gen = torch.Generator().manual_seed(23)
+    B, P, C = 3, 1100, 96
+    x0 = (torch.randn(B, P, C, generator=gen) * 1.7 + 0.4).to(DEV)
+    gamma, beta = (torch.randn(B, P, C, generator=gen) * 0.3).to(DEV), (torch.randn(B, P, C, generator=gen) * 0.3).to(DEV)
+    w = torch.randn(B, P, C, generator=gen).to(DEV)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(spade, "FUSED_BOOKKEEPING", mode)
+        norm = torch.nn.BatchNorm1d(C, affine=True).to(DEV)
+        with torch.no_grad():
+            norm.weight.copy_(torch.linspace(0.5, 1.5, C)); norm.bias.copy_(torch.linspace(-0.2, 0.2, C))
+            norm.running_mean.fill_(0.3); norm.running_var.fill_(2.0)
+        x = x0.clone().requires_grad_(True)
+        y = spade.spade_norm_act(x, norm, gamma, beta, True, group=False)
+        (y * w).sum().backward()
+        res[mode] = (y.detach(), x.grad, norm.weight.grad, norm.bias.grad, norm.running_mean.clone(), norm.running_var.clone(),
+                     int(norm.num_batches_tracked))
+    for a, e, name in zip(res[True][:6], res[False][:6], ("y", "dx", "d_weight", "d_bias", "running_mean", "running_var")):
+        assert rel_err(a, e) < 2e-6, name
+    assert res[True][6] == res[False][6] == 1
+    # the running variance is the UNBIASED one, as nn.BatchNorm's
+    ref = torch.nn.BatchNorm1d(C).to(DEV).train()
+    with torch.no_grad():
+        ref.running_mean.fill_(0.3); ref.running_var.fill_(2.0)
+        ref(x0.reshape(B * P, C))
+    assert rel_err(res[True][4], ref.running_mean) < 1e-5 and rel_err(res[True][5], ref.running_var) < 1e-5

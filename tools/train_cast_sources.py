@@ -1,0 +1,54 @@
+"""Where do the small type conversions of the AMP config-4 iteration come from?  torch.profiler with Python stacks, grouped by the
+innermost frames inside this repository.  usage: python tools/train_cast_sources.py [op-name-substring, default _to_copy]"""
+import collections
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "_to_copy"
+dev = "cuda"
+trainers = importlib.import_module("3dhumangan_amd.lib.trainers")
+disc = importlib.import_module("3dhumangan_amd.lib.discriminators")
+G, cfg = bench.build_generator("MAP3DBN512", (512, 256), (96, 48), 32, dev)
+G.train()
+z, cond, jitter = bench.make_inputs(cfg, 4, dev)
+torch.manual_seed(99)
+D = disc.UNetDiscriminator(**{k: v for k, v in cfg.items() if k != "neural_field_cls"}).to(dev)
+meta = {k: v for k, v in cfg.items() if k != "neural_field_cls"}
+meta.update(gan_lambda=1.0, segmentation_lambda=1.0, r1_lambda=10.0, gen_lr=5e-5, betas=(0.0, 0.9))
+opt_d = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.0, 0.9))
+opt_g = trainers.make_generator_optimizer(G, meta)
+g = torch.Generator().manual_seed(7)
+real = torch.randn(4, 3, 512, 256, generator=g).clamp(-1, 1).to(dev)
+gt = torch.randint(0, max(1, cfg.get("label_dim", 1)), (4, 512, 256), generator=g).to(dev)
+scaler = torch.amp.GradScaler("cuda")
+
+
+def step():
+    trainers.adversarial_iteration(G, D, opt_d, opt_g, z, cond, real, gt, meta, generator_kwargs=dict(jitter=jitter),
+                                   grad_clip=cfg.get("grad_clip", 10.0), amp_dtype=torch.float16, scaler=scaler)
+
+
+for _ in range(6):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+    step()
+    torch.cuda.synchronize()
+count = collections.Counter()
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
+    if what in e.key and e.input_shapes and e.input_shapes[0] and len(e.input_shapes[0]) <= 2:
+        frames = [f for f in (e.stack or []) if "3dhumangan_amd" in f or "bench.py" in f or "torch/nn/modules" in f or "autograd" in f]
+        key = (str(e.input_shapes[0]), " <- ".join(f.split("3dhumangan_amd/")[-1].split("dist-packages/")[-1] for f in frames[:3]))
+        count[key] += e.count
+for (shape, where), n in count.most_common(40):
+    print(f"{n:5d}  {shape:14s} {where}")
