@@ -27,8 +27,10 @@ import torch.nn.functional as F
 from ..components.ops.film import film_sin
 from ..components.ops.linear import linear
 from ..components.ops.spade import spade_norm_act
+from ..components.ops.spectral import _SpectralWeight
 from ..components.resample import bilinear_resize_cl
 
+FUSED_SPECTRAL = os.environ.get("H3D_GEN_SN", "hip") != "torch"      # the generator's spectral norm on csrc/spectral_norm.hip (round 6)
 ALIAS_GRADS = os.environ.get("H3D_SPADE_ALIAS", "1") != "0"      # gradients of a skip block's input summed inside the SPADE backward kernel (round 6)
 
 
@@ -69,8 +71,13 @@ def spectral_weight(conv, training, eps=1e-12):
 
 
 def _spectral_weight_fp32(conv, training, eps):
+    w0, u, v = conv.weight_orig, conv.weight_u, conv.weight_v
+    if (training and FUSED_SPECTRAL and w0.is_cuda and w0.dtype == torch.float32 and u.dtype == torch.float32 and v.dtype == torch.float32
+            and u.is_contiguous() and v.is_contiguous()):
+        # round 6: the discriminator's fused kernels (ops/spectral.py: three launches forward, two backward) instead of ~16 + ~10
+        # tensor operations per layer and pass -- 36 calls per config-4 iteration
+        return _SpectralWeight.apply(w0, u, v, eps).flatten(1)
     w = conv.weight_orig.flatten(1).float()
-    u, v = conv.weight_u, conv.weight_v
     if training:
         with torch.no_grad():
             v_new = F.normalize(torch.mv(w.t(), u), dim=0, eps=eps)

@@ -40,6 +40,33 @@ for _ in range(6):
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
+amp = os.environ.get("AMP", "fp16")
+if what == "LAUNCHES":
+    # every operator that launches device work, by the innermost frame of this repository: where do the launches come from?
+    if amp != "fp16":
+        scaler = None
+        def step():      # noqa: E306
+            trainers.adversarial_iteration(G, D, opt_d, opt_g, z, cond, real, gt, meta, generator_kwargs=dict(jitter=jitter),
+                                           grad_clip=cfg.get("grad_clip", 10.0))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+        step()
+        torch.cuda.synchronize()
+    launches, dev_ms = collections.Counter(), collections.Counter()
+    for e in prof.key_averages(group_by_stack_n=14):
+        if e.self_device_time_total <= 0 or not e.key.startswith("aten::"):
+            continue
+        frames = [f for f in (e.stack or []) if "3dhumangan_amd" in f or "bench.py" in f or "torch/optim" in f or "torch/nn/utils" in f or "torch/amp" in f]
+        where = frames[0].split("3dhumangan_amd/")[-1].split("dist-packages/")[-1] if frames else "(autograd engine / other)"
+        launches[(where, e.key)] += e.count
+        dev_ms[(where, e.key)] += e.self_device_time_total / 1e3
+    print("aten operators with device time:", sum(launches.values()), "calls,", round(sum(dev_ms.values()), 2), "ms")
+    for (where, op), n in launches.most_common(60):
+        print(f"{n:5d}  {dev_ms[(where, op)]:7.2f} ms  {op:28s} {where}")
+    sys.exit(0)
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
