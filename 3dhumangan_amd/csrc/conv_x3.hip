@@ -15,14 +15,26 @@
 // AMP tier (HALF instantiations): the activations ARE f16 -- one exact plane -- so the loaded words are the B fragments as they
 // are (no conversion, no split) on the F16 matrix instruction, the weights travel as f16 hi + f16 lo (to max(2^-22 |W|, 2^-25);
 // h3d_conv_x3_pack_f16), and a product is W_hi x + W_lo x: two matrix instructions instead of three, no vector work per element.
+// The ring's write-after-read safety is BY CONSTRUCTION in this file (round 6): every wave retires its LDS reads (lgkmcnt(0)) before the
+// barrier behind which a stage's buffer is refilled.  The engines argue by distance (x3_common.hpp: acquire) -- one workgroup per CU
+// there.  Here several workgroups share a CU (two by design for 1x1, up to four at NT = 2), and with another workgroup's moments
+// epilogue loading the LDS pipe the distance was NOT kept: 1-4 % of 0.5 M x 64 x 256 launches returned one wave's tile computed from a
+// half-refilled stage (tools/conv_determinism.py; found by the run-to-run comparison of the training loss).  The wait costs nothing
+// measurable on these kernels (tools/moments_ab.py: every 1x1 / 3x3 shape within 1 %).
+#define H3D_RING_WAIT_LDS
 #include "x3_common.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 using namespace h3d;
 
 namespace {
 
-constexpr int kDepth = 7;          // ring stages (NT * 2 KiB each)
+// ring stages (NT * 2 KiB each): 7 with one workgroup per CU (3x3: the matrix pipe is what binds, the deep ring keeps it fed); 4 in
+// the two-workgroups-per-CU instantiations (OCC = 2: the 1x1 convolutions / dense layers, which move 2 x 4 bytes per 2 x 256 flops
+// and are bound by how much memory traffic a CU keeps in flight -- a second resident workgroup loads while the first computes or
+// stores; round 6, tools/moments_ab.py: 0.5 M x 256 x 256 fp32 462 -> 379 us, f16 274 -> 213 us; the 3x3 shapes lose 5-12 % there)
+template <int OCC> struct RingDepth { static constexpr int value = OCC == 2 ? 4 : 7; };
 
 struct Args {
     const void* x;                 // [P, Cin] fp32, or _Float16 in the HALF instantiations (AMP: activations travel as f16)
@@ -34,6 +46,7 @@ struct Args {
     int ldx, ldo;                  // row strides (elements) of x and out: >= Cin / Cout (channel slices of wider tensors)
     const void* add;               // optional [P, Cout] addend of the output's type (a residual connection), row stride lda; or null
     int lda;
+    float* moments;                // optional [ceil(P / 128), 2, Cout]: per workgroup, the column sums of the output as stored and of its square
 };
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -72,8 +85,9 @@ __device__ __forceinline__ void split_chunk(const float4 (&raw)[2 * KSC], BF16::
 // MODE 0: fp32 activations, split-bf16 x3.  MODE 1: f16 activations, weights as f16 hi + lo (two products per weight).  MODE 2: f16
 // activations, weights rounded to f16 ONCE -- the reference's autocast semantics (lib/trainers/base_trainer.py:50-51: autocast
 // rounds the weight to 11 bits) -- one product per weight, a ring stage carries two k-steps (gemm_x3_roll PAIRK), half the stream.
-template <int NT, int KSC, int MODE = 0>
-__global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
+template <int NT, int KSC, int MODE = 0, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void conv_x3_kernel(Args A) {
+    constexpr int kDepth = RingDepth<OCC>::value;
     constexpr bool HALF = MODE != 0, ONE = MODE == 2;
     constexpr int KST = ONE ? KSC / 2 : KSC;          // ring stages per chunk
     typedef typename std::conditional<HALF, _Float16, float>::type TX;
@@ -139,10 +153,19 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
         gemm_x3_roll<TE, NT, KST, KSC, false, L, 0, false, !HALF, ONE>(acc, xh, xl, ring);
     }
     ring.drain();
+    // Batch moments of the output (round 6; the BatchNorm statistic of the SPADE that reads this layer, map3d_layers.py:176-190) from
+    // the accumulators instead of a pass of its own over the stored tensor: every tile goes through the LDS the ring no longer needs
+    // ([channel quad][pixel][4], 4 KiB per wave), a lane sums ONE channel over 16 pixels (rotated by the channel quad: 32 lanes, 32
+    // banks), the halves meet through one cross-lane move, the four waves through LDS; one [2, NT * 32] row per workgroup, summed in
+    // float64 by the caller (h3d_rows_sum_f64).  Pixels past the end contribute zeros.
+    const bool mom = A.moments != nullptr;
+    float* const stage = reinterpret_cast<float*>(ring_lds) + wave * 1024;
+    float* const wsum = reinterpret_cast<float*>(ring_lds) + 4096;            // [4 waves][NT * 32][2]
+    if (mom) __syncthreads();                                                 // the other waves' last fragment reads of the ring
     // accumulator tile nt: lane holds pixel m, channels 32 nt + 8 rg + 4 h + {0..3} in registers 4 rg .. 4 rg + 3
-    if (okp) {
+    if (okp || mom) {
         TX* __restrict__ o = static_cast<TX*>(A.out) + p * A.ldo + oblk * (NT * 32);
-        const TX* __restrict__ ad = A.add ? static_cast<const TX*>(A.add) + p * A.lda + oblk * (NT * 32) : nullptr;
+        const TX* __restrict__ ad = (A.add && okp) ? static_cast<const TX*>(A.add) + p * A.lda + oblk * (NT * 32) : nullptr;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
@@ -167,11 +190,38 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(Args A) {
                 if constexpr (HALF) {            // round to f16 once, after the fp32 accumulation and the bias
                     typedef float f2 __attribute__((ext_vector_type(2)));
                     const h16x2 a = __builtin_convertvector(f2{v.x, v.y}, h16x2), c = __builtin_convertvector(f2{v.z, v.w}, h16x2);
-                    *reinterpret_cast<uint2*>(o + n) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c));
+                    if (okp) *reinterpret_cast<uint2*>(o + n) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c));
+                    if (mom) v = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);      // the moments of what was stored
                 } else {
-                    *reinterpret_cast<float4*>(o + n) = v;
+                    if (okp) *reinterpret_cast<float4*>(o + n) = v;
                 }
+                if (mom) *reinterpret_cast<float4*>(stage + ((2 * rg + h) * 32 + m) * 4) = okp ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (mom) {
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                const int cq = m >> 2;
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float val = stage[(cq * 32 + 16 * h + ((i + cq) & 15)) * 4 + (m & 3)];
+                    s += val;
+                    q = __builtin_fmaf(val, val, q);
+                }
+                s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 32);
+                if (h == 0) *reinterpret_cast<float2*>(wsum + ((wave * NT + nt) * 32 + m) * 2) = make_float2(s, q);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+    if (mom) {
+        __syncthreads();
+        for (int idx = t; idx < NT * 64; idx += 256) {                       // (channel of this output block, statistic)
+            if (oblk * (NT * 32) + (idx >> 1) >= A.Cout) break;
+            const float tot = (wsum[idx] + wsum[NT * 64 + idx]) + (wsum[2 * NT * 64 + idx] + wsum[3 * NT * 64 + idx]);
+            A.moments[((int64_t)blockIdx.x * 2 + (idx & 1)) * A.Cout + oblk * (NT * 32) + (idx >> 1)] = tot;
         }
     }
 }
@@ -208,12 +258,19 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __
     stream[((base + 1) * 64 + 32 * h + j) * 8 + e] = lb;
 }
 
-template <int NT, int KSC, int MODE>
+// LDS of a launch: the ring, or -- with moments, at two tiles -- the staging area that takes its place after the last k-step
+template <int NT, int OCC>
+constexpr size_t lds_bytes() {
+    constexpr size_t ring = (size_t)RingDepth<OCC>::value * NT * 2048, stage = (size_t)(4096 + 256 * NT) * 4;
+    return ring > stage ? ring : stage;
+}
+template <int NT, int KSC, int MODE, int OCC>
 int launch(const Args& A, int n_oblk, hipStream_t st) {
-    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, MODE>));
+    H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, MODE, OCC>));
     const int64_t tiles = (A.P + 127) / 128;
     h3d::pre_launch();
-    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, MODE>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), (size_t)kDepth * NT * 2048, st, A);
+    constexpr size_t lds = lds_bytes<NT, OCC>();
+    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, MODE, OCC>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), lds, st, A);
     return h3d::launch_status("h3d_conv_x3");
 }
 
@@ -221,22 +278,45 @@ int launch(const Args& A, int n_oblk, hipStream_t st) {
 
 // Tiling of a [Cout <- Cin] convolution: out[0] = tiles NT per output block (2, 4 or 8), out[1] = output blocks, out[2] = k-steps
 // per channel chunk (4 or 8), out[3] = chunks.  -1 when the channel counts are not supported (both must be multiples of 64).
-extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) {
+static int tiling_nt(int Cin, int Cout, int NT, int* out) {
     if (!out || Cin < 64 || Cout < 64 || Cin % 64 || Cout % 64) return -1;
-    const int NT = Cout % 256 == 0 ? 8 : Cout % 128 == 0 ? 4 : 2;
+    if (NT == 0) NT = Cout % 256 == 0 ? 8 : Cout % 128 == 0 ? 4 : 2;
+    if ((NT != 2 && NT != 4 && NT != 8) || Cout % (32 * NT)) return -1;
     const int KSC = Cin % 128 == 0 ? 8 : 4;
     out[0] = NT; out[1] = Cout / (32 * NT); out[2] = KSC; out[3] = Cin / (16 * KSC);
     return 0;
+}
+extern "C" int h3d_conv_x3_tiling(int Cin, int Cout, int* out) { return tiling_nt(Cin, Cout, 0, out); }
+// Tiles per output block for a launch over P output pixels (HOST helper, round 6): the widest blocking (fewest re-reads of the
+// activations) whose grid -- ceil(P / 128) pixel tiles x output blocks -- still has a workgroup for every one of the 256 CUs, else the
+// narrowest.  The discriminator's 512-channel 3x3 layers at 64 x 32 .. 8 x 4 pixels launched 8 .. 128 workgroups at NT = 8
+// (tools/moments_ab.py: B = 4, 512 channels, 64 x 32: 199 -> 157 us at NT = 4; 32 x 16: 176 -> 107 us at NT = 2).  The blocking changes
+// neither the order of any sum nor a single bit of the result.  0 when the channel counts are not supported.
+extern "C" int h3d_conv_x3_nt_for(int Cin, int Cout, int64_t P) {
+    int til[4];
+    if (tiling_nt(Cin, Cout, 0, til)) return 0;
+    static const int nt_max = [] { const char* e = getenv("H3D_CONV_NT_MAX"); return e ? atoi(e) : 8; }();      // A/B knob
+    static const bool fill = [] { const char* e = getenv("H3D_CONV_FILL"); return !(e && e[0] == '0'); }();       // A/B knob: 0 = always the widest
+    const int64_t tiles = (P + 127) / 128;
+    int best = 0;
+    for (int NT = 8; NT >= 2; NT >>= 1) {
+        if (NT > nt_max || Cout % (32 * NT)) continue;
+        if (!best) best = NT;                             // the widest
+        if (!fill) break;
+        best = NT;
+        if (tiles * (Cout / (32 * NT)) >= 256) break;
+    }
+    return best;
 }
 
 // Pack OIHW fp32 weights `w` (device) into the stream h3d_conv_x3 reads (2 * Cout * Cin * k * k bf16, device).  transposed = 0:
 // w is [Cout, Cin, k, k], the forward convolution; transposed = 1: w is [Cin, Cout, k, k] and the stream is that of its
 // backward-data convolution (Cout <- Cin channels, flipped taps).
-static int conv_pack_any(const float* w, void* stream, int Cout, int Cin, int k, int transposed, int f16, h3d_stream_t stream_) {
+static int conv_pack_any(const float* w, void* stream, int Cout, int Cin, int k, int transposed, int f16, h3d_stream_t stream_, int NT = 0) {
     H3D_REQUIRE(w && stream && (k == 1 || k == 3), "h3d_conv_x3_pack: null pointer / kernel size");
     int til[4];
-    if (h3d_conv_x3_tiling(Cin, Cout, til)) {
-        h3d::set_error("h3d_conv_x3_pack: channel counts must be multiples of 64 (got %d -> %d)", Cin, Cout);
+    if (tiling_nt(Cin, Cout, NT, til)) {
+        h3d::set_error("h3d_conv_x3_pack: channel counts must be multiples of 64 and of 32 * NT (got %d -> %d, NT %d)", Cin, Cout, NT);
         return H3D_EUNSUPPORTED;
     }
     const int64_t total = (int64_t)Cout * Cin * k * k;
@@ -257,9 +337,17 @@ extern "C" int h3d_conv_x3_pack_f16(const float* w, void* stream, int Cout, int 
 extern "C" int h3d_conv_x3_pack_f16x1(const float* w, void* stream, int Cout, int Cin, int k, int transposed, h3d_stream_t stream_) {
     return conv_pack_any(w, stream, Cout, Cin, k, transposed, 2, stream_);
 }
+// Any of the three streams (planes: 0 = bf16 hi + lo, 1 = f16 hi + lo, 2 = one f16 plane) blocked for NT tiles per output block
+// (2, 4 or 8 with Cout % (32 NT) == 0; 0 = the default blocking of h3d_conv_x3_tiling): the stream h3d_conv_x3_ex reads at that NT.
+extern "C" int h3d_conv_x3_pack_nt(const float* w, void* stream, int Cout, int Cin, int k, int transposed, int planes, int NT,
+                                   h3d_stream_t stream_) {
+    H3D_REQUIRE(planes >= 0 && planes <= 2, "h3d_conv_x3_pack_nt: planes %d (0 = bf16 pair, 1 = f16 pair, 2 = one f16 plane)", planes);
+    return conv_pack_any(w, stream, Cout, Cin, k, transposed, planes, stream_, NT);
+}
 
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
-                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add = nullptr, int lda = 0);
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add = nullptr, int lda = 0,
+                       float* moments = nullptr, int NT = 0);
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     return conv_x3_any(0, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
@@ -293,28 +381,51 @@ extern "C" int h3d_conv_x3_add(int mode, const void* x, const void* stream, cons
                 "h3d_conv_x3_add: row strides must be multiples of %d (ldx=%d ldo=%d lda=%d)", gran, ldx, ldo, lda);
     return conv_x3_any(mode, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_, add, lda);
 }
+/* The general entry (round 6): h3d_conv_x3_add with the addend optional, the blocking explicit and, optionally, the batch moments of
+ * the output.  NT: tiles per output block the stream was packed for (h3d_conv_x3_pack_nt; 0 = the default blocking).  moments (or
+ * null): [ceil(B*H*W / h3d_conv_x3_moment_rows()), 2, Cout] fp32 -- per workgroup of the launch, the column sums of the output AS
+ * STORED (after bias, addend and, in the f16 modes, the rounding) and of its square.  Their float64 sum over the rows
+ * (h3d_rows_sum_f64) is what h3d_channel_moments computes in a pass of its own over the stored tensor: the BatchNorm statistic of
+ * the SPADE behind the layer (reference lib/components/map3d_layers.py:162, 176-190), taken from the accumulators. */
+extern "C" int h3d_conv_x3_ex(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, float* moments,
+                              int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT, h3d_stream_t stream_) {
+    H3D_REQUIRE(mode >= 0 && mode <= 2, "h3d_conv_x3_ex: mode %d (0 = fp32, 1 = f16 two planes, 2 = f16 one plane)", mode);
+    H3D_REQUIRE(!moments || h3d::aligned16(moments), "h3d_conv_x3_ex: misaligned moments buffer");
+    H3D_REQUIRE(!add || h3d::aligned16(add), "h3d_conv_x3_ex: misaligned addend");
+    const int gran = mode ? 8 : 4;
+    H3D_REQUIRE((!add || (lda >= Cout && lda % gran == 0)) && ldx % gran == 0 && ldo % gran == 0,
+                "h3d_conv_x3_ex: row strides must be multiples of %d (ldx=%d ldo=%d lda=%d)", gran, ldx, ldo, lda);
+    return conv_x3_any(mode, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_, add, add ? lda : 0, moments, NT);
+}
+/* Output pixels behind one row of h3d_conv_x3_ex's moments buffer (128: one workgroup). */
+extern "C" int h3d_conv_x3_moment_rows(void) { return 128; }
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
-                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add, int lda) {
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add, int lda, float* moments, int NT_) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
     H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
                 "h3d_conv_x3: operands must be 16-byte aligned");
     H3D_REQUIRE(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0, "h3d_conv_x3: row strides must be multiples of 4 and cover the channels (ldx=%d ldo=%d)", ldx, ldo);
     int til[4];
-    if (h3d_conv_x3_tiling(Cin, Cout, til)) {
-        h3d::set_error("h3d_conv_x3: channel counts must be multiples of 64 (got %d -> %d)", Cin, Cout);
+    if (tiling_nt(Cin, Cout, NT_, til)) {
+        h3d::set_error("h3d_conv_x3: channel counts must be multiples of 64 and of 32 * NT (got %d -> %d, NT %d)", Cin, Cout, NT_);
         return H3D_EUNSUPPORTED;
     }
     if (B == 0) return H3D_OK;
+    // 1x1: two workgroups per CU on 4-k-step chunks (the stream's layout does not depend on the chunking); H3D_CONV_OCC=1: A/B knob
+    static const bool occ2_ok = [] { const char* e = getenv("H3D_CONV_OCC"); return !(e && e[0] == '1'); }();
+    const bool occ2 = occ2_ok && k == 1;
+    if (occ2 && til[2] == 8) { til[2] = 4; til[3] *= 2; }
     Args A{};
-    A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out; A.add = add; A.lda = lda;
+    A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out; A.add = add; A.lda = lda; A.moments = moments;
     A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
     A.n_chunks = til[3]; A.stages_per_oblk = k * k * til[3] * (mode == 2 ? til[2] / 2 : til[2]); A.ldx = ldx; A.ldo = ldo;
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const int NT = til[0], KSC = til[2];
-#define H3D_CASE(N, K) if (NT == N && KSC == K) return mode == 2 ? launch<N, K, 2>(A, til[1], st) : mode == 1 ? launch<N, K, 1>(A, til[1], st) : launch<N, K, 0>(A, til[1], st)
-    H3D_CASE(8, 8); H3D_CASE(8, 4); H3D_CASE(4, 8); H3D_CASE(4, 4); H3D_CASE(2, 8); H3D_CASE(2, 4);
+#define H3D_CASE(N, K, O) if (NT == N && KSC == K && occ2 == (O == 2)) return mode == 2 ? launch<N, K, 2, O>(A, til[1], st) : mode == 1 ? launch<N, K, 1, O>(A, til[1], st) : launch<N, K, 0, O>(A, til[1], st)
+    H3D_CASE(8, 8, 1); H3D_CASE(8, 4, 1); H3D_CASE(4, 8, 1); H3D_CASE(4, 4, 1); H3D_CASE(2, 8, 1); H3D_CASE(2, 4, 1);
+    H3D_CASE(8, 4, 2); H3D_CASE(4, 4, 2); H3D_CASE(2, 4, 2);
 #undef H3D_CASE
     return H3D_EUNSUPPORTED;
 }

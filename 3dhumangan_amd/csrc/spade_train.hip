@@ -443,6 +443,32 @@ __global__ __launch_bounds__(1024) void rows_sum_f64_kernel(const float* __restr
     }
 }
 
+// the same sums for n_cols % 4 == 0: a thread owns FOUR consecutive columns (one 16-byte load per row) and 64 row groups share a
+// block -- h3d_conv_x3_moments hands over one row per 128 pixels (4 096 rows at config 4), where the 16-group kernel above spends
+// 256 dependent iterations per thread (~100 us); here 64 iterations with four independent accumulators
+__global__ __launch_bounds__(1024) void rows_sum_f64_v4_kernel(const float* __restrict__ partial, double* __restrict__ out, int64_t n_rows,
+                                                               int n_cols) {
+    __shared__ double part[64][65];
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int col = (int)blockIdx.x * 64 + 4 * q;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (col < n_cols) {
+#pragma unroll 4
+        for (int64_t r = grp; r < n_rows; r += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + r * n_cols + col);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+    }
+    part[grp][4 * q] = a0; part[grp][4 * q + 1] = a1; part[grp][4 * q + 2] = a2; part[grp][4 * q + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 64 && (int)blockIdx.x * 64 + (int)threadIdx.x < n_cols) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int g = 0; g < 64; ++g) t += part[g][threadIdx.x];
+        out[blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ sums, const double* __restrict__ count,
                                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                                         float* __restrict__ run_var, int64_t* __restrict__ tracked, int C, float eps,
@@ -485,8 +511,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __rest
 extern "C" int h3d_rows_sum_f64(const float* partial, double* out, int64_t n_rows, int n_cols, h3d_stream_t stream) {
     H3D_REQUIRE(partial && out && n_rows >= 0 && n_cols >= 1, "h3d_rows_sum_f64: bad arguments");
     h3d::pre_launch();
-    hipLaunchKernelGGL(rows_sum_f64_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), partial, out,
-                       n_rows, n_cols);
+    if (n_cols % 4 == 0 && h3d::aligned16(partial) && n_rows >= 256)
+        hipLaunchKernelGGL(rows_sum_f64_v4_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                           partial, out, n_rows, n_cols);
+    else
+        hipLaunchKernelGGL(rows_sum_f64_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
+                           out, n_rows, n_cols);
     return h3d::launch_status("h3d_rows_sum_f64");
 }
 

@@ -243,7 +243,11 @@ struct WeightRing {
         // vmcnt only (expcnt / lgkmcnt fields left at "no wait"): stages t+1 .. t+kBuf-2 may stay in flight
         constexpr int kKeep = (kBuf - 2 - LAG) * kChunks;
 #ifndef H3D_EXPERIMENT_NO_BARRIER
+#ifdef H3D_RING_WAIT_LDS            // every LDS read of this wave retired before the barrier: the refill's write-after-read safety by construction
+        __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0000);
+#else
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
+#endif
         __builtin_amdgcn_s_barrier();
 #endif
         return slot<4>(next_read());

@@ -58,7 +58,7 @@ FUSED_PAD = os.environ.get("H3D_CONV_PAD", "fused") != "torch"             # cha
 FUSED_REDUCE = os.environ.get("H3D_WGRAD_REDUCE", "fused") != "torch"      # the slices' sum on h3d_wgrad_reduce (round 6)
 
 
-def pack_stream(w, transposed=False, half=False, owner=None, planes=2):
+def pack_stream(w, transposed=False, half=False, owner=None, planes=2, nt=0):
     """w [Co, Ci, k, k] fp32 (device) -> the bf16 hi/lo weight stream of h3d_conv_x3 (int16 bit patterns; include/h3d.h), one
     kernel launch (h3d_conv_x3_pack).  transposed: the stream of w's backward-data convolution (Ci -> Co channels swapped,
     taps flipped) instead.  Cached per tensor OBJECT and version: the same (spectrally normalised) weight is convolved with in the
@@ -66,11 +66,12 @@ def pack_stream(w, transposed=False, half=False, owner=None, planes=2):
     per call.  `owner`: the long-lived tensor `w` is a per-call view / reshape of (the dense layers hand in
     ``weight.detach()[:, :, None, None]``, a new object every call): the cache is keyed on the owner's identity and version, so
     those calls hit too.  Inference tensors (torch.inference_mode) have no version counter: they are packed every call.
-    half: the f16 hi/lo stream of h3d_conv_x3_f16."""
+    half: the f16 hi/lo stream of h3d_conv_x3_f16.  nt: tiles per output block the stream is laid out for (h3d_conv_x3_nt_for;
+    0 = the default blocking) -- part of the cache key."""
     ref = w if owner is None else owner
     cacheable = not ref.is_inference()
     one = bool(half) and planes == 1
-    key = (id(ref), bool(transposed), bool(half), tuple(w.shape), one)
+    key = (id(ref), bool(transposed), bool(half), tuple(w.shape), one, int(nt))
     if cacheable:
         e = _stream_cache.get(key)
         if e is not None and e[0] == ref._version and e[1]() is ref:
@@ -78,9 +79,9 @@ def pack_stream(w, transposed=False, half=False, owner=None, planes=2):
     wd = w.detach().contiguous()
     co, ci, k, _ = wd.shape
     out = torch.empty((1 if one else 2) * wd.numel(), device=wd.device, dtype=torch.int16)
-    pack = _lib.load().h3d_conv_x3_pack_f16x1 if one else _lib.load().h3d_conv_x3_pack_f16 if half else _lib.load().h3d_conv_x3_pack
-    rc = pack(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed), _lib.stream_handle())
-    _lib.check(rc, "h3d_conv_x3_pack")
+    rc = _lib.load().h3d_conv_x3_pack_nt(_lib.ptr(wd), _lib.ptr(out), ci if transposed else co, co if transposed else ci, k, int(transposed),
+                                         2 if one else 1 if half else 0, int(nt), _lib.stream_handle())
+    _lib.check(rc, "h3d_conv_x3_pack_nt")
     if not cacheable:
         return out
     if len(_stream_cache) > 32:            # dead entries (their tensors are gone) hold device memory: drop them early
@@ -121,34 +122,38 @@ def _rows(x):
     return _lib.aligned16(x.contiguous(memory_format=torch.channels_last)), C
 
 
-def _run_conv(x, w, bias=None, transposed=False, owner=None, add=None):
+def _run_conv(x, w, bias=None, transposed=False, owner=None, add=None, moments=False):
     """x [B, Ci, H, W] (any layout), w [Co, Ci, k, k] -> [B, Co, H, W] channels-last; no autograd.  transposed: w is
     [Ci, Co, k, k] and the backward-data convolution of w runs instead (x has w's OUTPUT channel count).  add [B, Co, H, W] of x's
-    type: added to the output in the kernel's epilogue (h3d_conv_x3_add: a residual connection without a pass of its own)."""
+    type: added to the output in the kernel's epilogue (h3d_conv_x3_add: a residual connection without a pass of its own).
+    moments: -> (out, partial [rows, 2, Co] fp32), the per-workgroup column sums of the stored output and of its square
+    (h3d_conv_x3_moments: the BatchNorm statistic of the next SPADE from the accumulators)."""
     x, ldx = _rows(x)
     B, ci, H, W = x.shape
     k = w.shape[2]
     co = w.shape[1] if transposed else w.shape[0]
     wf = w.float()                         # fp32 weights come back as the same object: the cache key survives
     half = x.dtype == torch.float16
-    stream = pack_stream(wf, transposed, half=half, owner=owner if (owner is not None and wf is w) else None, planes=AMP_WEIGHT_PLANES)
+    lib = _lib.load()
+    # blocking for THIS pixel count (round 6): the widest whose grid still fills the chip -- part of the stream's layout, so of its cache key
+    nt = lib.h3d_conv_x3_nt_for(ci, co, B * H * W)
+    stream = pack_stream(wf, transposed, half=half, owner=owner if (owner is not None and wf is w) else None, planes=AMP_WEIGHT_PLANES, nt=nt)
     out = torch.empty((B, co, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     b = None if bias is None else _lib.aligned16(bias.detach().float().contiguous())      # a slice of a larger bias vector may start anywhere
-    lib = _lib.load()
+    mode = 0 if not half else (2 if AMP_WEIGHT_PLANES == 1 else 1)
+    lda = 0
     if add is not None:
         if add.dtype != x.dtype or tuple(add.shape) != (B, co, H, W):
             raise ValueError(f"addend {tuple(add.shape)} {add.dtype} does not match the output {(B, co, H, W)} {x.dtype}")
         add, lda = _rows(add)
-        mode = 0 if not half else (2 if AMP_WEIGHT_PLANES == 1 else 1)
-        rc = lib.h3d_conv_x3_add(mode, _lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(add), _lib.ptr(out), B, H, W, ci, co, k, ldx,
-                                 co, lda, _lib.stream_handle())
-        _lib.check(rc, "h3d_conv_x3_add")
-        return out
-    entry = lib.h3d_conv_x3 if not half else (lib.h3d_conv_x3_f16x1 if AMP_WEIGHT_PLANES == 1 else lib.h3d_conv_x3_f16)   # f16 in -> f16 out (AMP)
-    rc = entry(_lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(out), B, H, W, ci, co, k, ldx, co,
-                                 _lib.stream_handle())
-    _lib.check(rc, "h3d_conv_x3")
-    return out
+    partial = None
+    if moments:
+        per = lib.h3d_conv_x3_moment_rows()
+        partial = torch.empty(((B * H * W + per - 1) // per, 2, co), device=x.device, dtype=torch.float32)
+    rc = lib.h3d_conv_x3_ex(mode, _lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(add), _lib.ptr(out), _lib.ptr(partial),
+                            B, H, W, ci, co, k, ldx, co, lda, nt, _lib.stream_handle())
+    _lib.check(rc, "h3d_conv_x3_ex")
+    return (out, partial) if moments else out
 
 
 def _run_wgrad(x, g, k, with_bias=False):

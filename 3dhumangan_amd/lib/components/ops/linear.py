@@ -21,6 +21,7 @@ ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
 FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # residual addend in the GEMM epilogue (round 6; A/B switch)
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
+FUSED_MOMENTS = os.environ.get("H3D_FUSED_MOMENTS", "1") != "0"             # BatchNorm moments from the GEMM's accumulators (round 6; A/B switch)
 
 
 _half_cache = {}
@@ -50,13 +51,16 @@ def _as_image(t2):
     return torch.as_strided(t2, (1, C, 1, M), (M * ld, 1, M * ld, ld))
 
 
-def gemm_x3(x2, w, bias=None, transposed=False, add=None):
+def gemm_x3(x2, w, bias=None, transposed=False, add=None, moments=False):
     """x2 [M, Ci] @ w[Co, Ci]^T (+ bias) (+ add [M, Co]) -> [M, Co]; transposed: x2 [M, Co] @ w[Co, Ci] -> [M, Ci].  Split-bf16
-    matrix-core kernel; the addend (a residual connection) joins in the epilogue."""
+    matrix-core kernel; the addend (a residual connection) joins in the epilogue.  moments: -> (y, partial [rows, 2, Co]), the
+    column sums of y and y^2 per workgroup, from the accumulators (h3d_conv_x3_moments)."""
     from . import conv
     # owner=w: the packed weight stream is cached on the caller's (long-lived) weight, not on this per-call view of it
     y = conv._run_conv(_as_image(x2), w.detach()[:, :, None, None], bias, transposed=transposed,
-                       owner=w if w.dtype == torch.float32 else None, add=None if add is None else _as_image(add))
+                       owner=w if w.dtype == torch.float32 else None, add=None if add is None else _as_image(add), moments=moments)
+    if moments:
+        return y[0].permute(0, 2, 3, 1).reshape(x2.shape[0], -1), y[1]
     return y.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
 
 
@@ -123,18 +127,24 @@ def _rows(t):
 
 class _LinearX3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, add=None):
+    def forward(ctx, x, w, b, add=None, moments=False):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         if _native_ok(*w.shape):
             a2 = None if add is None else _rows(add.detach())
+            if moments:           # (y, partial moments of y): the second output carries no gradient
+                y, partial = gemm_x3(_rows(x), w, b, add=a2, moments=True)
+                ctx.mark_non_differentiable(partial)
+                return y.view(*x.shape[:-1], w.shape[0]), partial
             return gemm_x3(_rows(x), w, b, add=a2).view(*x.shape[:-1], w.shape[0])
+        if moments:
+            raise ValueError("moments need the native GEMM")
         y = F.linear(x, w, b)
         return y if add is None else y + add
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         dy2 = _rows(dy)
@@ -158,7 +168,7 @@ class _LinearX3(torch.autograd.Function):
                 dw = wgrad_x3(dy2, _rows(x))
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0)
-        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)          # the addend's gradient is the output's
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None    # the addend's gradient is the output's
 
 
 class _LinearAmp(torch.autograd.Function):
@@ -210,9 +220,24 @@ class _LinearAmp(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x, w, b=None, add=None):
+def linear(x, w, b=None, add=None, moments=False):
     """F.linear(x, w, b) (+ add: a residual connection, fused into the native GEMM's epilogue where that runs); the weight gradient
-    goes to the HIP kernel when the problem is one it is built for."""
+    goes to the HIP kernel when the problem is one it is built for.
+    moments=True: -> (y, partial): partial [rows, 2, Co] fp32 holds per-workgroup column sums of y and y^2 taken from the GEMM's
+    accumulators (h3d_conv_x3_moments; spade_norm_act(.., moments=partial) then skips its own pass over y), or None where the call
+    does not run on the native fp32 GEMM (the SPADE computes them itself)."""
+    if moments:
+        Co, Ci = w.shape
+        rows = x.numel() // max(Ci, 1)
+        ok = (FUSED_MOMENTS and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled()
+              and rows >= MIN_ROWS and _native_ok(Co, Ci) and (add is None or (FUSED_ADD and add.dtype == torch.float32
+                                                                              and add.shape == x.shape[:-1] + (Co,))))
+        if ok and ENABLED and torch.is_grad_enabled() and w.requires_grad and Co >= 32 and Ci >= 32:
+            return _LinearX3.apply(x, w, b, add, True)
+        if ok and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (add is not None and add.requires_grad))):
+            y, partial = gemm_x3(_rows(x), w, b, add=None if add is None else _rows(add), moments=True)
+            return y.view(*x.shape[:-1], Co), partial
+        return linear(x, w, b, add), None
     Co, Ci = w.shape
     rows = x.numel() // max(Ci, 1)
     if add is not None:

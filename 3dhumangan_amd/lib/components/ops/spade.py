@@ -187,10 +187,12 @@ class _SpadeNormAct(torch.autograd.Function):
         return dx, d_g, d_b, dgamma, dbeta, None, None, None, None, None, None
 
 
-def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1, kernels=None, aliases=0):
+def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentum=0.1, kernels=None, aliases=0, moments=None):
     """x [B,P,C]; norm: the first_norm parameter holder (weight, bias, running_mean, running_var, num_batches_tracked);
     gamma / beta [B,P,C] or [B,1,C].  training: batch statistics (all-reduced over `group`) + running-statistics update.
-    aliases > 0: -> (y, x_1, .., x_aliases), views of x whose gradients are added into dx by the backward kernel itself."""
+    aliases > 0: -> (y, x_1, .., x_aliases), views of x whose gradients are added into dx by the backward kernel itself.
+    moments: [rows, 2, C] fp32 partial column sums of x and x^2 that the layer which produced x took from its accumulators
+    (ops/linear.py: linear(.., moments=True)); with them the training-mode pass over x for the batch statistics is skipped."""
     k = _HIP if kernels is None else kernels
     if k is _HIP:
         _lib.need_cuda(x, gamma, beta)
@@ -210,7 +212,10 @@ def spade_norm_act(x, norm, gamma, beta, training, group=None, eps=1e-5, momentu
              and norm.running_mean.is_contiguous() and norm.running_var.is_contiguous())
     if fused:
         with torch.no_grad():
-            sums = k.moments(x)
+            if moments is not None and moments.dim() == 3 and moments.shape[1:] == (2, C) and moments.dtype == torch.float32:
+                sums = k._sum_rows(moments.unsqueeze(0))
+            else:
+                sums = k.moments(x)
             count = _row_count(B * P, x.device)
             if _sync_on(group):
                 packed = torch.cat([sums.flatten(), count])

@@ -165,6 +165,9 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
 
     rgb = None
     pending = None      # ToRGB head of the previous block's output, evaluated on a view the next block's first SPADE hands out
+    # Training mode: the batch moments every SPADE needs of its input come out of the epilogue of the GEMM that produced it
+    # (h3d_conv_x3_moments, round 6) -- a [rows, 2, C] buffer of per-workgroup sums instead of a pass over [B, P, C] per SPADE.
+    mom_x = None
     for idx, name in enumerate(names):
         blk = sn.network[name]
         skip = idx >= nb // 2
@@ -172,17 +175,22 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
         # records, the last two read x through views handed out by the SPADE node, whose backward kernel adds their gradients into
         # dx as it writes it (h3d_spade_bwd_apply_acc) -- two accumulation passes over [B, P, C] less per block (round 6).
         n_alias = (int(skip) + int(pending is not None)) if (ALIAS_GRADS and torch.is_grad_enabled() and x.requires_grad) else 0
-        out = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels, aliases=n_alias)
+        out = spade_norm_act(x, *modulation(name, "spade_0", idx), training, group, kernels=spade_kernels, aliases=n_alias,
+                             moments=mom_x)
         h, views = (out[0], list(out[1:])) if n_alias else (out, [])
         x_in = (views.pop(0) if views else x) if skip else None
         if pending is not None:
             o = linear(views.pop(0) if views else x, pending.weight.flatten(1), pending.bias)
             rgb = o if rgb is None else o + rgb
             pending = None
-        h = linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias)
-        h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels)
+        h, mom_h = linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias, moments=True) if training else \
+            (linear(h, spectral_weight(blk.conv_0, training), blk.conv_0.bias), None)
+        h = spade_norm_act(h, *modulation(name, "spade_1", idx), training, group, kernels=spade_kernels, moments=mom_h)
         # skip blocks: the residual connection joins in the GEMM's epilogue (h3d_conv_x3_add) instead of a pass of its own
-        x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in)
+        if training and idx + 1 < nb:
+            x, mom_x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in, moments=True)
+        else:
+            x, mom_x = linear(h, spectral_weight(blk.conv_1, training), blk.conv_1.bias, add=x_in), None
         if idx >= nb // 2 - 1:
             lin = sn.to_rgbs[name].linear
             if idx + 1 < nb:

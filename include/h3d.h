@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define H3D_VERSION 100            /* major*10000 + minor*100 + patch */
+#define H3D_VERSION 101            /* major*10000 + minor*100 + patch */
 
 #define H3D_OK            0
 #define H3D_EINVAL       -1        /* bad argument (shape, alignment, flag)        */
@@ -244,6 +244,25 @@ int h3d_conv_x3_f16x1(const void* x, const void* stream, const float* bias, void
  * `x = h + x_in` (/root/reference/lib/components/map3d_layers.py:236) without a pass of its own. */
 int h3d_conv_x3_add(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, int B, int H, int W,
                     int Cin, int Cout, int k, int ldx, int ldo, int lda, h3d_stream_t stream_handle);
+/* The general entry of the convolution (round 6): h3d_conv_x3_add with the addend optional, the blocking explicit and, optionally,
+ * the batch moments of the output.
+ *   NT       tiles per output block the stream was packed for (h3d_conv_x3_pack_nt), 0 = the default blocking.  h3d_conv_x3_nt_for
+ *            (HOST helper) returns the blocking for P output pixels: the widest whose grid still has a workgroup for every CU -- the
+ *            discriminator's low-resolution 512-channel layers (/root/reference/lib/discriminators/unet_discriminators.py:100-118)
+ *            launch 8 .. 128 workgroups at the default.  No bit of the result depends on NT.
+ *   moments  null, or [ceil(B*H*W / h3d_conv_x3_moment_rows()), 2, Cout] fp32 -- per workgroup of the launch, the column sums of the
+ *            output AS STORED (after bias, addend and, in the f16 modes, the rounding) and of its square, taken from the
+ *            accumulators.  Their float64 sum over the rows (h3d_rows_sum_f64) is h3d_channel_moments' result without its pass over
+ *            the stored tensor: the batch statistic of the BatchNorm inside the SPADE that reads this layer
+ *            (/root/reference/lib/components/map3d_layers.py:162, 176-190: first_norm in training mode).
+ * 1x1 convolutions (the dense layers) run two workgroups per CU on a 4-stage ring; 3x3 ones keep one workgroup and 7 stages. */
+int h3d_conv_x3_ex(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, float* moments,
+                   int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT, h3d_stream_t stream_handle);
+int h3d_conv_x3_moment_rows(void);      /* output pixels behind one row of the moments buffer (HOST helper) */
+int h3d_conv_x3_nt_for(int Cin, int Cout, int64_t P);      /* HOST helper; 0 = unsupported channel counts */
+/* planes: 0 = bf16 hi + lo (h3d_conv_x3_pack), 1 = f16 hi + lo (_pack_f16), 2 = one f16 plane (_pack_f16x1) */
+int h3d_conv_x3_pack_nt(const float* w, void* stream, int Cout, int Cin, int k, int transposed, int planes, int NT,
+                        h3d_stream_t stream_handle);
 int h3d_conv_wgrad_x3_f16(const void* dY, const void* X, float* partial, int B, int H, int W, int Co, int Ci, int k, int ldy,
                           int ldx, int slices, h3d_stream_t stream);
 /* ... with the convolution's bias gradient riding along (round 4): colsum [slices][Co] fp32 = column sums of dY over each slice's

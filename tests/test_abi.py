@@ -31,7 +31,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_error_string(lib):
     lib.h3d_version.restype = ctypes.c_int
-    assert lib.h3d_version() == 100
+    assert lib.h3d_version() == 101
     lib.h3d_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.h3d_last_error(), bytes)
 

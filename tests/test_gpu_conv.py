@@ -234,3 +234,57 @@ def test_channel_padding_kernel(layout, dtype):
         assert gv.is_contiguous(memory_format=torch.channels_last) and torch.equal(gv[:, :C], xr) and float(gv.detach()[:, C:].abs().max()) == 0.0
         (gxx,) = torch.autograd.grad((gv * w).sum(), xr)                           # second order: back through the pair
         assert torch.equal(gxx, w[:, :C])
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,k,half", [(1, 16, 8, 512, 512, 3, False), (2, 8, 4, 256, 512, 3, True), (1, 40, 33, 128, 256, 1, False),
+                                                 (1, 64, 32, 256, 256, 1, True)])
+def test_blocking_for_the_pixel_count_changes_no_bit(B, H, W, ci, co, k, half):
+    """h3d_conv_x3_nt_for picks the tiles per output block that still fill the chip (the discriminator's low-resolution layers);
+    h3d_conv_x3_pack_nt / h3d_conv_x3_ex at NT = 2, 4, 8 return the SAME bits (the blocking reorders no sum), and _run_conv -- which
+    asks the helper -- matches float64."""
+    lib = importlib.import_module("3dhumangan_amd._lib")
+    L = lib.load()
+    g = torch.Generator().manual_seed(ci + co + H)
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    if half:
+        x = x.half()
+    outs = []
+    for nt in (8, 4, 2):
+        stream = torch.empty((1 if half else 2) * w.numel(), device=DEV, dtype=torch.int16)
+        lib.check(L.h3d_conv_x3_pack_nt(lib.ptr(w), lib.ptr(stream), co, ci, k, 0, 2 if half else 0, nt, lib.stream_handle()), "pack")
+        out = torch.empty((B, co, H, W), device=DEV, dtype=x.dtype, memory_format=torch.channels_last)
+        lib.check(L.h3d_conv_x3_ex(2 if half else 0, lib.ptr(x), lib.ptr(stream), lib.ptr(b), None, lib.ptr(out), None, B, H, W, ci, co, k,
+                                   ci, co, 0, nt, lib.stream_handle()), "conv")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    nt = L.h3d_conv_x3_nt_for(ci, co, B * H * W)
+    tiles = (B * H * W + 127) // 128
+    assert nt in (2, 4, 8) and (nt == 2 or tiles * (co // (32 * nt)) >= 256)
+    conv_mod_planes = conv.AMP_WEIGHT_PLANES
+    got = conv._run_conv(x, w, b)
+    if not half or conv_mod_planes == 1:
+        assert torch.equal(got, outs[0])
+    wq = w.half().double() if half else w.double()
+    assert rel_err(got.double().cpu(), F.conv2d(x.double(), wq, b.double(), padding=k // 2).cpu()) < (2e-3 if half else TOL)
+    # a blocking the channel count does not divide is refused
+    assert L.h3d_conv_x3_pack_nt(lib.ptr(w), lib.ptr(stream), 64, 64, 1, 0, 0, 4, lib.stream_handle()) != 0
+
+
+def test_runs_are_bit_identical_with_several_workgroups_per_cu():
+    """The weight ring's write-after-read safety in conv_x3.hip is by construction (lgkmcnt(0) before the stage barrier): with the
+    distance argument of the engines, 1-4 % of these launches (narrow blocking -> four workgroups per CU, the moments epilogue of
+    one loading the LDS pipe under another's k-loop) returned a tile computed from a half-refilled stage."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(3)
+    for (M, Co, Ci, dt) in ((524288, 64, 256, torch.float16), (524288, 256, 256, torch.float32)):
+        x = torch.randn(M, Ci, generator=g).to(DEV, dt)
+        w, b = (torch.randn(Co, Ci, generator=g) * 0.06).to(DEV), torch.randn(Co, generator=g).to(DEV)
+        r = torch.randn(M, Co, generator=g).to(DEV, dt)
+        y0, p0 = lin.gemm_x3(x, w, b, add=r, moments=True)
+        bad = 0
+        for _ in range(120):
+            y, p = lin.gemm_x3(x, w, b, add=r, moments=True)
+            bad += int(not (torch.equal(y, y0) and torch.equal(p, p0)))
+        assert bad == 0, (M, Co, Ci, dt, bad)

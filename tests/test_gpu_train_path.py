@@ -269,6 +269,84 @@ def test_conv_epilogue_addend_in_half_precision(planes, monkeypatch):
     assert rel_err(got.float(), plain.float() + r.float()) < 1e-3
 
 
+@pytest.mark.parametrize("M,Co,Ci,with_add", [(20000, 256, 256, False), (16500, 256, 128, True), (17001, 64, 64, False),
+                                               (16384, 512, 256, True), (19999, 128, 192, False)])
+def test_gemm_epilogue_moments(M, Co, Ci, with_add):
+    """h3d_conv_x3_moments: the per-workgroup column sums of the stored output and of its square, from the accumulators -- against
+    the sums over the output the same call wrote (ragged last workgroup, 1 / 2 output blocks, 2 / 4 / 8 tiles); the output itself is
+    bit-identical to the call without moments, and linear(.., moments=True) hands them to autograd as a non-differentiable output."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(M + Co)
+    x = (torch.randn(M, Ci, generator=g) * 1.5 + 0.3).to(DEV)
+    w, b = (torch.randn(Co, Ci, generator=g) * 0.1).to(DEV), torch.randn(Co, generator=g).to(DEV)
+    r = torch.randn(M, Co, generator=g).to(DEV) if with_add else None
+    y, partial = lin.gemm_x3(x, w, b, add=r, moments=True)
+    assert partial.shape == ((M + 127) // 128, 2, Co) and partial.dtype == torch.float32
+    assert torch.equal(y, lin.gemm_x3(x, w, b, add=r))
+    sums = partial.double().sum(0)
+    assert rel_err(sums[0], y.double().sum(0)) < 1e-6
+    assert rel_err(sums[1], (y.double() ** 2).sum(0)) < 1e-6
+    # every row is its workgroup's 128 rows alone
+    k = (M + 127) // 128 - 1
+    assert rel_err(partial[k, 0].double(), y[128 * k:].double().sum(0)) < 1e-6
+    # recorded: same values, gradients as without the second output
+    xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    out = lin.linear(xx, ww, b, add=r, moments=True)
+    assert isinstance(out, tuple) and out[1] is not None and not out[1].requires_grad
+    assert torch.equal(out[0], y) and torch.equal(out[1], partial)
+    out[0].square().sum().backward()
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    lin.linear(x2, w2, b, add=r).square().sum().backward()
+    assert torch.equal(xx.grad, x2.grad) and torch.equal(ww.grad, w2.grad)
+    # a call the native GEMM does not cover returns no moments
+    assert lin.linear(x[:100], w, b, moments=True)[1] is None
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_gemm_epilogue_moments_in_half_precision(planes, monkeypatch):
+    """... in the f16 modes the moments are those of the ROUNDED output (what the next layer reads)."""
+    conv = importlib.import_module("3dhumangan_amd.lib.components.ops.conv")
+    monkeypatch.setattr(conv, "AMP_WEIGHT_PLANES", planes)
+    g = torch.Generator().manual_seed(planes)
+    x = torch.randn(2, 128, 50, 33, generator=g).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    w, b = (torch.randn(256, 128, 1, 1, generator=g) * 0.05).to(DEV), torch.randn(256, generator=g).to(DEV)
+    y, partial = conv._run_conv(x, w, b, moments=True)
+    assert y.dtype == torch.float16 and torch.equal(y, conv._run_conv(x, w, b))
+    sums = partial.double().sum(0)
+    assert rel_err(sums[0], y.double().sum((0, 2, 3))) < 1e-6
+    assert rel_err(sums[1], (y.double() ** 2).sum((0, 2, 3))) < 1e-6
+
+
+def test_synthesis_train_forward_with_epilogue_moments(monkeypatch):
+    """The train-mode synthesis with the SPADEs' batch moments taken from the producing GEMMs' epilogues (default) against the
+    same forward with every SPADE making its own pass (H3D_FUSED_MOMENTS=0): outputs, gradients and running statistics."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    diff = importlib.import_module("3dhumangan_amd.lib.generators.differentiable")
+    import bench
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(lin, "FUSED_MOMENTS", fused)
+        G, cfg = bench.build_generator("MAP3DBN512", (128, 128), (32, 32), 8, DEV)
+        G.train()
+        torch.manual_seed(5)
+        fmap = torch.randn(2, 32 * 32, cfg["feature_dim"], device=DEV)
+        styles = torch.randn(2, 1, cfg["feature_dim"], device=DEV)
+        rgb = diff.synthesis_forward(G, fmap, styles, (32, 32), (128, 128), True, group=False)
+        rgb.square().mean().backward()
+        sn = G.synthesis_network
+        res[fused] = (rgb.detach(), [p.grad.clone() for p in sn.parameters() if p.grad is not None],
+                      [b.clone() for n, b in sn.named_buffers() if "running" in n])
+    assert rel_err(res[True][0], res[False][0]) < 5e-5      # fp32 partial sums in another order, through 18 BatchNorms
+    assert len(res[True][1]) == len(res[False][1]) > 0
+    scale = max(float(e.abs().max()) for e in res[False][1])
+    for a, e in zip(res[True][1], res[False][1]):
+        if float(e.abs().max()) < 1e-6 * scale:       # a bias in front of a BatchNorm: its gradient is rounding noise around zero
+            continue
+        assert rel_err(a, e) < 2e-4
+    for a, e in zip(res[True][2], res[False][2]):
+        assert rel_err(a, e) < 1e-6
+
+
 # ------------------------------------------------------------------ SPADE kernels
 
 @pytest.mark.parametrize("B,P,C", [(2, 1300, 32), (3, 513, 40), (2, 700, 30), (2, 2100, 256), (1, 600, 420), (2, 64, 1028)])
