@@ -125,7 +125,8 @@ _SIGNATURES = {
     "h3d_wgrad_x3_bias": (C.c_int, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "h3d_wgrad_reduce": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "h3d_conv_x3_add": (C.c_int, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "h3d_conv_x3_ex": (C.c_int, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_ex": (C.c_int, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_conv_x3_slices": (C.c_int, [_i, _i, _i, _l, _i]),
     "h3d_conv_x3_moment_rows": (C.c_int, []),
     "h3d_conv_x3_nt_for": (C.c_int, [_i, _i, _l]),
     "h3d_conv_x3_pack_nt": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -47,6 +47,8 @@ struct Args {
     const void* add;               // optional [P, Cout] addend of the output's type (a residual connection), row stride lda; or null
     int lda;
     float* moments;                // optional [ceil(P / 128), 2, Cout]: per workgroup, the column sums of the output as stored and of its square
+    float* partial;                // split-K (gridDim.z slices of the tap x chunk loop): [slices, P, Cout] fp32 sums WITHOUT bias / addend; or null
+    int it_per_slice;
 };
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -104,10 +106,14 @@ __global__ __launch_bounds__(256, OCC) void conv_x3_kernel(Args A) {
     const int rem = (int)(pc % HW);
     const int y = rem / A.W, x = rem - y * A.W;
     const int pad = A.k / 2;
-    const int n_iter = A.k * A.k * A.n_chunks;
+    // split-K: slice blockIdx.z owns the iterations [it0, n_iter) of the tap x chunk loop -- a contiguous piece of the weight stream
+    const int it0 = A.partial ? (int)blockIdx.z * A.it_per_slice : 0;
+    const int n_all = A.k * A.k * A.n_chunks;
+    const int n_iter = A.partial ? (it0 + A.it_per_slice < n_all ? it0 + A.it_per_slice : n_all) : n_all;
 
     WeightRing<NT, kDepth> ring;
-    ring.init(A.stream + (int64_t)oblk * A.stages_per_oblk * (NT * 2048), ring_lds, A.stages_per_oblk, wave, lane);
+    ring.init(A.stream + ((int64_t)oblk * A.stages_per_oblk + (int64_t)it0 * KST) * (NT * 2048), ring_lds,
+              A.partial ? (n_iter - it0) * KST : A.stages_per_oblk, wave, lane);
 
     f32x16 acc[NT];
     typename std::conditional<HALF, u32x4[KSC], float4[2 * KSC]>::type raw;
@@ -130,19 +136,19 @@ __global__ __launch_bounds__(256, OCC) void conv_x3_kernel(Args A) {
     };
     {
         bool valid;
-        const TX* src = source(0, valid);
+        const TX* src = source(it0, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
     // first chunk: fresh accumulators
     fragments();
-    if (n_iter > 1) {
+    if (it0 + 1 < n_iter) {
         bool valid;
-        const TX* src = source(1, valid);
+        const TX* src = source(it0 + 1, valid);
         load_chunk<KSC>(raw, src, valid, h);
     }
     gemm_x3_roll<TE, NT, KST, KSC, false, L, 0, true, !HALF, ONE>(acc, xh, xl, ring);
 #pragma unroll 1
-    for (int it = 1; it < n_iter; ++it) {
+    for (int it = it0 + 1; it < n_iter; ++it) {
         pin_agpr<NT>(acc);
         fragments();
         if (it + 1 < n_iter) {
@@ -158,6 +164,20 @@ __global__ __launch_bounds__(256, OCC) void conv_x3_kernel(Args A) {
     // ([channel quad][pixel][4], 4 KiB per wave), a lane sums ONE channel over 16 pixels (rotated by the channel quad: 32 lanes, 32
     // banks), the halves meet through one cross-lane move, the four waves through LDS; one [2, NT * 32] row per workgroup, summed in
     // float64 by the caller (h3d_rows_sum_f64).  Pixels past the end contribute zeros.
+    if (A.partial) {               // split-K: this slice's fp32 sums as they are; bias, addend and the output's type belong to the reduction
+        if (okp) {
+            float* __restrict__ o = A.partial + ((int64_t)blockIdx.z * A.P + p) * A.Cout + oblk * (NT * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (oblk * (NT * 32) + nt * 32 >= A.Cout) break;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<float4*>(o + nt * 32 + rg * 8 + 4 * h) =
+                        make_float4(acc[nt][4 * rg], acc[nt][4 * rg + 1], acc[nt][4 * rg + 2], acc[nt][4 * rg + 3]);
+            }
+        }
+        return;
+    }
     const bool mom = A.moments != nullptr;
     float* const stage = reinterpret_cast<float*>(ring_lds) + wave * 1024;
     float* const wsum = reinterpret_cast<float*>(ring_lds) + 4096;            // [4 waves][NT * 32][2]
@@ -226,6 +246,39 @@ __global__ __launch_bounds__(256, OCC) void conv_x3_kernel(Args A) {
     }
 }
 
+// out[p, c] = bias[c] + add[p, c] + sum over the slices of partial[s, p, c], in the output's type: the second half of a split-K launch
+template <typename TX>
+__global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                          const TX* __restrict__ add, int lda, TX* __restrict__ out, int ldo, int64_t P,
+                                                          int Cout, int slices) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (pixel, channel quad)
+    const int cq = Cout / 4;
+    if (idx >= P * cq) return;
+    const int64_t p = idx / cq;
+    const int c = (int)(idx - p * cq) * 4;
+    float4 v = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < slices; ++sl) {
+        const float4 q = *reinterpret_cast<const float4*>(partial + ((int64_t)sl * P + p) * Cout + c);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if constexpr (std::is_same<TX, float>::value) {
+        if (add) {
+            const float4 r = *reinterpret_cast<const float4*>(add + p * lda + c);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(out + p * ldo + c) = v;
+    } else {
+        if (add) {
+            const uint2 r = *reinterpret_cast<const uint2*>(add + p * lda + c);
+            const h16x2 r0 = __builtin_bit_cast(h16x2, r.x), r1 = __builtin_bit_cast(h16x2, r.y);
+            v.x += (float)r0[0]; v.y += (float)r0[1]; v.z += (float)r1[0]; v.w += (float)r1[1];
+        }
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const h16x2 a = __builtin_convertvector(f2{v.x, v.y}, h16x2), b = __builtin_convertvector(f2{v.z, v.w}, h16x2);
+        *reinterpret_cast<uint2*>(out + p * ldo + c) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    }
+}
+
 // Weight stream of h3d_conv_x3 from OIHW fp32 weights, one launch: thread <-> (o, i, tap) of the convolution that will RUN
 // (transposed: the backward-data convolution of w, W'[o][i][tap] = w[i][o][k*k - 1 - tap]).
 __global__ void conv_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ stream, int Cout, int Cin, int kk, int NT,
@@ -265,12 +318,12 @@ constexpr size_t lds_bytes() {
     return ring > stage ? ring : stage;
 }
 template <int NT, int KSC, int MODE, int OCC>
-int launch(const Args& A, int n_oblk, hipStream_t st) {
+int launch(const Args& A, int n_oblk, hipStream_t st, int slices) {
     H3D_ALLOW_MAX_LDS((conv_x3_kernel<NT, KSC, MODE, OCC>));
     const int64_t tiles = (A.P + 127) / 128;
     h3d::pre_launch();
     constexpr size_t lds = lds_bytes<NT, OCC>();
-    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, MODE, OCC>), dim3((unsigned)tiles, (unsigned)n_oblk), dim3(256), lds, st, A);
+    hipLaunchKernelGGL((conv_x3_kernel<NT, KSC, MODE, OCC>), dim3((unsigned)tiles, (unsigned)n_oblk, (unsigned)slices), dim3(256), lds, st, A);
     return h3d::launch_status("h3d_conv_x3");
 }
 
@@ -347,7 +400,8 @@ extern "C" int h3d_conv_x3_pack_nt(const float* w, void* stream, int Cout, int C
 
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
                        int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add = nullptr, int lda = 0,
-                       float* moments = nullptr, int NT = 0);
+                       float* moments = nullptr, int NT = 0, float* workspace = nullptr, int slices = 1);
+static int conv_plan(int Cin, int Cout, int k, int NT_, int* til, bool& occ2);
 extern "C" int h3d_conv_x3(const float* x, const void* stream, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, int k, int ldx, int ldo, h3d_stream_t stream_) {
     return conv_x3_any(0, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_);
@@ -388,34 +442,64 @@ extern "C" int h3d_conv_x3_add(int mode, const void* x, const void* stream, cons
  * (h3d_rows_sum_f64) is what h3d_channel_moments computes in a pass of its own over the stored tensor: the BatchNorm statistic of
  * the SPADE behind the layer (reference lib/components/map3d_layers.py:162, 176-190), taken from the accumulators. */
 extern "C" int h3d_conv_x3_ex(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, float* moments,
-                              int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT, h3d_stream_t stream_) {
+                              float* workspace, int slices, int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT,
+                              h3d_stream_t stream_) {
+    H3D_REQUIRE(slices >= 0 && (slices <= 1 || (workspace && h3d::aligned16(workspace) && !moments)),
+                "h3d_conv_x3_ex: %d K-slices need a workspace of slices * B*H*W * Cout floats (and return no moments)", slices);
     H3D_REQUIRE(mode >= 0 && mode <= 2, "h3d_conv_x3_ex: mode %d (0 = fp32, 1 = f16 two planes, 2 = f16 one plane)", mode);
     H3D_REQUIRE(!moments || h3d::aligned16(moments), "h3d_conv_x3_ex: misaligned moments buffer");
     H3D_REQUIRE(!add || h3d::aligned16(add), "h3d_conv_x3_ex: misaligned addend");
     const int gran = mode ? 8 : 4;
     H3D_REQUIRE((!add || (lda >= Cout && lda % gran == 0)) && ldx % gran == 0 && ldo % gran == 0,
                 "h3d_conv_x3_ex: row strides must be multiples of %d (ldx=%d ldo=%d lda=%d)", gran, ldx, ldo, lda);
-    return conv_x3_any(mode, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_, add, add ? lda : 0, moments, NT);
+    return conv_x3_any(mode, x, stream, bias, out, B, H, W, Cin, Cout, k, ldx, ldo, stream_, add, add ? lda : 0, moments, NT,
+                       slices > 1 ? workspace : nullptr, slices);
+}
+// The loop of a launch: tiling (NT_ = 0: the default blocking), whether it runs two workgroups per CU, iterations of the tap x chunk loop
+static int conv_plan(int Cin, int Cout, int k, int NT_, int* til, bool& occ2) {
+    if (tiling_nt(Cin, Cout, NT_, til)) return -1;
+    // 1x1: two workgroups per CU on 4-k-step chunks (the stream's layout does not depend on the chunking); H3D_CONV_OCC=1: A/B knob
+    static const bool occ2_ok = [] { const char* e = getenv("H3D_CONV_OCC"); return !(e && e[0] == '1'); }();
+    occ2 = occ2_ok && k == 1;
+    if (occ2 && til[2] == 8) { til[2] = 4; til[3] *= 2; }
+    return k * k * til[3];
+}
+/* K-slices worth asking h3d_conv_x3_ex for (HOST helper, round 6): 1, or -- when even the narrowest blocking leaves CUs without a
+ * workgroup -- the number of pieces of the tap x channel-chunk loop (at least 4 iterations each, at most 16 pieces) that brings the grid
+ * to ~256 workgroups.  The discriminator's 16 x 8 and 8 x 4 layers (4 and 1 pixel tiles) run 9 x 512 / 16 = 288 k-steps in sequence per
+ * workgroup otherwise.  The caller provides slices * B*H*W * Cout floats of workspace; the slices are summed in slice order by a second
+ * launch (deterministic), which also adds bias and addend and rounds once to the output's type. */
+extern "C" int h3d_conv_x3_slices(int Cin, int Cout, int k, int64_t P, int NT) {
+    int til[4];
+    bool occ2;
+    const int n_iter = conv_plan(Cin, Cout, k, NT, til, occ2);
+    static const bool split = [] { const char* e = getenv("H3D_CONV_SPLITK"); return !(e && e[0] == '0'); }();       // A/B knob
+    if (n_iter < 16 || !split) return 1;          // a short loop gains less than the second launch costs (1x1, 512 channels: 18 -> 24 us)
+    const int64_t wgs = ((P + 127) / 128) * til[1];
+    if (wgs >= 160) return 1;
+    int s = (int)((256 + wgs - 1) / wgs);
+    if (s > n_iter / 4) s = n_iter / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
 }
 /* Output pixels behind one row of h3d_conv_x3_ex's moments buffer (128: one workgroup). */
 extern "C" int h3d_conv_x3_moment_rows(void) { return 128; }
 static int conv_x3_any(int mode, const void* x, const void* stream, const float* bias, void* out, int B, int H, int W, int Cin,
-                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add, int lda, float* moments, int NT_) {
+                       int Cout, int k, int ldx, int ldo, h3d_stream_t stream_, const void* add, int lda, float* moments, int NT_,
+                       float* workspace, int slices) {
     H3D_REQUIRE(x && stream && out, "h3d_conv_x3: null pointer");
     H3D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && (k == 1 || k == 3), "h3d_conv_x3: bad shape / kernel size (1 or 3)");
     H3D_REQUIRE(h3d::aligned16(x) && h3d::aligned16(stream) && h3d::aligned16(out) && (!bias || h3d::aligned16(bias)),
                 "h3d_conv_x3: operands must be 16-byte aligned");
     H3D_REQUIRE(ldx >= Cin && ldo >= Cout && ldx % 4 == 0 && ldo % 4 == 0, "h3d_conv_x3: row strides must be multiples of 4 and cover the channels (ldx=%d ldo=%d)", ldx, ldo);
     int til[4];
-    if (tiling_nt(Cin, Cout, NT_, til)) {
+    bool occ2 = false;
+    const int n_iter = (k == 1 || k == 3) ? conv_plan(Cin, Cout, k, NT_, til, occ2) : -1;
+    if (n_iter < 0) {
         h3d::set_error("h3d_conv_x3: channel counts must be multiples of 64 and of 32 * NT (got %d -> %d, NT %d)", Cin, Cout, NT_);
         return H3D_EUNSUPPORTED;
     }
     if (B == 0) return H3D_OK;
-    // 1x1: two workgroups per CU on 4-k-step chunks (the stream's layout does not depend on the chunking); H3D_CONV_OCC=1: A/B knob
-    static const bool occ2_ok = [] { const char* e = getenv("H3D_CONV_OCC"); return !(e && e[0] == '1'); }();
-    const bool occ2 = occ2_ok && k == 1;
-    if (occ2 && til[2] == 8) { til[2] = 4; til[3] *= 2; }
     Args A{};
     A.x = x; A.stream = static_cast<const unsigned char*>(stream); A.bias = bias; A.out = out; A.add = add; A.lda = lda; A.moments = moments;
     A.P = (int64_t)B * H * W; A.H = H; A.W = W; A.Cin = Cin; A.Cout = Cout; A.k = k;
@@ -423,9 +507,25 @@ static int conv_x3_any(int mode, const void* x, const void* stream, const float*
     H3D_REQUIRE((A.P + 127) / 128 < (int64_t(1) << 31), "h3d_conv_x3: too many pixels");
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const int NT = til[0], KSC = til[2];
-#define H3D_CASE(N, K, O) if (NT == N && KSC == K && occ2 == (O == 2)) return mode == 2 ? launch<N, K, 2, O>(A, til[1], st) : mode == 1 ? launch<N, K, 1, O>(A, til[1], st) : launch<N, K, 0, O>(A, til[1], st)
+    int nz = 1;
+    if (workspace && slices > 1) {                    // split-K: ceil(n_iter / it_per_slice) slices actually run
+        A.it_per_slice = (n_iter + slices - 1) / slices;
+        nz = (n_iter + A.it_per_slice - 1) / A.it_per_slice;
+        if (nz > 1) A.partial = workspace;
+    }
+    int rc = H3D_EUNSUPPORTED;
+#define H3D_CASE(N, K, O) if (NT == N && KSC == K && occ2 == (O == 2)) rc = mode == 2 ? launch<N, K, 2, O>(A, til[1], st, nz) : mode == 1 ? launch<N, K, 1, O>(A, til[1], st, nz) : launch<N, K, 0, O>(A, til[1], st, nz)
     H3D_CASE(8, 8, 1); H3D_CASE(8, 4, 1); H3D_CASE(4, 8, 1); H3D_CASE(4, 4, 1); H3D_CASE(2, 8, 1); H3D_CASE(2, 4, 1);
     H3D_CASE(8, 4, 2); H3D_CASE(4, 4, 2); H3D_CASE(2, 4, 2);
 #undef H3D_CASE
-    return H3D_EUNSUPPORTED;
+    if (rc != H3D_OK || !A.partial) return rc;
+    const int64_t quads = A.P * (Cout / 4);
+    h3d::pre_launch();
+    if (mode == 0)
+        hipLaunchKernelGGL(conv_splitk_reduce<float>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, A.partial, bias,
+                           static_cast<const float*>(add), lda, static_cast<float*>(out), ldo, A.P, Cout, nz);
+    else
+        hipLaunchKernelGGL(conv_splitk_reduce<_Float16>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, A.partial, bias,
+                           static_cast<const _Float16*>(add), lda, static_cast<_Float16*>(out), ldo, A.P, Cout, nz);
+    return h3d::launch_status("h3d_conv_x3 (slice sum)");
 }

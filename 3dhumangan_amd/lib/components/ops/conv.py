@@ -150,8 +150,11 @@ def _run_conv(x, w, bias=None, transposed=False, owner=None, add=None, moments=F
     if moments:
         per = lib.h3d_conv_x3_moment_rows()
         partial = torch.empty(((B * H * W + per - 1) // per, 2, co), device=x.device, dtype=torch.float32)
+    # K-slices (round 6): a layer whose grid leaves CUs idle even at the narrowest blocking runs its tap x chunk loop in pieces
+    slices = 1 if moments else lib.h3d_conv_x3_slices(ci, co, k, B * H * W, nt)
+    work = torch.empty((slices, B * H * W, co), device=x.device, dtype=torch.float32) if slices > 1 else None
     rc = lib.h3d_conv_x3_ex(mode, _lib.ptr(x), _lib.ptr(stream), _lib.ptr(b), _lib.ptr(add), _lib.ptr(out), _lib.ptr(partial),
-                            B, H, W, ci, co, k, ldx, co, lda, nt, _lib.stream_handle())
+                            _lib.ptr(work), slices, B, H, W, ci, co, k, ldx, co, lda, nt, _lib.stream_handle())
     _lib.check(rc, "h3d_conv_x3_ex")
     return (out, partial) if moments else out
 

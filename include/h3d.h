@@ -257,7 +257,14 @@ int h3d_conv_x3_add(int mode, const void* x, const void* stream, const float* bi
  *            (/root/reference/lib/components/map3d_layers.py:162, 176-190: first_norm in training mode).
  * 1x1 convolutions (the dense layers) run two workgroups per CU on a 4-stage ring; 3x3 ones keep one workgroup and 7 stages. */
 int h3d_conv_x3_ex(int mode, const void* x, const void* stream, const float* bias, const void* add, void* out, float* moments,
-                   int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT, h3d_stream_t stream_handle);
+                   float* workspace, int slices, int B, int H, int W, int Cin, int Cout, int k, int ldx, int ldo, int lda, int NT,
+                   h3d_stream_t stream_handle);
+/*   slices   K-slices (<= 1: none): the tap x channel-chunk loop is cut into that many pieces, each a workgroup of its own writing
+ *            fp32 sums into workspace [slices, B*H*W, Cout]; a second launch adds them in slice order with bias and addend and rounds
+ *            once to the output's type.  h3d_conv_x3_slices (HOST helper) says how many are worth it: > 1 only when the grid at the
+ *            narrowest blocking still leaves CUs idle (the discriminator's 16 x 8 and 8 x 4 layers: 288 k-steps in sequence on 32 or 8
+ *            workgroups otherwise).  moments and slices exclude each other. */
+int h3d_conv_x3_slices(int Cin, int Cout, int k, int64_t P, int NT);
 int h3d_conv_x3_moment_rows(void);      /* output pixels behind one row of the moments buffer (HOST helper) */
 int h3d_conv_x3_nt_for(int Cin, int Cout, int64_t P);      /* HOST helper; 0 = unsupported channel counts */
 /* planes: 0 = bf16 hi + lo (h3d_conv_x3_pack), 1 = f16 hi + lo (_pack_f16), 2 = one f16 plane (_pack_f16x1) */

@@ -255,8 +255,8 @@ def test_blocking_for_the_pixel_count_changes_no_bit(B, H, W, ci, co, k, half):
         stream = torch.empty((1 if half else 2) * w.numel(), device=DEV, dtype=torch.int16)
         lib.check(L.h3d_conv_x3_pack_nt(lib.ptr(w), lib.ptr(stream), co, ci, k, 0, 2 if half else 0, nt, lib.stream_handle()), "pack")
         out = torch.empty((B, co, H, W), device=DEV, dtype=x.dtype, memory_format=torch.channels_last)
-        lib.check(L.h3d_conv_x3_ex(2 if half else 0, lib.ptr(x), lib.ptr(stream), lib.ptr(b), None, lib.ptr(out), None, B, H, W, ci, co, k,
-                                   ci, co, 0, nt, lib.stream_handle()), "conv")
+        lib.check(L.h3d_conv_x3_ex(2 if half else 0, lib.ptr(x), lib.ptr(stream), lib.ptr(b), None, lib.ptr(out), None, None, 1, B, H, W,
+                                   ci, co, k, ci, co, 0, nt, lib.stream_handle()), "conv")
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     nt = L.h3d_conv_x3_nt_for(ci, co, B * H * W)
@@ -264,7 +264,7 @@ def test_blocking_for_the_pixel_count_changes_no_bit(B, H, W, ci, co, k, half):
     assert nt in (2, 4, 8) and (nt == 2 or tiles * (co // (32 * nt)) >= 256)
     conv_mod_planes = conv.AMP_WEIGHT_PLANES
     got = conv._run_conv(x, w, b)
-    if not half or conv_mod_planes == 1:
+    if (not half or conv_mod_planes == 1) and L.h3d_conv_x3_slices(ci, co, k, B * H * W, nt) == 1:      # K-slices add in another order
         assert torch.equal(got, outs[0])
     wq = w.half().double() if half else w.double()
     assert rel_err(got.double().cpu(), F.conv2d(x.double(), wq, b.double(), padding=k // 2).cpu()) < (2e-3 if half else TOL)
@@ -288,3 +288,39 @@ def test_runs_are_bit_identical_with_several_workgroups_per_cu():
             y, p = lin.gemm_x3(x, w, b, add=r, moments=True)
             bad += int(not (torch.equal(y, y0) and torch.equal(p, p0)))
         assert bad == 0, (M, Co, Ci, dt, bad)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co,k,half,slices", [(4, 16, 8, 512, 512, 3, False, 8), (4, 8, 4, 512, 512, 3, True, 9), (1, 13, 7, 256, 128, 3, False, 3),
+                                                        (2, 32, 16, 1024, 256, 1, False, 4), (4, 32, 16, 256, 512, 3, True, 2), (1, 5, 5, 64, 64, 3, False, 16)])
+def test_k_slices(B, H, W, ci, co, k, half, slices):
+    """h3d_conv_x3_ex with the tap x chunk loop cut into K-slices (own workgroups, fp32 partial sums, a second launch adding them in
+    slice order with bias and addend): against float64 and against the unsliced launch, fp32 and f16, with more slices asked for than
+    the loop has pieces to give; h3d_conv_x3_slices asks for them only where the grid leaves CUs idle."""
+    lib = importlib.import_module("3dhumangan_amd._lib")
+    L = lib.load()
+    g = torch.Generator().manual_seed(ci + co + H + slices)
+    dt = torch.float16 if half else torch.float32
+    x = torch.randn(B, ci, H, W, generator=g).to(DEV, dt).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(DEV)
+    b = torch.randn(co, generator=g).to(DEV)
+    r = torch.randn(B, co, H, W, generator=g).to(DEV, dt).contiguous(memory_format=torch.channels_last)
+    nt = L.h3d_conv_x3_nt_for(ci, co, B * H * W)
+    stream = torch.empty((1 if half else 2) * w.numel(), device=DEV, dtype=torch.int16)
+    lib.check(L.h3d_conv_x3_pack_nt(lib.ptr(w), lib.ptr(stream), co, ci, k, 0, 2 if half else 0, nt, lib.stream_handle()), "pack")
+    outs = []
+    for s_ in (1, slices):
+        out = torch.full((B, co, H, W), float("nan"), device=DEV, dtype=dt).contiguous(memory_format=torch.channels_last)
+        work = torch.full((max(s_, 1), B * H * W, co), float("nan"), device=DEV) if s_ > 1 else None
+        lib.check(L.h3d_conv_x3_ex(2 if half else 0, lib.ptr(x), lib.ptr(stream), lib.ptr(b), lib.ptr(r), lib.ptr(out), None, lib.ptr(work), s_,
+                                   B, H, W, ci, co, k, ci, co, co, nt, lib.stream_handle()), "conv")
+        outs.append(out)
+    wq = w.half().double() if half else w.double()
+    want = F.conv2d(x.double(), wq, b.double(), padding=k // 2) + r.double()
+    tol = 2e-3 if half else TOL
+    assert rel_err(outs[0].double().cpu(), want.cpu()) < tol and rel_err(outs[1].double().cpu(), want.cpu()) < tol
+    assert rel_err(outs[1].double(), outs[0].double()) < (1e-3 if half else 1e-5)
+    auto = L.h3d_conv_x3_slices(ci, co, k, B * H * W, nt)
+    assert auto >= 1 and (auto == 1 or ((B * H * W + 127) // 128) * (co // (32 * nt)) < 160)
+    # slices without a workspace, or together with moments, are refused
+    assert L.h3d_conv_x3_ex(0, lib.ptr(x), lib.ptr(stream), None, None, lib.ptr(outs[0]), None, None, 4, B, H, W, ci, co, k, ci, co, 0, nt,
+                            lib.stream_handle()) != 0
