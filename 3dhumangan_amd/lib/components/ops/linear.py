@@ -22,6 +22,10 @@ NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
 FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # residual addend in the GEMM epilogue (round 6; A/B switch)
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
 FUSED_MOMENTS = os.environ.get("H3D_FUSED_MOMENTS", "1") != "0"             # BatchNorm moments from the GEMM's accumulators (round 6; A/B switch)
+# ... under float16 autocast too, on the own f16 GEMM: opt-in.  Same lease (profiles/r6_ab_amp_fused_moments_not_kept.txt): AMP iteration
+# 109.7 -> 111.8 ms -- the own f16 GEMM takes 200 us where the library takes 140, and the moments pass it saves reads a tensor the
+# infinity cache still holds
+AMP_FUSED_MOMENTS = os.environ.get("H3D_AMP_FUSED_MOMENTS", "0") == "1"
 
 
 _half_cache = {}
@@ -179,17 +183,27 @@ class _LinearAmp(torch.autograd.Function):
     stays fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, add=None, moments=False):
         xh = x.half()
         ctx.save_for_backward(xh, w)
         ctx.has_bias = b is not None
+        if moments:
+            # a layer in front of a SPADE (round 6): the own f16 GEMM (one weight plane = autocast's arithmetic) is slower than the
+            # library's (200 vs 140 us at 0.5 M x 256 x 256) but hands over the batch moments from its accumulators (a 94 us pass
+            # otherwise) and takes the residual addend in fp32 before the one rounding (another pass and another rounding otherwise)
+            a2 = None if add is None else _rows(add.detach().half())
+            y, partial = gemm_x3(_rows(xh), w, b, add=a2, moments=True)
+            ctx.mark_non_differentiable(partial)
+            return y.view(*x.shape[:-1], w.shape[0]), partial
         if AMP_NATIVE_GEMM and _native_ok(*w.shape):
-            return gemm_x3(_rows(xh), w, b).view(*x.shape[:-1], w.shape[0])
-        return F.linear(xh, _half_cached(w), _half_cached(b))
+            y = gemm_x3(_rows(xh), w, b, add=None if add is None else _rows(add.detach().half()))
+            return y.view(*x.shape[:-1], w.shape[0])
+        y = F.linear(xh, _half_cached(w), _half_cached(b))
+        return y if add is None else y + add
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         xh, w = ctx.saved_tensors
         dyh = dy.half()
         dx = dw = db = None
@@ -217,7 +231,7 @@ class _LinearAmp(torch.autograd.Function):
                 dw = wgrad_x3(dy2, x2)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(dim=0, dtype=torch.float32)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
 def linear(x, w, b=None, add=None, moments=False):
@@ -229,6 +243,10 @@ def linear(x, w, b=None, add=None, moments=False):
     if moments:
         Co, Ci = w.shape
         rows = x.numel() // max(Ci, 1)
+        if (AMP_FUSED_MOMENTS and FUSED_MOMENTS and ENABLED and x.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.float16 and w.dtype == torch.float32 and rows >= MIN_ROWS and _native_ok(Co, Ci) and Co >= 32 and Ci >= 32
+                and (add is None or add.shape == x.shape[:-1] + (Co,))):
+            return _LinearAmp.apply(x, w, b, add, True)
         ok = (FUSED_MOMENTS and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled()
               and rows >= MIN_ROWS and _native_ok(Co, Ci) and (add is None or (FUSED_ADD and add.dtype == torch.float32
                                                                               and add.shape == x.shape[:-1] + (Co,))))
@@ -251,7 +269,7 @@ def linear(x, w, b=None, add=None, moments=False):
     if (ENABLED and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
             and torch.is_grad_enabled() and w.requires_grad and w.dtype == torch.float32 and rows >= MIN_ROWS
             and ((Co % 8 == 0 and Ci % 8 == 0 and Co >= 32 and Ci >= 32) or (Co <= 4 and Ci >= 32) or (Ci <= 4 and Co >= 32))):
-        return _LinearAmp.apply(x, w, b)
+        return _LinearAmp.apply(x, w, b, None, False)
     if (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and torch.is_grad_enabled()
             and w.requires_grad and not torch.is_autocast_enabled() and rows >= MIN_ROWS
             and ((Co % 4 == 0 and Ci % 4 == 0 and Co >= 32 and Ci >= 32)           # h3d_wgrad_x3

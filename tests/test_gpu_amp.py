@@ -206,3 +206,32 @@ def test_discriminator_under_autocast_vs_the_reference_under_autocast(monkeypatc
     e32 = rel_err(a["grad"][gkey], g["grad"][gkey])
     print(f"weight gradient of the D loss: vs reference-under-autocast {e:.2e} (reference AMP vs fp32: {e32:.2e})")
     assert e < 3e-2
+
+
+def test_dense_layer_in_front_of_a_spade_under_autocast(monkeypatch):
+    """linear(.., add=, moments=True) under float16 autocast: the own f16 GEMM with the residual addend and the batch moments in its
+    epilogue -- output against the library path (F.linear on halves + add), moments against the stored output, gradients against the
+    moment-less call; with and without autograd recording (the D step's generator forward runs under no_grad)."""
+    monkeypatch.setattr(lin, "AMP_FUSED_MOMENTS", True)          # opt-in (H3D_AMP_FUSED_MOMENTS=1): measured slower in the iteration, not the default
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 9000, 256, generator=g).to(DEV)
+    w, b = (torch.randn(256, 256, generator=g) * 0.06).to(DEV).requires_grad_(True), torch.randn(256, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(2, 9000, 256, generator=g).to(DEV).half()
+    with torch.autocast("cuda", dtype=torch.float16):
+        xx = x.clone().requires_grad_(True)
+        y, partial = lin.linear(xx, w, b, add=r, moments=True)
+        assert y.dtype == torch.float16 and partial is not None and partial.shape[1:] == (2, 256)
+        sums = partial.double().sum(0)
+        assert rel_err(sums[0], y.double().sum((0, 1))) < 1e-6 and rel_err(sums[1], (y.double() ** 2).sum((0, 1))) < 1e-6
+        want = torch.nn.functional.linear(x.half().double(), w.detach().half().double(), b.detach().half().double()) + r.double()
+        assert rel_err(y.double(), want) < 1e-3
+        (y.float().square().sum() * 1e-3).backward()             # gradients well inside the f16 range
+        gx, gw, gb = xx.grad.clone(), w.grad.clone(), b.grad.clone()
+        w.grad = b.grad = None
+        x2 = x.clone().requires_grad_(True)
+        y2 = lin.linear(x2, w, b) + r
+        (y2.float().square().sum() * 1e-3).backward()
+        assert rel_err(gx, x2.grad) < 2e-3 and rel_err(gw, w.grad) < 2e-3 and rel_err(gb, b.grad) < 2e-3
+        with torch.no_grad():
+            y3, p3 = lin.linear(x, w, b, add=r, moments=True)
+        assert torch.equal(y3, y) and torch.equal(p3, partial)
