@@ -15,13 +15,9 @@
 // AMP tier (HALF instantiations): the activations ARE f16 -- one exact plane -- so the loaded words are the B fragments as they
 // are (no conversion, no split) on the F16 matrix instruction, the weights travel as f16 hi + f16 lo (to max(2^-22 |W|, 2^-25);
 // h3d_conv_x3_pack_f16), and a product is W_hi x + W_lo x: two matrix instructions instead of three, no vector work per element.
-// The ring's write-after-read safety is BY CONSTRUCTION in this file (round 6): every wave retires its LDS reads (lgkmcnt(0)) before the
-// barrier behind which a stage's buffer is refilled.  The engines argue by distance (x3_common.hpp: acquire) -- one workgroup per CU
-// there.  Here several workgroups share a CU (two by design for 1x1, up to four at NT = 2), and with another workgroup's moments
-// epilogue loading the LDS pipe the distance was NOT kept: 1-4 % of 0.5 M x 64 x 256 launches returned one wave's tile computed from a
-// half-refilled stage (tools/conv_determinism.py; found by the run-to-run comparison of the training loss).  The wait costs nothing
-// measurable on these kernels (tools/moments_ab.py: every 1x1 / 3x3 shape within 1 %).
-#define H3D_RING_WAIT_LDS
+// Several workgroups share a CU here (two by design for 1x1, up to four at NT = 2).  That is where the weight ring's former
+// write-after-read argument by distance failed (x3_common.hpp: acquire; tools/conv_determinism.py; profiles/r6_conv_ring_war_race.txt)
+// -- the ring now waits for its LDS reads before every stage barrier, in every kernel.
 #include "x3_common.hpp"
 #include <type_traits>
 #include <stdlib.h>

@@ -234,16 +234,21 @@ struct WeightRing {
     }
     // Make the next stage (t) readable by every wave.  The caller then issues stage t + kBuf - 1 with
     // issue_chunk(0..kChunks-1), one chunk after each tile pair's MFMAs of the k-step it computes next, so the DMA
-    // issue hides under the matrix pipe.  The refill lands in the buffer of stage t - 1.  Its last fragment reads
-    // were issued by every wave BEFORE it arrived at this barrier; the first refill chunk is issued >= 192 MFMA
-    // cycles after the barrier and its data lands an L2 round trip (>= 300 cycles) later still, whereas an LDS read
-    // retires within ~130 cycles of issue -- the write-after-read distance is a few hundred cycles of margin on a
-    // bounded-latency path.  (Waiting lgkmcnt(0) here instead costs ~15 % on the whole kernel.)
+    // issue hides under the matrix pipe.  The refill lands in the buffer of stage t - 1.
+    // Write-after-read safety (round 6: BY CONSTRUCTION).  Every wave waits for its own LDS reads (lgkmcnt(0)) before it arrives
+    // at the barrier, so when the barrier opens the last fragment reads of stage t - 1 have RETURNED in every wave, and the
+    // refill is issued after the barrier.  Rounds 2-5 argued by distance instead (the reads were only *issued* before the barrier;
+    // the refill's data lands an L2 round trip later, an LDS read retires within ~130 cycles) because the wait cost ~15 % on the
+    // round-2 kernels.  On today's kernels it costs nothing (same lease, profiles/r6_ab_ring_wait_lds.txt: 358.2 / 359.3 vs
+    // 360.5 / 359.7 images/s; every convolution shape within 1 %) -- and the distance argument FAILED where several workgroups
+    // share a CU: conv_x3.hip at two to four workgroups per CU with another workgroup's moments epilogue loading the LDS pipe
+    // returned a tile computed from a half-refilled stage in 1-4 % of launches (profiles/r6_conv_ring_war_race.txt).
+    // H3D_RING_DISTANCE restores the old wait (development only).
     __device__ __forceinline__ lds_ptr acquire() {
         // vmcnt only (expcnt / lgkmcnt fields left at "no wait"): stages t+1 .. t+kBuf-2 may stay in flight
         constexpr int kKeep = (kBuf - 2 - LAG) * kChunks;
 #ifndef H3D_EXPERIMENT_NO_BARRIER
-#ifdef H3D_RING_WAIT_LDS            // every LDS read of this wave retired before the barrier: the refill's write-after-read safety by construction
+#ifndef H3D_RING_DISTANCE           // every LDS read of this wave returned before the barrier
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0000);
 #else
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
@@ -265,7 +270,11 @@ struct WeightRing {
         static_assert(kBuf - 3 - LAG >= 0, "ring too shallow for paired acquires");
         constexpr int kKeep = (kBuf - 3 - LAG) * kChunks;
 #ifndef H3D_EXPERIMENT_NO_BARRIER
+#ifndef H3D_RING_DISTANCE
+        __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0000);
+#else
         __builtin_amdgcn_s_waitcnt((kKeep & 0xF) | ((kKeep >> 4) << 14) | 0x0070 | 0x0F00);
+#endif
         __builtin_amdgcn_s_barrier();
 #endif
         r0 = slot<4>(next_read());

@@ -1,13 +1,13 @@
 """Stress test of the LDS weight ring of the register-resident x3 engines (csrc/x3_common.hpp: WeightRing::acquire).
 
-The ring's write-after-read hazard (a refill landing in a buffer whose last fragment reads are still in flight) is closed
-by a distance argument, not by a wait: the refill of stage t-1's buffer is issued >= 192 MFMA cycles after the barrier that
-every wave passes only after ISSUING its last reads of that buffer, and lands an L2 round trip later, while an LDS read
-retires within ~130 cycles.  A violation would show up as a corrupted weight fragment in some workgroup, i.e. as a
-different image.  Here the two kernels run 200 times back to back on the bench geometry (small batch), alone and next to a
-second stream that thrashes HBM / L2 (which stretches LDS-DMA latencies and perturbs the relative timing of the waves), and
-every output must be BIT-identical to the first one; the result is also checked against the strict fp32-MFMA engines, which
-have no ring."""
+The ring's write-after-read hazard (a refill landing in a buffer whose last fragment reads are still in flight) is closed by
+construction since round 6: every wave waits for its LDS reads (lgkmcnt(0)) before the stage barrier behind which the buffer is
+refilled (rounds 2-5: by a distance argument, which failed in conv_x3.hip once several workgroups shared a CU --
+tests/test_gpu_conv.py::test_runs_are_bit_identical_with_several_workgroups_per_cu).  A violation would show up as a corrupted
+weight fragment in some workgroup, i.e. as a different image.  Here the two kernels run 200 times back to back on the bench
+geometry (small batch), alone and next to a second stream that thrashes HBM / L2 (which stretches LDS-DMA latencies and perturbs
+the relative timing of the waves), and every output must be BIT-identical to the first one; the result is also checked against the
+strict fp32-MFMA engines, which have no ring."""
 import importlib
 
 import pytest

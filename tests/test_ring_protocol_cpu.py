@@ -1,8 +1,8 @@
 """Model check of the hand-synchronised weight ring (csrc/x3_common.hpp: WeightRing, gemm_x3_roll, gemm_x2_roll) on the CPU.
 
 The ring is synchronised by counting: an `acquire` is an `s_waitcnt vmcnt(keep)` on the wave's own DMA queue plus a workgroup
-barrier, and a buffer is refilled without waiting for its readers -- the argument being that every wave issued its last read of
-that buffer before a barrier that precedes the refill's issue.  This test restates the CONTROL FLOW of the two GEMM loops (which
+barrier, and a buffer is refilled only behind a barrier that follows every wave's last read of it (since round 6 the waves also
+wait for those reads to RETURN -- lgkmcnt(0) -- before that barrier, so the ordering this model checks is sufficient by itself).  This test restates the CONTROL FLOW of the two GEMM loops (which
 section loads which fragments, where the acquires sit, which sections issue a refill chunk) as an event list in program order --
 the same for all four waves, which meet at every barrier -- and checks, for sequences of matrices like the ones the engines run:
 
