@@ -278,8 +278,11 @@ __global__ __launch_bounds__(kThreads) void wgrad_x3_kernel(Args A) {
 // 3x3 convolution weight gradient with the three taps of a filter row fused: a workgroup owns a K-slice of pixels, one filter
 // row ty and a [64 NA x 64 NB] block of dW for tx = -1, 0, +1 (3 NA NB accumulator tiles per wave, NA, NB <= 2), so dY and X are
 // read three times (once per ty) instead of nine.  partial[3 ty + tx][slice][Co][Ci].
+#ifndef H3D_WGRAD3_OCC
+#define H3D_WGRAD3_OCC 2
+#endif
 template <int NA, int NB, bool HALF>
-__global__ __launch_bounds__(kThreads) void wgrad_conv3_kernel(Args A) {
+__global__ __launch_bounds__(kThreads, (HALF && NA == 2 && NB == 2) ? H3D_WGRAD3_OCC : 1) void wgrad_conv3_kernel(Args A) {
     typedef typename Raw4<HALF>::type raw_t;
     constexpr int WA = 64 * NA, WB = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
