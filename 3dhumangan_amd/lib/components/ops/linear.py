@@ -21,6 +21,7 @@ ENABLED = os.environ.get("H3D_WGRAD", "x3") == "x3"
 NATIVE_GEMM = os.environ.get("H3D_LINEAR", "x3") == "x3"
 FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # residual addend in the GEMM epilogue (round 6; A/B switch)
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
+PAD_ODD_WIDTH = os.environ.get("H3D_LINEAR_PAD", "1") != "0"                 # odd input widths padded for the weight-gradient kernel (round 6; A/B switch)
 FUSED_MOMENTS = os.environ.get("H3D_FUSED_MOMENTS", "1") != "0"             # BatchNorm moments from the GEMM's accumulators (round 6; A/B switch)
 # ... under float16 autocast too, on the own f16 GEMM: opt-in.  Same lease (profiles/r6_ab_amp_fused_moments_not_kept.txt): AMP iteration
 # 109.7 -> 111.8 ms -- the own f16 GEMM takes 200 us where the library takes 140, and the moments pass it saves reads a tensor the
@@ -258,6 +259,14 @@ def linear(x, w, b=None, add=None, moments=False):
         return linear(x, w, b, add), None
     Co, Ci = w.shape
     rows = x.numel() // max(Ci, 1)
+    if (PAD_ODD_WIDTH and ENABLED and add is None and x.is_cuda and w.dtype == torch.float32 and torch.is_grad_enabled() and w.requires_grad
+            and not x.requires_grad and rows >= MIN_ROWS and Co % 8 == 0 and Co >= 32 and Ci > 4 and Ci % 8
+            and (x.dtype == torch.float32 or torch.is_autocast_enabled())):
+        # an input width the weight-gradient kernel does not take (the field's 31 geometry features, map3d_layers / smpl.py:210-249):
+        # one zero column more and the layer's weight gradient leaves the library's tall-skinny TN GEMM (0.99 ms at 0.59 M rows x 31 ->
+        # 256) for h3d_wgrad_x3 (round 6).  The input needs no gradient (it is data), the weight's comes back through the pad.
+        pad = 8 - Ci % 8
+        return linear(F.pad(x, (0, pad)), F.pad(w, (0, pad)), b)
     if add is not None:
         fp32 = (FUSED_ADD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and add.dtype == torch.float32
                 and not torch.is_autocast_enabled() and rows >= MIN_ROWS and _native_ok(Co, Ci) and add.shape == x.shape[:-1] + (Co,))

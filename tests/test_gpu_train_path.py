@@ -302,6 +302,27 @@ def test_gemm_epilogue_moments(M, Co, Ci, with_add):
     assert lin.linear(x[:100], w, b, moments=True)[1] is None
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_linear_with_an_odd_input_width(amp):
+    """linear on data of a width the weight-gradient kernel does not take (31 geometry features): padded by a zero column, so the
+    weight gradient runs on h3d_wgrad_x3; values and gradients against float64."""
+    lin = importlib.import_module("3dhumangan_amd.lib.components.ops.linear")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 9000, 31, generator=g)
+    w, b = torch.randn(256, 31, generator=g) * 0.2, torch.randn(256, generator=g)
+    p = torch.randn(2, 9000, 256, generator=g)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    (torch.nn.functional.linear(x.double(), w64, b64) * p.double()).sum().backward()
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        y = lin.linear(x.to(DEV), wd, bd)
+    assert y.shape == (2, 9000, 256)
+    (y.float() * p.to(DEV)).sum().backward()
+    tol = 3e-3 if amp else 1e-4
+    assert rel_err(y.detach().double().cpu(), torch.nn.functional.linear(x.double(), w.double(), b.double())) < tol
+    assert wd.grad.shape == (256, 31) and rel_err(wd.grad.double().cpu(), w64.grad) < tol and rel_err(bd.grad.double().cpu(), b64.grad) < tol
+
+
 @pytest.mark.parametrize("planes", [1, 2])
 def test_gemm_epilogue_moments_in_half_precision(planes, monkeypatch):
     """... in the f16 modes the moments are those of the ROUNDED output (what the next layer reads)."""
