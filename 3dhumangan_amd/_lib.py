@@ -107,6 +107,8 @@ _SIGNATURES = {
     "h3d_bilinear_resize": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_bilinear_resize_cl": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_bilinear_resize_cl_bwd": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_bilinear_resize_cl_relu": (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "h3d_bilinear_resize_cl_relu_bwd": (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "h3d_film_sin_rows": (C.c_int, []),
     "h3d_film_sin": (C.c_int, [_p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),
     "h3d_film_sin_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _f, _p]),

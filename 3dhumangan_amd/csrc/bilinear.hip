@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void bilinear_rows(const float* __restrict__ i
 
 // ---- channels-last maps [B, h, w, C] (the training path's layout; C % 4 == 0) ------------------------------------------------
 // forward: a thread writes 4 channels of one output pixel (16-byte store; the four taps are 16-byte loads from the small source)
+// RELU: the ReLU behind the resize in the same pass (the SPADEs' shared map, lib/components/map3d_layers.py:170-174: mlp_shared = conv + ReLU)
+template <bool RELU>
 __global__ __launch_bounds__(256) void bilinear_cl_fwd(const float* __restrict__ in, float* __restrict__ out, int h, int w, int H, int W,
                                                        int C4, float ry, float rx) {
     const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(256) void bilinear_cl_fwd(const float* __restrict__
     const float4 c = src[((int64_t)y1 * w + x0) * C4], d = src[((int64_t)y1 * w + x1) * C4];
     auto mix = [&](float a_, float b_, float c_, float d_) {
         const float top = a_ * (1.f - tx) + b_ * tx, bot = c_ * (1.f - tx) + d_ * tx;       // same association as bilinear_kernel
-        return top * (1.f - ty) + bot * ty;
+        const float v = top * (1.f - ty) + bot * ty;
+        return RELU ? (v > 0.f ? v : 0.f) : v;
     };
     reinterpret_cast<float4*>(out)[(((int64_t)b * H + Y) * W + X) * C4 + c4] =
         make_float4(mix(a.x, bq.x, c.x, d.x), mix(a.y, bq.y, c.y, d.y), mix(a.z, bq.z, c.z, d.z), mix(a.w, bq.w, c.w, d.w));
@@ -145,18 +148,29 @@ __global__ __launch_bounds__(256) void bilinear_cl_fwd(const float* __restrict__
 // adjoint along ONE axis: dst[o, i, r] = sum_I weight(I -> i) src[o, I, r] for src [O, N, R4] float4 rows, dst [O, n, R4].
 // A thread owns (o, r) and walks I = 0 .. N-1 once: the source index i0(I) is non-decreasing, so two running sums (rows i0 and
 // i0 + 1) are enough and each finished row is written exactly once -- the source is read once, coalesced over r, no atomics.
-__global__ __launch_bounds__(256) void bilinear_cl_adjoint_axis(const float* __restrict__ src, float* __restrict__ dst, int N, int n,
-                                                                int64_t R4, int64_t total, float ratio) {
+// MASK: src is the gradient of relu(resize(x)) and `mask` (same shape) the forward's output: rows are read as src * (mask > 0)
+template <bool MASK>
+__global__ __launch_bounds__(256) void bilinear_cl_adjoint_axis(const float* __restrict__ src, const float* __restrict__ mask,
+                                                                float* __restrict__ dst, int N, int n, int64_t R4, int64_t total, float ratio) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int64_t o = idx / R4, r = idx - o * R4;
     const float4* __restrict__ s = reinterpret_cast<const float4*>(src) + o * N * R4 + r;
+    const float4* __restrict__ m = MASK ? reinterpret_cast<const float4*>(mask) + o * N * R4 + r : nullptr;
     float4* __restrict__ d = reinterpret_cast<float4*>(dst) + o * n * R4 + r;
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
     int cur = 0;
-    float4 v = s[0];
+    auto row = [&](int I) {
+        float4 q = s[(int64_t)I * R4];
+        if constexpr (MASK) {
+            const float4 k = m[(int64_t)I * R4];
+            q.x = k.x > 0.f ? q.x : 0.f; q.y = k.y > 0.f ? q.y : 0.f; q.z = k.z > 0.f ? q.z : 0.f; q.w = k.w > 0.f ? q.w : 0.f;
+        }
+        return q;
+    };
+    float4 v = row(0);
     for (int I = 0; I < N; ++I) {
-        const float4 nxt = I + 1 < N ? s[(int64_t)(I + 1) * R4] : v;                       // one row ahead of the arithmetic
+        const float4 nxt = I + 1 < N ? row(I + 1) : v;                                      // one row ahead of the arithmetic
         int i0, i1;
         float t;
         src_index(I, ratio, n, i0, i1, t);
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void bilinear_cl_adjoint_axis(const float* __r
 }  // namespace
 
 // Channels-last variant: in [B,h,w,C] -> out [B,H,W,C] (C a multiple of 4, 16-byte aligned), same arithmetic as h3d_bilinear_resize.
-extern "C" int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream) {
+static int resize_cl_any(bool relu, const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream) {
     H3D_REQUIRE(in && out, "h3d_bilinear_resize_cl: null pointer");
     H3D_REQUIRE(B >= 0 && C >= 4 && C % 4 == 0 && h >= 1 && w >= 1 && H >= 1 && W >= 1, "h3d_bilinear_resize_cl: bad shape (C must be a multiple of 4)");
     H3D_REQUIRE(h3d::aligned16(in) && h3d::aligned16(out), "h3d_bilinear_resize_cl: operands must be 16-byte aligned");
@@ -190,17 +204,21 @@ extern "C" int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h,
     if (B == 0) return H3D_OK;
     const int C4 = C / 4;
     h3d::pre_launch();
-    hipLaunchKernelGGL(bilinear_cl_fwd, dim3((C4 + 63) / 64, (W + 3) / 4, B * H), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
-                       h, w, H, W, C4, (float)h / (float)H, (float)w / (float)W);
+    const dim3 grid((C4 + 63) / 64, (W + 3) / 4, B * H);
+    if (relu)
+        hipLaunchKernelGGL(bilinear_cl_fwd<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, h, w, H, W, C4,
+                           (float)h / (float)H, (float)w / (float)W);
+    else
+        hipLaunchKernelGGL(bilinear_cl_fwd<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, h, w, H, W, C4,
+                           (float)h / (float)H, (float)w / (float)W);
     return h3d::launch_status("h3d_bilinear_resize_cl");
 }
-
-// Adjoint of h3d_bilinear_resize_cl: dout [B,H,W,C] -> din [B,h,w,C]; tmp: B*h*W*C floats of scratch (rows first, then columns).
-extern "C" int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
-                                          h3d_stream_t stream) {
+static int resize_cl_bwd_any(const float* dout, const float* mask, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
+                             h3d_stream_t stream) {
     H3D_REQUIRE(dout && tmp && din, "h3d_bilinear_resize_cl_bwd: null pointer");
     H3D_REQUIRE(B >= 0 && C >= 4 && C % 4 == 0 && h >= 1 && w >= 1 && H >= 1 && W >= 1, "h3d_bilinear_resize_cl_bwd: bad shape (C must be a multiple of 4)");
-    H3D_REQUIRE(h3d::aligned16(dout) && h3d::aligned16(tmp) && h3d::aligned16(din), "h3d_bilinear_resize_cl_bwd: operands must be 16-byte aligned");
+    H3D_REQUIRE(h3d::aligned16(dout) && h3d::aligned16(tmp) && h3d::aligned16(din) && (!mask || h3d::aligned16(mask)),
+                "h3d_bilinear_resize_cl_bwd: operands must be 16-byte aligned");
     if (B == 0) return H3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t C4 = C / 4;
@@ -208,18 +226,40 @@ extern "C" int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* 
         const int64_t R4 = (int64_t)W * C4, total = (int64_t)B * R4;
         H3D_REQUIRE((total + 255) / 256 < (int64_t(1) << 31), "h3d_bilinear_resize_cl_bwd: tensor too large");
         h3d::pre_launch();
-        hipLaunchKernelGGL(bilinear_cl_adjoint_axis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout, tmp, H, h, R4, total,
-                           (float)h / (float)H);
+        if (mask)
+            hipLaunchKernelGGL(bilinear_cl_adjoint_axis<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout, mask, tmp, H, h, R4,
+                               total, (float)h / (float)H);
+        else
+            hipLaunchKernelGGL(bilinear_cl_adjoint_axis<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout, nullptr, tmp, H, h,
+                               R4, total, (float)h / (float)H);
         const int rc = h3d::launch_status("h3d_bilinear_resize_cl_bwd");
         if (rc) return rc;
     }
     {   // columns: [B*h][W][C4] -> [B*h][w][C4]
         const int64_t R4 = C4, total = (int64_t)B * h * R4;
         h3d::pre_launch();
-        hipLaunchKernelGGL(bilinear_cl_adjoint_axis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, din, W, w, R4, total,
-                           (float)w / (float)W);
+        hipLaunchKernelGGL(bilinear_cl_adjoint_axis<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, nullptr, din, W, w, R4,
+                           total, (float)w / (float)W);
         return h3d::launch_status("h3d_bilinear_resize_cl_bwd");
     }
+}
+extern "C" int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream) {
+    return resize_cl_any(false, in, out, B, h, w, H, W, C, stream);
+}
+// Adjoint of h3d_bilinear_resize_cl: dout [B,H,W,C] -> din [B,h,w,C]; tmp: B*h*W*C floats of scratch (rows first, then columns).
+extern "C" int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
+                                          h3d_stream_t stream) {
+    return resize_cl_bwd_any(dout, nullptr, tmp, din, B, h, w, H, W, C, stream);
+}
+// relu(resize(in)) in one pass, and its gradient: din = resize^T(dout * (out > 0)) with `out` the forward's result (round 6: the
+// ReLU of the SPADEs' shared map and its mask no longer make passes of their own over the [B, H, W, 128 n] tensor).
+extern "C" int h3d_bilinear_resize_cl_relu(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream) {
+    return resize_cl_any(true, in, out, B, h, w, H, W, C, stream);
+}
+extern "C" int h3d_bilinear_resize_cl_relu_bwd(const float* dout, const float* out, float* tmp, float* din, int B, int h, int w, int H, int W,
+                                               int C, h3d_stream_t stream) {
+    H3D_REQUIRE(out, "h3d_bilinear_resize_cl_relu_bwd: null pointer");
+    return resize_cl_bwd_any(dout, out, tmp, din, B, h, w, H, W, C, stream);
 }
 
 extern "C" int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w, int H, int W,

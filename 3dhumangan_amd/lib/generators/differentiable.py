@@ -28,7 +28,7 @@ from ..components.ops.film import film_sin
 from ..components.ops.linear import linear
 from ..components.ops.spade import spade_norm_act
 from ..components.ops.spectral import _SpectralWeight
-from ..components.resample import bilinear_resize_cl
+from ..components.resample import bilinear_resize_cl, bilinear_resize_relu_cl
 
 FUSED_SPECTRAL = os.environ.get("H3D_GEN_SN", "hip") != "torch"      # the generator's spectral norm on csrc/spectral_norm.hip (round 6)
 ALIAS_GRADS = os.environ.get("H3D_SPADE_ALIAS", "1") != "0"      # gradients of a skip block's input summed inside the SPADE backward kernel (round 6)
@@ -97,17 +97,26 @@ def _coords(H, W, device, dtype):
     return torch.stack([ii, jj], dim=-1).reshape(H * W, 2)
 
 
-def _resize_channels_last(t, render_hw, gen_hw):
+FUSED_RESIZE_RELU = os.environ.get("H3D_RESIZE_RELU", "fused") != "torch"      # ReLU + its mask inside the resize kernels (round 6; A/B switch)
+
+
+def _resize_channels_last(t, render_hw, gen_hw, relu=False):
     """Bilinear (align_corners=False) resize of a channels-last map [B, Hr*Wr, C] -> [B, H*W, C] without leaving the
     channels-last layout (F.interpolate on the NCHW *view* of the same memory)."""
     B, _, C = t.shape
     if t.is_cuda and t.dtype in (torch.float32, torch.float16) and C % 4 == 0 and B * gen_hw[0] < 65536:
         # own kernels: the backward reads the gradient once, no atomics.  Under autocast too (F.interpolate's channels-last
         # kernels take 3.4 ms forward + 4.9 ms backward here, these 0.5 + 0.3 ms): computed in fp32, returned in the input's type
-        return bilinear_resize_cl(t.float(), render_hw, gen_hw).to(t.dtype)
+        if relu and FUSED_RESIZE_RELU and t.dtype == torch.float32:
+            # fp32 only: under float16 autocast the mask would be the saved fp32 output (twice the bytes of the f16 ReLU's) and
+            # the iteration gets 1.5 ms slower (profiles/r6_ab_resize_relu.txt)
+            return bilinear_resize_relu_cl(t, render_hw, gen_hw)
+        up = bilinear_resize_cl(t.float(), render_hw, gen_hw).to(t.dtype)
+        return torch.relu(up) if relu else up
     nchw = t.reshape(B, render_hw[0], render_hw[1], C).permute(0, 3, 1, 2)
     up = F.interpolate(nchw, gen_hw, mode="bilinear", align_corners=False)
-    return up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)
+    up = up.permute(0, 2, 3, 1).reshape(B, gen_hw[0] * gen_hw[1], C)
+    return torch.relu(up) if relu else up
 
 
 def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=None, spade_kernels=None):
@@ -147,7 +156,7 @@ def synthesis_forward(G, fmap_low, styles, render_hw, gen_hw, training, group=No
             low = linear(fmap_low, w_all)
             low = low + off_all.to(low.dtype)
         # ... and so is the ReLU: one pass over the whole map instead of one per (strided) piece
-        up = torch.relu(_resize_channels_last(low, render_hw, gen_hw))                          # [B, P, 128 * len(pix)]
+        up = _resize_channels_last(low, render_hw, gen_hw, relu=True)                           # [B, P, 128 * len(pix)]; ReLU in the resize kernel
         # split, not slices: the backward of a split is ONE concatenation of the pieces' gradients; slices would each
         # zero-fill a full-width gradient and add them up (6 x 1.6 GB at config 4)
         shared_up = dict(zip(pix, torch.split(up, 128, dim=-1)))

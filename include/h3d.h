@@ -167,6 +167,12 @@ int h3d_bilinear_resize(const float* in, float* out, int B, int C, int h, int w,
 int h3d_bilinear_resize_cl(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream);
 int h3d_bilinear_resize_cl_bwd(const float* dout, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
                                h3d_stream_t stream);
+/* relu(resize(in)) in one pass and its gradient din = resize^T(dout * (out > 0)), `out` being the forward's result (round 6): the ReLU of
+ * the SPADEs' shared 128-channel maps (/root/reference/lib/components/map3d_layers.py:170-174, mlp_shared = conv + ReLU, evaluated at ray
+ * resolution and resized) and its mask without passes of their own over the [B, H, W, 128 n] tensor. */
+int h3d_bilinear_resize_cl_relu(const float* in, float* out, int B, int h, int w, int H, int W, int C, h3d_stream_t stream);
+int h3d_bilinear_resize_cl_relu_bwd(const float* dout, const float* out, float* tmp, float* din, int B, int h, int w, int H, int W, int C,
+                                    h3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A5 / A5+A6 on the f16 matrix cores with split ("x3") operands: every fp32 operand is carried as hi + lo f16

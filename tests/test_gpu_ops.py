@@ -225,6 +225,31 @@ def test_bilinear_channels_last_forward_adjoint_and_double_backward(shape):
     assert rel_err(nchw.permute(0, 2, 3, 1).reshape(B, H * W, C).cpu(), got.detach().cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 6, 5, 20, 12), (1, 768, 12, 6, 64, 32), (1, 4, 1, 3, 7, 2), (3, 260, 9, 4, 50, 23)])
+def test_bilinear_channels_last_with_the_relu_inside(shape):
+    """h3d_bilinear_resize_cl_relu / _relu_bwd: relu(resize(x)) in one pass and its gradient through the mask of the saved output,
+    against relu(F.interpolate(..)) in float64 -- values bit-identical to relu of the plain kernel's output."""
+    B, C, h, w, H, W = shape
+    g = torch.Generator().manual_seed(h * W + C + 1)
+    x = torch.randn(B, h * w, C, generator=g)
+    cot = torch.randn(B, H * W, C, generator=g)
+    xr = x.double().requires_grad_()
+    ref = torch.nn.functional.interpolate(xr.view(B, h, w, C).permute(0, 3, 1, 2), (H, W), mode="bilinear")
+    ref = torch.relu(ref.permute(0, 2, 3, 1).reshape(B, H * W, C))
+    (gref,) = torch.autograd.grad(ref, xr, cot.double())
+    xd = dev(x).requires_grad_()
+    got = resample.bilinear_resize_relu_cl(xd, (h, w), (H, W))
+    assert torch.equal(got.detach(), torch.relu(resample.bilinear_resize_cl(dev(x), (h, w), (H, W))))
+    assert rel_err(got.detach().cpu(), ref.detach()) < 2e-6
+    (ggot,) = torch.autograd.grad(got, xd, dev(cot))
+    # a pixel within rounding of zero may take the other side of the mask than float64 does: compare where the reference is clear of it
+    plain = resample.bilinear_resize_cl(dev(x), (h, w), (H, W)).cpu().double()
+    if float((plain.abs() < 1e-6).sum()) == 0:
+        assert rel_err(ggot.cpu(), gref) < 5e-6
+    else:
+        assert rel_err(ggot.cpu(), gref) < 1e-3
+
+
 # ------------------------------------------------------------------ P1 / P2
 
 def test_bias_act_golden():
