@@ -57,14 +57,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_narrow_kernel(const T* __restr
 #pragma unroll
             for (int k = 0; k < V; ++k) red[j][t][k] = acc[j][k];
         __syncthreads();
-        if (g == 0 && q < Q) {
-            for (int j = 0; j < no; ++j)
-#pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    float s = 0.f;
-                    for (int gg = 0; gg < G; ++gg) s += red[j][gg * QP + t][k];
-                    out[(int64_t)j * C + q * V + k] = s;
-                }
+        // the row groups' sums, one output per thread and turn (round 6: all 256 threads; the first row group's QP threads alone
+        // spent no * V * G dependent LDS reads each -- 256 at eight halves per thread -- while the others idled); same order of addition
+        for (int o = t; o < no * QP * V; o += kThreads) {
+            const int j = o / (QP * V), cc = o - j * (QP * V), qq = cc / V, k = cc - qq * V;
+            if (q0 + qq < Q) {
+                float s = 0.f;
+                for (int gg = 0; gg < G; ++gg) s += red[j][gg * QP + qq][k];
+                out[(int64_t)j * C + (q0 + qq) * V + k] = s;
+            }
         }
         __syncthreads();
     }
