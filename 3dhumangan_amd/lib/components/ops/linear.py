@@ -23,6 +23,9 @@ FUSED_ADD = os.environ.get("H3D_LINEAR_ADD", "fused") != "torch"          # resi
 AMP_NATIVE_GEMM = os.environ.get("H3D_AMP_LINEAR", "library") == "x3"      # AMP forward / data gradient: library f16 GEMM by default
 PAD_ODD_WIDTH = os.environ.get("H3D_LINEAR_PAD", "1") != "0"                 # odd input widths padded for the weight-gradient kernel (round 6; A/B switch)
 FUSED_MOMENTS = os.environ.get("H3D_FUSED_MOMENTS", "1") != "0"             # BatchNorm moments from the GEMM's accumulators (round 6; A/B switch)
+# autocast dense layers WITH a residual addend on the own f16 GEMM (addend in the epilogue): opt-in -- measured slower in the iteration
+# (106.0 -> 110.4 ms, profiles/r6_ab_amp_linear_add_not_kept.txt): in situ the own GEMM loses more to the library's than the sum's pass costs
+AMP_ADD_NATIVE = os.environ.get("H3D_AMP_LINEAR_ADD", "library") == "x3"
 # ... under float16 autocast too, on the own f16 GEMM: opt-in.  Same lease (profiles/r6_ab_amp_fused_moments_not_kept.txt): AMP iteration
 # 109.7 -> 111.8 ms -- the own f16 GEMM takes 200 us where the library takes 140, and the moments pass it saves reads a tensor the
 # infinity cache still holds
@@ -196,7 +199,8 @@ class _LinearAmp(torch.autograd.Function):
             y, partial = gemm_x3(_rows(xh), w, b, add=a2, moments=True)
             ctx.mark_non_differentiable(partial)
             return y.view(*x.shape[:-1], w.shape[0]), partial
-        if AMP_NATIVE_GEMM and _native_ok(*w.shape):
+        if (AMP_NATIVE_GEMM or (add is not None and AMP_ADD_NATIVE)) and _native_ok(*w.shape):
+            # opt-in paths: the own f16 GEMM, the addend (if any) in its epilogue -- added in fp32, one rounding
             y = gemm_x3(_rows(xh), w, b, add=None if add is None else _rows(add.detach().half()))
             return y.view(*x.shape[:-1], w.shape[0])
         y = F.linear(xh, _half_cached(w), _half_cached(b))
@@ -267,6 +271,10 @@ def linear(x, w, b=None, add=None, moments=False):
         # 256) for h3d_wgrad_x3 (round 6).  The input needs no gradient (it is data), the weight's comes back through the pad.
         pad = 8 - Ci % 8
         return linear(F.pad(x, (0, pad)), F.pad(w, (0, pad)), b)
+    if (add is not None and AMP_ADD_NATIVE and FUSED_ADD and ENABLED and x.is_cuda and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.float16 and w.dtype == torch.float32 and rows >= MIN_ROWS and _native_ok(Co, Ci)
+            and Co >= 32 and Ci >= 32 and add.shape == x.shape[:-1] + (Co,)):
+        return _LinearAmp.apply(x, w, b, add, False)
     if add is not None:
         fp32 = (FUSED_ADD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and add.dtype == torch.float32
                 and not torch.is_autocast_enabled() and rows >= MIN_ROWS and _native_ok(Co, Ci) and add.shape == x.shape[:-1] + (Co,))

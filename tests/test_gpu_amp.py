@@ -235,3 +235,30 @@ def test_dense_layer_in_front_of_a_spade_under_autocast(monkeypatch):
         with torch.no_grad():
             y3, p3 = lin.linear(x, w, b, add=r, moments=True)
         assert torch.equal(y3, y) and torch.equal(p3, partial)
+
+
+def test_dense_layer_with_a_residual_addend_under_autocast(monkeypatch):
+    """linear(x, w, b, add=r) under float16 autocast on the own f16 GEMM with the addend in its epilogue (fp32 sum, one rounding; opt-in,
+    H3D_AMP_LINEAR_ADD=x3): values against float64 on the rounded operands, gradients against the library path + a separate sum."""
+    monkeypatch.setattr(lin, "AMP_ADD_NATIVE", True)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 9000, 256, generator=g).to(DEV)
+    w, b = (torch.randn(256, 256, generator=g) * 0.06).to(DEV).requires_grad_(True), torch.randn(256, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(2, 9000, 256, generator=g).to(DEV).half().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        xx = x.clone().requires_grad_(True)
+        y = lin.linear(xx, w, b, add=r)
+        assert y.dtype == torch.float16 and type(y.grad_fn).__name__.startswith("_LinearAmp")
+        want = torch.nn.functional.linear(x.half().double(), w.detach().half().double(), b.detach().double()) + r.detach().double()
+        assert rel_err(y.double(), want) < 1e-3
+        (y.float().square().sum() * 1e-3).backward()
+        got = [t.grad.clone() for t in (xx, w, b, r)]
+        for t in (w, b, r):
+            t.grad = None
+        monkeypatch.setattr(lin, "AMP_ADD_NATIVE", False)
+        x2 = x.clone().requires_grad_(True)
+        y2 = lin.linear(x2, w, b, add=r)
+        assert not type(y2.grad_fn).__name__.startswith("_LinearAmp")        # the default: library GEMM + a sum
+        (y2.float().square().sum() * 1e-3).backward()
+        for a, e in zip(got, (x2.grad, w.grad, b.grad, r.grad)):
+            assert rel_err(a.float(), e.float()) < 3e-3
